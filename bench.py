@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the MI355X FWT engine (contract: see the task statement / DESIGN.md §5).
+
+One "step" = one full ``wavedec2(x, "db4", level=3)`` over a 64 x 1024 x 1024 fp32 batch that is already
+resident in HBM (BASELINE.json configs[1], the configuration the metric is quoted on).  With N GPUs every
+rank transforms its own 64-image batch shard (weak scaling, no data-path collective: batch elements are
+independent); the only collectives are the barrier and the max-over-ranks of the wall time.
+
+Output: ONE JSON line on rank 0 with the whole-job throughput in Msamples/s, plus
+  "roofline"     achieved algorithmic GB/s of the dominant kernel (the level-1 analysis kernel), measured
+                 live with HIP events on the launch stream inside the timed region, against 8 TB/s HBM peak;
+  "cpu_baseline" the reference's CPU op sequence (oracle/torch_cpu_port.py) timed on this host's cores
+                 (N = 1 only).
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 --steps 50 --warmup 5
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (fn, shape, wavelet, level, mode, dtype)
+    "wavedec2_db4_L3_64x1024x1024_f32": ("wavedec2", (64, 1024, 1024), "db4", 3, "reflect", torch.float32),
+    "wavedec3_db2_L3_8x256x256x256_f32": ("wavedec3", (8, 256, 256, 256), "db2", 3, "zero", torch.float32),
+    "wavedec2_db8_L4_64x4096x4096_f32": ("wavedec2", (64, 4096, 4096), "db8", 4, "reflect", torch.float32),
+}
+
+
+def level_extents(shape, flen, level):
+    """Per-level sub-band extents of the transformed axes."""
+    cur, out = list(shape), []
+    for _ in range(level):
+        cur = [(n + flen - 1) // 2 for n in cur]
+        out.append(tuple(cur))
+    return out
+
+
+def prod(xs):
+    p = 1
+    for v in xs:
+        p *= v
+    return p
+
+
+def algorithmic_bytes(batch, sig, flen, level, esize):
+    """compulsory = input once + every returned coefficient once; per_level adds the
+    write + re-read of the intermediate approximations; level1 = what the dominant kernel moves."""
+    nd = len(sig)
+    exts = level_extents(sig, flen, level)
+    nb = 1 << nd
+    compulsory = prod(sig) + sum((nb - 1) * prod(e) for e in exts) + prod(exts[-1])
+    per_level = 0
+    cur = sig
+    for e in exts:
+        per_level += prod(cur) + nb * prod(e)
+        cur = e
+    level1 = prod(sig) + nb * prod(exts[0])
+    return (esize * batch * compulsory, esize * batch * per_level, esize * batch * level1)
+
+
+def cpu_baseline(fn, shape, wavelet, level, mode, dtype):
+    """The reference's CPU op sequence on this host's cores, on a bounded sample of the same workload."""
+    if fn != "wavedec2":
+        return None
+    from oracle import torch_cpu_port as P
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sample_b = min(shape[0], 32)
+    x = torch.randn(sample_b, *shape[1:], dtype=dtype)
+    P.wavedec2(x[:2], wavelet, mode=mode, level=level)  # warm-up (oneDNN primitive creation)
+    times = []
+    t_end = time.perf_counter() + 20.0
+    while len(times) < 5 and (time.perf_counter() < t_end or not times):
+        t0 = time.perf_counter()
+        P.wavedec2(x, wavelet, mode=mode, level=level)
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {
+        "value": round(x.numel() / med / 1e6, 2),
+        "unit": "Msamples/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{sample_b}x{shape[1]}x{shape[2]} {str(dtype).split('.')[-1]} images, {wavelet} level {level} {mode}, "
+                  f"median of {len(times)} runs (min {min(times):.3f}s, median {med:.3f}s); same ATen ops as ptwt's CPU path "
+                  "(pad + dense stride-2 conv2d), oracle/torch_cpu_port.py",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="wavedec2_db4_L3_64x1024x1024_f32", choices=sorted(WORKLOADS))
+    ap.add_argument("--buffers", type=int, default=3, help="distinct input buffers rotated to defeat the 256 MiB Infinity Cache")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world and distributed:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and not distributed:
+        raise SystemExit("for --gpus > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+
+    import __graft_entry__ as entry
+
+    if rank == 0:
+        entry.build(verbose=False)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        dist.barrier()
+    if rank != 0:
+        entry.build(verbose=False)
+
+    import ptwt_amd
+    from ptwt_amd import _engine
+
+    fn_name, shape, wavelet, level, mode, dtype = WORKLOADS[args.workload]
+    fn = getattr(ptwt_amd, fn_name)
+    flen = len(ptwt_amd._wavelets.as_wavelet(wavelet))
+    torch.manual_seed(1234 + rank)
+    bufs = [torch.randn(*shape, dtype=dtype, device=dev) for _ in range(max(1, args.buffers))]
+
+    def step(i):
+        return fn(bufs[i % len(bufs)], wavelet, mode=mode, level=level)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    _engine.level_events = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    events, _engine.level_events = _engine.level_events, None
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        samples_per_step = prod(shape) * world
+        ms_per_step = elapsed / args.steps * 1e3
+        esize = torch.empty(0, dtype=dtype).element_size()
+        comp_b, perlvl_b, lvl1_b = algorithmic_bytes(shape[0], shape[1:], flen, level, esize)
+        # dominant kernel = the level-1 analysis launch (largest signal extent); durations from HIP events
+        # recorded on the launch stream inside the timed region
+        lvl1 = [s.elapsed_time(e) for (tag, kid, ext, s, e) in events if tag == "fwd" and tuple(ext) == tuple(shape[1:])]
+        per_level_ms = {}
+        for tag, kid, ext, s, e in events:
+            per_level_ms.setdefault("x".join(map(str, ext)), []).append(s.elapsed_time(e))
+        kid1 = next((kid for (tag, kid, ext, s, e) in events if tuple(ext) == tuple(shape[1:])), -1)
+        avg_ms = sum(lvl1) / max(1, len(lvl1))
+        achieved = lvl1_b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        result = {
+            "metric": "Msamples/s",
+            "value": round(samples_per_step / (elapsed / args.steps) / 1e6, 1),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if dtype == torch.float32 else "f64",
+            "data": "synthetic (torch.randn, %d rotating input buffers resident in HBM)" % len(bufs),
+            "config": {
+                "workload": args.workload,
+                "api": f"ptwt_amd.{fn_name}(x, '{wavelet}', mode='{mode}', level={level})",
+                "per_gpu_shape": list(shape),
+                "parallelism": f"batch-sharded x{world}, no data-path collective",
+            },
+            "whole_call": {
+                "compulsory_bytes": comp_b,
+                "per_level_bytes": perlvl_b,
+                "achieved_GBps_compulsory": round(comp_b / (ms_per_step * 1e-3) / 1e9, 1),
+                "frac_of_hbm_peak": round(comp_b / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "level_kernel_ms": {k: round(sum(v) / len(v), 4) for k, v in per_level_ms.items()},
+            },
+            "roofline": {
+                "kernel": {1: "dwt2_fwd_stream_kernel<8> (level 1)", 0: "generic axis kernels (level 1)"}.get(kid1, f"kernel id {kid1} (level 1)"),
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_launch": lvl1_b,
+                "avg_launch_ms": round(avg_ms, 4),
+                "traffic": None,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(fn_name, shape, wavelet, level, mode, dtype)
+        print(json.dumps(result), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

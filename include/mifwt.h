@@ -1,0 +1,126 @@
+/*
+ * mifwt.h — C ABI of libmifwt.so, the MI355X (gfx950) fast-wavelet-transform engine.
+ *
+ * Drop-in seam.  The reference (v0lta/PyTorch-Wavelet-Toolbox, "ptwt") is pure Python and has no FFI;
+ * this ABI sits exactly where the reference hands one decomposition / reconstruction level to ATen:
+ *
+ *   analysis  level : F.pad (or _pad_symmetric) + F.conv{1,2,3}d(stride=2) + torch.split
+ *       src/ptwt/conv_transform.py:135-139     (1-D:  _fwt_pad :33-66,  conv1d :137)
+ *       src/ptwt/conv_transform_2.py:142-149   (2-D:  _fwt_pad2 :34-71, conv2d :144)
+ *       src/ptwt/conv_transform_3.py:121-141   (3-D:  _fwt_pad3 :34-73, conv3d :127)
+ *       src/ptwt/separable_conv_transform.py:38-72 (separable: the same level, axis by axis)
+ *   synthesis level : torch.stack + F.conv_transpose{1,2,3}d(stride=2) + crop
+ *       src/ptwt/conv_transform.py:184-199, conv_transform_2.py:222-249, conv_transform_3.py:205-249,
+ *       src/ptwt/separable_conv_transform.py:75-111
+ *
+ * One call = one level for the whole (folded) batch = ONE fused kernel on the fast paths: the boundary
+ * extension is an index map inside the kernel (no padded tensor in HBM), the 2^ndim sub-bands are written
+ * straight to their final planes (no split/stack copies) and only the cropped interior of a synthesis
+ * level is computed.
+ *
+ * Conventions
+ *   - All data pointers are DEVICE pointers owned by the caller (torch's caching allocator); filter taps
+ *     are HOST pointers (double, PyWavelets order, NOT flipped — the library applies the flip the
+ *     reference does at src/ptwt/_util.py:863-865).  Taps are copied into the kernel arguments, so there
+ *     is no device-side filter state and calls are re-entrant.
+ *   - Nothing here allocates, frees or synchronises.  Work is enqueued on `stream`
+ *     (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream) of the current HIP device.
+ *   - Strides are in ELEMENTS.  Index 0 of every stride array is the folded batch, then the transformed
+ *     axes outermost first.  The innermost transformed axis need not be contiguous (arbitrary strides are
+ *     accepted; unit innermost stride selects the fused fast kernels).
+ *   - Sub-band order: band index s in [0, 2^ndim); bit (ndim-1-a) of s set <=> axis a is HIGH-pass
+ *     ("aa","ad","da","dd" / "aaa","aad",...,"ddd": character i of the key <-> transformed axis i,
+ *     as in src/ptwt/_util.py:926-934).  Band 0 is the approximation; details[s-1] is band s.
+ *     (ptwt's 2-D tuple is (H,V,D) = ('da','ad','dd') = details[1], details[0], details[2].)
+ *   - Return value: MIFWT_OK or a negative error code; never throws.
+ */
+#ifndef MIFWT_H
+#define MIFWT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIFWT_ABI_VERSION 1
+#define MIFWT_MAX_NDIM 3
+#define MIFWT_MAX_FILT 128 /* longest PyWavelets discrete filter is coif17 = 102 taps */
+
+enum mifwt_dtype { MIFWT_F32 = 0, MIFWT_F64 = 1, MIFWT_F16 = 2 /* f16 storage, f32 arithmetic */ };
+
+/* Boundary rules of ptwt.constants.BoundaryMode (src/ptwt/constants.py:85-108, _util.py:36-44). */
+enum mifwt_mode {
+  MIFWT_MODE_ZERO = 0,      /* ... 0  0 | x1 x2 ... xn | 0  0 ...        (torch "constant")  */
+  MIFWT_MODE_CONSTANT = 1,  /* ... x1 x1 | x1 x2 ... xn | xn xn ...      (torch "replicate") */
+  MIFWT_MODE_REFLECT = 2,   /* ... x3 x2 | x1 x2 ... xn | xn-1 xn-2 ...  (torch "reflect")   */
+  MIFWT_MODE_PERIODIC = 3,  /* ... xn-1 xn | x1 x2 ... xn | x1 x2 ...    (torch "circular")  */
+  MIFWT_MODE_SYMMETRIC = 4  /* ... x2 x1 | x1 x2 ... xn | xn xn-1 ...    (_pad_symmetric)    */
+};
+
+enum mifwt_status {
+  MIFWT_OK = 0,
+  MIFWT_ERR_BADARG = -1,      /* null pointer, ndim/dtype/mode/filt_len out of range, extents inconsistent */
+  MIFWT_ERR_UNSUPPORTED = -2, /* valid request this build has no kernel for */
+  MIFWT_ERR_WORKSPACE = -3,   /* workspace smaller than mifwt_workspace_bytes() */
+  MIFWT_ERR_LAUNCH = -4       /* hipLaunchKernel reported an error (see hipGetLastError) */
+};
+
+/* One decomposition / reconstruction level of an ndim-dimensional transform over a folded batch. */
+typedef struct mifwt_level_desc {
+  int32_t ndim;     /* 1..3 transformed axes */
+  int32_t dtype;    /* enum mifwt_dtype */
+  int32_t mode;     /* enum mifwt_mode (analysis only; synthesis ignores it) */
+  int32_t filt_len; /* L, 2..MIFWT_MAX_FILT */
+  int64_t batch;    /* folded leading dims (src/ptwt/_util.py:271-286) */
+  /* signal side: analysis input / synthesis output.  Synthesis output extent per axis must be
+   * 2*M - L + 2 - t with t in {0,1}: t = 1 is the reference's extra end-crop
+   * (src/ptwt/_util.py:231-244); only these samples are computed. */
+  int64_t sig_extent[MIFWT_MAX_NDIM];
+  int64_t sig_stride[1 + MIFWT_MAX_NDIM];
+  /* coefficient side: every sub-band has extent M = floor((N + L - 1) / 2) per axis
+   * (= the conv output length of src/ptwt/_util.py:204-217; passed, not recomputed). */
+  int64_t coef_extent[MIFWT_MAX_NDIM];
+  int64_t approx_stride[1 + MIFWT_MAX_NDIM]; /* band 0 */
+  int64_t detail_stride[1 + MIFWT_MAX_NDIM]; /* bands 1..2^ndim-1 share one stride set */
+} mifwt_level_desc;
+
+/* Replaces: F.pad/_pad_symmetric + F.conv{1,2,3}d(stride=2) + split (citations above).
+ *   x        analysis input                        [batch, N_0.., N_{ndim-1}] via sig_stride
+ *   approx   band 0 output                         [batch, M_0..]             via approx_stride
+ *   details  HOST array of 2^ndim-1 device ptrs    [batch, M_0..] each        via detail_stride
+ *   dec_lo/dec_hi  HOST taps, PyWavelets order (wavelet.dec_lo / dec_hi), L doubles each
+ *   workspace      device scratch of >= mifwt_workspace_bytes(desc, 0) bytes (may be NULL if that is 0) */
+int mifwt_dwt_fwd(const mifwt_level_desc* desc, const void* x, void* approx, void* const* details,
+                  const double* dec_lo, const double* dec_hi, void* workspace, size_t workspace_bytes,
+                  void* stream);
+
+/* Replaces: torch.stack + F.conv_transpose{1,2,3}d(stride=2) + crop (citations above).
+ *   approx / details  inputs laid out as above;  y  output [batch, sig_extent..] via sig_stride
+ *   rec_lo/rec_hi     HOST taps, PyWavelets order (wavelet.rec_lo / rec_hi) */
+int mifwt_dwt_inv(const mifwt_level_desc* desc, const void* approx, const void* const* details, void* y,
+                  const double* rec_lo, const double* rec_hi, void* workspace, size_t workspace_bytes,
+                  void* stream);
+
+/* Scratch bytes one call needs (0 on the fused paths).  direction: 0 = analysis, 1 = synthesis. */
+size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
+
+/* Which kernel family a call would dispatch to: 0 = generic per-axis passes, >0 = fused kernel id
+ * (tests use it to assert the fast path is the one that ran); negative = error code. */
+int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
+
+/* Library-wide diagnostic switches (process-global, meant for tests and A/B measurements).
+ *   MIFWT_OPT_FORCE_GENERIC (0): non-zero routes every call through the generic per-axis passes.
+ *   MIFWT_OPT_ROWS_PER_CHUNK (1): >0 overrides the fused kernels' output rows per streamed chunk. */
+#define MIFWT_OPT_FORCE_GENERIC 0
+#define MIFWT_OPT_ROWS_PER_CHUNK 1
+int mifwt_set_option(int key, int value);
+
+const char* mifwt_strerror(int code);
+int mifwt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIFWT_H */

@@ -1,0 +1,247 @@
+"""Host side of the padded-convolution FWT: one N-D implementation behind the ten ptwt entry points.
+
+What the reference spreads over conv_transform{,_2,_3}.py and separable_conv_transform.py is a single
+level loop here, parameterised by the number of transformed axes; every level is one call into
+``libmifwt.so`` (:mod:`._engine`).  This module restates only the thin glue: argument checks and their
+error types, moving the transformed axes last and folding the batch, default levels, the per-level
+extent / trim arithmetic, and the return containers — so results, shapes, containers and errors match the
+reference (citations inline; /root/reference = ptwt 1.0.2-dev).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import _engine
+from ._wavelets import dwtn_max_level, filter_length, host_taps
+from .constants import SUPPORTED_DTYPES, WaveletDetailTuple2d
+
+AxisHint = Union[int, Sequence[int], None]
+
+# detail-band order of each public container, as band indices of the engine (bit (n-1-a) <=> axis a high-pass)
+_KEYS_ND = {
+    2: ("ad", "da", "dd"),
+    3: ("aad", "ada", "add", "daa", "dad", "dda", "ddd"),  # src/ptwt/conv_transform_3.py:131-141
+}
+# insertion order of the separable recursion (src/ptwt/separable_conv_transform.py:63-72)
+_KEYS_FS = {
+    2: ("da", "ad", "dd"),
+    3: ("daa", "ada", "dda", "aad", "dad", "add", "ddd"),
+}
+
+
+def _band(key: str) -> int:
+    return int(key.replace("a", "0").replace("d", "1"), 2)
+
+
+# ------------------------------------------------------------------------------------------ arguments
+def _mode_id(mode) -> int:
+    """src/ptwt/_util.py:48-68: None means reflect, unknown strings are a ValueError."""
+    if mode is None:
+        mode = "reflect"
+    try:
+        return _engine.MODE_IDS[mode]
+    except (KeyError, TypeError):
+        raise ValueError(f"Padding mode not supported: {mode}") from None
+
+
+def _ensure_axes(axes: AxisHint, ndim: int) -> Tuple[int, ...]:
+    """src/ptwt/_util.py:817-826."""
+    if axes is None:
+        return tuple(range(-ndim, 0))
+    if isinstance(axes, int):
+        if ndim != 1:
+            raise ValueError(f"tried passing single axis to {ndim}D transform")
+        return (axes,)
+    if len(axes) != ndim:
+        raise ValueError(f"tried passing {len(axes)}D axes {axes} to {ndim}D transform")
+    if len(set(axes)) != len(axes):
+        raise ValueError("Cant transform the same axis twice.")
+    return tuple(axes)
+
+
+def _permutation(axes: Sequence[int], rank: int) -> List[int]:
+    """Order that moves ``axes`` (in the given order) to the end (src/ptwt/_util.py:351-363)."""
+    back = [a + rank if a < 0 else a for a in axes]
+    if len(set(back)) != len(back):
+        raise ValueError("Cant transform the same axis twice.")
+    if any(a < 0 or a >= rank for a in back):
+        raise ValueError(f"axes {tuple(axes)} out of range for a {rank}-dimensional tensor")
+    return [a for a in range(rank) if a not in back] + back
+
+
+class _Layout:
+    """Remembers how a tensor was brought to [B, N_0..N_{n-1}] so that results can be taken back
+    (src/ptwt/_util.py:493-570 forward, :613-676 backward)."""
+
+    def __init__(self, proto: torch.Tensor, ndim: int, axes: Tuple[int, ...]):
+        if not isinstance(proto, torch.Tensor):
+            raise ValueError("First element of coeffs must be the approximation coefficient tensor.")
+        if proto.dtype not in SUPPORTED_DTYPES:
+            raise ValueError(f"Input dtype {proto.dtype} not supported")
+        self.ndim = ndim
+        self.perm = None if axes == tuple(range(-ndim, 0)) else _permutation(axes, proto.dim())
+        shape = list(proto.shape) if self.perm is None else [proto.shape[p] for p in self.perm]
+        if len(shape) < ndim:
+            raise ValueError(f"At least {ndim} input dimensions required.")
+        self.lead = shape[:-ndim]  # leading (batch) dims after the swap
+
+    def fold(self, t: torch.Tensor) -> torch.Tensor:
+        if self.perm is not None:
+            t = t.permute(self.perm)
+        if len(self.lead) == 0:
+            return t.unsqueeze(0)
+        if len(self.lead) > 1:
+            return t.reshape([-1] + list(t.shape[-self.ndim:]))
+        return t
+
+    def unfold(self, t: torch.Tensor) -> torch.Tensor:
+        if len(self.lead) == 0:
+            t = t.squeeze(0)
+        elif len(self.lead) > 1:
+            t = t.reshape(self.lead + list(t.shape[-self.ndim:]))
+        if self.perm is not None:
+            inv = [0] * len(self.perm)
+            for i, p in enumerate(self.perm):
+                inv[p] = i
+            t = t.permute(inv)
+        return t
+
+
+def _check_pad(extents: Sequence[int], flen: int, mode: str) -> None:
+    """The reference pads with torch.nn.functional.pad, which refuses reflect pad >= N and circular
+    pad > N (RuntimeError); symmetric/zero/constant accept anything (src/ptwt/conv_transform.py:59-66)."""
+    if mode not in ("reflect", "periodic"):
+        return
+    for n in extents:
+        padl = (2 * flen - 3) // 2
+        padr = padl + n % 2
+        if mode == "reflect" and max(padl, padr) >= n:
+            raise RuntimeError(
+                f"Padding size should be less than the corresponding input dimension, but got: padding "
+                f"({padl}, {padr}) at an axis of extent {n} (reflect mode, filter length {flen})"
+            )
+        if mode == "periodic" and max(padl, padr) > n:
+            raise RuntimeError(
+                f"Padding value causes wrapping around more than once: padding ({padl}, {padr}) at an axis "
+                f"of extent {n} (periodic mode, filter length {flen})"
+            )
+
+
+# ------------------------------------------------------------------------------------------ analysis
+def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: AxisHint, ndim: int,
+             fs_level_rule: bool = False):
+    """Multi-level analysis.  Returns ``(layout, approx [B,*M], [buffer [B,2^n,*M] per level, coarsest first])``."""
+    axes = _ensure_axes(axes, ndim)
+    layout = _Layout(data, ndim, axes)
+    x = layout.fold(data)
+    dec_lo, dec_hi, _, _ = host_taps(wavelet)
+    flen = len(dec_lo)
+    if level is None:
+        level = dwtn_max_level(x.shape[1:], flen)
+    bufs: List[torch.Tensor] = []
+    cur = x
+    for _ in range(level):
+        mode_id = _mode_id(mode)
+        _check_pad(cur.shape[1:], flen, "reflect" if mode is None else mode)
+        buf = _engine.ENGINE.analysis(cur, dec_lo, dec_hi, mode_id)
+        bufs.append(buf)
+        cur = buf[:, 0]
+    bufs.reverse()
+    return layout, cur, bufs
+
+
+# ------------------------------------------------------------------------------------------ synthesis
+def _adjust_trim(res_size: int, next_size: int) -> int:
+    """src/ptwt/_util.py:231-244 on the already L-2-cropped size."""
+    if next_size == res_size:
+        return 0
+    if next_size == res_size - 1:
+        return 1
+    raise AssertionError("padding error, please check if dec and rec wavelets are identical.")
+
+
+def _check_same_device_dtype(tensors: Sequence[torch.Tensor]) -> None:
+    """src/ptwt/_util.py:307-348."""
+    first = tensors[0]
+    for t in tensors:
+        if t.device != first.device:
+            raise ValueError("coefficients must be on the same device")
+    for t in tensors:
+        if t.dtype != first.dtype:
+            raise ValueError("coefficients must have the same dtype")
+
+
+def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, axes: AxisHint, ndim: int,
+              separable: bool) -> torch.Tensor:
+    """Multi-level synthesis.  ``levels``: per level (coarsest first) the 2^n-1 detail tensors in band order."""
+    axes = _ensure_axes(axes, ndim)
+    layout = _Layout(approx, ndim, axes)
+    flat = [approx] + [t for lvl in levels for t in lvl]
+    for t in flat:
+        if not isinstance(t, torch.Tensor):
+            raise ValueError(f"Unexpected input type {type(t)}")
+    _check_same_device_dtype(flat)
+    _, _, rec_lo, rec_hi = host_taps(wavelet)
+    flen = len(rec_lo)
+    cur = layout.fold(approx)
+    folded = [[layout.fold(t) for t in lvl] for lvl in levels]
+    for pos, det in enumerate(folded):
+        if separable:
+            # the separable reference crops the running approximation to the detail shape
+            # (src/ptwt/separable_conv_transform.py:94-97) and never trims the synthesis output
+            cur = cur[tuple(slice(0, s) for s in det[0].shape)]
+            trims = [0] * ndim
+        else:
+            trims = [0] * ndim
+            if pos + 1 < len(folded):
+                nxt = folded[pos + 1][0].shape
+                trims = [_adjust_trim(2 * cur.shape[1 + a] - flen + 2, nxt[1 + a]) for a in range(ndim)]
+        for t in det:
+            if t.shape != cur.shape:
+                if ndim == 1:  # torch.stack in the reference (src/ptwt/conv_transform.py:186)
+                    raise RuntimeError("stack expects each tensor to be equal size")
+                raise ValueError("All coefficients on each level must have the same shape")
+        out_ext = [2 * cur.shape[1 + a] - flen + 2 - trims[a] for a in range(ndim)]
+        if min(out_ext) < 1:
+            raise ValueError("coefficients too short for this wavelet")
+        cur = _engine.ENGINE.synthesis(cur, det, rec_lo, rec_hi, out_ext)
+    return layout.unfold(cur)
+
+
+# ------------------------------------------------------------------------------------------ containers
+def pack_1d(layout: _Layout, approx, bufs) -> List[torch.Tensor]:
+    return [layout.unfold(approx)] + [layout.unfold(b[:, 1]) for b in bufs]
+
+
+def pack_2d(layout: _Layout, approx, bufs):
+    out = [layout.unfold(approx)]
+    for b in bufs:  # (H, V, D) = ('da', 'ad', 'dd') = bands 2, 1, 3
+        out.append(WaveletDetailTuple2d(layout.unfold(b[:, 2]), layout.unfold(b[:, 1]), layout.unfold(b[:, 3])))
+    return tuple(out)
+
+
+def pack_dict(layout: _Layout, approx, bufs, keys: Sequence[str]):
+    out: list = [layout.unfold(approx)]
+    for b in bufs:
+        out.append({k: layout.unfold(b[:, _band(k)]) for k in keys})
+    return tuple(out)
+
+
+def unpack_dict_levels(coeffs, ndim: int, what: str) -> List[List[torch.Tensor]]:
+    """dict levels -> band-ordered lists; validates like src/ptwt/conv_transform_3.py:194-204 /
+    separable_conv_transform.py:174-177."""
+    nb = 1 << ndim
+    levels = []
+    for c in coeffs[1:]:
+        if not isinstance(c, dict) or len([k for k in c if k != "a" * ndim]) != nb - 1:
+            raise ValueError(
+                f"Unexpected detail coefficient type: {type(c)}. Detail coefficients must be a dict containing "
+                f"{nb - 1} tensors as returned by {what}."
+            )
+        try:
+            levels.append([c[format(s, f"0{ndim}b").replace("0", "a").replace("1", "d")] for s in range(1, nb)])
+        except KeyError as e:
+            raise ValueError(f"missing detail coefficient key {e} for a {ndim}D transform") from None
+    return levels

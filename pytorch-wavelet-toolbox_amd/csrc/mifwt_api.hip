@@ -1,0 +1,304 @@
+// mifwt_api.hip — the C-ABI of libmifwt.so (declared in include/mifwt.h) and its dispatcher.
+//
+// One call = one decomposition / reconstruction level over the folded batch.  The dispatcher picks a
+// fused single-launch kernel when the descriptor is inside a fast path's envelope and otherwise
+// assembles the level from generic per-axis passes through caller-provided scratch.
+#include <string.h>
+
+#include "mifwt_common.h"
+
+using namespace mifwt;
+
+namespace {
+
+inline int64_t elem_size(int dtype) { return dtype == MIFWT_F64 ? 8 : (dtype == MIFWT_F16 ? 2 : 4); }
+
+int validate(const mifwt_level_desc* d, int direction) {
+  if (!d) return MIFWT_ERR_BADARG;
+  if (d->ndim < 1 || d->ndim > MIFWT_MAX_NDIM) return MIFWT_ERR_BADARG;
+  if (d->dtype != MIFWT_F32 && d->dtype != MIFWT_F64 && d->dtype != MIFWT_F16) return MIFWT_ERR_BADARG;
+  if (d->filt_len < 2 || d->filt_len > MIFWT_MAX_FILT) return MIFWT_ERR_BADARG;
+  if (d->batch < 0) return MIFWT_ERR_BADARG;
+  if (direction == 0 && (d->mode < MIFWT_MODE_ZERO || d->mode > MIFWT_MODE_SYMMETRIC)) return MIFWT_ERR_BADARG;
+  for (int a = 0; a < d->ndim; ++a) {
+    const int64_t n = d->sig_extent[a], m = d->coef_extent[a], L = d->filt_len;
+    if (n < 1 || m < 1 || n > INT32_MAX / 4 || m > INT32_MAX / 4) return MIFWT_ERR_BADARG;
+    if (direction == 0) {
+      // conv output length of the padded signal (reference src/ptwt/_util.py:204-217)
+      const int64_t pad = 2 * ((2 * L - 3) / 2) + (n % 2);
+      if (m != (n + pad - L) / 2 + 1) return MIFWT_ERR_BADARG;
+    } else {
+      const int64_t full = 2 * m - L + 2;  // after cropping L-2 on both sides
+      if (n != full && n != full - 1) return MIFWT_ERR_BADARG;
+      if (n < 1) return MIFWT_ERR_BADARG;
+    }
+  }
+  return MIFWT_OK;
+}
+
+// scratch layout of the generic N-D path: stage s holds 2^(s+1) (analysis) arrays, dense, batch-major.
+struct Stage {
+  int64_t ext[4];    // (batch, axis0, axis1, axis2) extents of each array of this stage
+  int64_t stride[4];
+  int64_t elems;     // per array
+  int narrays;
+};
+
+// analysis: axes are transformed innermost first; after transforming axes a..ndim-1 the arrays have
+// coefficient extents on those axes and signal extents on the rest.
+int plan_fwd(const mifwt_level_desc* d, Stage st[MIFWT_MAX_NDIM]) {
+  int ns = 0;
+  for (int a = d->ndim - 1; a >= 1; --a) {  // the last pass (axis 0) writes the final bands
+    Stage& s = st[ns++];
+    s.ext[0] = d->batch;
+    for (int i = 0; i < 3; ++i) s.ext[1 + i] = i < d->ndim ? (i >= a ? d->coef_extent[i] : d->sig_extent[i]) : 1;
+    s.elems = 1;
+    for (int i = 3; i >= 0; --i) {
+      s.stride[i] = s.elems;
+      s.elems *= s.ext[i];
+    }
+    s.narrays = 1 << (d->ndim - a);
+  }
+  return ns;
+}
+
+// synthesis: axes are expanded outermost first.
+int plan_inv(const mifwt_level_desc* d, Stage st[MIFWT_MAX_NDIM]) {
+  int ns = 0;
+  for (int a = 0; a < d->ndim - 1; ++a) {  // the last pass (innermost axis) writes y
+    Stage& s = st[ns++];
+    s.ext[0] = d->batch;
+    for (int i = 0; i < 3; ++i) s.ext[1 + i] = i < d->ndim ? (i <= a ? d->sig_extent[i] : d->coef_extent[i]) : 1;
+    s.elems = 1;
+    for (int i = 3; i >= 0; --i) {
+      s.stride[i] = s.elems;
+      s.elems *= s.ext[i];
+    }
+    s.narrays = 1 << (d->ndim - 1 - a);
+  }
+  return ns;
+}
+
+inline void pad_strides(const int64_t src[1 + MIFWT_MAX_NDIM], int ndim, int64_t dst[4]) {
+  for (int i = 0; i < 4; ++i) dst[i] = i <= ndim ? src[i] : 0;
+}
+
+int generic_fwd(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo,
+                const double* hi, void* ws, hipStream_t stream) {
+  Stage st[MIFWT_MAX_NDIM];
+  const int ns = plan_fwd(d, st);
+  const int64_t esz = elem_size(d->dtype);
+  const int nd = d->ndim;
+  // current arrays, indexed by partial band bits
+  const void* cur[8];
+  int64_t cur_stride[8][4];
+  int ncur = 1;
+  cur[0] = x;
+  pad_strides(d->sig_stride, nd, cur_stride[0]);
+  char* wsp = static_cast<char*>(ws);
+  for (int pass = 0; pass < nd; ++pass) {
+    const int a = nd - 1 - pass;           // axis transformed in this pass
+    const int bit = 1 << (nd - 1 - a);     // its bit in the band index
+    const bool last = (a == 0);
+    void* nxt[8];
+    int64_t nxt_stride[8][4];
+    int64_t out_ext[4] = {d->batch, 1, 1, 1};
+    for (int i = 0; i < nd; ++i) out_ext[1 + i] = i >= a ? d->coef_extent[i] : d->sig_extent[i];
+    for (int s = 0; s < ncur; ++s) {
+      for (int h = 0; h < 2; ++h) {
+        const int band = s | (h ? bit : 0);
+        if (last) {
+          nxt[band] = band == 0 ? approx : details[band - 1];
+          pad_strides(band == 0 ? d->approx_stride : d->detail_stride, nd, nxt_stride[band]);
+        } else {
+          nxt[band] = wsp;
+          wsp += st[pass].elems * esz;
+          memcpy(nxt_stride[band], st[pass].stride, sizeof(int64_t) * 4);
+        }
+      }
+    }
+    for (int s0 = 0; s0 < ncur; s0 += 4) {
+      AxisJob jobs[4];
+      const int nj = ncur - s0 < 4 ? ncur - s0 : 4;
+      for (int j = 0; j < nj; ++j) {
+        const int s = s0 + j;
+        AxisJob& jb = jobs[j];
+        memset(&jb, 0, sizeof(jb));
+        jb.in0 = cur[s];
+        memcpy(jb.in0_stride, cur_stride[s], sizeof(int64_t) * 4);
+        jb.out0 = nxt[s];
+        jb.out1 = nxt[s | bit];
+        memcpy(jb.out0_stride, nxt_stride[s], sizeof(int64_t) * 4);
+        memcpy(jb.out1_stride, nxt_stride[s | bit], sizeof(int64_t) * 4);
+      }
+      const int rc = launch_axis_fwd(d->dtype, jobs, nj, out_ext, 1 + a, d->sig_extent[a], d->mode, d->filt_len, lo,
+                                     hi, stream);
+      if (rc != MIFWT_OK) return rc;
+    }
+    ncur *= 2;
+    // band indices produced so far are all combinations of the bits of axes >= a: compact is not
+    // needed because bits are assigned from the least significant end.
+    for (int s = 0; s < ncur; ++s) {
+      cur[s] = nxt[s];
+      memcpy(cur_stride[s], nxt_stride[s], sizeof(int64_t) * 4);
+    }
+  }
+  return MIFWT_OK;
+}
+
+int generic_inv(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y,
+                const double* lo, const double* hi, void* ws, hipStream_t stream) {
+  Stage st[MIFWT_MAX_NDIM];
+  plan_inv(d, st);
+  const int64_t esz = elem_size(d->dtype);
+  const int nd = d->ndim;
+  const int nb = 1 << nd;
+  const void* cur[8];
+  int64_t cur_stride[8][4];
+  for (int s = 0; s < nb; ++s) {
+    cur[s] = s == 0 ? approx : details[s - 1];
+    pad_strides(s == 0 ? d->approx_stride : d->detail_stride, nd, cur_stride[s]);
+  }
+  char* wsp = static_cast<char*>(ws);
+  int ncur = nb;
+  for (int a = 0; a < nd; ++a) {  // outermost axis first: its bit is the most significant of the remaining
+    const bool last = (a == nd - 1);
+    const int nnext = ncur / 2;   // arrays pair up as (s, s + nnext): low / high along axis a
+    int64_t out_ext[4] = {d->batch, 1, 1, 1};
+    for (int i = 0; i < nd; ++i) out_ext[1 + i] = i <= a ? d->sig_extent[i] : d->coef_extent[i];
+    void* nxt[4];
+    int64_t nxt_stride[4][4];
+    for (int s = 0; s < nnext; ++s) {
+      if (last) {
+        nxt[s] = y;
+        pad_strides(d->sig_stride, nd, nxt_stride[s]);
+      } else {
+        nxt[s] = wsp;
+        wsp += st[a].elems * esz;
+        memcpy(nxt_stride[s], st[a].stride, sizeof(int64_t) * 4);
+      }
+    }
+    AxisJob jobs[4];
+    for (int s = 0; s < nnext; ++s) {
+      AxisJob& jb = jobs[s];
+      memset(&jb, 0, sizeof(jb));
+      jb.in0 = cur[s];
+      jb.in1 = cur[s + nnext];
+      memcpy(jb.in0_stride, cur_stride[s], sizeof(int64_t) * 4);
+      memcpy(jb.in1_stride, cur_stride[s + nnext], sizeof(int64_t) * 4);
+      jb.out0 = nxt[s];
+      memcpy(jb.out0_stride, nxt_stride[s], sizeof(int64_t) * 4);
+    }
+    const int rc = launch_axis_inv(d->dtype, jobs, nnext, out_ext, 1 + a, d->coef_extent[a], d->filt_len, lo, hi, stream);
+    if (rc != MIFWT_OK) return rc;
+    ncur = nnext;
+    for (int s = 0; s < ncur; ++s) {
+      cur[s] = nxt[s];
+      memcpy(cur_stride[s], nxt_stride[s], sizeof(int64_t) * 4);
+    }
+  }
+  return MIFWT_OK;
+}
+
+size_t generic_ws(const mifwt_level_desc* d, int direction) {
+  Stage st[MIFWT_MAX_NDIM];
+  const int ns = direction == 0 ? plan_fwd(d, st) : plan_inv(d, st);
+  int64_t total = 0;
+  for (int i = 0; i < ns; ++i) total += st[i].elems * st[i].narrays;
+  return (size_t)(total * elem_size(d->dtype));
+}
+
+int pick_kernel(const mifwt_level_desc* d, int direction) {
+  if (g_options[MIFWT_OPT_FORCE_GENERIC]) return kGeneric;
+  if (direction == 0) {
+    if (dwt2_fwd_stream_supported(d)) return kDwt2FwdStream;
+  } else {
+    if (dwt2_inv_stream_supported(d)) return kDwt2InvStream;
+  }
+  return kGeneric;
+}
+
+}  // namespace
+
+namespace mifwt {
+int g_options[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+}
+
+extern "C" {
+
+int mifwt_set_option(int key, int value) {
+  if (key < 0 || key >= 8) return MIFWT_ERR_BADARG;
+  g_options[key] = value;
+  return MIFWT_OK;
+}
+
+int mifwt_abi_version(void) { return MIFWT_ABI_VERSION; }
+
+const char* mifwt_strerror(int code) {
+  switch (code) {
+    case MIFWT_OK: return "ok";
+    case MIFWT_ERR_BADARG: return "bad argument (null pointer, ndim/dtype/mode/filt_len out of range or inconsistent extents)";
+    case MIFWT_ERR_UNSUPPORTED: return "valid request this build has no kernel for";
+    case MIFWT_ERR_WORKSPACE: return "workspace smaller than mifwt_workspace_bytes()";
+    case MIFWT_ERR_LAUNCH: return "HIP kernel launch failed";
+    default: return "unknown mifwt error code";
+  }
+}
+
+int mifwt_kernel_id(const mifwt_level_desc* desc, int direction) {
+  const int rc = validate(desc, direction);
+  if (rc != MIFWT_OK) return rc;
+  return pick_kernel(desc, direction);
+}
+
+size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction) {
+  if (validate(desc, direction) != MIFWT_OK) return 0;
+  if (pick_kernel(desc, direction) != kGeneric) return 0;
+  return generic_ws(desc, direction);
+}
+
+int mifwt_dwt_fwd(const mifwt_level_desc* desc, const void* x, void* approx, void* const* details,
+                  const double* dec_lo, const double* dec_hi, void* workspace, size_t workspace_bytes,
+                  void* stream) {
+  int rc = validate(desc, 0);
+  if (rc != MIFWT_OK) return rc;
+  if (!x || !approx || !details || !dec_lo || !dec_hi) return MIFWT_ERR_BADARG;
+  for (int s = 1; s < (1 << desc->ndim); ++s)
+    if (!details[s - 1]) return MIFWT_ERR_BADARG;
+  if (desc->batch == 0) return MIFWT_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (pick_kernel(desc, 0)) {
+    case kDwt2FwdStream:
+      return dwt2_fwd_stream(desc, x, approx, details, dec_lo, dec_hi, st);
+    default:
+      break;
+  }
+  if (desc->dtype == MIFWT_F16) return MIFWT_ERR_UNSUPPORTED;
+  const size_t need = generic_ws(desc, 0);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return MIFWT_ERR_WORKSPACE;
+  return generic_fwd(desc, x, approx, details, dec_lo, dec_hi, workspace, st);
+}
+
+int mifwt_dwt_inv(const mifwt_level_desc* desc, const void* approx, const void* const* details, void* y,
+                  const double* rec_lo, const double* rec_hi, void* workspace, size_t workspace_bytes,
+                  void* stream) {
+  int rc = validate(desc, 1);
+  if (rc != MIFWT_OK) return rc;
+  if (!y || !approx || !details || !rec_lo || !rec_hi) return MIFWT_ERR_BADARG;
+  for (int s = 1; s < (1 << desc->ndim); ++s)
+    if (!details[s - 1]) return MIFWT_ERR_BADARG;
+  if (desc->batch == 0) return MIFWT_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (pick_kernel(desc, 1)) {
+    case kDwt2InvStream:
+      return dwt2_inv_stream(desc, approx, details, y, rec_lo, rec_hi, st);
+    default:
+      break;
+  }
+  if (desc->dtype == MIFWT_F16) return MIFWT_ERR_UNSUPPORTED;
+  const size_t need = generic_ws(desc, 1);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return MIFWT_ERR_WORKSPACE;
+  return generic_inv(desc, approx, details, y, rec_lo, rec_hi, workspace, st);
+}
+
+}  // extern "C"

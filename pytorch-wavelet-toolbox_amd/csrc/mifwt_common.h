@@ -1,0 +1,72 @@
+// mifwt_common.h — internal declarations shared by the gfx950 kernels and the C-ABI dispatcher.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mifwt.h"
+
+namespace mifwt {
+
+constexpr int kMaxFilt = MIFWT_MAX_FILT;
+extern int g_options[8];  // mifwt_set_option() switches
+
+// Boundary extension as an index map (replaces F.pad / _pad_symmetric of the reference:
+// src/ptwt/conv_transform.py:59-66, src/ptwt/_util.py:163-195).  Returns the source index in [0, n) of
+// extended-signal index i, or -1 for an implicit zero.  reflect = whole-sample mirror, symmetric =
+// half-sample mirror; both fold repeatedly, so any |i| is legal (the host layer reproduces torch's
+// refusal of reflect pad >= n / circular pad > n before a kernel is ever launched).
+__host__ __device__ __forceinline__ int ext_index(int i, int n, int mode) {
+  if ((unsigned)i < (unsigned)n) return i;
+  switch (mode) {
+    case MIFWT_MODE_ZERO:
+      return -1;
+    case MIFWT_MODE_CONSTANT:
+      return i < 0 ? 0 : n - 1;
+    case MIFWT_MODE_PERIODIC: {
+      int p = i % n;
+      return p < 0 ? p + n : p;
+    }
+    case MIFWT_MODE_SYMMETRIC: {
+      const int t = 2 * n;
+      int p = i % t;
+      if (p < 0) p += t;
+      return p < n ? p : t - 1 - p;
+    }
+    default: {  // MIFWT_MODE_REFLECT
+      if (n == 1) return 0;
+      const int t = 2 * (n - 1);
+      int p = i % t;
+      if (p < 0) p += t;
+      return p < n ? p : t - p;
+    }
+  }
+}
+
+// ---- generic per-axis passes (any L <= 128, any strides, f32/f64) ---------------------------------
+struct AxisJob {
+  const void* in0;  // analysis: input          synthesis: low-pass band
+  const void* in1;  // analysis: unused         synthesis: high-pass band
+  void* out0;       // analysis: low-pass band  synthesis: output
+  void* out1;       // analysis: high-pass band synthesis: unused
+  int64_t in0_stride[4], in1_stride[4], out0_stride[4], out1_stride[4];
+};
+
+int launch_axis_fwd(int dtype, const AxisJob* jobs, int njobs, const int64_t out_ext[4], int taxis, int64_t n_in,
+                    int mode, int filt_len, const double* lo, const double* hi, hipStream_t stream);
+int launch_axis_inv(int dtype, const AxisJob* jobs, int njobs, const int64_t out_ext[4], int taxis, int64_t m_in,
+                    int filt_len, const double* lo, const double* hi, hipStream_t stream);
+
+// ---- fused fast paths --------------------------------------------------------------------------------
+// Each returns MIFWT_ERR_UNSUPPORTED when the descriptor is outside its envelope (the dispatcher then
+// falls back to the generic passes) and never touches the workspace.
+enum KernelId { kGeneric = 0, kDwt2FwdStream = 1, kDwt2InvStream = 2, kDwt1FwdRow = 3, kDwt1InvRow = 4, kDwt3FwdStream = 5, kDwt3InvStream = 6 };
+
+bool dwt2_fwd_stream_supported(const mifwt_level_desc* d);
+int dwt2_fwd_stream(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
+                    const double* dec_lo, const double* dec_hi, hipStream_t stream);
+
+bool dwt2_inv_stream_supported(const mifwt_level_desc* d);
+int dwt2_inv_stream(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y,
+                    const double* rec_lo, const double* rec_hi, hipStream_t stream);
+
+}  // namespace mifwt

@@ -1,0 +1,162 @@
+// mifwt_generic.hip — generic per-axis analysis / synthesis kernels for gfx950.
+//
+// The catch-all behind the fused fast paths: one transformed axis per launch, any filter length up to
+// 128 taps, any boundary mode, arbitrary element strides, f32 or f64.  A thread owns one output
+// coefficient position and produces the low- and high-pass value together (analysis), or one output
+// sample (synthesis, polyphase gather: only the L/2 non-zero products of the transposed convolution are
+// formed and only the cropped interior is computed).  Up to four independent (input -> lo, hi) jobs of
+// identical geometry ride in one launch (blockIdx.y), which is how an N-D level is assembled from axis
+// passes without extra launches.
+//
+// Math (reference src/ptwt/conv_transform.py:133-139 and :184-199):
+//   analysis  c[k] = sum_m h[m] * x_ext[2k + 1 - m],     k in [0, M),  M = floor((N + L - 1) / 2)
+//   synthesis y[n] = sum_k a[k] g_lo[n + L - 2 - 2k] + d[k] g_hi[n + L - 2 - 2k],  n in [0, 2M - L + 2 - t)
+#include "mifwt_common.h"
+
+namespace mifwt {
+
+template <typename T>
+struct Taps {
+  T lo[kMaxFilt];
+  T hi[kMaxFilt];
+};
+
+struct AxisGeom {
+  int64_t ext[4];  // output iteration space (batch, axis0, axis1, axis2), unused dims = 1
+  int64_t total;   // product of ext
+  int taxis;       // transformed dim of the iteration space
+  int n_src;       // source extent along taxis (analysis: N, synthesis: M)
+  int mode;
+  int filt_len;
+};
+
+struct AxisJobs {
+  AxisJob job[4];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) axis_fwd_kernel(AxisJobs jobs, AxisGeom g, Taps<T> taps) {
+  const AxisJob& jb = jobs.job[blockIdx.y];
+  const T* __restrict__ in = static_cast<const T*>(jb.in0);
+  T* __restrict__ lo = static_cast<T*>(jb.out0);
+  T* __restrict__ hi = static_cast<T*>(jb.out1);
+  const int64_t stride_t = jb.in0_stride[g.taxis];
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < g.total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t rem = idx;
+    int64_t c[4];
+#pragma unroll
+    for (int d = 3; d >= 0; --d) {
+      c[d] = rem % g.ext[d];
+      rem /= g.ext[d];
+    }
+    int64_t ibase = 0, lbase = 0, hbase = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      if (d != g.taxis) ibase += c[d] * jb.in0_stride[d];
+      lbase += c[d] * jb.out0_stride[d];
+      hbase += c[d] * jb.out1_stride[d];
+    }
+    const int k = (int)c[g.taxis];
+    T acc_lo = 0, acc_hi = 0;
+    for (int m = 0; m < g.filt_len; ++m) {
+      const int src = ext_index(2 * k + 1 - m, g.n_src, g.mode);
+      const T v = src >= 0 ? in[ibase + (int64_t)src * stride_t] : T(0);
+      acc_lo = fma(taps.lo[m], v, acc_lo);
+      acc_hi = fma(taps.hi[m], v, acc_hi);
+    }
+    lo[lbase] = acc_lo;
+    hi[hbase] = acc_hi;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) axis_inv_kernel(AxisJobs jobs, AxisGeom g, Taps<T> taps) {
+  const AxisJob& jb = jobs.job[blockIdx.y];
+  const T* __restrict__ a = static_cast<const T*>(jb.in0);
+  const T* __restrict__ dd = static_cast<const T*>(jb.in1);
+  T* __restrict__ y = static_cast<T*>(jb.out0);
+  const int64_t sa = jb.in0_stride[g.taxis], sd = jb.in1_stride[g.taxis];
+  const int L = g.filt_len;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < g.total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t rem = idx;
+    int64_t c[4];
+#pragma unroll
+    for (int d = 3; d >= 0; --d) {
+      c[d] = rem % g.ext[d];
+      rem /= g.ext[d];
+    }
+    int64_t abase = 0, dbase = 0, ybase = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      if (d != g.taxis) {
+        abase += c[d] * jb.in0_stride[d];
+        dbase += c[d] * jb.in1_stride[d];
+      }
+      ybase += c[d] * jb.out0_stride[d];
+    }
+    // y[n] = u[n + L - 2];  u[q] = sum_k a[k] g[q - 2k]  with 0 <= q - 2k <= L - 1
+    const int q = (int)c[g.taxis] + L - 2;
+    int k_lo = (q - (L - 1) + 1) >> 1;  // ceil((q - L + 1) / 2), q - L + 1 may be negative
+    if (k_lo < 0) k_lo = 0;
+    int k_hi = q >> 1;
+    if (k_hi > g.n_src - 1) k_hi = g.n_src - 1;
+    T acc = 0;
+    for (int k = k_lo; k <= k_hi; ++k) {
+      const int t = q - 2 * k;
+      acc = fma(taps.lo[t], a[abase + (int64_t)k * sa], acc);
+      acc = fma(taps.hi[t], dd[dbase + (int64_t)k * sd], acc);
+    }
+    y[ybase] = acc;
+  }
+}
+
+template <typename T>
+static int launch_axis(bool inverse, const AxisJob* jobs, int njobs, const int64_t out_ext[4], int taxis,
+                       int64_t n_src, int mode, int filt_len, const double* lo, const double* hi,
+                       hipStream_t stream) {
+  if (njobs < 1 || njobs > 4 || filt_len < 1 || filt_len > kMaxFilt) return MIFWT_ERR_BADARG;
+  AxisJobs js;
+  for (int i = 0; i < 4; ++i) js.job[i] = jobs[i < njobs ? i : 0];
+  AxisGeom g;
+  g.total = 1;
+  for (int d = 0; d < 4; ++d) {
+    g.ext[d] = out_ext[d];
+    g.total *= out_ext[d];
+  }
+  if (g.total == 0) return MIFWT_OK;
+  g.taxis = taxis;
+  g.n_src = (int)n_src;
+  g.mode = mode;
+  g.filt_len = filt_len;
+  Taps<T> taps;
+  for (int m = 0; m < kMaxFilt; ++m) {
+    taps.lo[m] = m < filt_len ? (T)lo[m] : T(0);
+    taps.hi[m] = m < filt_len ? (T)hi[m] : T(0);
+  }
+  const int64_t want = (g.total + 255) / 256;
+  const unsigned gx = (unsigned)(want < 8192 ? want : 8192);  // grid-stride beyond 256 CUs x 32 blocks
+  dim3 grid(gx, (unsigned)njobs), block(256);
+  if (inverse)
+    hipLaunchKernelGGL(axis_inv_kernel<T>, grid, block, 0, stream, js, g, taps);
+  else
+    hipLaunchKernelGGL(axis_fwd_kernel<T>, grid, block, 0, stream, js, g, taps);
+  return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
+}
+
+int launch_axis_fwd(int dtype, const AxisJob* jobs, int njobs, const int64_t out_ext[4], int taxis, int64_t n_in,
+                    int mode, int filt_len, const double* lo, const double* hi, hipStream_t stream) {
+  if (dtype == MIFWT_F32) return launch_axis<float>(false, jobs, njobs, out_ext, taxis, n_in, mode, filt_len, lo, hi, stream);
+  if (dtype == MIFWT_F64) return launch_axis<double>(false, jobs, njobs, out_ext, taxis, n_in, mode, filt_len, lo, hi, stream);
+  return MIFWT_ERR_UNSUPPORTED;
+}
+
+int launch_axis_inv(int dtype, const AxisJob* jobs, int njobs, const int64_t out_ext[4], int taxis, int64_t m_in,
+                    int filt_len, const double* lo, const double* hi, hipStream_t stream) {
+  if (dtype == MIFWT_F32) return launch_axis<float>(true, jobs, njobs, out_ext, taxis, m_in, 0, filt_len, lo, hi, stream);
+  if (dtype == MIFWT_F64) return launch_axis<double>(true, jobs, njobs, out_ext, taxis, m_in, 0, filt_len, lo, hi, stream);
+  return MIFWT_ERR_UNSUPPORTED;
+}
+
+}  // namespace mifwt

@@ -1,0 +1,33 @@
+"""TEST-ONLY level engine: the numpy oracle dressed as ``ptwt_amd._engine.ENGINE``.
+
+The product has no CPU path.  To exercise its *host logic* (axes handling, batch folding, level loop, trim
+arithmetic, containers, error types) without a GPU, the CPU tests monkeypatch ``_engine.ENGINE`` with this
+object.  It lives under tests/ and is never imported by the package.
+"""
+import numpy as np
+import torch
+
+from oracle import fwt_oracle as O
+
+_MODES = {v: k for k, v in {"zero": 0, "constant": 1, "reflect": 2, "periodic": 3, "symmetric": 4}.items()}
+
+
+class OracleLevelEngine:
+    def analysis(self, x, dec_lo, dec_hi, mode_id):
+        ndim = x.dim() - 1
+        bank = (np.asarray(dec_lo), np.asarray(dec_hi), None, None)
+        bands = O._dwtn(x.detach().numpy(), bank, _MODES[mode_id], list(range(1, ndim + 1)))
+        keys = [format(s, f"0{ndim}b").replace("0", "a").replace("1", "d") for s in range(1 << ndim)]
+        return torch.from_numpy(np.stack([bands[k] for k in keys], axis=1))
+
+    def synthesis(self, approx, details, rec_lo, rec_hi, out_extent):
+        ndim = approx.dim() - 1
+        flen = len(rec_lo)
+        bank = (None, None, np.asarray(rec_lo), np.asarray(rec_hi))
+        keys = [format(s, f"0{ndim}b").replace("0", "a").replace("1", "d") for s in range(1 << ndim)]
+        bands = {keys[0]: approx.detach().numpy()}
+        for k, t in zip(keys[1:], details):
+            bands[k] = t.detach().numpy()
+        trims = [2 * approx.shape[1 + a] - flen + 2 - out_extent[a] for a in range(ndim)]
+        y = O._idwtn(bands, bank, list(range(1, ndim + 1)), trims)
+        return torch.from_numpy(np.ascontiguousarray(y))

@@ -1,0 +1,251 @@
+"""GPU parity tests (``-m gpu``): the HIP path, called through the C ABI by the ptwt_amd host layer, against
+the CPU oracle and the committed golden vectors.
+
+Tolerances (norm-wise per sub-band): fp64 <= 1e-12 vs pywt/reference goldens; fp32 <= 1e-6 vs
+the reference's fp32 CPU output and vs the fp64 oracle; round trips fp32 <= 1e-6 / fp64 <= 1e-13.
+"""
+import numpy as np
+import pytest
+import torch
+
+import ptwt_amd
+from oracle import fwt_oracle as O
+from ptwt_amd import _engine
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+TOL64 = 1e-12
+TOL32 = 1e-6
+MODES = ["reflect", "zero", "constant", "periodic", "symmetric"]
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def to_np(t):
+    return t.detach().cpu().numpy()
+
+
+def check_tree(got, want, tol, what=""):
+    gf, wf = G.flatten_coeffs(got), G.flatten_coeffs(want)
+    assert [n for n, _ in gf] == [n for n, _ in wf]
+    for (n, a), (_, b) in zip(gf, wf):
+        assert tuple(a.shape) == tuple(np.shape(b)), (what, n)
+        err = G.relerr(to_np(a), b)
+        assert err < tol, f"{what} {n}: rel err {err:.3e} >= {tol}"
+
+
+def test_extension_loaded_and_fast_path_selected():
+    lib = _engine.load_library()
+    assert lib.mifwt_abi_version() == 1
+    assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (1024, 1024)) == 1
+
+
+def test_kat_ripples_haar_gpu():
+    class Haar:
+        filter_bank = ([0.5, 0.5], [-0.5, 0.5], [0.5, 0.5], [0.5, -0.5])
+
+        def __len__(self):
+            return 2
+
+    x = torch.tensor([56.0, 40.0, 8.0, 24.0, 48.0, 48.0, 40.0, 16.0], device=dev())
+    c = ptwt_amd.wavedec(x, Haar(), level=3)
+    assert c[0].item() == 35.0 and c[1].item() == -3.0
+    assert c[2].tolist() == [16.0, 10.0] and c[3].tolist() == [8.0, -8.0, 0.0, 12.0]
+
+
+def test_baseline_config1_haar_4096_fp64():
+    """BASELINE configs[0]: 1-D Haar, N = 4096, batch 1, fp64, 12 levels, against the reference golden."""
+    z, idx = G.load("ptwt_ref.npz")
+    case = idx[0]
+    assert case["shape"] == [1, 4096] and case["wavelet"] == "haar"
+    x = torch.from_numpy(z["r000_x"]).to(dev())
+    c = ptwt_amd.wavedec(x, "haar")
+    assert [t.shape[-1] for t in c] == [1, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048]
+    for name, t in G.flatten_coeffs(c):
+        assert G.relerr(to_np(t), z["r000_" + name]) < TOL64
+    rec = ptwt_amd.waverec(c, "haar")
+    assert (rec - x).abs().max().item() < 1e-13
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_vs_pywt_goldens_1d(dtype):
+    z, idx = G.load("pywt_wavedec1d.npz")
+    tol = TOL64 if dtype == torch.float64 else TOL32
+    for case in idx:
+        x = torch.from_numpy(z[case["key"] + "_x"]).to(dtype).to(dev())
+        got = ptwt_amd.wavedec(x, case["wavelet"], mode=case["mode"], level=case["level"])
+        assert len(got) == case["ncoef"]
+        for i, g in enumerate(got):
+            err = G.relerr(to_np(g), z["%s_%d" % (case["key"], i)])
+            assert err < tol, (case, i, err)
+        rec = ptwt_amd.waverec(got, case["wavelet"])
+        assert G.relerr(to_np(rec[..., : x.shape[-1]]), to_np(x)) < (1e-9 if dtype == torch.float64 else 2e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_vs_pywt_goldens_2d(dtype):
+    z, idx = G.load("pywt_wavedec2d.npz")
+    tol = TOL64 if dtype == torch.float64 else TOL32
+    for case in idx:
+        k = case["key"]
+        x = torch.from_numpy(z[k + "_x"]).to(dtype).to(dev())
+        got = ptwt_amd.wavedec2(x, case["wavelet"], mode=case["mode"], level=case["level"])
+        assert G.relerr(to_np(got[0]), z[k + "_a"]) < tol, case
+        for i, det in enumerate(got[1:]):
+            for n, t in zip("hvd", det):
+                err = G.relerr(to_np(t), z["%s_%d_%s" % (k, i, n)])
+                assert err < tol, (case, i, n, err)
+        rec = ptwt_amd.waverec2(got, case["wavelet"])
+        assert G.relerr(to_np(rec[..., : x.shape[-2], : x.shape[-1]]), to_np(x)) < (1e-9 if dtype == torch.float64 else 2e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_vs_pywt_goldens_3d(dtype):
+    z, idx = G.load("pywt_wavedec3d.npz")
+    tol = TOL64 if dtype == torch.float64 else TOL32
+    for case in idx:
+        k = case["key"]
+        x = torch.from_numpy(z[k + "_x"]).to(dtype).to(dev())
+        got = ptwt_amd.wavedec3(x, case["wavelet"], mode=case["mode"], level=case["level"])
+        assert G.relerr(to_np(got[0]), z[k + "_a"]) < tol, case
+        for i, dct in enumerate(got[1:]):
+            for key, t in dct.items():
+                assert G.relerr(to_np(t), z["%s_%d_%s" % (k, i, key)]) < tol, (case, i, key)
+        rec = ptwt_amd.waverec3(got, case["wavelet"])
+        s = x.shape
+        assert G.relerr(to_np(rec[..., : s[-3], : s[-2], : s[-1]]), to_np(x)) < (1e-9 if dtype == torch.float64 else 2e-6)
+
+
+def test_vs_reference_goldens_all_entry_points():
+    """Every reference golden case (all ten functions, axes, folded batches, f32 + f64) on the HIP path."""
+    z, idx = G.load("ptwt_ref.npz")
+    for case in idx:
+        k = case["key"]
+        x = torch.from_numpy(z[k + "_x"]).to(dev())
+        kw = {a: (tuple(v) if isinstance(v, list) else v) for a, v in case["kw"].items()}
+        coeffs = getattr(ptwt_amd, case["fn"])(x, case["wavelet"], **kw)
+        flat = G.flatten_coeffs(coeffs)
+        assert [n for n, _ in flat] == case["names"], case
+        tol = TOL64 if case["dtype"] == "float64" else TOL32
+        for name, val in flat:
+            want = z["%s_%s" % (k, name)]
+            assert val.dtype == x.dtype and val.device == x.device
+            assert tuple(val.shape) == want.shape, (case, name)
+            err = G.relerr(to_np(val), want)
+            assert err < tol, (case, name, err)
+        rkw = {a: v for a, v in kw.items() if a in ("axis", "axes")}
+        rec = getattr(ptwt_amd, case["rec"])(coeffs, case["wavelet"], **rkw)
+        want = z[k + "_rec"]
+        assert tuple(rec.shape) == want.shape, case
+        assert G.relerr(to_np(rec), want) < (1e-11 if case["dtype"] == "float64" else 2e-6), case
+
+
+FUSED_WAVELETS = ["haar", "db2", "db3", "db4", "db5", "db6", "db7", "db8"]  # L = 2..16
+
+
+@pytest.mark.parametrize("wavelet", FUSED_WAVELETS)
+@pytest.mark.parametrize("mode", MODES)
+def test_fused_dwt2_vs_oracle(wavelet, mode):
+    """The fused streaming kernel (kernel id 1) against the fp64 oracle: several strips, edge strips on both
+    sides, odd and even extents, odd row pitches from level 2 on, a chunk boundary inside the image."""
+    rng = np.random.default_rng(hash((wavelet, mode)) % (2**32))
+    for shape in [(3, 70, 530), (2, 131, 257), (1, 300, 1101), (2, 40, 36)]:
+        flen = len(O.filter_bank(wavelet)[0])
+        if _engine.kernel_id(2, torch.float32, mode, flen, shape[0], shape[1:]) != 1:
+            pytest.fail("fused path not selected")
+        x = rng.standard_normal(shape)
+        level = 3 if min(shape[1:]) > 4 * flen else 1
+        try:
+            want = O.wavedec2(x, wavelet, mode=mode, level=level)
+        except RuntimeError:
+            with pytest.raises(RuntimeError):
+                ptwt_amd.wavedec2(torch.from_numpy(x).float().to(dev()), wavelet, mode=mode, level=level)
+            continue
+        got = ptwt_amd.wavedec2(torch.from_numpy(x).float().to(dev()), wavelet, mode=mode, level=level)
+        check_tree(got, want, TOL32, f"{wavelet} {mode} {shape}")
+
+
+def test_fused_equals_generic():
+    """Fused kernel vs the generic axis passes on the same input: differences are fp32 rounding only."""
+    x = torch.randn(4, 203, 610, device=dev())
+    for mode in MODES:
+        fused = ptwt_amd.wavedec2(x, "db4", mode=mode, level=2)
+        _engine.set_option(_engine.OPT_FORCE_GENERIC, 1)
+        try:
+            generic = ptwt_amd.wavedec2(x, "db4", mode=mode, level=2)
+        finally:
+            _engine.set_option(_engine.OPT_FORCE_GENERIC, 0)
+        for (n, a), (_, b) in zip(G.flatten_coeffs(fused), G.flatten_coeffs(generic)):
+            assert G.relerr(to_np(a), to_np(b)) < 5e-7, (mode, n)
+
+
+def test_strided_inputs_and_axes():
+    """Non-contiguous inputs / non-default axes go through the stride-aware descriptor, no hidden copies needed."""
+    base = torch.randn(3, 50, 2, 66, device=dev(), dtype=torch.float64)
+    want = O.wavedec2(to_np(base), "db3", level=2, axes=(1, 3))
+    got = ptwt_amd.wavedec2(base, "db3", level=2, axes=(1, 3))
+    check_tree(got, want, TOL64, "axes=(1,3)")
+    view = torch.randn(2, 64, 96, device=dev())[:, ::2, 8:72]  # strided rows, offset columns
+    want = O.wavedec2(to_np(view).astype(np.float64), "db2", level=2)
+    check_tree(ptwt_amd.wavedec2(view, "db2", level=2), want, TOL32, "strided view")
+    rec = ptwt_amd.waverec2(ptwt_amd.wavedec2(view, "db2", level=2), "db2")
+    assert (rec - view).abs().max().item() < 5e-6
+
+
+@pytest.mark.parametrize("ndim,fn,rec", [(1, "wavedec", "waverec"), (2, "wavedec2", "waverec2"), (3, "wavedec3", "waverec3"),
+                                         (2, "fswavedec2", "fswaverec2"), (3, "fswavedec3", "fswaverec3")])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_roundtrip_random(ndim, fn, rec, dtype):
+    shape = {1: (5, 1001), 2: (3, 65, 130), 3: (2, 33, 34, 35)}[ndim]
+    x = torch.randn(*shape, device=dev(), dtype=dtype)
+    for wavelet in ("haar", "db4", "sym5"):
+        c = getattr(ptwt_amd, fn)(x, wavelet, mode="symmetric", level=2)
+        y = getattr(ptwt_amd, rec)(c, wavelet)
+        sl = tuple(slice(0, s) for s in x.shape)
+        err = G.relerr(to_np(y[sl]), to_np(x))
+        assert err < (1e-6 if dtype == torch.float32 else 1e-13), (fn, wavelet, err)
+
+
+def test_long_filters_generic_path():
+    """sym16 (32 taps) and coif17 (102 taps): outside the fused envelope, served by the generic kernels."""
+    x = torch.randn(2, 150, 170, device=dev(), dtype=torch.float64)
+    for wavelet in ("sym16", "coif17"):
+        want = O.wavedec2(to_np(x), wavelet, mode="symmetric", level=1)
+        got = ptwt_amd.wavedec2(x, wavelet, mode="symmetric", level=1)
+        check_tree(got, want, TOL64, wavelet)
+
+
+def test_full_size_config2_properties():
+    """BASELINE configs[1] at full size (64 x 1024 x 1024 fp32, db4, level 3): oracle check on two images,
+    linearity and the round trip."""
+    torch.manual_seed(0)
+    x = torch.randn(64, 1024, 1024, device=dev())
+    c = ptwt_amd.wavedec2(x, "db4", level=3)
+    assert [tuple(t.shape[-2:]) for t in (c[0], c[1][0], c[2][0], c[3][0])] == [(134, 134), (134, 134), (261, 261), (515, 515)]
+    for b in (0, 63):
+        want = O.wavedec2(to_np(x[b]).astype(np.float64), "db4", level=3)
+        got = tuple([c[0][b]] + [tuple(t[b] for t in det) for det in c[1:]])
+        check_tree(got, want, TOL32, f"image {b}")
+    # linearity: T(2x + y) = 2 T(x) + T(y)
+    y = torch.randn_like(x)
+    cy = ptwt_amd.wavedec2(y, "db4", level=3)
+    cz = ptwt_amd.wavedec2(2 * x + y, "db4", level=3)
+    for (n, a), (_, b), (_, d) in zip(G.flatten_coeffs(cz), G.flatten_coeffs(c), G.flatten_coeffs(cy)):
+        assert G.relerr(to_np(a[:4]), to_np((2 * b + d)[:4])) < 2e-6, n
+    rec = ptwt_amd.waverec2(c, "db4")
+    assert rec.shape == x.shape
+    assert (rec - x).abs().max().item() < 5e-6
+    assert G.relerr(to_np(rec[:2]), to_np(x[:2])) < 1e-6
+
+
+def test_config3_wavedec3_db2():
+    """BASELINE configs[2] shape family (wavedec3 db2 level 3, mode zero) at a reduced batch vs the oracle."""
+    x = torch.randn(1, 128, 128, 128, device=dev())
+    want = O.wavedec3(to_np(x).astype(np.float64), "db2", level=3)
+    got = ptwt_amd.wavedec3(x, "db2", level=3)
+    check_tree(got, want, TOL32, "wavedec3")
+    rec = ptwt_amd.waverec3(got, "db2")
+    assert (rec - x).abs().max().item() < 5e-6

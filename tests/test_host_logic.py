@@ -1,0 +1,225 @@
+"""CPU tests of the host layer (no GPU): argument handling, containers, error behaviour, C-ABI surface.
+
+The level engine is replaced by the oracle (tests/_oracle_engine.py) so the whole Python glue of
+``ptwt_amd`` runs against the reference's golden outputs here; the HIP path itself is tested in
+tests/test_gpu_parity.py (``-m gpu``).
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import ptwt_amd
+from ptwt_amd import _engine, _fwt, _wavelets
+from tests import _golden as G
+from tests._oracle_engine import OracleLevelEngine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def oracle_engine(monkeypatch):
+    monkeypatch.setattr(_engine, "ENGINE", OracleLevelEngine())
+
+
+def test_public_surface_matches_reference():
+    """The ten functions + type aliases of reference src/ptwt/__init__.py:12-19 (conv-FWT path)."""
+    for name in ["wavedec", "waverec", "wavedec2", "waverec2", "wavedec3", "waverec3", "fswavedec2", "fswavedec3",
+                 "fswaverec2", "fswaverec3", "Wavelet", "WaveletDetailTuple2d", "WaveletCoeff2d", "WaveletCoeffNd",
+                 "WaveletCoeff2dSeparable", "WaveletDetailDict", "WaveletTensorTuple"]:
+        assert hasattr(ptwt_amd, name), name
+    import inspect
+
+    sig = inspect.signature(ptwt_amd.wavedec2)
+    assert [p.name for p in sig.parameters.values()] == ["data", "wavelet", "mode", "level", "axes"]
+    assert sig.parameters["mode"].default == "reflect" and sig.parameters["axes"].default == (-2, -1)
+    assert sig.parameters["mode"].kind is inspect.Parameter.KEYWORD_ONLY
+    assert inspect.signature(ptwt_amd.wavedec3).parameters["mode"].default == "zero"
+    assert inspect.signature(ptwt_amd.wavedec).parameters["axis"].default == -1
+    assert inspect.signature(ptwt_amd.fswavedec2).parameters["axes"].default is None
+    from ptwt_amd.conv_transform_2 import wavedec2  # same module names as the reference
+    from ptwt_amd.separable_conv_transform import fswaverec3  # noqa: F401
+
+    assert wavedec2 is ptwt_amd.wavedec2
+
+
+def test_no_cpu_fallback():
+    """A CPU tensor must fail loudly: the product path has no CPU/eager fallback."""
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        ptwt_amd.wavedec2(torch.zeros(2, 16, 16), "haar", level=1)
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        ptwt_amd.waverec([torch.zeros(1, 8), torch.zeros(1, 8)], "haar")
+
+
+def test_builtin_wavelets_equal_pywt_table():
+    import json
+
+    with open(os.path.join(G.GOLDEN, "pywt_filter_banks.json")) as f:
+        gold = json.load(f)
+    names = _wavelets.wavelist()
+    assert len(names) == 106
+    for n in names:
+        w = _wavelets.as_wavelet(n)
+        assert list(w.dec_lo) == gold[n]["dec_lo"] and list(w.rec_hi) == gold[n]["rec_hi"]
+        assert len(w) == len(gold[n]["dec_lo"])
+    assert _wavelets.host_taps("db1") == _wavelets.host_taps("haar")
+    with pytest.raises(ValueError):
+        _wavelets.as_wavelet("not-a-wavelet")
+    assert _wavelets.dwt_max_level(4096, 2) == 12 and _wavelets.dwt_max_level(5, 8) == 0
+    assert _wavelets.dwtn_max_level([1024, 1024], 8) == 7
+
+
+def test_wavelet_argument_forms(oracle_engine):
+    """str | object with .filter_bank | 4-tuple of tensors (reference src/ptwt/_util.py:71-126)."""
+    x = torch.randn(2, 40, dtype=torch.float64)
+    w = _wavelets.as_wavelet("db3")
+    a = ptwt_amd.wavedec(x, "db3", level=2)
+    b = ptwt_amd.wavedec(x, w, level=2)
+    c = ptwt_amd.wavedec(x, ptwt_amd.WaveletTensorTuple.from_wavelet(w, torch.float64), level=2)
+
+    class Bank:
+        filter_bank = w.filter_bank
+
+        def __len__(self):
+            return 6
+
+    d = ptwt_amd.wavedec(x, Bank(), level=2)
+    for u, v, y, z in zip(a, b, c, d):
+        assert torch.equal(u, v) and torch.equal(u, y) and torch.equal(u, z)
+
+
+def test_kat_ripples_haar(oracle_engine):
+    """Reference tests/test_convolution_fwt.py:98-118 through the ptwt_amd host layer."""
+
+    class Haar:
+        filter_bank = ([0.5, 0.5], [-0.5, 0.5], [0.5, 0.5], [0.5, -0.5])
+
+        def __len__(self):
+            return 2
+
+    c = ptwt_amd.wavedec(torch.tensor([56.0, 40.0, 8.0, 24.0, 48.0, 48.0, 40.0, 16.0]), Haar(), level=3)
+    assert c[0].item() == 35.0 and c[1].item() == -3.0
+    assert c[2].tolist() == [16.0, 10.0] and c[3].tolist() == [8.0, -8.0, 0.0, 12.0]
+
+
+@pytest.mark.parametrize("case", G.ref_cases(), ids=lambda c: "%s-%s-%s-%s" % (c["key"], c["fn"], c["wavelet"], c["dtype"]))
+def test_host_layer_vs_reference_goldens(case, oracle_engine):
+    """Containers, key order, shapes, dtype, axes/fold handling and the synthesis trims, on every reference
+    golden case (the arithmetic is the oracle's; the plumbing is the product's)."""
+    z, _ = G.load("ptwt_ref.npz")
+    k = case["key"]
+    x = torch.from_numpy(z[k + "_x"])
+    kw = {a: (tuple(v) if isinstance(v, list) else v) for a, v in case["kw"].items()}
+    coeffs = getattr(ptwt_amd, case["fn"])(x, case["wavelet"], **kw)
+    assert isinstance(coeffs, list if case["fn"] == "wavedec" else tuple)
+    flat = G.flatten_coeffs(coeffs)
+    assert [n for n, _ in flat] == case["names"]
+    tol = 1e-12 if case["dtype"] == "float64" else 1e-6
+    for name, val in flat:
+        want = z["%s_%s" % (k, name)]
+        assert val.dtype == x.dtype and tuple(val.shape) == want.shape
+        assert G.relerr(val.numpy(), want) < tol
+    if case["fn"] == "wavedec2":
+        assert all(isinstance(c, ptwt_amd.WaveletDetailTuple2d) for c in coeffs[1:])
+    rkw = {a: v for a, v in kw.items() if a in ("axis", "axes")}
+    rec = getattr(ptwt_amd, case["rec"])(coeffs, case["wavelet"], **rkw)
+    want = z[k + "_rec"]
+    assert tuple(rec.shape) == want.shape
+    assert G.relerr(rec.numpy(), want) < (1e-11 if case["dtype"] == "float64" else 2e-6)
+
+
+def test_error_behaviour(oracle_engine):
+    """Error types pinned by the reference (reference tests/test_convolution_fwt.py:347-402,
+    tests/test_convolution_fwt_3.py:167-178)."""
+    x = torch.randn(3, 16, 16, dtype=torch.float64)
+    with pytest.raises(ValueError):
+        ptwt_amd.wavedec2(x.to(torch.float16), "haar")  # unsupported dtype
+    with pytest.raises(ValueError):
+        ptwt_amd.wavedec2(x.to(torch.int32), "haar")
+    with pytest.raises(ValueError):
+        ptwt_amd.wavedec2(torch.randn(16, dtype=torch.float64), "haar")  # too few dims
+    with pytest.raises(ValueError):
+        ptwt_amd.wavedec3(torch.randn(4, 4, dtype=torch.float64), "haar")
+    with pytest.raises(ValueError):
+        ptwt_amd.wavedec2(x, "haar", mode="bogus", level=1)
+    with pytest.raises(ValueError):
+        ptwt_amd.wavedec2(x, "haar", axes=(1, 1))  # repeated axis
+    with pytest.raises(ValueError):
+        ptwt_amd.wavedec2(x, "haar", axes=(0, 1, 2))  # wrong count
+    with pytest.raises(ValueError):
+        ptwt_amd.wavedec2(x, "haar", axes=1)  # int for a 2-D transform
+    with pytest.raises(RuntimeError):
+        ptwt_amd.wavedec(torch.randn(1, 6, dtype=torch.float64), "db4", mode="reflect", level=1)  # pad >= N
+    ptwt_amd.wavedec(torch.randn(1, 4, dtype=torch.float64), "db4", mode="symmetric", level=1)  # tolerated
+    c = ptwt_amd.wavedec2(x, "db2", level=2)
+    with pytest.raises(ValueError):
+        ptwt_amd.waverec2((c[0], tuple(c[1][:2])), "db2")  # not a 3-tuple
+    with pytest.raises(ValueError):
+        ptwt_amd.waverec2((c[0], c[2]), "db2")  # shape mismatch inside a level
+    with pytest.raises(ValueError):
+        ptwt_amd.waverec2((c[0].to(torch.float32), c[1], c[2]), "db2")  # dtype mismatch
+    with pytest.raises(ValueError):
+        ptwt_amd.waverec2(([1, 2], c[1]), "db2")  # first element not a tensor
+    with pytest.raises(AssertionError):
+        ptwt_amd.waverec2((c[0], c[1], c[2]), "db4")  # wavelet does not match the coefficients
+    c3 = ptwt_amd.wavedec3(torch.randn(8, 8, 8, dtype=torch.float64), "haar", level=1)
+    bad = dict(c3[1])
+    bad.pop("ddd")
+    with pytest.raises(ValueError):
+        ptwt_amd.waverec3((c3[0], bad), "haar")
+    with pytest.raises(ValueError):
+        ptwt_amd.fswaverec2((c3[0], [1, 2, 3]), "haar")
+    # level = 0 returns the input as the only coefficient, list for 1-D / tuple otherwise
+    assert isinstance(ptwt_amd.wavedec(x, "haar", level=0), list)
+    out = ptwt_amd.wavedec2(x, "haar", level=0)
+    assert isinstance(out, tuple) and len(out) == 1 and torch.equal(out[0], x)
+
+
+def test_fswaverec_does_not_mutate_input(oracle_engine):
+    x = torch.randn(2, 17, 18, dtype=torch.float64)
+    c = ptwt_amd.fswavedec2(x, "db2", level=2)
+    keys = [list(d.keys()) for d in c[1:]]
+    rec = ptwt_amd.fswaverec2(c, "db2")
+    assert [list(d.keys()) for d in c[1:]] == keys == [["da", "ad", "dd"]] * 2
+    assert torch.allclose(rec[..., :17, :18], x, atol=1e-10)
+
+
+# ------------------------------------------------------------------------------------------ C ABI (no GPU)
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "mifwt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mifwt_[a-z_]+)\s*\(", text)))
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    lib = _engine.load_library()
+    syms = _header_symbols()
+    assert {"mifwt_dwt_fwd", "mifwt_dwt_inv", "mifwt_workspace_bytes", "mifwt_kernel_id", "mifwt_strerror",
+            "mifwt_abi_version", "mifwt_set_option"} <= set(syms)
+    for s in syms:
+        assert getattr(lib, s) is not None
+    assert lib.mifwt_abi_version() == 1
+    assert lib.mifwt_strerror(0) == b"ok" and b"argument" in lib.mifwt_strerror(-1)
+
+
+def test_cabi_descriptor_validation_and_dispatch():
+    """Argument validation and kernel selection run on the host, so they are testable without a GPU."""
+    lib = _engine.load_library()
+    d = _engine.LevelDesc()
+    assert lib.mifwt_kernel_id(ctypes.byref(d), 0) == -1  # ndim = 0
+    assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (1024, 1024)) == 1  # fused 2-D analysis
+    assert _engine.kernel_id(2, torch.float64, "reflect", 8, 64, (1024, 1024)) == 0  # f64 -> generic
+    assert _engine.kernel_id(2, torch.float32, "reflect", 32, 4, (512, 512)) == 0    # L = 32 -> generic
+    assert _engine.kernel_id(1, torch.float64, "zero", 2, 1, (4096,)) == 0
+    # generic 3-D level needs scratch, the fused 2-D level none
+    d = _engine.LevelDesc()
+    d.ndim, d.dtype, d.mode, d.filt_len, d.batch = 3, 0, 0, 4, 2
+    for a in range(3):
+        d.sig_extent[a], d.coef_extent[a] = 16, 9
+    assert lib.mifwt_workspace_bytes(ctypes.byref(d), 0) == 4 * 2 * (2 * 16 * 16 * 9 + 4 * 16 * 9 * 9)
+    d.coef_extent[1] = 8  # inconsistent with (N + L - 1) // 2
+    assert lib.mifwt_kernel_id(ctypes.byref(d), 0) == -1
+    assert lib.mifwt_dwt_fwd(ctypes.byref(d), None, None, None, None, None, None, 0, None) == -1

@@ -166,3 +166,18 @@ def test_oracle_vs_live_reference():
         del sys.path[:2]
         for m in [m for m in sys.modules if m == "pywt" or m.startswith(("pywt.", "ptwt")) or m == "more_itertools"]:
             del sys.modules[m]
+
+
+@pytest.mark.parametrize("mode", O.MODES)
+def test_torch_cpu_port_matches_oracle(mode):
+    """The cpu_baseline port (dense conv2d, as the reference does on CPU) equals the separable oracle."""
+    import torch
+
+    from oracle import torch_cpu_port as P
+
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 45, 52))
+    want = O.wavedec2(x, "db4", mode=mode, level=2)
+    got = P.wavedec2(torch.from_numpy(x), "db4", mode=mode, level=2)
+    for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(want)):
+        assert G.relerr(a.numpy(), b) < TOL64, (mode, n)
