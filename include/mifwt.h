@@ -112,9 +112,11 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 
 /* Library-wide diagnostic switches (process-global, meant for tests and A/B measurements).
  *   MIFWT_OPT_FORCE_GENERIC (0): non-zero routes every call through the generic per-axis passes.
- *   MIFWT_OPT_ROWS_PER_CHUNK (1): >0 overrides the fused kernels' output rows per streamed chunk. */
+ *   MIFWT_OPT_ROWS_PER_CHUNK (1): >0 overrides the fused kernels' output rows per streamed chunk.
+ *   MIFWT_OPT_PREFETCH_PAIRS (2): >0 overrides the fused kernels' register-ring prefetch depth. */
 #define MIFWT_OPT_FORCE_GENERIC 0
 #define MIFWT_OPT_ROWS_PER_CHUNK 1
+#define MIFWT_OPT_PREFETCH_PAIRS 2 /* >0 overrides the fused kernels' prefetch depth (row pairs in flight) */
 int mifwt_set_option(int key, int value);
 
 const char* mifwt_strerror(int code);

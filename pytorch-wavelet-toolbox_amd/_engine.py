@@ -101,6 +101,8 @@ def _require_gpu(t: torch.Tensor) -> None:
 level_events: Optional[list] = None
 
 OPT_FORCE_GENERIC = 0
+OPT_ROWS_PER_CHUNK = 1
+OPT_PREFETCH_PAIRS = 2
 
 
 def set_option(key: int, value: int) -> None:

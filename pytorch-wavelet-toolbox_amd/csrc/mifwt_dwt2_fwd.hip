@@ -11,10 +11,10 @@
 //     no s_barrier anywhere, a workgroup is just four independent waves sharing a CU.
 //   * Column (vertical) pass in REGISTERS: each lane keeps a ring of the most recent input rows of its
 //     4 columns; rows are requested several rows ahead of use, which is what keeps HBM busy.
-//   * Row (horizontal) pass through a 4 KiB per-wave LDS slab: the vertical low/high rows of two
-//     consecutive output rows are written with ds_write_b128, then lanes 0-31 / 32-63 each produce 4
-//     consecutive output columns of all four bands for one of the two rows and store them with one
-//     16-byte store per band.
+//   * Row (horizontal) pass through a 4.25 KiB per-wave LDS slab: the vertical (low, high) results of two
+//     consecutive output rows are written with ds_write_b128 (bank-conflict-free padded layout), then
+//     lanes 0-31 / 32-63 each produce 4 consecutive output columns of all four bands for one of the two
+//     rows and store them with one 16-byte store per band.
 //   * Boundary handling never touches the bulk of the image.  Output columns are split into
 //       - INTERIOR strips: every tap of every output lies inside the image and inside fully valid 4-column
 //         groups -> no column index map at all, plain vector loads;
@@ -32,6 +32,7 @@ namespace mifwt {
 
 namespace {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 // 16-byte vectors that are only guaranteed 4-byte aligned (odd row pitches such as 515 floats)
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -49,32 +50,69 @@ struct Dwt2FwdArgs {
   int nstrips, nchunks, ntasks;
   int rows_per_chunk;  // output rows per chunk (even)
   int mode;
-  float lo[L], hi[L];  // dec_lo / dec_hi in PyWavelets order
+  f2 tap[L];           // (dec_lo[m], dec_hi[m]) in PyWavelets order: one SGPR pair per tap
 };
 
 constexpr int round4(int v) { return (v + 3) & ~3; }
 constexpr int kMaxRowsPerChunk = 64;
 constexpr int kRowTab = 2 * kMaxRowsPerChunk + 4 + 28;  // >= 4 * npairs + RING for every configuration
 
-template <int L>
+template <int L, int D = 1>
 struct Cfg {
   static constexpr int R4 = round4(L - 2);                 // left overlap of a strip (columns)
   static constexpr int KS = ((256 - R4) / 2) & ~3;         // output columns per strip (multiple of 4)
   static constexpr int KL = round4((L - 2) / 2);           // outputs whose taps reach columns < 0
   static constexpr int NCH = (R4 + 8) / 4;                 // float4 chunks a lane reads per filter row
-  static constexpr int RING = L <= 8 ? 16 : (L <= 12 ? 20 : 24);  // register ring depth (rows)
+  static constexpr int RING = round4(L + 2 + 4 * D);        // register ring depth (rows): window + D pairs ahead
   static constexpr int U = RING / 4;                       // row pairs per unrolled loop body
   static_assert(RING >= L + 6, "ring must hold a row pair's window plus the rows being refilled");
+  static_assert(4 * (kMaxRowsPerChunk / 2) + RING <= kRowTab, "row table too small");
   static_assert(2 * KL >= R4, "interior strips must start at a non-negative column");
 };
 
 // One wave: output columns [k_base, k_end) x output rows [j0, j1) of image `img`, all four bands.
 //   EDGE : columns go through the per-element boundary index map (interior strips need none)
-template <int L, bool EDGE>
-__device__ __forceinline__ void strip_body(const Dwt2FwdArgs<L>& a, float (*lds)[2][256], int* rowtab, const int lane,
-                                           const int img, const int k_base, const int k_end, const int j0,
-                                           const int j1) {
-  using C = Cfg<L>;
+//   D    : prefetch depth in row pairs (ring = window + 4*D rows)
+// Arithmetic layout: both passes issue v_pk_fma_f32 with the FILTER PAIR packed — accumulator pair
+// (low-pass, high-pass) += (lo[m], hi[m]) * broadcast(sample) — so a tap is one SGPR pair, the sample is a
+// single (op_sel-broadcast) VGPR with no pairing/alignment constraint, and the vertical results leave the
+// registers already interleaved (lo, hi) per column, which is the LDS layout the horizontal pass reads.
+// The streaming loop is branch-free around its loads (rows come from a per-wave table of clamped source
+// rows; implicit-zero rows/columns are handled by multiplying with 0/1 masks at first use), so that the
+// compiler keeps counted s_waitcnt vmcnt(N) and the prefetched rows stay in flight across iterations.
+// All global addresses are (wave-uniform SGPR base) + (per-lane 32-bit byte offset).
+
+// LDS row image: 256 columns x (lo, hi) = 128 16-byte slots, one pad slot after every 4 (physical slot =
+// s + (s >> 2)): ds_write_b128 (lane l -> slots 2l, 2l+1) and ds_read_b128 (lane q -> slots 4q + c) are
+// bank-conflict-free and the read offsets are compile-time constants relative to one per-lane base.
+constexpr int kLdsRowFloats = 168 * 4;
+
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+// acc(lo-band, hi-band) += (h_lo[m], h_hi[m]) * broadcast(sample); the sample is the low / high half of an
+// even-aligned VGPR pair, the tap pair lives in SGPRs.
+__device__ __forceinline__ void pkfma_lo(f2& acc, const f2 tap, const f2 pair) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(tap), "v"(pair));
+}
+__device__ __forceinline__ void pkfma_hi(f2& acc, const f2 tap, const f2 pair) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "s"(tap), "v"(pair));
+}
+__device__ __forceinline__ f2 pkmul_lo(const f2 tap, const f2 pair) {
+  f2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "s"(tap), "v"(pair));
+  return r;
+}
+__device__ __forceinline__ f2 pkmul_hi(const f2 tap, const f2 pair) {
+  f2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "s"(tap), "v"(pair));
+  return r;
+}
+
+template <int L, int D, bool EDGE>
+__device__ __forceinline__ void strip_body(const Dwt2FwdArgs<L>& a, float (*lds)[kLdsRowFloats], int* rowtab,
+                                           const int lane, const int img, const int k_base, const int k_end,
+                                           const int j0, const int j1) {
+  using C = Cfg<L, D>;
   constexpr int R4 = C::R4, KS = C::KS, NCH = C::NCH, RING = C::RING, U = C::U;
 
   const int c_first = 2 * k_base - R4 + 4 * lane;  // first extended input column of this lane
@@ -82,43 +120,58 @@ __device__ __forceinline__ void strip_body(const Dwt2FwdArgs<L>& a, float (*lds)
   const int row_first = 2 * j0 - (L - 2);          // extended input row of ring index t = 0
   const int nrows_in = 2 * (j1 - j0) + L - 2;      // ring indices t in [0, nrows_in) are needed
 
-  const float* __restrict__ xb = a.x + (int64_t)img * a.xs_b;
+  // input image as a buffer resource: loads are (SGPR descriptor) + (per-lane byte offset) + (uniform row
+  // offset), no 64-bit address arithmetic in the loop
+  const uint32_t row_bytes = (uint32_t)a.xs_h * 4u;
+  const uint32_t img_bytes = ((uint32_t)(a.H - 1) * (uint32_t)a.xs_h + (uint32_t)a.W) * 4u;
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (int64_t)img * a.xs_b), 0, img_bytes, 0x00020000);
 
-  // per-lane column addressing
-  int coff[4];     // EDGE: mapped source column per element (clamped to 0 when it is an implicit zero)
-  float cmask[4];  // EDGE: 0 for implicit zeros, else 1
-  int cvec = 0;    // !EDGE: column of the 16-byte load (lanes right of the image re-load column 0; unused)
+  // per-lane column addressing (byte offsets inside a row)
+  uint32_t coff[4];  // EDGE: mapped source column per element (0 when it is an implicit zero or not needed)
+  float cmask[4];    // EDGE: 0 for implicit zeros, else 1
+  uint32_t cvec = 0; // !EDGE: offset of the 16-byte load (lanes right of the image re-load column 0; unused)
   if (EDGE) {
     // lanes right of the last column this strip needs all read column 0 (one broadcast line, unused)
     const bool needed = c_first <= 2 * (k_end - 1) + 1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int m = needed ? ext_index(c_first + e, a.W, a.mode) : 0;
-      coff[e] = m < 0 ? 0 : m;
+      coff[e] = m < 0 ? 0u : 4u * (uint32_t)m;
       cmask[e] = m < 0 ? 0.f : 1.f;
     }
   } else {
-    cvec = (c_first + 3 < a.W) ? c_first : 0;
+    cvec = (c_first + 3 < a.W) ? 4u * (uint32_t)c_first : 0u;
   }
 
-  // source row (or -1: all-zero row / not needed) of every ring index this chunk can touch
-  for (int t = lane; t < kRowTab; t += 64) rowtab[t] = t < nrows_in ? ext_index(row_first + t, a.H, a.mode) : -1;
+  // Per-wave row table: byte offset of the clamped source row of every ring index this chunk can touch
+  // (rows past the chunk re-read its last row: an L1/L2 hit, never used) and, for zero mode, whether the
+  // row is an implicit zero.
+  const bool rows_inside = row_first >= 0 && row_first + nrows_in <= a.H;
+  const bool zero_rows = a.mode == MIFWT_MODE_ZERO && !rows_inside;
+  float* rowmask = reinterpret_cast<float*>(rowtab + kRowTab);
+  if (rows_inside) {
+    for (int t = lane; t < kRowTab; t += 64) rowtab[t] = (row_first + (t < nrows_in ? t : nrows_in - 1)) * (int)row_bytes;
+  } else {
+    for (int t = lane; t < kRowTab; t += 64) {
+      const int m = ext_index(row_first + (t < nrows_in ? t : nrows_in - 1), a.H, a.mode);
+      rowtab[t] = (m < 0 ? 0 : m) * (int)row_bytes;
+      rowmask[t] = m < 0 ? 0.f : 1.f;
+    }
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  auto load_row = [&](int src) -> f4 {  // src is wave-uniform
-    f4 v = {0.f, 0.f, 0.f, 0.f};
-    if (src >= 0) {
-      const float* __restrict__ rp = xb + (int64_t)src * a.xs_h;
-      if (EDGE) {
-        v.x = rp[coff[0]] * cmask[0];
-        v.y = rp[coff[1]] * cmask[1];
-        v.z = rp[coff[2]] * cmask[2];
-        v.w = rp[coff[3]] * cmask[3];
-      } else {
-        v = *reinterpret_cast<const f4u*>(rp + cvec);
-      }
+  auto load_row = [&](int soff) -> f4 {  // soff: wave-uniform byte offset of a valid row
+    f4 v;
+    if (EDGE) {
+      v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, coff[0], soff, 0));
+      v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, coff[1], soff, 0));
+      v.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, coff[2], soff, 0));
+      v.w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, coff[3], soff, 0));
+    } else {
+      v = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, cvec, soff, 0));
     }
     return v;
   };
@@ -129,10 +182,21 @@ __device__ __forceinline__ void strip_body(const Dwt2FwdArgs<L>& a, float (*lds)
     r2 = load_row(__builtin_amdgcn_readfirstlane(src.z));
     r3 = load_row(__builtin_amdgcn_readfirstlane(src.w));
   };
+  auto mask_rows4 = [&](int t0, f4& r0, f4& r1, f4& r2, f4& r3) {  // zero mode, image top / bottom only
+    const f4 mk = *reinterpret_cast<const f4*>(&rowmask[t0]);
+    r0 *= mk.x;
+    r1 *= mk.y;
+    r2 *= mk.z;
+    r3 *= mk.w;
+  };
 
   f4 ring[RING];
 #pragma unroll
   for (int t = 0; t < RING - 4; t += 4) load_rows4(t, ring[t], ring[t + 1], ring[t + 2], ring[t + 3]);
+  if (zero_rows) {
+#pragma unroll
+    for (int t = 0; t < RING - 4; t += 4) mask_rows4(t, ring[t], ring[t + 1], ring[t + 2], ring[t + 3]);
+  }
 
   // horizontal-pass role of this lane
   const int hrow = lane >> 5;       // which of the two output rows of a pair
@@ -141,75 +205,109 @@ __device__ __forceinline__ void strip_body(const Dwt2FwdArgs<L>& a, float (*lds)
   const bool hactive = q < KS / 4 && kcol < k_end;
   const bool full4 = kcol + 3 < k_end;
 
-  float* __restrict__ ob[4];
+  // output addressing: uniform base (band, image, row pair) + per-lane byte offset (row of the pair, column)
+  char* __restrict__ obase[4];
+  int64_t opair_bytes[4];
+  uint32_t ooff[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) ob[s] = a.out[s] + (int64_t)img * a.os_b[s] + kcol;
+  for (int s = 0; s < 4; ++s) {
+    obase[s] = reinterpret_cast<char*>(a.out[s] + (int64_t)img * a.os_b[s] + (int64_t)j0 * a.os_h[s]);
+    opair_bytes[s] = a.os_h[s] * 8;
+    ooff[s] = 4u * ((uint32_t)hrow * (uint32_t)a.os_h[s] + (uint32_t)kcol);
+  }
+
+  // LDS addressing (float indices, padded layout): this lane writes its 4 columns (logical slots 2l, 2l+1
+  // -> 32 contiguous bytes) and reads the 2*NCH logical slots from 4q on
+  float* const wr = &lds[0][(2 * lane + (lane >> 1)) * 4];
+  const float* const rdp = &lds[hrow][5 * q * 4];
 
   for (int g = 0;; ++g) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int p = g * U + u;  // pair index inside the chunk
       if (p >= npairs) return;
-      // refill the four ring slots that the previous pair released
+      // refill the four ring slots that the previous pair released (rows 4p+RING-4 .. 4p+RING-1)
       load_rows4(4 * p + RING - 4, ring[(4 * u + RING - 4) % RING], ring[(4 * u + RING - 3) % RING],
                  ring[(4 * u + RING - 2) % RING], ring[(4 * u + RING - 1) % RING]);
+      if (zero_rows && p > 0) {
+        // rows that were requested one iteration ago are masked just before their first use
+        mask_rows4(4 * p + RING - 8, ring[(4 * u + RING - 8) % RING], ring[(4 * u + RING - 7) % RING],
+                   ring[(4 * u + RING - 6) % RING], ring[(4 * u + RING - 5) % RING]);
+      }
 
-      // ---- vertical pass: two output rows, both filters, this lane's 4 columns -----------------------
+      // ---- vertical pass: two output rows, this lane's 4 columns, (lo, hi) packed -----------------------
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr) {
-        f4 vlo = {0.f, 0.f, 0.f, 0.f}, vhi = {0.f, 0.f, 0.f, 0.f};
+        f2 v[4];
 #pragma unroll
         for (int m = 0; m < L; ++m) {
           // c[j] = sum_m h[m] * x_ext[2j + 1 - m];  ring index of row 2j+1-m is 4p + 2rr + (L-1) - m
           const f4 xv = ring[(4 * u + 2 * rr + (L - 1) - m) % RING];
-          vlo += a.lo[m] * xv;
-          vhi += a.hi[m] * xv;
+          const f2 x01 = {xv.x, xv.y}, x23 = {xv.z, xv.w};
+          if (m == 0) {
+            v[0] = pkmul_lo(a.tap[0], x01);
+            v[1] = pkmul_hi(a.tap[0], x01);
+            v[2] = pkmul_lo(a.tap[0], x23);
+            v[3] = pkmul_hi(a.tap[0], x23);
+          } else {
+            pkfma_lo(v[0], a.tap[m], x01);
+            pkfma_hi(v[1], a.tap[m], x01);
+            pkfma_lo(v[2], a.tap[m], x23);
+            pkfma_hi(v[3], a.tap[m], x23);
+          }
         }
-        *reinterpret_cast<f4*>(&lds[rr][0][4 * lane]) = vlo;
-        *reinterpret_cast<f4*>(&lds[rr][1][4 * lane]) = vhi;
+        if (EDGE) {  // implicit-zero columns (the vertical filter commutes with the column extension)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] *= cmask[c];
+        }
+        *reinterpret_cast<f4*>(wr + rr * kLdsRowFloats) = (f4){v[0].x, v[0].y, v[1].x, v[1].y};
+        *reinterpret_cast<f4*>(wr + rr * kLdsRowFloats + 4) = (f4){v[2].x, v[2].y, v[3].x, v[3].y};
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
       // ---- horizontal pass: 4 output columns x 4 bands of one row --------------------------------------
-      float wl[4 * NCH], wh[4 * NCH];
+      f2 w[4 * NCH];  // w[i] = vertical (low, high) result of column 8q + i
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const f4 tl = *reinterpret_cast<const f4*>(&lds[hrow][0][(8 * q + 4 * c) & 255]);
-        const f4 th = *reinterpret_cast<const f4*>(&lds[hrow][1][(8 * q + 4 * c) & 255]);
-        wl[4 * c + 0] = tl.x; wl[4 * c + 1] = tl.y; wl[4 * c + 2] = tl.z; wl[4 * c + 3] = tl.w;
-        wh[4 * c + 0] = th.x; wh[4 * c + 1] = th.y; wh[4 * c + 2] = th.z; wh[4 * c + 3] = th.w;
+      for (int c = 0; c < 2 * NCH; ++c) {
+        const f4 t = *reinterpret_cast<const f4*>(rdp + (c + (c >> 2)) * 4);
+        w[2 * c] = (f2){t.x, t.y};
+        w[2 * c + 1] = (f2){t.z, t.w};
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-      f4 o[4];
+      f2 ol[4], oh[4];  // ol[e] = (aa, ad), oh[e] = (da, dd) of output column e
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float s_aa = 0.f, s_ad = 0.f, s_da = 0.f, s_dd = 0.f;
 #pragma unroll
         for (int m = 0; m < L; ++m) {
           const int idx = 2 * e + 1 + R4 - m;  // extended column 2k+1-m relative to this lane's chunk base
-          s_aa = fmaf(a.lo[m], wl[idx], s_aa);
-          s_ad = fmaf(a.hi[m], wl[idx], s_ad);
-          s_da = fmaf(a.lo[m], wh[idx], s_da);
-          s_dd = fmaf(a.hi[m], wh[idx], s_dd);
+          if (m == 0) {
+            ol[e] = pkmul_lo(a.tap[0], w[idx]);
+            oh[e] = pkmul_hi(a.tap[0], w[idx]);
+          } else {
+            pkfma_lo(ol[e], a.tap[m], w[idx]);
+            pkfma_hi(oh[e], a.tap[m], w[idx]);
+          }
         }
-        o[0][e] = s_aa; o[1][e] = s_ad; o[2][e] = s_da; o[3][e] = s_dd;
       }
-      const int j = j0 + 2 * p + hrow;
-      if (hactive && j < j1) {
+      if (hactive && j0 + 2 * p + hrow < j1) {
+        const f4 o[4] = {{ol[0].x, ol[1].x, ol[2].x, ol[3].x},
+                         {ol[0].y, ol[1].y, ol[2].y, ol[3].y},
+                         {oh[0].x, oh[1].x, oh[2].x, oh[3].x},
+                         {oh[0].y, oh[1].y, oh[2].y, oh[3].y}};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          float* __restrict__ op = ob[s] + (int64_t)j * a.os_h[s];
+          char* __restrict__ op = obase[s] + (int64_t)p * opair_bytes[s];
           if (!EDGE || full4) {
-            *reinterpret_cast<f4u*>(op) = o[s];
+            *reinterpret_cast<f4u*>(op + ooff[s]) = o[s];
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (kcol + e < k_end) op[e] = o[s][e];
+              if (kcol + e < k_end) *reinterpret_cast<float*>(op + ooff[s] + 4 * e) = o[s][e];
           }
         }
       }
@@ -217,11 +315,11 @@ __device__ __forceinline__ void strip_body(const Dwt2FwdArgs<L>& a, float (*lds)
   }
 }
 
-template <int L>
-__global__ void __launch_bounds__(256) dwt2_fwd_stream_kernel(const Dwt2FwdArgs<L> a) {
-  using C = Cfg<L>;
-  __shared__ __attribute__((aligned(16))) float lds_all[4][2][2][256];  // [wave][row][lo/hi][col]
-  __shared__ __attribute__((aligned(16))) int rowtab_all[4][kRowTab];     // [wave][ring index] -> source row
+template <int L, int D>
+__global__ void __launch_bounds__(256, (L <= 8 && D <= 2) ? 3 : 2) dwt2_fwd_stream_kernel(const Dwt2FwdArgs<L> a) {
+  using C = Cfg<L, D>;
+  __shared__ __attribute__((aligned(16))) float lds_all[4][2][kLdsRowFloats];  // [wave][row][col x (lo,hi), padded]
+  __shared__ __attribute__((aligned(16))) int rowtab_all[4][2 * kRowTab];  // [wave]: source rows, then 0/1 row masks
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: everything below is wave-uniform
@@ -242,13 +340,13 @@ __global__ void __launch_bounds__(256) dwt2_fwd_stream_kernel(const Dwt2FwdArgs<
 
   const int j0 = chunk * a.rows_per_chunk;
   const int j1 = min(j0 + a.rows_per_chunk, a.Ho);
-  float(*lds)[2][256] = lds_all[wave];
+  float(*lds)[kLdsRowFloats] = lds_all[wave];
   int* rowtab = rowtab_all[wave];
 
   if (strip < a.n_int) {
     const int k_base = a.kl + strip * C::KS;
     const int k_end = min(k_base + C::KS, a.ke);
-    strip_body<L, false>(a, lds, rowtab, lane, img, k_base, k_end, j0, j1);
+    strip_body<L, D, false>(a, lds, rowtab, lane, img, k_base, k_end, j0, j1);
   } else {
     const int e = strip - a.n_int;  // right edge strips first, the left edge strip (if any) last
     int k_base, k_end;
@@ -259,14 +357,14 @@ __global__ void __launch_bounds__(256) dwt2_fwd_stream_kernel(const Dwt2FwdArgs<
       k_base = 0;
       k_end = a.kl;
     }
-    strip_body<L, true>(a, lds, rowtab, lane, img, k_base, k_end, j0, j1);
+    strip_body<L, D, true>(a, lds, rowtab, lane, img, k_base, k_end, j0, j1);
   }
 }
 
-template <int L>
+template <int L, int D>
 int launch(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo,
            const double* hi, hipStream_t stream) {
-  using C = Cfg<L>;
+  using C = Cfg<L, D>;
   Dwt2FwdArgs<L> a;
   a.x = static_cast<const float*>(x);
   a.out[0] = static_cast<float*>(approx);
@@ -283,8 +381,8 @@ int launch(const mifwt_level_desc* d, const void* x, void* approx, void* const* 
   a.Wo = (int)d->coef_extent[1];
   a.mode = d->mode;
   for (int m = 0; m < L; ++m) {
-    a.lo[m] = (float)lo[m];
-    a.hi[m] = (float)hi[m];
+    a.tap[m].x = (float)lo[m];
+    a.tap[m].y = (float)hi[m];
   }
   // column partition: [0, kl) left edge | [kl, ke) interior | [ke, Wo) right edge.
   // interior outputs k need extended columns 2k-(L-2) .. 2k+1, all inside [0, W4) with W4 = W & ~3, so
@@ -299,11 +397,11 @@ int launch(const mifwt_level_desc* d, const void* x, void* approx, void* const* 
   a.n_int = (ke - kl + C::KS - 1) / C::KS;
   a.n_edge_r = (a.Wo - ke + C::KS - 1) / C::KS;
   a.nstrips = a.n_int + a.n_edge_r + (kl > 0 ? 1 : 0);
-  // rows per chunk: enough tasks to spread over 256 CUs x ~12 waves, but chunks tall enough that the
-  // L-2 rows of vertical overlap stay a small fraction
-  int rpc = 32;
+  // rows per chunk: short chunks win on MI355X (measured, profiles/r01_level1_sweep.txt: 8 rows beats 16/32/64
+  // by 10-30 %): the L-2 halo rows are re-read from L2, not HBM, while many short tasks keep every CU's wave
+  // slots refilled and balanced.
+  int rpc = 8;
   const int64_t per_chunk_units = (int64_t)d->batch * a.nstrips;
-  while (rpc > 8 && per_chunk_units * ((a.Ho + rpc - 1) / rpc) < 256 * 12) rpc >>= 1;
   if (g_options[MIFWT_OPT_ROWS_PER_CHUNK] > 0) rpc = (g_options[MIFWT_OPT_ROWS_PER_CHUNK] + 1) & ~1;
   if (rpc > kMaxRowsPerChunk) rpc = kMaxRowsPerChunk;
   a.rows_per_chunk = rpc;
@@ -312,7 +410,7 @@ int launch(const mifwt_level_desc* d, const void* x, void* approx, void* const* 
   if (ntasks > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
   a.ntasks = (int)ntasks;
   const unsigned nblk = (unsigned)((ntasks + 3) / 4);
-  hipLaunchKernelGGL(dwt2_fwd_stream_kernel<L>, dim3(nblk), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((dwt2_fwd_stream_kernel<L, D>), dim3(nblk), dim3(256), 0, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 
@@ -323,21 +421,36 @@ bool dwt2_fwd_stream_supported(const mifwt_level_desc* d) {
   const int L = d->filt_len;
   if (L < 2 || L > 16 || (L & 1)) return false;
   if (d->sig_stride[2] != 1 || d->approx_stride[2] != 1 || d->detail_stride[2] != 1) return false;
-  if (d->sig_extent[0] > (1 << 28) || d->sig_extent[1] > (1 << 28)) return false;
+  // one image must be addressable with 32-bit byte offsets (buffer-resource loads)
+  const int64_t span = (d->sig_extent[0] - 1) * d->sig_stride[1] + d->sig_extent[1];
+  if (d->sig_stride[1] < 0 || span >= (int64_t(1) << 29)) return false;
+  if (d->approx_stride[1] < 0 || d->detail_stride[1] < 0) return false;
+  if (d->approx_stride[1] >= (int64_t(1) << 29) || d->detail_stride[1] >= (int64_t(1) << 29)) return false;
   return true;
+}
+
+template <int L>
+int launch_depth(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo,
+                 const double* hi, hipStream_t stream) {
+  // prefetch depth (row pairs in flight beyond the current window); MIFWT_OPT_PREFETCH_PAIRS overrides
+  int depth = g_options[MIFWT_OPT_PREFETCH_PAIRS];
+  if (depth <= 0) depth = L <= 8 ? 2 : 1;
+  if (L <= 8 && depth >= 3) return launch<L, 3>(d, x, approx, details, lo, hi, stream);
+  if (depth >= 2) return launch<L, 2>(d, x, approx, details, lo, hi, stream);
+  return launch<L, 1>(d, x, approx, details, lo, hi, stream);
 }
 
 int dwt2_fwd_stream(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
                     const double* lo, const double* hi, hipStream_t stream) {
   switch (d->filt_len) {
-    case 2: return launch<2>(d, x, approx, details, lo, hi, stream);
-    case 4: return launch<4>(d, x, approx, details, lo, hi, stream);
-    case 6: return launch<6>(d, x, approx, details, lo, hi, stream);
-    case 8: return launch<8>(d, x, approx, details, lo, hi, stream);
-    case 10: return launch<10>(d, x, approx, details, lo, hi, stream);
-    case 12: return launch<12>(d, x, approx, details, lo, hi, stream);
-    case 14: return launch<14>(d, x, approx, details, lo, hi, stream);
-    case 16: return launch<16>(d, x, approx, details, lo, hi, stream);
+    case 2: return launch_depth<2>(d, x, approx, details, lo, hi, stream);
+    case 4: return launch_depth<4>(d, x, approx, details, lo, hi, stream);
+    case 6: return launch_depth<6>(d, x, approx, details, lo, hi, stream);
+    case 8: return launch_depth<8>(d, x, approx, details, lo, hi, stream);
+    case 10: return launch_depth<10>(d, x, approx, details, lo, hi, stream);
+    case 12: return launch_depth<12>(d, x, approx, details, lo, hi, stream);
+    case 14: return launch_depth<14>(d, x, approx, details, lo, hi, stream);
+    case 16: return launch_depth<16>(d, x, approx, details, lo, hi, stream);
     default: return MIFWT_ERR_UNSUPPORTED;
   }
 }

@@ -23,6 +23,7 @@ ap.add_argument("--shape", default="64,1024,1024")
 ap.add_argument("--wavelet", default="db4")
 ap.add_argument("--mode", default="reflect")
 ap.add_argument("--rpc", default="0", help="comma list of rows-per-chunk overrides (0 = library default)")
+ap.add_argument("--depth", default="0", help="comma list of prefetch-depth overrides (0 = library default)")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--generic", action="store_true", help="also time the generic axis-pass path")
@@ -39,14 +40,15 @@ bytes_algo = 4 * shape[0] * (torch.Size(shape[1:]).numel() + nb * torch.Size(coe
 eng = _engine.ENGINE
 mode_id = _engine.MODE_IDS[args.mode]
 
-variants = [("rpc=%s" % r, int(r), 0) for r in args.rpc.split(",")]
+variants = [("rpc=%s depth=%s" % (r, d), int(r), 0, int(d)) for r in args.rpc.split(",") for d in args.depth.split(",")]
 if args.generic:
-    variants.append(("generic", 0, 1))
-results = {name: [] for name, _, _ in variants}
+    variants.append(("generic", 0, 1, 0))
+results = {name: [] for name, _, _, _ in variants}
 for rnd in range(args.rounds + 1):
-    for name, rpc, gen in variants:
+    for name, rpc, gen, depth in variants:
         _engine.set_option(1, rpc)
         _engine.set_option(0, gen)
+        _engine.set_option(2, depth)
         eng.analysis(bufs[0], taps[0], taps[1], mode_id)
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -59,6 +61,7 @@ for rnd in range(args.rounds + 1):
             results[name].append(s.elapsed_time(e) / args.iters)
 _engine.set_option(1, 0)
 _engine.set_option(0, 0)
+_engine.set_option(2, 0)
 for name, ts in results.items():
     med = statistics.median(ts)
     print(json.dumps({"variant": name, "shape": shape, "wavelet": args.wavelet, "ms_median": round(med, 4),
