@@ -392,6 +392,11 @@ int launch(const mifwt_level_desc* d, const void* x, void* approx, void* const* 
   int ke = kl;
   if (w4 / 2 > kl) ke = kl + ((w4 / 2 - kl) & ~3);
   if (ke > a.Wo) ke = kl + ((a.Wo - kl) & ~3);
+  // a short interior remainder rides with the right edge strip instead of occupying a wave of its own
+  {
+    const int rem = (ke - kl) % C::KS;
+    if (rem > 0 && rem <= 32 && rem + (a.Wo - ke) <= C::KS) ke -= rem;
+  }
   a.kl = kl;
   a.ke = ke;
   a.n_int = (ke - kl + C::KS - 1) / C::KS;
@@ -434,7 +439,8 @@ int launch_depth(const mifwt_level_desc* d, const void* x, void* approx, void* c
                  const double* hi, hipStream_t stream) {
   // prefetch depth (row pairs in flight beyond the current window); MIFWT_OPT_PREFETCH_PAIRS overrides
   int depth = g_options[MIFWT_OPT_PREFETCH_PAIRS];
-  if (depth <= 0) depth = L <= 8 ? 2 : 1;
+  // two pairs ahead pays on big planes; small planes (later levels) prefer the higher occupancy of depth 1
+  if (depth <= 0) depth = (L <= 8 && d->sig_extent[0] * d->sig_extent[1] >= (1 << 19)) ? 2 : 1;
   if (L <= 8 && depth >= 3) return launch<L, 3>(d, x, approx, details, lo, hi, stream);
   if (depth >= 2) return launch<L, 2>(d, x, approx, details, lo, hi, stream);
   return launch<L, 1>(d, x, approx, details, lo, hi, stream);
