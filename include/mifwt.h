@@ -117,6 +117,8 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 #define MIFWT_OPT_FORCE_GENERIC 0
 #define MIFWT_OPT_ROWS_PER_CHUNK 1
 #define MIFWT_OPT_PREFETCH_PAIRS 2 /* >0 overrides the fused kernels' prefetch depth (row pairs in flight) */
+#define MIFWT_OPT_COOP 3           /* non-zero selects the workgroup-cooperative full-line output writer */
+#define MIFWT_OPT_NT_STORE 4       /* non-zero: nontemporal stores for the sub-band planes */
 int mifwt_set_option(int key, int value);
 
 const char* mifwt_strerror(int code);

@@ -103,6 +103,8 @@ level_events: Optional[list] = None
 OPT_FORCE_GENERIC = 0
 OPT_ROWS_PER_CHUNK = 1
 OPT_PREFETCH_PAIRS = 2
+OPT_COOP = 3
+OPT_NT_STORE = 4
 
 
 def set_option(key: int, value: int) -> None:

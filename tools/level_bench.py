@@ -27,6 +27,8 @@ ap.add_argument("--depth", default="0", help="comma list of prefetch-depth overr
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--generic", action="store_true", help="also time the generic axis-pass path")
+ap.add_argument("--coop", default="0", help="comma list: 1 = cooperative full-line writer, 0 = independent waves")
+ap.add_argument("--nt", default="0", help="comma list: 1 = nontemporal stores")
 args = ap.parse_args()
 
 shape = tuple(int(v) for v in args.shape.split(","))
@@ -40,15 +42,18 @@ bytes_algo = 4 * shape[0] * (torch.Size(shape[1:]).numel() + nb * torch.Size(coe
 eng = _engine.ENGINE
 mode_id = _engine.MODE_IDS[args.mode]
 
-variants = [("rpc=%s depth=%s" % (r, d), int(r), 0, int(d)) for r in args.rpc.split(",") for d in args.depth.split(",")]
+variants = [("coop=%s nt=%s rpc=%s depth=%s" % (c, n, r, d), int(r), 0, int(d), int(c), int(n)) for c in args.coop.split(",")
+            for n in args.nt.split(",") for r in args.rpc.split(",") for d in args.depth.split(",")]
 if args.generic:
-    variants.append(("generic", 0, 1, 0))
-results = {name: [] for name, _, _, _ in variants}
+    variants.append(("generic", 0, 1, 0, 0, 0))
+results = {name: [] for name, _, _, _, _, _ in variants}
 for rnd in range(args.rounds + 1):
-    for name, rpc, gen, depth in variants:
+    for name, rpc, gen, depth, coop, nt in variants:
+        _engine.set_option(4, nt)
         _engine.set_option(1, rpc)
         _engine.set_option(0, gen)
         _engine.set_option(2, depth)
+        _engine.set_option(3, coop)
         eng.analysis(bufs[0], taps[0], taps[1], mode_id)
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -62,6 +67,8 @@ for rnd in range(args.rounds + 1):
 _engine.set_option(1, 0)
 _engine.set_option(0, 0)
 _engine.set_option(2, 0)
+_engine.set_option(3, 0)
+_engine.set_option(4, 0)
 for name, ts in results.items():
     med = statistics.median(ts)
     print(json.dumps({"variant": name, "shape": shape, "wavelet": args.wavelet, "ms_median": round(med, 4),
