@@ -26,16 +26,12 @@
 //     (re-read through L2); blockIdx is remapped so that neighbours share an XCD's L2.
 //
 // Algorithmic traffic per level: 4*B*H*W bytes read + 4*4*B*Ho*Wo bytes written (f32).
-#include "mifwt_common.h"
+#include "mifwt_stream.h"
 
 namespace mifwt {
 
 namespace {
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-// 16-byte vectors that are only guaranteed 4-byte aligned (odd row pitches such as 515 floats)
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 
 template <int L>
 struct Dwt2FwdArgs {
@@ -87,27 +83,6 @@ struct Cfg {
 // s + (s >> 2)): ds_write_b128 (lane l -> slots 2l, 2l+1) and ds_read_b128 (lane q -> slots 4q + c) are
 // bank-conflict-free and the read offsets are compile-time constants relative to one per-lane base.
 constexpr int kLdsRowFloats = 168 * 4;
-
-typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-
-// acc(lo-band, hi-band) += (h_lo[m], h_hi[m]) * broadcast(sample); the sample is the low / high half of an
-// even-aligned VGPR pair, the tap pair lives in SGPRs.
-__device__ __forceinline__ void pkfma_lo(f2& acc, const f2 tap, const f2 pair) {
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(tap), "v"(pair));
-}
-__device__ __forceinline__ void pkfma_hi(f2& acc, const f2 tap, const f2 pair) {
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "s"(tap), "v"(pair));
-}
-__device__ __forceinline__ f2 pkmul_lo(const f2 tap, const f2 pair) {
-  f2 r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "s"(tap), "v"(pair));
-  return r;
-}
-__device__ __forceinline__ f2 pkmul_hi(const f2 tap, const f2 pair) {
-  f2 r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "s"(tap), "v"(pair));
-  return r;
-}
 
 // Workgroup-cooperative full-line writer (COOP kernels).  The waves of one workgroup cover ALL column strips
 // of a chunk of rows, so for every band the two output rows of an iteration, and the rows of consecutive
@@ -185,9 +160,7 @@ __device__ __forceinline__ void strip_body(const Dwt2FwdArgs<L>& a, float (*lds)
       rowmask[t] = m < 0 ? 0.f : 1.f;
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  wave_lds_fence();
 
   auto load_row = [&](int soff) -> f4 {  // soff: wave-uniform byte offset of a valid row
     f4 v;
@@ -289,9 +262,7 @@ __device__ __forceinline__ void strip_body(const Dwt2FwdArgs<L>& a, float (*lds)
         *reinterpret_cast<f4*>(wr + rr * kLdsRowFloats) = (f4){v[0].x, v[0].y, v[1].x, v[1].y};
         *reinterpret_cast<f4*>(wr + rr * kLdsRowFloats + 4) = (f4){v[2].x, v[2].y, v[3].x, v[3].y};
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      wave_lds_fence();
 
       // ---- horizontal pass: 4 output columns x 4 bands of one row --------------------------------------
       f2 w[4 * NCH];  // w[i] = vertical (low, high) result of column 8q + i
@@ -301,9 +272,7 @@ __device__ __forceinline__ void strip_body(const Dwt2FwdArgs<L>& a, float (*lds)
         w[2 * c] = (f2){t.x, t.y};
         w[2 * c + 1] = (f2){t.z, t.w};
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      wave_lds_fence();
 
       f2 ol[4], oh[4];  // ol[e] = (aa, ad), oh[e] = (da, dd) of output column e
 #pragma unroll
@@ -403,12 +372,7 @@ __global__ void __launch_bounds__(256, (L <= 8 && D <= 2) ? 3 : 2) dwt2_fwd_stre
 
   // XCD-aware block remap (block b runs on XCD b % 8): give each XCD a contiguous range of tasks so that
   // strips / chunks that share halo columns / rows meet in the same L2.
-  int bid = blockIdx.x;
-  {
-    const int nblk = gridDim.x;
-    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
   CoopSink nosink;
   const int task = bid * 4 + wave;
   if (task >= a.ntasks) return;
@@ -451,12 +415,7 @@ __global__ void __launch_bounds__(64 * kCoopMaxWaves, (L <= 8 && D <= 2) ? 3 : 2
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int bid = blockIdx.x;
-  {
-    const int nblk = gridDim.x;
-    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int chunk = bid % a.nchunks;
   const int img = bid / a.nchunks;
   const int j0 = chunk * a.rows_per_chunk;
@@ -637,13 +596,6 @@ int dwt2_fwd_stream(const mifwt_level_desc* d, const void* x, void* approx, void
     case 16: return launch_depth<16>(d, x, approx, details, lo, hi, stream);
     default: return MIFWT_ERR_UNSUPPORTED;
   }
-}
-
-// synthesis fast path: not built yet — the dispatcher falls back to the generic axis passes
-bool dwt2_inv_stream_supported(const mifwt_level_desc*) { return false; }
-int dwt2_inv_stream(const mifwt_level_desc*, const void*, const void* const*, void*, const double*, const double*,
-                    hipStream_t) {
-  return MIFWT_ERR_UNSUPPORTED;
 }
 
 }  // namespace mifwt

@@ -1,0 +1,50 @@
+// mifwt_stream.h — idioms shared by the fused streaming kernels (gfx950).
+#pragma once
+#include "mifwt_common.h"
+
+namespace mifwt {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+// 8/16-byte vectors that are only guaranteed 4-byte aligned (odd row pitches such as 515 floats)
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+// v_pk_fma_f32 with a PACKED TAP PAIR and a BROADCAST sample:
+//   acc(.x, .y) += (tap.x, tap.y) * sample,  sample = low (…_lo) or high (…_hi) half of an even-aligned VGPR pair.
+// The tap pair lives in SGPRs (one 64-bit scalar operand), the sample needs no pairing of its own.
+__device__ __forceinline__ void pkfma_lo(f2& acc, const f2 tap, const f2 pair) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(tap), "v"(pair));
+}
+__device__ __forceinline__ void pkfma_hi(f2& acc, const f2 tap, const f2 pair) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "s"(tap), "v"(pair));
+}
+__device__ __forceinline__ f2 pkmul_lo(const f2 tap, const f2 pair) {
+  f2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "s"(tap), "v"(pair));
+  return r;
+}
+__device__ __forceinline__ f2 pkmul_hi(const f2 tap, const f2 pair) {
+  f2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "s"(tap), "v"(pair));
+  return r;
+}
+
+// Ordering of one wave's own LDS traffic (different lanes write and read the same slab): DS operations of a
+// wave execute in order, this only stops the compiler from moving them across.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// XCD-aware block remap (block b runs on XCD b % 8): every XCD gets a contiguous range of logical blocks so
+// that tasks sharing halo rows / columns meet in one L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+}  // namespace mifwt

@@ -27,6 +27,7 @@ ap.add_argument("--depth", default="0", help="comma list of prefetch-depth overr
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--generic", action="store_true", help="also time the generic axis-pass path")
+ap.add_argument("--inverse", action="store_true", help="time the synthesis level that reconstructs --shape instead")
 ap.add_argument("--coop", default="0", help="comma list: 1 = cooperative full-line writer, 0 = independent waves")
 ap.add_argument("--nt", default="0", help="comma list: 1 = nontemporal stores")
 args = ap.parse_args()
@@ -41,6 +42,16 @@ nb = 1 << (len(shape) - 1)
 bytes_algo = 4 * shape[0] * (torch.Size(shape[1:]).numel() + nb * torch.Size(coef).numel())
 eng = _engine.ENGINE
 mode_id = _engine.MODE_IDS[args.mode]
+if args.inverse:
+    cbufs = [eng.analysis(b, taps[0], taps[1], mode_id) for b in bufs]
+    out_ext = [2 * m - flen + 2 - (n % 2) for m, n in zip(coef, shape[1:])]
+
+    def run(i):
+        cb = cbufs[i % 3]
+        return eng.synthesis(cb[:, 0], [cb[:, s] for s in range(1, nb)], taps[2], taps[3], out_ext)
+else:
+    def run(i):
+        return eng.analysis(bufs[i % 3], taps[0], taps[1], mode_id)
 
 variants = [("coop=%s nt=%s rpc=%s depth=%s" % (c, n, r, d), int(r), 0, int(d), int(c), int(n)) for c in args.coop.split(",")
             for n in args.nt.split(",") for r in args.rpc.split(",") for d in args.depth.split(",")]
@@ -54,12 +65,12 @@ for rnd in range(args.rounds + 1):
         _engine.set_option(0, gen)
         _engine.set_option(2, depth)
         _engine.set_option(3, coop)
-        eng.analysis(bufs[0], taps[0], taps[1], mode_id)
+        run(0)
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for i in range(args.iters):
-            eng.analysis(bufs[i % 3], taps[0], taps[1], mode_id)
+            run(i)
         e.record()
         torch.cuda.synchronize()
         if rnd > 0:
