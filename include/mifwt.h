@@ -106,8 +106,14 @@ int mifwt_dwt_inv(const mifwt_level_desc* desc, const void* approx, const void* 
 /* Scratch bytes one call needs (0 on the fused paths).  direction: 0 = analysis, 1 = synthesis. */
 size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
 
-/* Which kernel family a call would dispatch to: 0 = generic per-axis passes, >0 = fused kernel id
- * (tests use it to assert the fast path is the one that ran); negative = error code. */
+/* Which kernel family a call would dispatch to (tests use it to assert the fast path is the one that ran);
+ * negative = error code.
+ *   0  generic per-axis passes (any strides, any L <= 128)
+ *   1 / 2  fused single-launch 2-D analysis / synthesis level (f32, even L <= 16)
+ *   3 / 4  streaming axis passes, analysis / synthesis: inner-axis kernel (+ one outer-axis pass per further
+ *          axis); unit innermost stride, f32 / f64 / f16, L in {2..20 even, 24, 32}
+ *   5 / 6  3-D analysis / synthesis (f32, even L <= 16): fused 2-D kernel over every depth slice + one
+ *          streaming pass along depth */
 int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 
 /* Library-wide diagnostic switches (process-global, meant for tests and A/B measurements).

@@ -17,6 +17,7 @@ from .constants import (
     WaveletDetailDict,
     WaveletDetailTuple2d,
     WaveletTensorTuple,
+    set_half_storage,
 )
 from .conv_transform import wavedec, waverec
 from .conv_transform_2 import wavedec2, waverec2
@@ -43,4 +44,5 @@ __all__ = [
     "fswavedec3",
     "fswaverec2",
     "fswaverec3",
+    "set_half_storage",
 ]

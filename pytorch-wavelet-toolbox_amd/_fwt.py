@@ -15,7 +15,7 @@ import torch
 
 from . import _engine
 from ._wavelets import dwtn_max_level, filter_length, host_taps
-from .constants import SUPPORTED_DTYPES, WaveletDetailTuple2d
+from .constants import WaveletDetailTuple2d, supported_dtypes
 
 AxisHint = Union[int, Sequence[int], None]
 
@@ -78,7 +78,7 @@ class _Layout:
     def __init__(self, proto: torch.Tensor, ndim: int, axes: Tuple[int, ...]):
         if not isinstance(proto, torch.Tensor):
             raise ValueError("First element of coeffs must be the approximation coefficient tensor.")
-        if proto.dtype not in SUPPORTED_DTYPES:
+        if proto.dtype not in supported_dtypes():
             raise ValueError(f"Input dtype {proto.dtype} not supported")
         self.ndim = ndim
         self.perm = None if axes == tuple(range(-ndim, 0)) else _permutation(axes, proto.dim())

@@ -10,6 +10,7 @@ import torch
 __all__ = [
     "BoundaryMode",
     "SUPPORTED_DTYPES",
+    "set_half_storage",
     "Wavelet",
     "WaveletCoeff1d",
     "WaveletCoeff2d",
@@ -22,6 +23,21 @@ __all__ = [
 
 #: dtypes the reference accepts (src/ptwt/constants.py:27); anything else raises ``ValueError``.
 SUPPORTED_DTYPES = {torch.float32, torch.float64}
+
+#: Engine extension (NOT in the reference, which raises ``ValueError`` for it): float16 STORAGE with float32
+#: arithmetic (C ABI ``MIFWT_F16``).  Off by default so that error behaviour matches the reference; switch it on
+#: with :func:`set_half_storage` (BASELINE.json configs[4] is an fp16 workload).
+_half_storage = False
+
+
+def set_half_storage(enabled: bool) -> None:
+    """Accept ``torch.float16`` inputs (coefficients are returned in float16, accumulated in float32)."""
+    global _half_storage
+    _half_storage = bool(enabled)
+
+
+def supported_dtypes():
+    return SUPPORTED_DTYPES | {torch.float16} if _half_storage else SUPPORTED_DTYPES
 
 #: boundary rules (src/ptwt/constants.py:85): zero | constant (edge replicate) | reflect (whole-sample
 #: mirror) | periodic | symmetric (half-sample mirror)

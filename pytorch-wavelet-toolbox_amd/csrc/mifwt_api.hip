@@ -208,12 +208,28 @@ size_t generic_ws(const mifwt_level_desc* d, int direction) {
   return (size_t)(total * elem_size(d->dtype));
 }
 
+size_t route_ws(const mifwt_level_desc* d, int direction, int kid) {
+  switch (kid) {
+    case kDwt2FwdStream:
+    case kDwt2InvStream: return 0;
+    case kDwt3FwdStream:
+    case kDwt3InvStream: return plane3_ws_bytes(d, direction);
+    case kDwt1FwdRow:
+    case kDwt1InvRow: return rows_ws_bytes(d, direction);
+    default: return d->dtype == MIFWT_F16 ? 0 : generic_ws(d, direction);
+  }
+}
+
 int pick_kernel(const mifwt_level_desc* d, int direction) {
   if (g_options[MIFWT_OPT_FORCE_GENERIC]) return kGeneric;
   if (direction == 0) {
     if (dwt2_fwd_stream_supported(d)) return kDwt2FwdStream;
+    if (plane3_route_ok(d, 0)) return kDwt3FwdStream;
+    if (rows_route_ok(d, 0)) return kDwt1FwdRow;
   } else {
     if (dwt2_inv_stream_supported(d)) return kDwt2InvStream;
+    if (plane3_route_ok(d, 1)) return kDwt3InvStream;
+    if (rows_route_ok(d, 1)) return kDwt1InvRow;
   }
   return kGeneric;
 }
@@ -253,8 +269,7 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction) {
 
 size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction) {
   if (validate(desc, direction) != MIFWT_OK) return 0;
-  if (pick_kernel(desc, direction) != kGeneric) return 0;
-  return generic_ws(desc, direction);
+  return route_ws(desc, direction, pick_kernel(desc, direction));
 }
 
 int mifwt_dwt_fwd(const mifwt_level_desc* desc, const void* x, void* approx, void* const* details,
@@ -267,15 +282,16 @@ int mifwt_dwt_fwd(const mifwt_level_desc* desc, const void* x, void* approx, voi
     if (!details[s - 1]) return MIFWT_ERR_BADARG;
   if (desc->batch == 0) return MIFWT_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (pick_kernel(desc, 0)) {
-    case kDwt2FwdStream:
-      return dwt2_fwd_stream(desc, x, approx, details, dec_lo, dec_hi, st);
-    default:
-      break;
-  }
-  if (desc->dtype == MIFWT_F16) return MIFWT_ERR_UNSUPPORTED;
-  const size_t need = generic_ws(desc, 0);
+  const int kid = pick_kernel(desc, 0);
+  if (kid == kGeneric && desc->dtype == MIFWT_F16) return MIFWT_ERR_UNSUPPORTED;
+  const size_t need = route_ws(desc, 0, kid);
   if (need > 0 && (!workspace || workspace_bytes < need)) return MIFWT_ERR_WORKSPACE;
+  switch (kid) {
+    case kDwt2FwdStream: return dwt2_fwd_stream(desc, x, approx, details, dec_lo, dec_hi, st);
+    case kDwt3FwdStream: return plane3_fwd(desc, x, approx, details, dec_lo, dec_hi, workspace, st);
+    case kDwt1FwdRow: return rows_fwd(desc, x, approx, details, dec_lo, dec_hi, workspace, st);
+    default: break;
+  }
   return generic_fwd(desc, x, approx, details, dec_lo, dec_hi, workspace, st);
 }
 
@@ -289,15 +305,16 @@ int mifwt_dwt_inv(const mifwt_level_desc* desc, const void* approx, const void* 
     if (!details[s - 1]) return MIFWT_ERR_BADARG;
   if (desc->batch == 0) return MIFWT_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (pick_kernel(desc, 1)) {
-    case kDwt2InvStream:
-      return dwt2_inv_stream(desc, approx, details, y, rec_lo, rec_hi, st);
-    default:
-      break;
-  }
-  if (desc->dtype == MIFWT_F16) return MIFWT_ERR_UNSUPPORTED;
-  const size_t need = generic_ws(desc, 1);
+  const int kid = pick_kernel(desc, 1);
+  if (kid == kGeneric && desc->dtype == MIFWT_F16) return MIFWT_ERR_UNSUPPORTED;
+  const size_t need = route_ws(desc, 1, kid);
   if (need > 0 && (!workspace || workspace_bytes < need)) return MIFWT_ERR_WORKSPACE;
+  switch (kid) {
+    case kDwt2InvStream: return dwt2_inv_stream(desc, approx, details, y, rec_lo, rec_hi, st);
+    case kDwt3InvStream: return plane3_inv(desc, approx, details, y, rec_lo, rec_hi, workspace, st);
+    case kDwt1InvRow: return rows_inv(desc, approx, details, y, rec_lo, rec_hi, workspace, st);
+    default: break;
+  }
   return generic_inv(desc, approx, details, y, rec_lo, rec_hi, workspace, st);
 }
 

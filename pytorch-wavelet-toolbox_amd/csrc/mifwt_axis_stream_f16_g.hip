@@ -1,0 +1,4 @@
+// mifwt_axis_stream_f16_g.hip — streaming single-axis kernels (mifwt_axis_stream.h): _Float16 storage, L = 32.
+#include "mifwt_axis_stream.h"
+
+MIFWT_STREAM_DEFINE(f16, _Float16, 32)

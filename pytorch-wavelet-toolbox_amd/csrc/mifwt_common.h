@@ -56,6 +56,35 @@ int launch_axis_fwd(int dtype, const AxisJob* jobs, int njobs, const int64_t out
 int launch_axis_inv(int dtype, const AxisJob* jobs, int njobs, const int64_t out_ext[4], int taxis, int64_t m_in,
                     int filt_len, const double* lo, const double* hi, hipStream_t stream);
 
+// ---- streaming single-axis kernels (mifwt_axis_stream.h; any mode, L in the instantiated set) ----------
+// One (input -> low, high) or (low, high -> output) job; up to four jobs of identical geometry per launch.
+// Strides are in elements.  outer kernels: s[0] = batch, s[1] = transformed axis (the inner run is dense);
+// inner kernels: s[0..2] = the three row dims (the transformed axis has stride 1).
+struct StreamJob {
+  const void* in0;  // analysis: x            synthesis: low-pass band
+  const void* in1;  // analysis: unused       synthesis: high-pass band
+  void* out0;       // analysis: low-pass     synthesis: y
+  void* out1;       // analysis: high-pass    synthesis: unused
+  int64_t in0_s[3], in1_s[3], out0_s[3], out1_s[3];
+};
+
+struct StreamCall {
+  int filt_len, mode;
+  const StreamJob* jobs;
+  int njobs;
+  int64_t batch;       // outer
+  int64_t rows[3];     // inner
+  int64_t n_in, n_out;
+  int64_t inner;       // outer
+  const double* lo;
+  const double* hi;
+  hipStream_t stream;
+};
+
+enum StreamKind { kOuterFwd = 0, kOuterInv = 1, kInnerFwd = 2, kInnerInv = 3 };
+bool stream_filter_supported(int filt_len);
+int stream_call(int dtype, int kind, const StreamCall& c);  // dispatches on dtype (f32 / f64 / f16) and filt_len
+
 // ---- fused fast paths --------------------------------------------------------------------------------
 // Each returns MIFWT_ERR_UNSUPPORTED when the descriptor is outside its envelope (the dispatcher then
 // falls back to the generic passes) and never touches the workspace.
@@ -68,5 +97,19 @@ int dwt2_fwd_stream(const mifwt_level_desc* d, const void* x, void* approx, void
 bool dwt2_inv_stream_supported(const mifwt_level_desc* d);
 int dwt2_inv_stream(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y,
                     const double* rec_lo, const double* rec_hi, hipStream_t stream);
+
+// ---- composed routes (mifwt_compose.hip) --------------------------------------------------------------------
+bool plane3_route_ok(const mifwt_level_desc* d, int direction);  // ndim 3 f32: fused 2-D planes + depth pass
+bool rows_route_ok(const mifwt_level_desc* d, int direction);    // streaming inner pass + outer passes
+size_t plane3_ws_bytes(const mifwt_level_desc* d, int direction);
+size_t rows_ws_bytes(const mifwt_level_desc* d, int direction);
+int plane3_fwd(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo,
+               const double* hi, void* ws, hipStream_t stream);
+int plane3_inv(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y, const double* lo,
+               const double* hi, void* ws, hipStream_t stream);
+int rows_fwd(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo,
+             const double* hi, void* ws, hipStream_t stream);
+int rows_inv(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y, const double* lo,
+             const double* hi, void* ws, hipStream_t stream);
 
 }  // namespace mifwt

@@ -1,0 +1,409 @@
+// mifwt_compose.hip — N-D levels composed from the fused 2-D plane kernel and the streaming axis passes.
+//
+// Routes (kernel ids, include/mifwt.h mifwt_kernel_id):
+//   kDwt3FwdStream / kDwt3InvStream  (5, 6)  ndim 3, f32, L <= 16: the fused 2-D kernel over the (H, W) plane of
+//                                            every (batch, depth) slice + ONE streaming pass along depth
+//                                            (replaces F.conv3d / F.conv_transpose3d of the reference,
+//                                            src/ptwt/conv_transform_3.py:127, :218); scratch = 4 planes per
+//                                            slice, traffic = 2x the algorithmic bytes
+//   kDwt1FwdRow / kDwt1InvRow        (3, 4)  unit innermost stride and L in the streaming set, f32 / f64 / f16:
+//                                            the inner-axis pass (the whole transform in 1-D: F.conv1d /
+//                                            F.conv_transpose1d, src/ptwt/conv_transform.py:137, :187) plus
+//                                            one outer-axis pass per further axis through dense scratch
+#include <string.h>
+
+#include "mifwt_common.h"
+
+namespace mifwt {
+
+#define MIFWT_STREAM_LENGTHS(X, n) X(n, 2) X(n, 4) X(n, 6) X(n, 8) X(n, 10) X(n, 12) X(n, 14) X(n, 16) X(n, 18) X(n, 20) X(n, 24) X(n, 32)
+#define MIFWT_DECL(n, L) int stream_call_##n##_L##L(int, const StreamCall&);
+MIFWT_STREAM_LENGTHS(MIFWT_DECL, f32)
+MIFWT_STREAM_LENGTHS(MIFWT_DECL, f64)
+MIFWT_STREAM_LENGTHS(MIFWT_DECL, f16)
+#undef MIFWT_DECL
+
+bool stream_filter_supported(int L) {
+  return (L >= 2 && L <= 20 && (L & 1) == 0) || L == 24 || L == 32;
+}
+
+int stream_call(int dtype, int kind, const StreamCall& c) {
+#define MIFWT_CASE(n, L) case L: return stream_call_##n##_L##L(kind, c);
+  switch (dtype) {
+    case MIFWT_F32:
+      switch (c.filt_len) { MIFWT_STREAM_LENGTHS(MIFWT_CASE, f32) default: break; }
+      break;
+    case MIFWT_F64:
+      switch (c.filt_len) { MIFWT_STREAM_LENGTHS(MIFWT_CASE, f64) default: break; }
+      break;
+    case MIFWT_F16:
+      switch (c.filt_len) { MIFWT_STREAM_LENGTHS(MIFWT_CASE, f16) default: break; }
+      break;
+    default: break;
+  }
+#undef MIFWT_CASE
+  return MIFWT_ERR_UNSUPPORTED;
+}
+
+namespace {
+
+inline int64_t elem_size(int dtype) { return dtype == MIFWT_F64 ? 8 : (dtype == MIFWT_F16 ? 2 : 4); }
+
+// axes from..nd-1 form one dense run (innermost stride 1, each outer one = product of the inner extents)
+inline bool dense_under(const int64_t* stride, const int64_t* ext, int nd, int from) {
+  int64_t run = 1;
+  for (int a = nd - 1; a >= from; --a) {
+    if (stride[1 + a] != run) return false;
+    run *= ext[a];
+  }
+  return true;
+}
+
+inline void set3(int64_t dst[3], int64_t a, int64_t b, int64_t c) {
+  dst[0] = a;
+  dst[1] = b;
+  dst[2] = c;
+}
+
+// the 2-D problem of the depth slices of a 3-D level, writing / reading scratch [slices, 4, Ho, Wo]
+mifwt_level_desc plane_desc(const mifwt_level_desc* d, int64_t depth, bool* foldable) {
+  mifwt_level_desc p = *d;
+  const int64_t plane = d->coef_extent[1] * d->coef_extent[2];
+  p.ndim = 2;
+  for (int a = 0; a < 2; ++a) {
+    p.sig_extent[a] = d->sig_extent[1 + a];
+    p.coef_extent[a] = d->coef_extent[1 + a];
+    p.sig_stride[1 + a] = d->sig_stride[2 + a];
+  }
+  p.approx_stride[1] = p.detail_stride[1] = d->coef_extent[2];
+  p.approx_stride[2] = p.detail_stride[2] = 1;
+  p.approx_stride[0] = p.detail_stride[0] = 4 * plane;
+  *foldable = d->batch == 1 || d->sig_stride[0] == depth * d->sig_stride[1];
+  p.batch = *foldable ? d->batch * depth : depth;
+  p.sig_stride[0] = d->sig_stride[1];
+  return p;
+}
+
+}  // namespace
+
+bool rows_route_ok(const mifwt_level_desc* d, int direction) {
+  (void)direction;
+  if (!stream_filter_supported(d->filt_len)) return false;
+  const int nd = d->ndim;
+  if (d->sig_stride[nd] != 1 || d->approx_stride[nd] != 1 || d->detail_stride[nd] != 1) return false;
+  for (int i = 0; i <= nd; ++i)
+    if (d->sig_stride[i] < 0 || d->approx_stride[i] < 0 || d->detail_stride[i] < 0) return false;
+  int64_t rows = d->batch;
+  for (int a = 0; a < nd - 1; ++a) rows *= d->sig_extent[a] > d->coef_extent[a] ? d->sig_extent[a] : d->coef_extent[a];
+  if (rows > INT32_MAX / 4) return false;
+  // the last analysis pass writes / the first synthesis pass reads the caller's band tensors as
+  // [batch, axis 0, dense run of the remaining axes]
+  if (nd >= 2 && (!dense_under(d->approx_stride, d->coef_extent, nd, 1) || !dense_under(d->detail_stride, d->coef_extent, nd, 1)))
+    return false;
+  return true;
+}
+
+bool plane3_route_ok(const mifwt_level_desc* d, int direction) {
+  if (d->ndim != 3 || d->dtype != MIFWT_F32 || !rows_route_ok(d, direction)) return false;
+  bool foldable;
+  const mifwt_level_desc p = plane_desc(d, d->sig_extent[0], &foldable);
+  return direction == 0 ? dwt2_fwd_stream_supported(&p) : dwt2_inv_stream_supported(&p);
+}
+
+size_t plane3_ws_bytes(const mifwt_level_desc* d, int direction) {
+  (void)direction;  // analysis: [B, D, 4, Ho, Wo];  synthesis: [B, Dout, 4, Ho, Wo]
+  return (size_t)(4 * d->batch * d->sig_extent[0] * d->coef_extent[1] * d->coef_extent[2]) * sizeof(float);
+}
+
+size_t rows_ws_bytes(const mifwt_level_desc* d, int direction) {
+  const int nd = d->ndim;
+  int64_t total = 0;
+  if (direction == 0) {
+    // after transforming axes a..nd-1 (innermost first): 2^(nd-a) arrays [B, sig(0..a-1), coef(a..nd-1)]
+    for (int a = nd - 1; a >= 1; --a) {
+      int64_t e = d->batch;
+      for (int i = 0; i < nd; ++i) e *= i >= a ? d->coef_extent[i] : d->sig_extent[i];
+      total += e << (nd - a);
+    }
+  } else {
+    // after expanding axes 0..a (outermost first): 2^(nd-1-a) arrays [B, sig(0..a), coef(a+1..nd-1)]
+    for (int a = 0; a < nd - 1; ++a) {
+      int64_t e = d->batch;
+      for (int i = 0; i < nd; ++i) e *= i <= a ? d->sig_extent[i] : d->coef_extent[i];
+      total += e << (nd - 1 - a);
+    }
+  }
+  return (size_t)(total * elem_size(d->dtype));
+}
+
+// ---- ndim 3, f32 ----------------------------------------------------------------------------------------
+int plane3_fwd(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo,
+               const double* hi, void* ws, hipStream_t stream) {
+  const int64_t D = d->sig_extent[0], plane = d->coef_extent[1] * d->coef_extent[2];
+  float* scratch = static_cast<float*>(ws);  // [B, D, 4, Ho, Wo]
+  bool foldable;
+  const mifwt_level_desc p = plane_desc(d, D, &foldable);
+  const int64_t nb = foldable ? 1 : d->batch;
+  for (int64_t b = 0; b < nb; ++b) {
+    const float* xb = static_cast<const float*>(x) + b * d->sig_stride[0];
+    float* sb = scratch + b * D * 4 * plane;
+    void* det[3] = {sb + plane, sb + 2 * plane, sb + 3 * plane};
+    const int rc = dwt2_fwd_stream(&p, xb, sb, det, lo, hi, stream);
+    if (rc != MIFWT_OK) return rc;
+  }
+  StreamJob jobs[4];
+  for (int s = 0; s < 4; ++s) {  // plane band s (axes H, W) -> bands s (depth low) and 4 + s (depth high)
+    StreamJob& j = jobs[s];
+    memset(&j, 0, sizeof(j));
+    j.in0 = scratch + s * plane;
+    set3(j.in0_s, D * 4 * plane, 4 * plane, 0);
+    j.out0 = s == 0 ? approx : details[s - 1];
+    j.out1 = details[s + 4 - 1];
+    const int64_t* os = s == 0 ? d->approx_stride : d->detail_stride;
+    set3(j.out0_s, os[0], os[1], 0);
+    set3(j.out1_s, d->detail_stride[0], d->detail_stride[1], 0);
+  }
+  StreamCall c;
+  memset(&c, 0, sizeof(c));
+  c.filt_len = d->filt_len;
+  c.mode = d->mode;
+  c.jobs = jobs;
+  c.njobs = 4;
+  c.batch = d->batch;
+  c.n_in = D;
+  c.n_out = d->coef_extent[0];
+  c.inner = plane;
+  c.lo = lo;
+  c.hi = hi;
+  c.stream = stream;
+  return stream_call(MIFWT_F32, kOuterFwd, c);
+}
+
+int plane3_inv(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y, const double* lo,
+               const double* hi, void* ws, hipStream_t stream) {
+  const int64_t Dout = d->sig_extent[0], plane = d->coef_extent[1] * d->coef_extent[2];
+  float* scratch = static_cast<float*>(ws);  // [B, Dout, 4, Ho, Wo]
+  StreamJob jobs[4];
+  for (int s = 0; s < 4; ++s) {
+    StreamJob& j = jobs[s];
+    memset(&j, 0, sizeof(j));
+    j.in0 = s == 0 ? approx : details[s - 1];
+    j.in1 = details[s + 4 - 1];
+    const int64_t* is = s == 0 ? d->approx_stride : d->detail_stride;
+    set3(j.in0_s, is[0], is[1], 0);
+    set3(j.in1_s, d->detail_stride[0], d->detail_stride[1], 0);
+    j.out0 = scratch + s * plane;
+    set3(j.out0_s, Dout * 4 * plane, 4 * plane, 0);
+  }
+  StreamCall c;
+  memset(&c, 0, sizeof(c));
+  c.filt_len = d->filt_len;
+  c.jobs = jobs;
+  c.njobs = 4;
+  c.batch = d->batch;
+  c.n_in = d->coef_extent[0];
+  c.n_out = Dout;
+  c.inner = plane;
+  c.lo = lo;
+  c.hi = hi;
+  c.stream = stream;
+  int rc = stream_call(MIFWT_F32, kOuterInv, c);
+  if (rc != MIFWT_OK) return rc;
+  bool foldable;
+  const mifwt_level_desc p = plane_desc(d, Dout, &foldable);
+  const int64_t nb = foldable ? 1 : d->batch;
+  for (int64_t b = 0; b < nb; ++b) {
+    float* yb = static_cast<float*>(y) + b * d->sig_stride[0];
+    const float* sb = scratch + b * Dout * 4 * plane;
+    const void* det[3] = {sb + plane, sb + 2 * plane, sb + 3 * plane};
+    rc = dwt2_inv_stream(&p, sb, det, yb, lo, hi, stream);
+    if (rc != MIFWT_OK) return rc;
+  }
+  return MIFWT_OK;
+}
+
+// ---- any ndim / dtype: inner-axis pass + one outer-axis pass per further axis ------------------------------
+int rows_fwd(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo,
+             const double* hi, void* ws, hipStream_t stream) {
+  const int nd = d->ndim;
+  const int64_t esz = elem_size(d->dtype);
+  char* wsp = static_cast<char*>(ws);
+  const void* cur[8];  // current arrays, indexed by partial band bits; strides for (batch, axis 0.., axis nd-1)
+  int64_t cur_stride[8][4];
+  int ncur = 1;
+  cur[0] = x;
+  for (int i = 0; i <= nd; ++i) cur_stride[0][i] = d->sig_stride[i];
+  StreamCall c;
+  memset(&c, 0, sizeof(c));
+  c.filt_len = d->filt_len;
+  c.mode = d->mode;
+  c.lo = lo;
+  c.hi = hi;
+  c.stream = stream;
+  for (int pass = 0; pass < nd; ++pass) {
+    const int a = nd - 1 - pass;        // axis transformed in this pass (innermost first)
+    const int bit = 1 << (nd - 1 - a);  // its bit in the band index
+    const bool last = a == 0;
+    int64_t ext[4] = {d->batch, 1, 1, 1};  // extents of the arrays this pass WRITES
+    for (int i = 0; i < nd; ++i) ext[1 + i] = i >= a ? d->coef_extent[i] : d->sig_extent[i];
+    int64_t dense[4], elems = 1;
+    for (int i = nd; i >= 0; --i) {
+      dense[i] = elems;
+      elems *= ext[i];
+    }
+    void* nxt[8];
+    int64_t nxt_stride[8][4];
+    for (int s = 0; s < ncur; ++s)
+      for (int h = 0; h < 2; ++h) {
+        const int band = s | (h ? bit : 0);
+        if (last) {
+          nxt[band] = band == 0 ? approx : details[band - 1];
+          for (int i = 0; i <= nd; ++i) nxt_stride[band][i] = band == 0 ? d->approx_stride[i] : d->detail_stride[i];
+        } else {
+          nxt[band] = wsp;
+          wsp += elems * esz;
+          for (int i = 0; i <= nd; ++i) nxt_stride[band][i] = dense[i];
+        }
+      }
+    for (int s0 = 0; s0 < ncur; s0 += 4) {
+      StreamJob jobs[4];
+      const int nj = ncur - s0 < 4 ? ncur - s0 : 4;
+      for (int j = 0; j < nj; ++j) {
+        const int s = s0 + j;
+        StreamJob& jb = jobs[j];
+        memset(&jb, 0, sizeof(jb));
+        jb.in0 = cur[s];
+        jb.out0 = nxt[s];
+        jb.out1 = nxt[s | bit];
+        if (a == nd - 1) {  // inner pass: row dims = (batch, axes 0..nd-2), padded to three
+          for (int i = 0; i < 3; ++i) {
+            const bool used = i < nd;
+            jb.in0_s[i] = used ? cur_stride[s][i] : 0;
+            jb.out0_s[i] = used ? nxt_stride[s][i] : 0;
+            jb.out1_s[i] = used ? nxt_stride[s | bit][i] : 0;
+          }
+        } else {
+          // outer pass over axis a: batch = (batch, axes < a) folded — every array it touches is dense scratch
+          // (or, for a == 0, addressed by its own batch stride); inner = dense run of axes > a
+          const int hi_band = s | bit;
+          set3(jb.in0_s, a == 0 ? cur_stride[s][0] : d->sig_extent[a] * cur_stride[s][1 + a], cur_stride[s][1 + a], 0);
+          set3(jb.out0_s, a == 0 ? nxt_stride[s][0] : ext[1 + a] * nxt_stride[s][1 + a], nxt_stride[s][1 + a], 0);
+          set3(jb.out1_s, a == 0 ? nxt_stride[hi_band][0] : ext[1 + a] * nxt_stride[hi_band][1 + a], nxt_stride[hi_band][1 + a], 0);
+        }
+      }
+      c.jobs = jobs;
+      c.njobs = nj;
+      c.n_in = d->sig_extent[a];
+      c.n_out = d->coef_extent[a];
+      int rc;
+      if (a == nd - 1) {
+        for (int i = 0; i < 3; ++i) c.rows[i] = i < nd ? (i == 0 ? d->batch : d->sig_extent[i - 1]) : 1;
+        rc = stream_call(d->dtype, kInnerFwd, c);
+      } else {
+        c.batch = d->batch;
+        for (int i = 0; i < a; ++i) c.batch *= d->sig_extent[i];
+        c.inner = 1;
+        for (int i = a + 1; i < nd; ++i) c.inner *= d->coef_extent[i];
+        rc = stream_call(d->dtype, kOuterFwd, c);
+      }
+      if (rc != MIFWT_OK) return rc;
+    }
+    ncur *= 2;
+    for (int s = 0; s < ncur; ++s) {
+      cur[s] = nxt[s];
+      memcpy(cur_stride[s], nxt_stride[s], sizeof(int64_t) * 4);
+    }
+  }
+  return MIFWT_OK;
+}
+
+int rows_inv(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y, const double* lo,
+             const double* hi, void* ws, hipStream_t stream) {
+  const int nd = d->ndim;
+  const int64_t esz = elem_size(d->dtype);
+  const int nb = 1 << nd;
+  const void* cur[8];
+  int64_t cur_stride[8][4];
+  for (int s = 0; s < nb; ++s) {
+    cur[s] = s == 0 ? approx : details[s - 1];
+    for (int i = 0; i <= nd; ++i) cur_stride[s][i] = s == 0 ? d->approx_stride[i] : d->detail_stride[i];
+  }
+  char* wsp = static_cast<char*>(ws);
+  StreamCall c;
+  memset(&c, 0, sizeof(c));
+  c.filt_len = d->filt_len;
+  c.lo = lo;
+  c.hi = hi;
+  c.stream = stream;
+  int ncur = nb;
+  for (int a = 0; a < nd; ++a) {  // outermost axis first: its bit is the most significant of the remaining
+    const bool last = a == nd - 1;
+    const int nnext = ncur / 2;            // arrays pair up as (s, s + nnext): low / high along axis a
+    int64_t ext[4] = {d->batch, 1, 1, 1};  // extents of the arrays this pass WRITES
+    for (int i = 0; i < nd; ++i) ext[1 + i] = i <= a ? d->sig_extent[i] : d->coef_extent[i];
+    int64_t dense[4], elems = 1;
+    for (int i = nd; i >= 0; --i) {
+      dense[i] = elems;
+      elems *= ext[i];
+    }
+    void* nxt[4];
+    int64_t nxt_stride[4][4];
+    for (int s = 0; s < nnext; ++s) {
+      if (last) {
+        nxt[s] = y;
+        for (int i = 0; i <= nd; ++i) nxt_stride[s][i] = d->sig_stride[i];
+      } else {
+        nxt[s] = wsp;
+        wsp += elems * esz;
+        for (int i = 0; i <= nd; ++i) nxt_stride[s][i] = dense[i];
+      }
+    }
+    StreamJob jobs[4];
+    for (int s = 0; s < nnext; ++s) {
+      StreamJob& jb = jobs[s];
+      memset(&jb, 0, sizeof(jb));
+      jb.in0 = cur[s];
+      jb.in1 = cur[s + nnext];
+      jb.out0 = nxt[s];
+      if (last) {
+        for (int i = 0; i < 3; ++i) {
+          const bool used = i < nd;
+          jb.in0_s[i] = used ? cur_stride[s][i] : 0;
+          jb.in1_s[i] = used ? cur_stride[s + nnext][i] : 0;
+          jb.out0_s[i] = used ? nxt_stride[s][i] : 0;
+        }
+      } else {
+        // batch = (batch, axes < a) folded: for a > 0 every array is dense scratch with signal extents there
+        const int64_t* s0 = cur_stride[s];
+        const int64_t* s1 = cur_stride[s + nnext];
+        set3(jb.in0_s, a == 0 ? s0[0] : d->coef_extent[a] * s0[1 + a], s0[1 + a], 0);
+        set3(jb.in1_s, a == 0 ? s1[0] : d->coef_extent[a] * s1[1 + a], s1[1 + a], 0);
+        set3(jb.out0_s, a == 0 ? nxt_stride[s][0] : ext[1 + a] * nxt_stride[s][1 + a], nxt_stride[s][1 + a], 0);
+      }
+    }
+    c.jobs = jobs;
+    c.njobs = nnext;
+    c.n_in = d->coef_extent[a];
+    c.n_out = d->sig_extent[a];
+    int rc;
+    if (last) {
+      for (int i = 0; i < 3; ++i) c.rows[i] = i < nd ? (i == 0 ? d->batch : d->sig_extent[i - 1]) : 1;
+      rc = stream_call(d->dtype, kInnerInv, c);
+    } else {
+      c.batch = d->batch;
+      for (int i = 0; i < a; ++i) c.batch *= d->sig_extent[i];
+      c.inner = 1;
+      for (int i = a + 1; i < nd; ++i) c.inner *= d->coef_extent[i];
+      rc = stream_call(d->dtype, kOuterInv, c);
+    }
+    if (rc != MIFWT_OK) return rc;
+    ncur = nnext;
+    for (int s = 0; s < ncur; ++s) {
+      cur[s] = nxt[s];
+      memcpy(cur_stride[s], nxt_stride[s], sizeof(int64_t) * 4);
+    }
+  }
+  return MIFWT_OK;
+}
+
+}  // namespace mifwt

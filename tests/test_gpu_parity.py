@@ -285,3 +285,86 @@ def test_config3_wavedec3_db2():
     check_tree(got, want, TOL32, "wavedec3")
     rec = ptwt_amd.waverec3(got, "db2")
     assert (rec - x).abs().max().item() < 5e-6
+
+
+# ------------------------------------------------------------------ streaming single-axis routes (kernel ids 3-6)
+def test_stream_routes_selected():
+    kid = _engine.kernel_id
+    assert kid(1, torch.float32, "reflect", 8, 4, (1000,)) == 3 and kid(1, torch.float32, "zero", 8, 4, (1000,), direction=1) == 4
+    assert kid(1, torch.float64, "reflect", 2, 1, (4096,)) == 3
+    assert kid(3, torch.float32, "zero", 4, 8, (256, 256, 256)) == 5 and kid(3, torch.float32, "zero", 4, 8, (256, 256, 256), direction=1) == 6
+    assert kid(3, torch.float64, "zero", 4, 2, (33, 34, 35)) == 3  # f64: inner pass + two outer passes
+    assert kid(2, torch.float64, "reflect", 8, 2, (64, 64)) == 3
+    assert kid(2, torch.float32, "symmetric", 32, 2, (300, 300)) == 3  # sym16: beyond the fused 2-D envelope
+    assert kid(2, torch.float32, "symmetric", 102, 2, (300, 300)) == 0  # coif17: generic passes
+
+
+STREAM_WAVELETS = ["haar", "db2", "db3", "db4", "db6", "db8", "db9", "db10", "db12", "sym16"]  # L = 2 .. 32
+
+
+@pytest.mark.parametrize("wavelet", STREAM_WAVELETS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_stream_axis_kernels_vs_oracle(wavelet, dtype):
+    """1-D (inner-axis kernels), 2-D f64 / long filters (inner + outer pass) and 3-D (f32: fused planes + depth pass,
+    f64: inner + two outer passes) against the fp64 oracle, every boundary mode, odd extents, ragged strips."""
+    rng = np.random.default_rng(len(wavelet) * 13 + (dtype == torch.float64))
+    flen = len(O.filter_bank(wavelet)[0])
+    tol = TOL32 if dtype == torch.float32 else TOL64
+    rt = 2e-6 if dtype == torch.float32 else 1e-9
+    shapes = {1: [(3, 1027), (1, 4 * flen + 1), (5, 2 * flen)], 2: [(2, 67, 3 * flen + 70)], 3: [(2, 2 * flen + 3, 2 * flen + 6, 2 * flen + 9)]}
+    fns = {1: ("wavedec", "waverec", O.wavedec), 2: ("wavedec2", "waverec2", O.wavedec2), 3: ("wavedec3", "waverec3", O.wavedec3)}
+    for nd, shape_list in shapes.items():
+        fn, rec, ofn = fns[nd]
+        for shape in shape_list:
+            x = rng.standard_normal(shape)
+            xg = torch.from_numpy(x).to(dtype).to(dev())
+            for mode in MODES:
+                try:
+                    want = ofn(x, wavelet, mode=mode, level=2 if min(shape[1:]) >= 3 * flen else 1)
+                except RuntimeError:
+                    continue
+                got = getattr(ptwt_amd, fn)(xg, wavelet, mode=mode, level=2 if min(shape[1:]) >= 3 * flen else 1)
+                check_tree(got, want, tol, f"{fn} {wavelet} {mode} {shape} {dtype}")
+                back = getattr(ptwt_amd, rec)(got, wavelet)
+                sl = tuple(slice(0, s) for s in shape)
+                assert G.relerr(to_np(back[sl]), x) < rt, (fn, wavelet, mode, shape)
+
+
+def test_stream_equals_generic():
+    for shape, fn, rec in [((4, 1003), "wavedec", "waverec"), ((2, 37, 41, 45), "wavedec3", "waverec3")]:
+        x = torch.randn(*shape, device=dev())
+        for mode in MODES:
+            fast = getattr(ptwt_amd, fn)(x, "db3", mode=mode, level=2)
+            yf = getattr(ptwt_amd, rec)(fast, "db3")
+            _engine.set_option(_engine.OPT_FORCE_GENERIC, 1)
+            try:
+                slow = getattr(ptwt_amd, fn)(x, "db3", mode=mode, level=2)
+                ys = getattr(ptwt_amd, rec)(slow, "db3")
+            finally:
+                _engine.set_option(_engine.OPT_FORCE_GENERIC, 0)
+            for (n, a), (_, b) in zip(G.flatten_coeffs(fast), G.flatten_coeffs(slow)):
+                assert G.relerr(to_np(a), to_np(b)) < 5e-7, (fn, mode, n)
+            assert G.relerr(to_np(yf), to_np(ys)) < 5e-7, (fn, mode)
+
+
+def test_half_storage_extension():
+    """float16 storage / float32 arithmetic (C ABI MIFWT_F16; BASELINE configs[4] dtype).  The reference rejects
+    float16, so the oracle is the fp64 transform of the fp16-quantised input; tolerance = fp16 output rounding
+    (5e-4 norm-wise per sub-band)."""
+    x = torch.randn(2, 200, 232).to(torch.float16)
+    with pytest.raises(ValueError):
+        ptwt_amd.wavedec2(x.to(dev()), "sym16", level=1)
+    ptwt_amd.set_half_storage(True)
+    try:
+        for wavelet, fn, ofn in [("sym16", "fswavedec2", O.fswavedec2), ("db4", "wavedec2", O.wavedec2)]:
+            want = ofn(x.double().numpy(), wavelet, mode="symmetric", level=2)
+            got = getattr(ptwt_amd, fn)(x.to(dev()), wavelet, mode="symmetric", level=2)
+            for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(want)):
+                assert a.dtype == torch.float16
+                assert G.relerr(to_np(a.double()), b) < 5e-4, (wavelet, n)
+        x1 = torch.randn(3, 1001).to(torch.float16)
+        c = ptwt_amd.wavedec(x1.to(dev()), "db4", level=2)
+        y = ptwt_amd.waverec(c, "db4")
+        assert G.relerr(to_np(y[..., :1001].double()), x1.double().numpy()) < 2e-3
+    finally:
+        ptwt_amd.set_half_storage(False)

@@ -211,10 +211,16 @@ def test_cabi_descriptor_validation_and_dispatch():
     d = _engine.LevelDesc()
     assert lib.mifwt_kernel_id(ctypes.byref(d), 0) == -1  # ndim = 0
     assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (1024, 1024)) == 1  # fused 2-D analysis
-    assert _engine.kernel_id(2, torch.float64, "reflect", 8, 64, (1024, 1024)) == 0  # f64 -> generic
-    assert _engine.kernel_id(2, torch.float32, "reflect", 32, 4, (512, 512)) == 0    # L = 32 -> generic
-    assert _engine.kernel_id(1, torch.float64, "zero", 2, 1, (4096,)) == 0
-    # generic 3-D level needs scratch, the fused 2-D level none
+    assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (1024, 1024), direction=1) == 2  # fused 2-D synthesis
+    assert _engine.kernel_id(2, torch.float64, "reflect", 8, 64, (1024, 1024)) == 3  # f64 -> streaming axis passes
+    assert _engine.kernel_id(2, torch.float32, "reflect", 32, 4, (512, 512)) == 3    # L = 32 -> streaming axis passes
+    assert _engine.kernel_id(1, torch.float64, "zero", 2, 1, (4096,)) == 3
+    assert _engine.kernel_id(1, torch.float32, "zero", 8, 1, (4096,), direction=1) == 4
+    assert _engine.kernel_id(3, torch.float32, "zero", 4, 8, (256, 256, 256)) == 5   # fused planes + depth pass
+    assert _engine.kernel_id(3, torch.float32, "zero", 4, 8, (256, 256, 256), direction=1) == 6
+    assert _engine.kernel_id(2, torch.float32, "reflect", 102, 4, (512, 512)) == 0   # coif17 -> generic passes
+    assert _engine.kernel_id(2, torch.float32, "reflect", 22, 4, (512, 512)) == 0    # L not in the streaming set
+    # a level described without strides (not unit innermost) is generic and needs scratch, the fused 2-D level none
     d = _engine.LevelDesc()
     d.ndim, d.dtype, d.mode, d.filt_len, d.batch = 3, 0, 0, 4, 2
     for a in range(3):
