@@ -37,6 +37,10 @@ WORKLOADS = {
     "wavedec2_db4_L3_64x1024x1024_f32": ("wavedec2", (64, 1024, 1024), "db4", 3, "reflect", torch.float32),
     "wavedec3_db2_L3_8x256x256x256_f32": ("wavedec3", (8, 256, 256, 256), "db2", 3, "zero", torch.float32),
     "wavedec2_db8_L4_64x4096x4096_f32": ("wavedec2", (64, 4096, 4096), "db8", 4, "reflect", torch.float32),
+    # BASELINE configs[4] at a 32-image slice of the 128 (the path is linear in the batch): f16 storage extension
+    "fswavedec2_sym16_L5_32x8192x8192_f16": ("fswavedec2", (32, 8192, 8192), "sym16", 5, "reflect", torch.float16),
+    # the reference's own 1-D speed test shape (examples/speed_tests/timeitconv_1d.py:16-36)
+    "wavedec_db5_L10_32x1000000_f32": ("wavedec", (32, 1000000), "db5", 10, "periodic", torch.float32),
 }
 
 
@@ -167,9 +171,11 @@ def main():
 
     fn_name, shape, wavelet, level, mode, dtype = WORKLOADS[args.workload]
     fn = getattr(ptwt_amd, fn_name)
+    if dtype == torch.float16:
+        ptwt_amd.set_half_storage(True)
     flen = len(ptwt_amd._wavelets.as_wavelet(wavelet))
     torch.manual_seed(1234 + rank)
-    bufs = [torch.randn(*shape, dtype=dtype, device=dev) for _ in range(max(1, args.buffers))]
+    bufs = [torch.randn(*shape, dtype=torch.float32, device=dev).to(dtype) for _ in range(max(1, args.buffers))]
 
     def step(i):
         return fn(bufs[i % len(bufs)], wavelet, mode=mode, level=level)
@@ -229,7 +235,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if dtype == torch.float32 else "f64",
+            "dtype": {torch.float32: "f32", torch.float64: "f64", torch.float16: "f16 storage / f32 arithmetic"}[dtype],
             "data": "synthetic (torch.randn, %d rotating input buffers resident in HBM)" % len(bufs),
             "config": {
                 "workload": args.workload,

@@ -84,10 +84,6 @@ def _check(rc: int) -> None:
         raise RuntimeError(f"libmifwt: {msg} (code {rc})")
 
 
-def _taps_array(taps: Sequence[float]):
-    return (ctypes.c_double * len(taps))(*taps)
-
-
 def _require_gpu(t: torch.Tensor) -> None:
     if not t.is_cuda:
         raise RuntimeError(
@@ -100,6 +96,8 @@ def _require_gpu(t: torch.Tensor) -> None:
 # appends (tag, kernel_id, start_event, end_event) recorded on the launch stream.
 level_events: Optional[list] = None
 
+ROW_ALIGN = int(os.environ.get("MIFWT_ROW_ALIGN", "1"))  # bytes; 1 = dense rows
+
 OPT_FORCE_GENERIC = 0
 OPT_ROWS_PER_CHUNK = 1
 OPT_PREFETCH_PAIRS = 2
@@ -110,28 +108,61 @@ OPT_NT_STORE = 4
 def set_option(key: int, value: int) -> None:
     """Library-wide test/diagnostic switches (e.g. ``OPT_FORCE_GENERIC`` to bypass the fused kernels)."""
     _check(load_library().mifwt_set_option(key, value))
+    _plans.clear()  # cached plans hold the scratch size and kernel id of the routing that was in force
+
+
+class _Plan:
+    """Everything about one level that depends only on geometry (extents, strides, dtype, mode, filter length):
+    the filled ``mifwt_level_desc``, the output allocation, scratch size and kernel id.  Cached, so a repeated
+    call costs one ``torch.empty`` + one C call per level on the host."""
+
+    __slots__ = ("desc", "ref", "alloc_shape", "view_last", "nb", "plane_bytes", "ws_bytes", "kid", "empty", "ptrs")
+
+
+_plans: dict = {}
+_taps_cache: dict = {}
+
+
+def _taps_array(taps: Sequence[float]):
+    key = tuple(taps)
+    arr = _taps_cache.get(key)
+    if arr is None:
+        if len(_taps_cache) > 512:
+            _taps_cache.clear()
+        arr = _taps_cache[key] = (ctypes.c_double * len(key))(*key)
+    return arr
+
+
+def _raw_stream(dev_index: int) -> int:
+    return torch._C._cuda_getCurrentRawStream(dev_index)
 
 
 class HipLevelEngine:
     """One decomposition / reconstruction level for a folded batch, on the GPU, through the C ABI."""
 
-    def analysis(self, x: torch.Tensor, dec_lo: Sequence[float], dec_hi: Sequence[float], mode_id: int) -> torch.Tensor:
-        """``x``: [B, N_0..N_{n-1}] (any strides) -> one buffer [B, 2^n, M_0..] whose plane ``s`` is band ``s``
-        (bit (n-1-a) of s set <=> high-pass along axis a; plane 0 = approximation)."""
-        _require_gpu(x)
+    @staticmethod
+    def _analysis_plan(x: torch.Tensor, flen: int, mode_id: int) -> _Plan:
         lib = load_library()
         ndim = x.dim() - 1
-        flen = len(dec_lo)
         batch = x.shape[0]
         sig = [int(n) for n in x.shape[1:]]
         coef = [(n + 2 * ((2 * flen - 3) // 2) + (n % 2) - flen) // 2 + 1 for n in sig]
         nb = 1 << ndim
-        buf = torch.empty((batch, nb, *coef), dtype=x.dtype, device=x.device)
-        if buf.numel() == 0:
-            return buf
+        # rows of the sub-band planes can be made to start on ROW_ALIGN-byte boundaries (pitch padded, the
+        # returned bands are views of the padded buffer).  Measured on MI355X: no gain at 16 B, a loss at 128 B
+        # (config 2), so the default is dense rows.
+        esz = x.element_size()
+        pitch = -(-coef[-1] * esz // ROW_ALIGN) * ROW_ALIGN // esz if ROW_ALIGN > esz and ndim >= 2 else coef[-1]
+        p = _Plan()
+        p.alloc_shape = (batch, nb, *coef[:-1], pitch)
+        p.view_last = coef[-1] if pitch != coef[-1] else None
+        p.nb = nb
+        p.empty = batch == 0 or min(coef) == 0
         d = LevelDesc()
         d.ndim, d.dtype, d.mode, d.filt_len, d.batch = ndim, _DTYPE_IDS[x.dtype], mode_id, flen, batch
-        bstride = buf.stride()
+        bstride = [1] * (ndim + 2)
+        for i in range(ndim, -1, -1):
+            bstride[i] = bstride[i + 1] * p.alloc_shape[i + 1]
         for a in range(ndim):
             d.sig_extent[a] = sig[a]
             d.coef_extent[a] = coef[a]
@@ -139,11 +170,38 @@ class HipLevelEngine:
             d.approx_stride[1 + a] = d.detail_stride[1 + a] = bstride[2 + a]
         d.sig_stride[0] = x.stride(0)
         d.approx_stride[0] = d.detail_stride[0] = bstride[0]
+        p.desc = d
+        p.ref = ctypes.byref(d)
+        p.plane_bytes = bstride[1] * esz
+        p.ptrs = (ctypes.c_void_p * (nb - 1))()
+        p.ws_bytes = 0 if p.empty else lib.mifwt_workspace_bytes(p.ref, 0)
+        p.kid = lib.mifwt_kernel_id(p.ref, 0)
+        return p
+
+    def analysis(self, x: torch.Tensor, dec_lo: Sequence[float], dec_hi: Sequence[float], mode_id: int) -> torch.Tensor:
+        """``x``: [B, N_0..N_{n-1}] (any strides) -> one buffer [B, 2^n, M_0..] whose plane ``s`` is band ``s``
+        (bit (n-1-a) of s set <=> high-pass along axis a; plane 0 = approximation)."""
+        _require_gpu(x)
+        flen = len(dec_lo)
+        key = (x.shape, x.stride(), x.dtype, mode_id, flen, ROW_ALIGN)
+        p = _plans.get(key)
+        if p is None:
+            if len(_plans) > 4096:
+                _plans.clear()
+            p = _plans[key] = self._analysis_plan(x, flen, mode_id)
+        buf = torch.empty(p.alloc_shape, dtype=x.dtype, device=x.device)
+        if p.view_last is not None:
+            buf = buf[..., : p.view_last]
+        if p.empty:
+            return buf
         base = buf.data_ptr()
-        plane = bstride[1] * buf.element_size()
-        details = (ctypes.c_void_p * (nb - 1))(*[base + s * plane for s in range(1, nb)])
-        self._run(lib, d, 0, x, lambda ws, wsb, stream: lib.mifwt_dwt_fwd(
-            ctypes.byref(d), x.data_ptr(), base, details, _taps_array(dec_lo), _taps_array(dec_hi), ws, wsb, stream))
+        ptrs = p.ptrs
+        for s in range(1, p.nb):
+            ptrs[s - 1] = base + s * p.plane_bytes
+        lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
+        lib = _lib
+        xp = x.data_ptr()
+        self._run(p, 0, x, lambda ws, wsb, stream: lib.mifwt_dwt_fwd(p.ref, xp, base, ptrs, lo, hi, ws, wsb, stream))
         return buf
 
     def synthesis(self, approx: torch.Tensor, details: List[torch.Tensor], rec_lo: Sequence[float],
@@ -158,44 +216,60 @@ class HipLevelEngine:
         if y.numel() == 0:
             return y
         ref_stride = details[0].stride()
-        details = [t if t.stride() == ref_stride else t.contiguous() for t in details]
-        if any(t.stride() != details[0].stride() for t in details):
+        if any(t.stride() != ref_stride for t in details):
             details = [t.contiguous() for t in details]
-        d = LevelDesc()
-        d.ndim, d.dtype, d.mode, d.filt_len, d.batch = ndim, _DTYPE_IDS[approx.dtype], 0, flen, batch
-        for a in range(ndim):
-            d.sig_extent[a] = int(out_extent[a])
-            d.coef_extent[a] = int(approx.shape[1 + a])
-        for a in range(ndim + 1):
-            d.sig_stride[a] = y.stride(a)
-            d.approx_stride[a] = approx.stride(a)
-            d.detail_stride[a] = details[0].stride(a)
-        dptr = (ctypes.c_void_p * len(details))(*[t.data_ptr() for t in details])
-        self._run(lib, d, 1, approx, lambda ws, wsb, stream: lib.mifwt_dwt_inv(
-            ctypes.byref(d), approx.data_ptr(), dptr, y.data_ptr(), _taps_array(rec_lo), _taps_array(rec_hi), ws, wsb, stream))
+            ref_stride = details[0].stride()
+        key = ("inv", approx.shape, approx.stride(), ref_stride, approx.dtype, flen, tuple(out_extent))
+        p = _plans.get(key)
+        if p is None:
+            if len(_plans) > 4096:
+                _plans.clear()
+            p = _Plan()
+            d = LevelDesc()
+            d.ndim, d.dtype, d.mode, d.filt_len, d.batch = ndim, _DTYPE_IDS[approx.dtype], 0, flen, batch
+            for a in range(ndim):
+                d.sig_extent[a] = int(out_extent[a])
+                d.coef_extent[a] = int(approx.shape[1 + a])
+            for a in range(ndim + 1):
+                d.sig_stride[a] = y.stride(a)
+                d.approx_stride[a] = approx.stride(a)
+                d.detail_stride[a] = ref_stride[a]
+            p.desc = d
+            p.ref = ctypes.byref(d)
+            p.ptrs = (ctypes.c_void_p * len(details))()
+            p.ws_bytes = lib.mifwt_workspace_bytes(p.ref, 1)
+            p.kid = lib.mifwt_kernel_id(p.ref, 1)
+            _plans[key] = p
+        ptrs = p.ptrs
+        for i, t in enumerate(details):
+            ptrs[i] = t.data_ptr()
+        lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
+        ap, yp = approx.data_ptr(), y.data_ptr()
+        self._run(p, 1, approx, lambda ws, wsb, stream: lib.mifwt_dwt_inv(p.ref, ap, ptrs, yp, lo, hi, ws, wsb, stream))
         return y
 
     @staticmethod
-    def _run(lib, d: LevelDesc, direction: int, anchor: torch.Tensor, call) -> None:
+    def _run(p: _Plan, direction: int, anchor: torch.Tensor, call) -> None:
         dev = anchor.device
         if dev.index is not None and dev.index != torch.cuda.current_device():
             with torch.cuda.device(dev):
-                return HipLevelEngine._run(lib, d, direction, anchor, call)
-        wsb = lib.mifwt_workspace_bytes(ctypes.byref(d), direction)
+                return HipLevelEngine._run(p, direction, anchor, call)
+        wsb = p.ws_bytes
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
-        stream = torch.cuda.current_stream(dev)
-        ev = None
-        if level_events is not None:
+        if level_events is None:
+            rc = call(ws.data_ptr() if ws is not None else None, wsb, _raw_stream(dev.index if dev.index is not None else torch.cuda.current_device()))
+        else:
+            stream = torch.cuda.current_stream(dev)
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(stream)
-        rc = call(ws.data_ptr() if ws is not None else None, wsb, stream.cuda_stream)
-        if ev is not None:
+            rc = call(ws.data_ptr() if ws is not None else None, wsb, stream.cuda_stream)
             ev[1].record(stream)
-            kid = lib.mifwt_kernel_id(ctypes.byref(d), direction)
-            level_events.append((("inv" if direction else "fwd"), kid, tuple(d.sig_extent[: d.ndim]), ev[0], ev[1]))
-        _check(rc)
-        if ws is not None:
-            ws.record_stream(stream)  # scratch is released to the allocator only after the level has run
+            d = p.desc
+            level_events.append((("inv" if direction else "fwd"), p.kid, tuple(d.sig_extent[: d.ndim]), ev[0], ev[1]))
+        if rc != 0:
+            _check(rc)
+        # the scratch block returns to the caching allocator when `ws` dies; the allocator only hands it to
+        # later work on the SAME stream (stream-ordered reuse), so the level that is still queued keeps it intact
 
 
 def kernel_id(ndim: int, dtype: torch.dtype, mode: str, filt_len: int, batch: int, sig_extent: Sequence[int],
