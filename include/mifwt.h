@@ -103,7 +103,23 @@ int mifwt_dwt_inv(const mifwt_level_desc* desc, const void* approx, const void* 
                   const double* rec_lo, const double* rec_hi, void* workspace, size_t workspace_bytes,
                   void* stream);
 
-/* Scratch bytes one call needs (0 on the fused paths).  direction: 0 = analysis, 1 = synthesis. */
+/* Adjoints (transposes) of the two level maps, for reverse-mode differentiation.  The reference gets them from
+ * ATen autograd through F.pad / _pad_symmetric + F.conv{1,2,3}d and torch.stack + F.conv_transpose{1,2,3}d
+ * (same call sites as above); here they are explicit entry points that take the SAME descriptor as the
+ * forward call they differentiate.
+ *   mifwt_dwt_fwd_adjoint: g_x = A^T (g_approx, g_details), A = the analysis level incl. its boundary extension
+ *       (the halo of the transposed convolution is folded back through the boundary index map).
+ *   mifwt_dwt_inv_adjoint: (g_approx, g_details) = S^T g_y, S = the (cropped) synthesis level.
+ * Taps are the forward call's taps (dec_* resp. rec_*), PyWavelets order. */
+int mifwt_dwt_fwd_adjoint(const mifwt_level_desc* desc, const void* g_approx, const void* const* g_details, void* g_x,
+                          const double* dec_lo, const double* dec_hi, void* workspace, size_t workspace_bytes,
+                          void* stream);
+int mifwt_dwt_inv_adjoint(const mifwt_level_desc* desc, const void* g_y, void* g_approx, void* const* g_details,
+                          const double* rec_lo, const double* rec_hi, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
+/* Scratch bytes one call needs (0 on the fused paths).  direction: 0 = analysis, 1 = synthesis,
+ * 2 = mifwt_dwt_fwd_adjoint, 3 = mifwt_dwt_inv_adjoint (same numbering for mifwt_kernel_id). */
 size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
 
 /* Which kernel family a call would dispatch to (tests use it to assert the fast path is the one that ran);

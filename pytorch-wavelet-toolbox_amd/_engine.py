@@ -70,6 +70,10 @@ def load_library() -> ctypes.CDLL:
     lib.mifwt_dwt_fwd.argtypes = [desc_p, vp, vp, ctypes.POINTER(vp), dbl_p, dbl_p, vp, ctypes.c_size_t, vp]
     lib.mifwt_dwt_inv.restype = ctypes.c_int
     lib.mifwt_dwt_inv.argtypes = [desc_p, vp, ctypes.POINTER(vp), vp, dbl_p, dbl_p, vp, ctypes.c_size_t, vp]
+    lib.mifwt_dwt_fwd_adjoint.restype = ctypes.c_int
+    lib.mifwt_dwt_fwd_adjoint.argtypes = [desc_p, vp, ctypes.POINTER(vp), vp, dbl_p, dbl_p, vp, ctypes.c_size_t, vp]
+    lib.mifwt_dwt_inv_adjoint.restype = ctypes.c_int
+    lib.mifwt_dwt_inv_adjoint.argtypes = [desc_p, vp, vp, ctypes.POINTER(vp), dbl_p, dbl_p, vp, ctypes.c_size_t, vp]
     lib.mifwt_set_option.restype = ctypes.c_int
     lib.mifwt_set_option.argtypes = [ctypes.c_int, ctypes.c_int]
     if lib.mifwt_abi_version() != ABI_VERSION:
@@ -248,6 +252,94 @@ class HipLevelEngine:
         self._run(p, 1, approx, lambda ws, wsb, stream: lib.mifwt_dwt_inv(p.ref, ap, ptrs, yp, lo, hi, ws, wsb, stream))
         return y
 
+    # ---- adjoints (reverse-mode differentiation; C ABI mifwt_dwt_fwd_adjoint / mifwt_dwt_inv_adjoint) -------------
+    def analysis_adjoint(self, g_buf: torch.Tensor, sig_shape: Sequence[int], dec_lo: Sequence[float],
+                         dec_hi: Sequence[float], mode_id: int) -> torch.Tensor:
+        """Transpose of :meth:`analysis`: ``g_buf`` [B, 2^n, M_0..] (gradient of the level buffer) -> gradient of
+        the level input, dense [B, *sig_shape]."""
+        _require_gpu(g_buf)
+        lib = load_library()
+        if g_buf.stride(-1) != 1:
+            g_buf = g_buf.contiguous()
+        ndim = g_buf.dim() - 2
+        flen = len(dec_lo)
+        batch = g_buf.shape[0]
+        g_x = torch.empty((batch, *sig_shape), dtype=g_buf.dtype, device=g_buf.device)
+        if g_x.numel() == 0:
+            return g_x
+        key = ("fwd_adj", g_buf.shape, g_buf.stride(), tuple(sig_shape), g_buf.dtype, mode_id, flen)
+        p = _plans.get(key)
+        if p is None:
+            p = _Plan()
+            d = LevelDesc()
+            d.ndim, d.dtype, d.mode, d.filt_len, d.batch = ndim, _DTYPE_IDS[g_buf.dtype], mode_id, flen, batch
+            for a in range(ndim):
+                d.sig_extent[a] = int(sig_shape[a])
+                d.coef_extent[a] = int(g_buf.shape[2 + a])
+                d.sig_stride[1 + a] = g_x.stride(1 + a)
+                d.approx_stride[1 + a] = d.detail_stride[1 + a] = g_buf.stride(2 + a)
+            d.sig_stride[0] = g_x.stride(0)
+            d.approx_stride[0] = d.detail_stride[0] = g_buf.stride(0)
+            p.desc, p.ref = d, ctypes.byref(d)
+            p.nb = 1 << ndim
+            p.plane_bytes = g_buf.stride(1) * g_buf.element_size()
+            p.ptrs = (ctypes.c_void_p * (p.nb - 1))()
+            p.ws_bytes = lib.mifwt_workspace_bytes(p.ref, 2)
+            p.kid = lib.mifwt_kernel_id(p.ref, 2)
+            _plans[key] = p
+        base = g_buf.data_ptr()
+        ptrs = p.ptrs
+        for s in range(1, p.nb):
+            ptrs[s - 1] = base + s * p.plane_bytes
+        lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
+        gp = g_x.data_ptr()
+        self._run(p, 2, g_buf, lambda ws, wsb, stream: lib.mifwt_dwt_fwd_adjoint(p.ref, base, ptrs, gp, lo, hi, ws, wsb, stream))
+        return g_x
+
+    def synthesis_adjoint(self, g_y: torch.Tensor, coef_shape: Sequence[int], rec_lo: Sequence[float],
+                          rec_hi: Sequence[float]) -> torch.Tensor:
+        """Transpose of :meth:`synthesis`: ``g_y`` [B, *out_extent] -> one buffer [B, 2^n, *coef_shape] whose plane
+        ``s`` is the gradient of band ``s`` (plane 0: the approximation)."""
+        _require_gpu(g_y)
+        lib = load_library()
+        if g_y.stride(-1) != 1:
+            g_y = g_y.contiguous()
+        ndim = g_y.dim() - 1
+        flen = len(rec_lo)
+        batch = g_y.shape[0]
+        nb = 1 << ndim
+        g_buf = torch.empty((batch, nb, *coef_shape), dtype=g_y.dtype, device=g_y.device)
+        if g_buf.numel() == 0:
+            return g_buf
+        key = ("inv_adj", g_y.shape, g_y.stride(), tuple(coef_shape), g_y.dtype, flen)
+        p = _plans.get(key)
+        if p is None:
+            p = _Plan()
+            d = LevelDesc()
+            d.ndim, d.dtype, d.mode, d.filt_len, d.batch = ndim, _DTYPE_IDS[g_y.dtype], 0, flen, batch
+            for a in range(ndim):
+                d.sig_extent[a] = int(g_y.shape[1 + a])
+                d.coef_extent[a] = int(coef_shape[a])
+                d.sig_stride[1 + a] = g_y.stride(1 + a)
+                d.approx_stride[1 + a] = d.detail_stride[1 + a] = g_buf.stride(2 + a)
+            d.sig_stride[0] = g_y.stride(0)
+            d.approx_stride[0] = d.detail_stride[0] = g_buf.stride(0)
+            p.desc, p.ref = d, ctypes.byref(d)
+            p.nb = nb
+            p.plane_bytes = g_buf.stride(1) * g_buf.element_size()
+            p.ptrs = (ctypes.c_void_p * (nb - 1))()
+            p.ws_bytes = lib.mifwt_workspace_bytes(p.ref, 3)
+            p.kid = lib.mifwt_kernel_id(p.ref, 3)
+            _plans[key] = p
+        base = g_buf.data_ptr()
+        ptrs = p.ptrs
+        for s in range(1, nb):
+            ptrs[s - 1] = base + s * p.plane_bytes
+        lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
+        yp = g_y.data_ptr()
+        self._run(p, 3, g_y, lambda ws, wsb, stream: lib.mifwt_dwt_inv_adjoint(p.ref, yp, base, ptrs, lo, hi, ws, wsb, stream))
+        return g_buf
+
     @staticmethod
     def _run(p: _Plan, direction: int, anchor: torch.Tensor, call) -> None:
         dev = anchor.device
@@ -265,7 +357,7 @@ class HipLevelEngine:
             rc = call(ws.data_ptr() if ws is not None else None, wsb, stream.cuda_stream)
             ev[1].record(stream)
             d = p.desc
-            level_events.append((("inv" if direction else "fwd"), p.kid, tuple(d.sig_extent[: d.ndim]), ev[0], ev[1]))
+            level_events.append((("fwd", "inv", "fwd_adj", "inv_adj")[direction], p.kid, tuple(d.sig_extent[: d.ndim]), ev[0], ev[1]))
         if rc != 0:
             _check(rc)
         # the scratch block returns to the caching allocator when `ws` dies; the allocator only hands it to

@@ -19,6 +19,58 @@ from .constants import WaveletDetailTuple2d, supported_dtypes
 
 AxisHint = Union[int, Sequence[int], None]
 
+
+# ------------------------------------------------------------------------------------------ autograd
+class _AnalysisLevel(torch.autograd.Function):
+    """One analysis level as a differentiable op w.r.t. its input.  The reference is differentiable because it is
+    built from ATen ops (F.pad + F.conv*d, src/ptwt/conv_transform.py:135-139 and the 2-D / 3-D twins); here the
+    backward is the explicit adjoint kernel (C ABI ``mifwt_dwt_fwd_adjoint``).  Filter taps are constants."""
+
+    @staticmethod
+    def forward(ctx, x, dec_lo, dec_hi, mode_id):
+        ctx.meta = (tuple(x.shape[1:]), dec_lo, dec_hi, mode_id)
+        return _engine.ENGINE.analysis(x, dec_lo, dec_hi, mode_id)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_buf):
+        sig_shape, dec_lo, dec_hi, mode_id = ctx.meta
+        return _engine.ENGINE.analysis_adjoint(g_buf, sig_shape, dec_lo, dec_hi, mode_id), None, None, None
+
+
+class _SynthesisLevel(torch.autograd.Function):
+    """One synthesis level, differentiable w.r.t. the approximation and every detail band (backward:
+    ``mifwt_dwt_inv_adjoint``; reference: autograd through torch.stack + F.conv_transpose*d + crop)."""
+
+    @staticmethod
+    def forward(ctx, rec_lo, rec_hi, out_ext, approx, *details):
+        ctx.meta = (tuple(approx.shape[1:]), rec_lo, rec_hi, len(details))
+        return _engine.ENGINE.synthesis(approx, list(details), rec_lo, rec_hi, out_ext)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_y):
+        coef_shape, rec_lo, rec_hi, ndet = ctx.meta
+        g = _engine.ENGINE.synthesis_adjoint(g_y, coef_shape, rec_lo, rec_hi)
+        return (None, None, None) + tuple(g[:, s] for s in range(ndet + 1))
+
+
+_warned_tap_grad = False
+
+
+def _warn_tap_grad(wavelet) -> None:
+    """Taps travel by value in the kernel arguments: gradients w.r.t. learnable filter taps are not propagated."""
+    global _warned_tap_grad
+    if _warned_tap_grad or isinstance(wavelet, str) or not torch.is_grad_enabled():
+        return
+    bank = wavelet if isinstance(wavelet, tuple) else getattr(wavelet, "filter_bank", ())
+    if any(isinstance(t, torch.Tensor) and t.requires_grad for t in bank):
+        import warnings
+
+        _warned_tap_grad = True
+        warnings.warn("ptwt_amd: filter taps are treated as constants; gradients w.r.t. learnable wavelet taps are not "
+                      "propagated (gradients w.r.t. the data are).", stacklevel=3)
+
 # detail-band order of each public container, as band indices of the engine (bit (n-1-a) <=> axis a high-pass)
 _KEYS_ND = {
     2: ("ad", "da", "dd"),
@@ -137,6 +189,7 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
     layout = _Layout(data, ndim, axes)
     x = layout.fold(data)
     dec_lo, dec_hi, _, _ = host_taps(wavelet)
+    _warn_tap_grad(wavelet)
     flen = len(dec_lo)
     if level is None:
         level = dwtn_max_level(x.shape[1:], flen)
@@ -145,7 +198,10 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
     for _ in range(level):
         mode_id = _mode_id(mode)
         _check_pad(cur.shape[1:], flen, "reflect" if mode is None else mode)
-        buf = _engine.ENGINE.analysis(cur, dec_lo, dec_hi, mode_id)
+        if cur.requires_grad and torch.is_grad_enabled():
+            buf = _AnalysisLevel.apply(cur, dec_lo, dec_hi, mode_id)
+        else:
+            buf = _engine.ENGINE.analysis(cur, dec_lo, dec_hi, mode_id)
         bufs.append(buf)
         cur = buf[:, 0]
     bufs.reverse()
@@ -184,6 +240,7 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
             raise ValueError(f"Unexpected input type {type(t)}")
     _check_same_device_dtype(flat)
     _, _, rec_lo, rec_hi = host_taps(wavelet)
+    _warn_tap_grad(wavelet)
     flen = len(rec_lo)
     cur = layout.fold(approx)
     folded = [[layout.fold(t) for t in lvl] for lvl in levels]
@@ -206,7 +263,10 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
         out_ext = [2 * cur.shape[1 + a] - flen + 2 - trims[a] for a in range(ndim)]
         if min(out_ext) < 1:
             raise ValueError("coefficients too short for this wavelet")
-        cur = _engine.ENGINE.synthesis(cur, det, rec_lo, rec_hi, out_ext)
+        if torch.is_grad_enabled() and (cur.requires_grad or any(t.requires_grad for t in det)):
+            cur = _SynthesisLevel.apply(rec_lo, rec_hi, tuple(out_ext), cur, *det)
+        else:
+            cur = _engine.ENGINE.synthesis(cur, det, rec_lo, rec_hi, out_ext)
     return layout.unfold(cur)
 
 

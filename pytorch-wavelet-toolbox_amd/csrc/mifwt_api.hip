@@ -146,8 +146,10 @@ int generic_fwd(const mifwt_level_desc* d, const void* x, void* approx, void* co
   return MIFWT_OK;
 }
 
+// adjoint == true: the transpose of the generic ANALYSIS of this descriptor (same pass structure as the
+// synthesis: band pairs in, signal-extent arrays out; lo / hi are then the DEC taps and the halo is folded back).
 int generic_inv(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y,
-                const double* lo, const double* hi, void* ws, hipStream_t stream) {
+                const double* lo, const double* hi, void* ws, hipStream_t stream, bool adjoint = false) {
   Stage st[MIFWT_MAX_NDIM];
   plan_inv(d, st);
   const int64_t esz = elem_size(d->dtype);
@@ -189,7 +191,9 @@ int generic_inv(const mifwt_level_desc* d, const void* approx, const void* const
       jb.out0 = nxt[s];
       memcpy(jb.out0_stride, nxt_stride[s], sizeof(int64_t) * 4);
     }
-    const int rc = launch_axis_inv(d->dtype, jobs, nnext, out_ext, 1 + a, d->coef_extent[a], d->filt_len, lo, hi, stream);
+    const int rc = adjoint ? launch_axis_adj(d->dtype, jobs, nnext, out_ext, 1 + a, d->coef_extent[a], d->sig_extent[a],
+                                             d->mode, d->filt_len, lo, hi, stream)
+                           : launch_axis_inv(d->dtype, jobs, nnext, out_ext, 1 + a, d->coef_extent[a], d->filt_len, lo, hi, stream);
     if (rc != MIFWT_OK) return rc;
     ncur = nnext;
     for (int s = 0; s < ncur; ++s) {
@@ -261,20 +265,50 @@ const char* mifwt_strerror(int code) {
   }
 }
 
+static mifwt_level_desc as_zero_mode(const mifwt_level_desc* desc) {
+  mifwt_level_desc z = *desc;
+  z.mode = MIFWT_MODE_ZERO;
+  return z;
+}
+
 int mifwt_kernel_id(const mifwt_level_desc* desc, int direction) {
+  if (direction == 2) {
+    const int rc = validate(desc, 0);
+    if (rc != MIFWT_OK) return rc;
+    return desc->mode == MIFWT_MODE_ZERO ? pick_kernel(desc, 1) : kGeneric;
+  }
+  if (direction == 3) {
+    const mifwt_level_desc z = as_zero_mode(desc);
+    const int rc = validate(&z, 0);
+    if (rc != MIFWT_OK) return rc;
+    return pick_kernel(&z, 0);
+  }
   const int rc = validate(desc, direction);
   if (rc != MIFWT_OK) return rc;
   return pick_kernel(desc, direction);
 }
 
+// direction 2 / 3 = adjoint of the analysis / synthesis level described by desc.  A zero-mode analysis adjoint IS a
+// synthesis level (reversed dec taps) and every synthesis adjoint IS a zero-mode analysis level (reversed rec
+// taps), so they ride on the fast kernels; other boundary modes fold their halo back in the generic adjoint passes.
 size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction) {
+  if (direction == 2) {
+    if (validate(desc, 0) != MIFWT_OK || desc->dtype == MIFWT_F16) return 0;
+    if (desc->mode == MIFWT_MODE_ZERO) return route_ws(desc, 1, pick_kernel(desc, 1));
+    return generic_ws(desc, 1);
+  }
+  if (direction == 3) {
+    const mifwt_level_desc z = as_zero_mode(desc);
+    if (validate(&z, 0) != MIFWT_OK) return 0;
+    return route_ws(&z, 0, pick_kernel(&z, 0));
+  }
   if (validate(desc, direction) != MIFWT_OK) return 0;
   return route_ws(desc, direction, pick_kernel(desc, direction));
 }
 
-int mifwt_dwt_fwd(const mifwt_level_desc* desc, const void* x, void* approx, void* const* details,
-                  const double* dec_lo, const double* dec_hi, void* workspace, size_t workspace_bytes,
-                  void* stream) {
+static int run_fwd(const mifwt_level_desc* desc, const void* x, void* approx, void* const* details,
+                   const double* dec_lo, const double* dec_hi, void* workspace, size_t workspace_bytes,
+                   void* stream) {
   int rc = validate(desc, 0);
   if (rc != MIFWT_OK) return rc;
   if (!x || !approx || !details || !dec_lo || !dec_hi) return MIFWT_ERR_BADARG;
@@ -295,9 +329,9 @@ int mifwt_dwt_fwd(const mifwt_level_desc* desc, const void* x, void* approx, voi
   return generic_fwd(desc, x, approx, details, dec_lo, dec_hi, workspace, st);
 }
 
-int mifwt_dwt_inv(const mifwt_level_desc* desc, const void* approx, const void* const* details, void* y,
-                  const double* rec_lo, const double* rec_hi, void* workspace, size_t workspace_bytes,
-                  void* stream) {
+static int run_inv(const mifwt_level_desc* desc, const void* approx, const void* const* details, void* y,
+                   const double* rec_lo, const double* rec_hi, void* workspace, size_t workspace_bytes,
+                   void* stream) {
   int rc = validate(desc, 1);
   if (rc != MIFWT_OK) return rc;
   if (!y || !approx || !details || !rec_lo || !rec_hi) return MIFWT_ERR_BADARG;
@@ -316,6 +350,62 @@ int mifwt_dwt_inv(const mifwt_level_desc* desc, const void* approx, const void* 
     default: break;
   }
   return generic_inv(desc, approx, details, y, rec_lo, rec_hi, workspace, st);
+}
+
+int mifwt_dwt_fwd(const mifwt_level_desc* desc, const void* x, void* approx, void* const* details,
+                  const double* dec_lo, const double* dec_hi, void* workspace, size_t workspace_bytes,
+                  void* stream) {
+  return run_fwd(desc, x, approx, details, dec_lo, dec_hi, workspace, workspace_bytes, stream);
+}
+
+int mifwt_dwt_inv(const mifwt_level_desc* desc, const void* approx, const void* const* details, void* y,
+                  const double* rec_lo, const double* rec_hi, void* workspace, size_t workspace_bytes,
+                  void* stream) {
+  return run_inv(desc, approx, details, y, rec_lo, rec_hi, workspace, workspace_bytes, stream);
+}
+
+int mifwt_dwt_fwd_adjoint(const mifwt_level_desc* desc, const void* g_approx, const void* const* g_details, void* g_x,
+                          const double* dec_lo, const double* dec_hi, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  int rc = validate(desc, 0);
+  if (rc != MIFWT_OK) return rc;
+  if (!g_x || !g_approx || !g_details || !dec_lo || !dec_hi) return MIFWT_ERR_BADARG;
+  const int L = desc->filt_len;
+  if (desc->mode == MIFWT_MODE_ZERO) {
+    // u[n] = sum_k a[k] h[2k + 1 - n] is the synthesis formula with g[j] = h[L - 1 - j]; its cropped interior
+    // [0, 2M - L + 2 - N%2) is exactly [0, N)
+    double lo[MIFWT_MAX_FILT], hi[MIFWT_MAX_FILT];
+    for (int j = 0; j < L; ++j) {
+      lo[j] = dec_lo[L - 1 - j];
+      hi[j] = dec_hi[L - 1 - j];
+    }
+    return run_inv(desc, g_approx, g_details, g_x, lo, hi, workspace, workspace_bytes, stream);
+  }
+  for (int s = 1; s < (1 << desc->ndim); ++s)
+    if (!g_details[s - 1]) return MIFWT_ERR_BADARG;
+  if (desc->batch == 0) return MIFWT_OK;
+  if (desc->dtype == MIFWT_F16) return MIFWT_ERR_UNSUPPORTED;
+  const size_t need = generic_ws(desc, 1);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return MIFWT_ERR_WORKSPACE;
+  return generic_inv(desc, g_approx, g_details, g_x, dec_lo, dec_hi, workspace, static_cast<hipStream_t>(stream), true);
+}
+
+int mifwt_dwt_inv_adjoint(const mifwt_level_desc* desc, const void* g_y, void* g_approx, void* const* g_details,
+                          const double* rec_lo, const double* rec_hi, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  int rc = validate(desc, 1);
+  if (rc != MIFWT_OK) return rc;
+  if (!rec_lo || !rec_hi) return MIFWT_ERR_BADARG;
+  // g_a[k] = sum_n g_y[n] g[n + L - 2 - 2k] is the zero-mode analysis formula with h[m] = g[L - 1 - m]; its
+  // output extent floor((Nout + L - 1) / 2) is exactly M
+  const int L = desc->filt_len;
+  double lo[MIFWT_MAX_FILT], hi[MIFWT_MAX_FILT];
+  for (int j = 0; j < L; ++j) {
+    lo[j] = rec_lo[L - 1 - j];
+    hi[j] = rec_hi[L - 1 - j];
+  }
+  const mifwt_level_desc z = as_zero_mode(desc);
+  return run_fwd(&z, g_y, g_approx, g_details, lo, hi, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -56,6 +56,11 @@ int launch_axis_fwd(int dtype, const AxisJob* jobs, int njobs, const int64_t out
 int launch_axis_inv(int dtype, const AxisJob* jobs, int njobs, const int64_t out_ext[4], int taxis, int64_t m_in,
                     int filt_len, const double* lo, const double* hi, hipStream_t stream);
 
+// adjoint of one analysis axis pass (g_lo, g_hi -> g_x, halo folded back through the boundary map); lo / hi are
+// the DEC taps in PyWavelets order, m_in the coefficient extent, n_sig the signal extent along taxis
+int launch_axis_adj(int dtype, const AxisJob* jobs, int njobs, const int64_t out_ext[4], int taxis, int64_t m_in,
+                    int64_t n_sig, int mode, int filt_len, const double* lo, const double* hi, hipStream_t stream);
+
 // ---- streaming single-axis kernels (mifwt_axis_stream.h; any mode, L in the instantiated set) ----------
 // One (input -> low, high) or (low, high -> output) job; up to four jobs of identical geometry per launch.
 // Strides are in elements.  outer kernels: s[0] = batch, s[1] = transformed axis (the inner run is dense);

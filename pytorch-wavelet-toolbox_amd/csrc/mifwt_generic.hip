@@ -25,7 +25,8 @@ struct AxisGeom {
   int64_t ext[4];  // output iteration space (batch, axis0, axis1, axis2), unused dims = 1
   int64_t total;   // product of ext
   int taxis;       // transformed dim of the iteration space
-  int n_src;       // source extent along taxis (analysis: N, synthesis: M)
+  int n_src;       // source extent along taxis (analysis: N, synthesis / adjoint: M)
+  int n_sig;       // adjoint only: signal extent N along taxis
   int mode;
   int filt_len;
 };
@@ -112,10 +113,68 @@ __global__ void __launch_bounds__(256) axis_inv_kernel(AxisJobs jobs, AxisGeom g
   }
 }
 
+// Adjoint (transpose) of one analysis axis pass: (g_lo, g_hi) -> g_x.  With u[e] the full transposed
+// convolution over the EXTENDED index range e in [-(L-2), N + L - 2 + N%2),
+//     u[e] = sum_k g_lo[k] h_lo[2k + 1 - e] + g_hi[k] h_hi[2k + 1 - e],
+// the gradient folds the halo back through the boundary index map:  g_x[i] = sum_{e : ext_index(e) = i} u[e].
+// (The reference gets this from ATen autograd through F.pad / _pad_symmetric + F.conv*d.)
 template <typename T>
-static int launch_axis(bool inverse, const AxisJob* jobs, int njobs, const int64_t out_ext[4], int taxis,
+__global__ void __launch_bounds__(256) axis_adj_kernel(AxisJobs jobs, AxisGeom g, Taps<T> taps) {
+  const AxisJob& jb = jobs.job[blockIdx.y];
+  const T* __restrict__ a = static_cast<const T*>(jb.in0);
+  const T* __restrict__ dd = static_cast<const T*>(jb.in1);
+  T* __restrict__ y = static_cast<T*>(jb.out0);
+  const int64_t sa = jb.in0_stride[g.taxis], sd = jb.in1_stride[g.taxis];
+  const int L = g.filt_len, N = g.n_sig, M = g.n_src;
+  const int pl = L - 2, pr = L - 2 + (N & 1);
+  const int border = (pl > pr ? pl : pr) + 1;  // halo indices only ever map into [0, border) or [N - border, N)
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < g.total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t rem = idx;
+    int64_t c[4];
+#pragma unroll
+    for (int d = 3; d >= 0; --d) {
+      c[d] = rem % g.ext[d];
+      rem /= g.ext[d];
+    }
+    int64_t abase = 0, dbase = 0, ybase = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      if (d != g.taxis) {
+        abase += c[d] * jb.in0_stride[d];
+        dbase += c[d] * jb.in1_stride[d];
+      }
+      ybase += c[d] * jb.out0_stride[d];
+    }
+    const int i = (int)c[g.taxis];
+    auto u = [&](int e) -> T {  // 2k + 1 - e in [0, L)  <=>  k in [ceil((e - 1) / 2), floor((e + L - 2) / 2)]
+      int k_lo = e >> 1;        // ceil((e - 1) / 2) = floor(e / 2) for every integer e
+      if (k_lo < 0) k_lo = 0;
+      int k_hi = (e + L - 2) >> 1;
+      if (k_hi > M - 1) k_hi = M - 1;
+      T acc = 0;
+      for (int k = k_lo; k <= k_hi; ++k) {
+        const int m = 2 * k + 1 - e;
+        acc = fma(taps.lo[m], a[abase + (int64_t)k * sa], acc);
+        acc = fma(taps.hi[m], dd[dbase + (int64_t)k * sd], acc);
+      }
+      return acc;
+    };
+    T acc = u(i);
+    if (g.mode != MIFWT_MODE_ZERO && (i < border || i >= N - border)) {
+      for (int e = -pl; e < 0; ++e)
+        if (ext_index(e, N, g.mode) == i) acc += u(e);
+      for (int e = N; e < N + pr; ++e)
+        if (ext_index(e, N, g.mode) == i) acc += u(e);
+    }
+    y[ybase] = acc;
+  }
+}
+
+template <typename T>
+static int launch_axis(int kind, const AxisJob* jobs, int njobs, const int64_t out_ext[4], int taxis,
                        int64_t n_src, int mode, int filt_len, const double* lo, const double* hi,
-                       hipStream_t stream) {
+                       hipStream_t stream, int64_t n_sig = 0) {  // kind: 0 analysis, 1 synthesis, 2 analysis adjoint
   if (njobs < 1 || njobs > 4 || filt_len < 1 || filt_len > kMaxFilt) return MIFWT_ERR_BADARG;
   AxisJobs js;
   for (int i = 0; i < 4; ++i) js.job[i] = jobs[i < njobs ? i : 0];
@@ -128,6 +187,7 @@ static int launch_axis(bool inverse, const AxisJob* jobs, int njobs, const int64
   if (g.total == 0) return MIFWT_OK;
   g.taxis = taxis;
   g.n_src = (int)n_src;
+  g.n_sig = (int)n_sig;
   g.mode = mode;
   g.filt_len = filt_len;
   Taps<T> taps;
@@ -138,7 +198,9 @@ static int launch_axis(bool inverse, const AxisJob* jobs, int njobs, const int64
   const int64_t want = (g.total + 255) / 256;
   const unsigned gx = (unsigned)(want < 8192 ? want : 8192);  // grid-stride beyond 256 CUs x 32 blocks
   dim3 grid(gx, (unsigned)njobs), block(256);
-  if (inverse)
+  if (kind == 2)
+    hipLaunchKernelGGL(axis_adj_kernel<T>, grid, block, 0, stream, js, g, taps);
+  else if (kind == 1)
     hipLaunchKernelGGL(axis_inv_kernel<T>, grid, block, 0, stream, js, g, taps);
   else
     hipLaunchKernelGGL(axis_fwd_kernel<T>, grid, block, 0, stream, js, g, taps);
@@ -147,15 +209,22 @@ static int launch_axis(bool inverse, const AxisJob* jobs, int njobs, const int64
 
 int launch_axis_fwd(int dtype, const AxisJob* jobs, int njobs, const int64_t out_ext[4], int taxis, int64_t n_in,
                     int mode, int filt_len, const double* lo, const double* hi, hipStream_t stream) {
-  if (dtype == MIFWT_F32) return launch_axis<float>(false, jobs, njobs, out_ext, taxis, n_in, mode, filt_len, lo, hi, stream);
-  if (dtype == MIFWT_F64) return launch_axis<double>(false, jobs, njobs, out_ext, taxis, n_in, mode, filt_len, lo, hi, stream);
+  if (dtype == MIFWT_F32) return launch_axis<float>(0, jobs, njobs, out_ext, taxis, n_in, mode, filt_len, lo, hi, stream);
+  if (dtype == MIFWT_F64) return launch_axis<double>(0, jobs, njobs, out_ext, taxis, n_in, mode, filt_len, lo, hi, stream);
   return MIFWT_ERR_UNSUPPORTED;
 }
 
 int launch_axis_inv(int dtype, const AxisJob* jobs, int njobs, const int64_t out_ext[4], int taxis, int64_t m_in,
                     int filt_len, const double* lo, const double* hi, hipStream_t stream) {
-  if (dtype == MIFWT_F32) return launch_axis<float>(true, jobs, njobs, out_ext, taxis, m_in, 0, filt_len, lo, hi, stream);
-  if (dtype == MIFWT_F64) return launch_axis<double>(true, jobs, njobs, out_ext, taxis, m_in, 0, filt_len, lo, hi, stream);
+  if (dtype == MIFWT_F32) return launch_axis<float>(1, jobs, njobs, out_ext, taxis, m_in, 0, filt_len, lo, hi, stream);
+  if (dtype == MIFWT_F64) return launch_axis<double>(1, jobs, njobs, out_ext, taxis, m_in, 0, filt_len, lo, hi, stream);
+  return MIFWT_ERR_UNSUPPORTED;
+}
+
+int launch_axis_adj(int dtype, const AxisJob* jobs, int njobs, const int64_t out_ext[4], int taxis, int64_t m_in,
+                    int64_t n_sig, int mode, int filt_len, const double* lo, const double* hi, hipStream_t stream) {
+  if (dtype == MIFWT_F32) return launch_axis<float>(2, jobs, njobs, out_ext, taxis, m_in, mode, filt_len, lo, hi, stream, n_sig);
+  if (dtype == MIFWT_F64) return launch_axis<double>(2, jobs, njobs, out_ext, taxis, m_in, mode, filt_len, lo, hi, stream, n_sig);
   return MIFWT_ERR_UNSUPPORTED;
 }
 
