@@ -22,6 +22,7 @@ from .constants import (
 from .conv_transform import wavedec, waverec
 from .conv_transform_2 import wavedec2, waverec2
 from .conv_transform_3 import wavedec3, waverec3
+from .packets import WaveletPacket, WaveletPacket2D
 from .separable_conv_transform import fswavedec2, fswavedec3, fswaverec2, fswaverec3
 
 __version__ = "0.1.0"
@@ -45,4 +46,6 @@ __all__ = [
     "fswaverec2",
     "fswaverec3",
     "set_half_storage",
+    "WaveletPacket",
+    "WaveletPacket2D",
 ]
