@@ -118,6 +118,21 @@ int mifwt_dwt_inv_adjoint(const mifwt_level_desc* desc, const void* g_y, void* g
                           const double* rec_lo, const double* rec_hi, void* workspace, size_t workspace_bytes,
                           void* stream);
 
+/* Stationary (undecimated) transform levels — ptwt.swt / ptwt.iswt, src/ptwt/stationary_transform.py:95-107
+ * (_circular_pad + F.conv1d(stride 1, dilation) + split) and :142-156 (stack + _circular_pad +
+ * F.conv_transpose1d(groups 2, dilation) + mean).  `rows` independent rows of `n` contiguous samples, row strides in
+ * elements, dilation = 2^level_index, periodic extension as an index map.  `scale` multiplies the result: 1 for swt,
+ * 0.5 for iswt (the reference's mean over the two reconstructions); with reversed taps and the other scale each
+ * call is the adjoint of the other (backward passes).  Even filt_len <= 20, f32 / f64 / f16.
+ *   fwd: lo/hi[n] = scale * sum_m dec_lo/hi[m] x[(n + D (L/2 - m)) mod N]
+ *   inv: y[n]     = scale * sum_j rec_lo[j] a[(n + D (L/2 - 1 - j)) mod N] + rec_hi[j] d[(same)] */
+int mifwt_swt_fwd(int dtype, int filt_len, int64_t rows, int64_t n, int64_t dilation, const void* x, int64_t x_row_stride,
+                  void* lo, void* hi, int64_t lo_row_stride, int64_t hi_row_stride, const double* dec_lo,
+                  const double* dec_hi, double scale, void* stream);
+int mifwt_swt_inv(int dtype, int filt_len, int64_t rows, int64_t n, int64_t dilation, const void* a, const void* d,
+                  int64_t a_row_stride, int64_t d_row_stride, void* y, int64_t y_row_stride, const double* rec_lo,
+                  const double* rec_hi, double scale, void* stream);
+
 /* Scratch bytes one call needs (0 on the fused paths).  direction: 0 = analysis, 1 = synthesis,
  * 2 = mifwt_dwt_fwd_adjoint, 3 = mifwt_dwt_inv_adjoint (same numbering for mifwt_kernel_id). */
 size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);

@@ -23,6 +23,7 @@ from .conv_transform import wavedec, waverec
 from .conv_transform_2 import wavedec2, waverec2
 from .conv_transform_3 import wavedec3, waverec3
 from .packets import WaveletPacket, WaveletPacket2D
+from .stationary_transform import iswt, swt
 from .separable_conv_transform import fswavedec2, fswavedec3, fswaverec2, fswaverec3
 
 __version__ = "0.1.0"
@@ -47,5 +48,7 @@ __all__ = [
     "fswaverec3",
     "set_half_storage",
     "WaveletPacket",
+    "swt",
+    "iswt",
     "WaveletPacket2D",
 ]

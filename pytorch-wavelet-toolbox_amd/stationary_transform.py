@@ -1,0 +1,165 @@
+"""Stationary (undecimated) wavelet transform: ``swt`` / ``iswt`` (API of reference src/ptwt/stationary_transform.py).
+
+Equivalent to ``pywt.swt(..., trim_approx=True, norm=False)`` like the reference.  Each level is one HIP kernel
+(C ABI ``mifwt_swt_fwd`` / ``mifwt_swt_inv``): stride-1 filter bank with dilation ``2^level`` and the periodic
+extension as an index map — the reference's ``_circular_pad`` + ``F.conv1d(dilation)`` + ``split`` (:95-107) and
+``stack`` + ``_circular_pad`` + grouped ``F.conv_transpose1d`` + ``mean`` (:142-156).  Differentiable w.r.t. the data
+(each level kernel is the other's adjoint with reversed taps).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Union
+
+import torch
+
+from . import _engine, _fwt
+from ._wavelets import host_taps
+from .constants import Wavelet, supported_dtypes
+
+__all__ = ["swt", "iswt"]
+
+_bound = False
+
+
+def _lib():
+    global _bound
+    lib = _engine.load_library()
+    if not _bound:
+        vp, i64, dbl_p = ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double)
+        lib.mifwt_swt_fwd.restype = ctypes.c_int
+        lib.mifwt_swt_fwd.argtypes = [ctypes.c_int, ctypes.c_int, i64, i64, i64, vp, i64, vp, vp, i64, i64, dbl_p, dbl_p,
+                                      ctypes.c_double, vp]
+        lib.mifwt_swt_inv.restype = ctypes.c_int
+        lib.mifwt_swt_inv.argtypes = [ctypes.c_int, ctypes.c_int, i64, i64, i64, vp, vp, i64, i64, vp, i64, dbl_p, dbl_p,
+                                      ctypes.c_double, vp]
+        _bound = True
+    return lib
+
+
+def _stream(t: torch.Tensor) -> int:
+    return _engine._raw_stream(t.device.index if t.device.index is not None else torch.cuda.current_device())
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """[B, N] with contiguous samples (row stride free)."""
+    return t if t.stride(-1) == 1 else t.contiguous()
+
+
+def _level_fwd(x: torch.Tensor, lo: Sequence[float], hi: Sequence[float], dilation: int, scale: float) -> torch.Tensor:
+    """x [B, N] -> buffer [B, 2, N]: plane 0 low-pass, plane 1 high-pass."""
+    _engine._require_gpu(x)
+    x = _rows(x)
+    b, n = x.shape
+    buf = torch.empty((b, 2, n), dtype=x.dtype, device=x.device)
+    if buf.numel() == 0:
+        return buf
+    with torch.cuda.device(x.device):
+        rc = _lib().mifwt_swt_fwd(_engine._DTYPE_IDS[x.dtype], len(lo), b, n, dilation, x.data_ptr(), x.stride(0),
+                                  buf.data_ptr(), buf.data_ptr() + n * buf.element_size(), 2 * n, 2 * n,
+                                  _engine._taps_array(lo), _engine._taps_array(hi), scale, _stream(x))
+    _engine._check(rc)
+    return buf
+
+
+def _level_inv(a: torch.Tensor, d: torch.Tensor, lo: Sequence[float], hi: Sequence[float], dilation: int,
+               scale: float) -> torch.Tensor:
+    _engine._require_gpu(a)
+    a, d = _rows(a), _rows(d)
+    b, n = a.shape
+    y = torch.empty((b, n), dtype=a.dtype, device=a.device)
+    if y.numel() == 0:
+        return y
+    with torch.cuda.device(a.device):
+        rc = _lib().mifwt_swt_inv(_engine._DTYPE_IDS[a.dtype], len(lo), b, n, dilation, a.data_ptr(), d.data_ptr(),
+                                  a.stride(0), d.stride(0), y.data_ptr(), n, _engine._taps_array(lo),
+                                  _engine._taps_array(hi), scale, _stream(a))
+    _engine._check(rc)
+    return y
+
+
+class _SwtLevel(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lo, hi, dilation):
+        ctx.meta = (lo, hi, dilation)
+        return _level_fwd(x, lo, hi, dilation, 1.0)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_buf):
+        lo, hi, dilation = ctx.meta
+        return _level_inv(g_buf[:, 0], g_buf[:, 1], lo[::-1], hi[::-1], dilation, 1.0), None, None, None
+
+
+class _IswtLevel(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, d, lo, hi, dilation):
+        ctx.meta = (lo, hi, dilation)
+        return _level_inv(a, d, lo, hi, dilation, 0.5)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_y):
+        lo, hi, dilation = ctx.meta
+        g = _level_fwd(g_y, lo[::-1], hi[::-1], dilation, 0.5)
+        return g[:, 0], g[:, 1], None, None, None
+
+
+def swt_max_level(input_len: int) -> int:
+    """``pywt.swt_max_level``: how often the length can be halved (src/ptwt/stationary_transform.py:93)."""
+    level = 0
+    while input_len > 0 and input_len % 2 == 0:
+        input_len //= 2
+        level += 1
+    return level
+
+
+def swt(data: torch.Tensor, wavelet: Union[Wavelet, str], level: Optional[int] = None, *,
+        axis: _fwt.AxisHint = None) -> List[torch.Tensor]:
+    """Multi-level 1-D stationary transform; returns ``[cA_n, cD_n, ..., cD_1]``, every entry as long as the input
+    (drop-in for ``ptwt.swt``, src/ptwt/stationary_transform.py:56-110)."""
+    axes = _fwt._ensure_axes(axis, 1)
+    layout = _fwt._Layout(data, 1, axes)
+    x = layout.fold(data)
+    dec_lo, dec_hi, _, _ = host_taps(wavelet)
+    _fwt._warn_tap_grad(wavelet)
+    if level is None:
+        level = swt_max_level(x.shape[-1])
+    out: List[torch.Tensor] = []
+    cur = x
+    for lvl in range(level):
+        if cur.requires_grad and torch.is_grad_enabled():
+            buf = _SwtLevel.apply(cur, dec_lo, dec_hi, 2 ** lvl)
+        else:
+            buf = _level_fwd(cur, dec_lo, dec_hi, 2 ** lvl, 1.0)
+        out.append(layout.unfold(buf[:, 1]))
+        cur = buf[:, 0]
+    out.append(layout.unfold(cur))
+    out.reverse()
+    return out
+
+
+def iswt(coeffs: Sequence[torch.Tensor], wavelet: Union[Wavelet, str], *, axis: _fwt.AxisHint = None) -> torch.Tensor:
+    """Inverse of :func:`swt` (drop-in for ``ptwt.iswt``, src/ptwt/stationary_transform.py:113-160)."""
+    coeffs = list(coeffs)
+    if not coeffs or not isinstance(coeffs[0], torch.Tensor):
+        raise ValueError("First element of coeffs must be the approximation coefficient tensor.")
+    axes = _fwt._ensure_axes(axis, 1)
+    layout = _fwt._Layout(coeffs[0], 1, axes)
+    for t in coeffs:
+        if not isinstance(t, torch.Tensor):
+            raise ValueError(f"Unexpected input type {type(t)}")
+    _fwt._check_same_device_dtype(coeffs)
+    _, _, rec_lo, rec_hi = host_taps(wavelet)
+    _fwt._warn_tap_grad(wavelet)
+    cur = layout.fold(coeffs[0])
+    details = [layout.fold(t) for t in coeffs[1:]]
+    for pos, det in enumerate(details):
+        dilation = 2 ** (len(details) - pos - 1)
+        if det.shape != cur.shape:
+            raise RuntimeError("stack expects each tensor to be equal size")  # torch.stack in the reference (:146)
+        if torch.is_grad_enabled() and (cur.requires_grad or det.requires_grad):
+            cur = _IswtLevel.apply(cur, det, rec_lo, rec_hi, dilation)
+        else:
+            cur = _level_inv(cur, det, rec_lo, rec_hi, dilation, 0.5)
+    return layout.unfold(cur)
