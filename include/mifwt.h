@@ -140,7 +140,8 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
 /* Which kernel family a call would dispatch to (tests use it to assert the fast path is the one that ran);
  * negative = error code.
  *   0  generic per-axis passes (any strides, any L <= 128)
- *   1 / 2  fused single-launch 2-D analysis / synthesis level (f32, even L <= 16)
+ *   1 / 2  fused single-launch 2-D analysis / synthesis level, streaming wave strips (f32, even L <= 16)
+ *   7      fused single-launch 2-D analysis level, LDS tiles (same envelope; picked for small planes)
  *   3 / 4  streaming axis passes, analysis / synthesis: inner-axis kernel (+ one outer-axis pass per further
  *          axis); unit innermost stride, f32 / f64 / f16, L in {2..20 even, 24, 32}
  *   5 / 6  3-D analysis / synthesis (f32, even L <= 16): fused 2-D kernel over every depth slice + one
@@ -156,6 +157,8 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 #define MIFWT_OPT_PREFETCH_PAIRS 2 /* >0 overrides the fused kernels' prefetch depth (row pairs in flight) */
 #define MIFWT_OPT_COOP 3           /* non-zero selects the workgroup-cooperative full-line output writer */
 #define MIFWT_OPT_NT_STORE 4       /* non-zero: nontemporal stores for the sub-band planes */
+#define MIFWT_OPT_TILE_MODE 5      /* 2-D analysis: 0 = auto (LDS-tile kernel on small planes), 1 = always tile, 2 = never */
+#define MIFWT_OPT_TILE_ROWS 6      /* >0 overrides the tile kernel's output rows per tile (8 or 16) */
 int mifwt_set_option(int key, int value);
 
 const char* mifwt_strerror(int code);

@@ -215,6 +215,7 @@ size_t generic_ws(const mifwt_level_desc* d, int direction) {
 size_t route_ws(const mifwt_level_desc* d, int direction, int kid) {
   switch (kid) {
     case kDwt2FwdStream:
+    case kDwt2FwdTile:
     case kDwt2InvStream: return 0;
     case kDwt3FwdStream:
     case kDwt3InvStream: return plane3_ws_bytes(d, direction);
@@ -227,7 +228,16 @@ size_t route_ws(const mifwt_level_desc* d, int direction, int kid) {
 int pick_kernel(const mifwt_level_desc* d, int direction) {
   if (g_options[MIFWT_OPT_FORCE_GENERIC]) return kGeneric;
   if (direction == 0) {
-    if (dwt2_fwd_stream_supported(d)) return kDwt2FwdStream;
+    if (dwt2_fwd_stream_supported(d)) {
+      // Two fused kernels share this envelope.  Measured on MI355X (64-image batches, 128^2 .. 4096^2 planes): the
+      // LDS-tile kernel wins for every L <= 14 (by 4-35 %) and for L = 16 up to ~1500^2 planes; only the longest
+      // filters on big planes favour the streaming kernel (its register ring re-reads no row halo).
+      const int tm = g_options[MIFWT_OPT_TILE_MODE];
+      if (tm == 1) return kDwt2FwdTile;
+      if (tm == 2) return kDwt2FwdStream;
+      const bool big_long = d->filt_len >= 16 && d->sig_extent[0] * d->sig_extent[1] >= (int64_t(1) << 21);
+      return big_long ? kDwt2FwdStream : kDwt2FwdTile;
+    }
     if (plane3_route_ok(d, 0)) return kDwt3FwdStream;
     if (rows_route_ok(d, 0)) return kDwt1FwdRow;
   } else {
@@ -322,6 +332,7 @@ static int run_fwd(const mifwt_level_desc* desc, const void* x, void* approx, vo
   if (need > 0 && (!workspace || workspace_bytes < need)) return MIFWT_ERR_WORKSPACE;
   switch (kid) {
     case kDwt2FwdStream: return dwt2_fwd_stream(desc, x, approx, details, dec_lo, dec_hi, st);
+    case kDwt2FwdTile: return dwt2_fwd_tile(desc, x, approx, details, dec_lo, dec_hi, st);
     case kDwt3FwdStream: return plane3_fwd(desc, x, approx, details, dec_lo, dec_hi, workspace, st);
     case kDwt1FwdRow: return rows_fwd(desc, x, approx, details, dec_lo, dec_hi, workspace, st);
     default: break;

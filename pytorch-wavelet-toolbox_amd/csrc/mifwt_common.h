@@ -93,11 +93,15 @@ int stream_call(int dtype, int kind, const StreamCall& c);  // dispatches on dty
 // ---- fused fast paths --------------------------------------------------------------------------------
 // Each returns MIFWT_ERR_UNSUPPORTED when the descriptor is outside its envelope (the dispatcher then
 // falls back to the generic passes) and never touches the workspace.
-enum KernelId { kGeneric = 0, kDwt2FwdStream = 1, kDwt2InvStream = 2, kDwt1FwdRow = 3, kDwt1InvRow = 4, kDwt3FwdStream = 5, kDwt3InvStream = 6 };
+enum KernelId { kGeneric = 0, kDwt2FwdStream = 1, kDwt2InvStream = 2, kDwt1FwdRow = 3, kDwt1InvRow = 4, kDwt3FwdStream = 5, kDwt3InvStream = 6, kDwt2FwdTile = 7 };
 
 bool dwt2_fwd_stream_supported(const mifwt_level_desc* d);
 int dwt2_fwd_stream(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
                     const double* dec_lo, const double* dec_hi, hipStream_t stream);
+
+// LDS-tile variant of the fused 2-D analysis level (same envelope as dwt2_fwd_stream; small planes)
+int dwt2_fwd_tile(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
+                  const double* dec_lo, const double* dec_hi, hipStream_t stream);
 
 bool dwt2_inv_stream_supported(const mifwt_level_desc* d);
 int dwt2_inv_stream(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y,

@@ -97,10 +97,10 @@ def test_backward_routes():
     for s in (d.approx_stride, d.detail_stride):
         s[0], s[1], s[2] = 4 * 515 * 515, 515, 1
     assert lib.mifwt_kernel_id(ctypes.byref(d), 2) == 2  # adjoint of a zero-mode analysis = fused synthesis kernel
-    assert lib.mifwt_kernel_id(ctypes.byref(d), 3) == 1  # adjoint of a synthesis = fused zero-mode analysis kernel
+    assert lib.mifwt_kernel_id(ctypes.byref(d), 3) == 7  # adjoint of a synthesis = fused zero-mode analysis kernel
     d.mode = 2
     assert lib.mifwt_kernel_id(ctypes.byref(d), 2) == 0  # reflect: generic adjoint passes (halo fold-back)
-    assert lib.mifwt_kernel_id(ctypes.byref(d), 3) == 1
+    assert lib.mifwt_kernel_id(ctypes.byref(d), 3) == 7
 
 
 def test_no_grad_and_detached_paths_unchanged():

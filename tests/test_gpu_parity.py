@@ -40,7 +40,8 @@ def check_tree(got, want, tol, what=""):
 def test_extension_loaded_and_fast_path_selected():
     lib = _engine.load_library()
     assert lib.mifwt_abi_version() == 1
-    assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (1024, 1024)) == 1
+    assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (1024, 1024)) == 7     # fused LDS-tile kernel
+    assert _engine.kernel_id(2, torch.float32, "reflect", 16, 64, (4096, 4096)) == 1   # fused streaming kernel
 
 
 def test_kat_ripples_haar_gpu():
@@ -152,20 +153,24 @@ def test_fused_dwt2_vs_oracle(wavelet, mode):
     """The fused streaming kernel (kernel id 1) against the fp64 oracle: several strips, edge strips on both
     sides, odd and even extents, odd row pitches from level 2 on, a chunk boundary inside the image."""
     rng = np.random.default_rng(hash((wavelet, mode)) % (2**32))
-    for shape in [(3, 70, 530), (2, 131, 257), (1, 300, 1101), (2, 40, 36)]:
-        flen = len(O.filter_bank(wavelet)[0])
-        if _engine.kernel_id(2, torch.float32, mode, flen, shape[0], shape[1:]) != 1:
-            pytest.fail("fused path not selected")
-        x = rng.standard_normal(shape)
-        level = 3 if min(shape[1:]) > 4 * flen else 1
-        try:
-            want = O.wavedec2(x, wavelet, mode=mode, level=level)
-        except RuntimeError:
-            with pytest.raises(RuntimeError):
-                ptwt_amd.wavedec2(torch.from_numpy(x).float().to(dev()), wavelet, mode=mode, level=level)
-            continue
-        got = ptwt_amd.wavedec2(torch.from_numpy(x).float().to(dev()), wavelet, mode=mode, level=level)
-        check_tree(got, want, TOL32, f"{wavelet} {mode} {shape}")
+    _engine.set_option(5, 2)  # tile mode 2: always the streaming kernel
+    try:
+        for shape in [(3, 70, 530), (2, 131, 257), (1, 300, 1101), (2, 40, 36)]:
+            flen = len(O.filter_bank(wavelet)[0])
+            if _engine.kernel_id(2, torch.float32, mode, flen, shape[0], shape[1:]) != 1:
+                pytest.fail("fused streaming path not selected")
+            x = rng.standard_normal(shape)
+            level = 3 if min(shape[1:]) > 4 * flen else 1
+            try:
+                want = O.wavedec2(x, wavelet, mode=mode, level=level)
+            except RuntimeError:
+                with pytest.raises(RuntimeError):
+                    ptwt_amd.wavedec2(torch.from_numpy(x).float().to(dev()), wavelet, mode=mode, level=level)
+                continue
+            got = ptwt_amd.wavedec2(torch.from_numpy(x).float().to(dev()), wavelet, mode=mode, level=level)
+            check_tree(got, want, TOL32, f"{wavelet} {mode} {shape}")
+    finally:
+        _engine.set_option(5, 0)
 
 
 def test_fused_equals_generic():
@@ -368,3 +373,29 @@ def test_half_storage_extension():
         assert G.relerr(to_np(y[..., :1001].double()), x1.double().numpy()) < 2e-3
     finally:
         ptwt_amd.set_half_storage(False)
+
+
+@pytest.mark.parametrize("wavelet", FUSED_WAVELETS)
+@pytest.mark.parametrize("tile_rows", [0, 8, 12, 16, 20, 24])
+def test_tile_dwt2_vs_oracle(wavelet, tile_rows):
+    """The LDS-tile analysis kernel (kernel id 7, forced) against the fp64 oracle: every mode, ragged tiles in both
+    directions, odd extents, strided LL input of the deeper levels, planes smaller than the halo."""
+    rng = np.random.default_rng(len(wavelet) * 31 + tile_rows)
+    flen = len(O.filter_bank(wavelet)[0])
+    _engine.set_option(5, 1)
+    _engine.set_option(6, tile_rows)
+    try:
+        assert _engine.kernel_id(2, torch.float32, "reflect", flen, 2, (131, 257)) == 7
+        for shape in [(3, 70, 530), (2, 131, 257), (2, 40, 36), (1, 2 * flen, 2 * flen + 1)]:
+            x = rng.standard_normal(shape)
+            level = 3 if min(shape[1:]) > 4 * flen else 1
+            for mode in MODES:
+                try:
+                    want = O.wavedec2(x, wavelet, mode=mode, level=level)
+                except RuntimeError:
+                    continue
+                got = ptwt_amd.wavedec2(torch.from_numpy(x).float().to(dev()), wavelet, mode=mode, level=level)
+                check_tree(got, want, TOL32, f"tile {wavelet} {mode} {shape}")
+    finally:
+        _engine.set_option(5, 0)
+        _engine.set_option(6, 0)

@@ -210,7 +210,9 @@ def test_cabi_descriptor_validation_and_dispatch():
     lib = _engine.load_library()
     d = _engine.LevelDesc()
     assert lib.mifwt_kernel_id(ctypes.byref(d), 0) == -1  # ndim = 0
-    assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (1024, 1024)) == 1  # fused 2-D analysis
+    assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (1024, 1024)) == 7  # fused 2-D analysis, LDS tiles
+    assert _engine.kernel_id(2, torch.float32, "reflect", 16, 64, (4096, 4096)) == 1  # fused 2-D analysis, streaming
+    assert _engine.kernel_id(2, torch.float32, "reflect", 16, 64, (1035, 1035)) == 7
     assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (1024, 1024), direction=1) == 2  # fused 2-D synthesis
     assert _engine.kernel_id(2, torch.float64, "reflect", 8, 64, (1024, 1024)) == 3  # f64 -> streaming axis passes
     assert _engine.kernel_id(2, torch.float32, "reflect", 32, 4, (512, 512)) == 3    # L = 32 -> streaming axis passes

@@ -30,6 +30,8 @@ ap.add_argument("--generic", action="store_true", help="also time the generic ax
 ap.add_argument("--inverse", action="store_true", help="time the synthesis level that reconstructs --shape instead")
 ap.add_argument("--coop", default="0", help="comma list: 1 = cooperative full-line writer, 0 = independent waves")
 ap.add_argument("--nt", default="0", help="comma list: 1 = nontemporal stores")
+ap.add_argument("--tile", default="2", help="comma list: tile mode (1 = LDS-tile kernel, 2 = streaming kernel, 0 = auto)")
+ap.add_argument("--tr", default="0", help="comma list: tile rows override (8 / 16)")
 args = ap.parse_args()
 
 shape = tuple(int(v) for v in args.shape.split(","))
@@ -53,18 +55,18 @@ else:
     def run(i):
         return eng.analysis(bufs[i % 3], taps[0], taps[1], mode_id)
 
-variants = [("coop=%s nt=%s rpc=%s depth=%s" % (c, n, r, d), int(r), 0, int(d), int(c), int(n)) for c in args.coop.split(",")
-            for n in args.nt.split(",") for r in args.rpc.split(",") for d in args.depth.split(",")]
+variants = [("tile=%s tr=%s rpc=%s depth=%s" % (c, n, r, d), int(r), 0, int(d), int(c), int(n)) for c in args.tile.split(",")
+            for n in args.tr.split(",") for r in args.rpc.split(",") for d in args.depth.split(",")]
 if args.generic:
     variants.append(("generic", 0, 1, 0, 0, 0))
 results = {name: [] for name, _, _, _, _, _ in variants}
 for rnd in range(args.rounds + 1):
     for name, rpc, gen, depth, coop, nt in variants:
-        _engine.set_option(4, nt)
+        _engine.set_option(6, nt)
         _engine.set_option(1, rpc)
         _engine.set_option(0, gen)
         _engine.set_option(2, depth)
-        _engine.set_option(3, coop)
+        _engine.set_option(5, coop)
         run(0)
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -78,8 +80,8 @@ for rnd in range(args.rounds + 1):
 _engine.set_option(1, 0)
 _engine.set_option(0, 0)
 _engine.set_option(2, 0)
-_engine.set_option(3, 0)
-_engine.set_option(4, 0)
+_engine.set_option(5, 0)
+_engine.set_option(6, 0)
 for name, ts in results.items():
     med = statistics.median(ts)
     print(json.dumps({"variant": name, "shape": shape, "wavelet": args.wavelet, "ms_median": round(med, 4),

@@ -17,7 +17,7 @@ os.makedirs("profiles", exist_ok=True)
 
 def short(name):
     name = name.replace("void ", "")
-    for key in ("dwt2_fwd_stream_kernel", "dwt2_inv_stream_kernel", "axis_fwd_kernel", "axis_inv_kernel", "dwt3_", "dwt1_"):
+    for key in ("dwt2_fwd_tile_kernel", "dwt2_fwd_stream_kernel", "dwt2_inv_stream_kernel", "outer_fwd_kernel", "outer_inv_kernel", "inner_fwd_kernel", "inner_inv_kernel", "swt_kernel", "axis_adj_kernel", "axis_fwd_kernel", "axis_inv_kernel", "dwt3_", "dwt1_"):
         if key in name:
             i = name.index(key)
             j = name.find("(", i)
@@ -39,7 +39,7 @@ if trace:
     # per-level durations of the fused kernel: group by grid size
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(trace[0])):
-        if "dwt2_fwd_stream" in r["Kernel_Name"]:
+        if "dwt2_fwd_" in r["Kernel_Name"]:
             agg[(short(r["Kernel_Name"]), r["Grid_Size_X"], r.get("VGPR_Count", ""), r.get("LDS_Block_Size", ""))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     with open(f"profiles/{tag}_kernel_trace_by_level.csv", "w", newline="") as f:
         w = csv.writer(f)
@@ -53,7 +53,7 @@ durs = []
 for p in sorted(glob.glob(os.path.join(src, "p*", "*_counter_collection.csv"))):
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(p)):
-        if "dwt2_fwd_stream" not in r["Kernel_Name"]:
+        if "dwt2_fwd_" not in r["Kernel_Name"]:
             continue
         per[r["Counter_Name"]].append(float(r["Counter_Value"]))
         pmc.setdefault("_kernel", short(r["Kernel_Name"]))
