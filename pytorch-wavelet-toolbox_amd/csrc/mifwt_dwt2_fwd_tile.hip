@@ -69,24 +69,45 @@ __global__ void __launch_bounds__(256, tile_occupancy(L, TR)) dwt2_fwd_tile_kern
   // columns / rows the tile's real outputs need (ragged last tiles request nothing beyond them)
   const int nc_need = 2 * (min(k0 + kTC, a.Wo) - k0) + L - 2;
   const int nr_need = 2 * (min(j0 + TR, a.Ho) - j0) + L - 2;
-  uint32_t coff[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int c = lane + 64 * q;
-    const int m = c < nc_need ? ext_index(2 * k0 - (L - 2) + c, a.W, a.mode) : -1;
-    coff[q] = m < 0 ? kOob : 4u * (uint32_t)m;
-  }
+  const int c_first = 2 * k0 - (L - 2), r_first = 2 * j0 - (L - 2);
+  // a tile whose window lies inside the image along an axis needs no boundary map there: the index arithmetic of the
+  // map (once per row and wave on the scalar unit, once per column and lane) otherwise rivals the filter's issue time
+  const bool cols_inside = c_first >= 0 && c_first + IC <= a.W;
+  const bool rows_inside = r_first >= 0 && r_first + IR <= a.H;
   const uint32_t row_bytes = (uint32_t)a.xs_h * 4u;
   constexpr int RPW = (IR + 3) / 4;  // rows per wave
+  uint32_t coff[NQ];
+  if (cols_inside) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) coff[q] = lane + 64 * q < IC ? 4u * (uint32_t)(c_first + lane + 64 * q) : kOob;
+  } else {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int c = lane + 64 * q;
+      const int m = c < nc_need ? ext_index_near(c_first + c, a.W, a.mode) : -1;
+      coff[q] = m < 0 ? kOob : 4u * (uint32_t)m;
+    }
+  }
   float v[RPW][NQ];
+  if (rows_inside) {
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int r = wave + 4 * i;  // wave-uniform
-    const int m = r < nr_need ? ext_index(2 * j0 - (L - 2) + r, a.H, a.mode) : -1;
-    const uint32_t soff = m < 0 ? 0u : (uint32_t)m * row_bytes;
+    for (int i = 0; i < RPW; ++i) {
+      const int r = wave + 4 * i;  // wave-uniform
+      const uint32_t soff = (uint32_t)(r_first + (r < IR ? r : IR - 1)) * row_bytes;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
-      v[i][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, m < 0 ? kOob : coff[q], soff, 0));
+      for (int q = 0; q < NQ; ++q)
+        v[i][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, coff[q], soff, 0));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int r = wave + 4 * i;  // wave-uniform
+      const int m = r < nr_need ? ext_index_near(r_first + r, a.H, a.mode) : -1;
+      const uint32_t soff = m < 0 ? 0u : (uint32_t)m * row_bytes;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        v[i][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, m < 0 ? kOob : coff[q], soff, 0));
+    }
   }
 #pragma unroll
   for (int i = 0; i < RPW; ++i) {
