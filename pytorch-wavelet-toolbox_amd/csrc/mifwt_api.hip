@@ -228,15 +228,9 @@ size_t route_ws(const mifwt_level_desc* d, int direction, int kid) {
 int pick_kernel(const mifwt_level_desc* d, int direction) {
   if (g_options[MIFWT_OPT_FORCE_GENERIC]) return kGeneric;
   if (direction == 0) {
-    if (dwt2_fwd_stream_supported(d)) {
-      // Two fused kernels share this envelope.  Measured on MI355X (64-image batches, 128^2 .. 4096^2 planes): the
-      // LDS-tile kernel wins for every L <= 14 (by 4-35 %) and for L = 16 up to ~1500^2 planes; only the longest
-      // filters on big planes favour the streaming kernel (its register ring re-reads no row halo).
-      const int tm = g_options[MIFWT_OPT_TILE_MODE];
-      if (tm == 1) return kDwt2FwdTile;
-      if (tm == 2) return kDwt2FwdStream;
-      const bool big_long = d->filt_len >= 16 && d->sig_extent[0] * d->sig_extent[1] >= (int64_t(1) << 21);
-      return big_long ? kDwt2FwdStream : kDwt2FwdTile;
+    {
+      const int k2 = dwt2_fwd_choice(d);
+      if (k2 >= 0) return k2;
     }
     if (plane3_route_ok(d, 0)) return kDwt3FwdStream;
     if (rows_route_ok(d, 0)) return kDwt1FwdRow;

@@ -122,9 +122,15 @@ bool dwt2_fwd_stream_supported(const mifwt_level_desc* d);
 int dwt2_fwd_stream(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
                     const double* dec_lo, const double* dec_hi, hipStream_t stream);
 
-// LDS-tile variant of the fused 2-D analysis level (same envelope as dwt2_fwd_stream; small planes)
+// LDS-tile fused 2-D analysis level (mifwt_dwt2_tile.h): f32 / f16 storage, even L <= 16 and L in {18, 20, 24, 32}
+bool dwt2_fwd_tile_supported(const mifwt_level_desc* d);
 int dwt2_fwd_tile(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
                   const double* dec_lo, const double* dec_hi, hipStream_t stream);
+
+// which fused 2-D analysis kernel serves this descriptor: kDwt2FwdTile, kDwt2FwdStream, or -1 (neither)
+int dwt2_fwd_choice(const mifwt_level_desc* d);
+int dwt2_fwd_fused(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
+                   const double* dec_lo, const double* dec_hi, hipStream_t stream);  // runs that choice
 
 bool dwt2_inv_stream_supported(const mifwt_level_desc* d);
 int dwt2_inv_stream(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y,

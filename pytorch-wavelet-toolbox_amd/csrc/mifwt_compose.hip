@@ -86,6 +86,63 @@ mifwt_level_desc plane_desc(const mifwt_level_desc* d, int64_t depth, bool* fold
 
 }  // namespace
 
+// ---- LDS-tile fused 2-D analysis: envelope and per-(type, length) instantiation units ---------------------------
+int dwt2_fwd_tile_f32_short(const mifwt_level_desc*, const void*, void*, void* const*, const double*, const double*, hipStream_t);
+int dwt2_fwd_tile_f16_short(const mifwt_level_desc*, const void*, void*, void* const*, const double*, const double*, hipStream_t);
+int dwt2_fwd_tile_long18(const mifwt_level_desc*, const void*, void*, void* const*, const double*, const double*, hipStream_t);
+int dwt2_fwd_tile_long20(const mifwt_level_desc*, const void*, void*, void* const*, const double*, const double*, hipStream_t);
+int dwt2_fwd_tile_long24(const mifwt_level_desc*, const void*, void*, void* const*, const double*, const double*, hipStream_t);
+int dwt2_fwd_tile_long32(const mifwt_level_desc*, const void*, void*, void* const*, const double*, const double*, hipStream_t);
+
+bool dwt2_fwd_tile_supported(const mifwt_level_desc* d) {
+  if (d->ndim != 2 || (d->dtype != MIFWT_F32 && d->dtype != MIFWT_F16)) return false;
+  const int L = d->filt_len;
+  if (!((L >= 2 && L <= 20 && (L & 1) == 0) || L == 24 || L == 32)) return false;
+  if (d->sig_stride[2] != 1 || d->approx_stride[2] != 1 || d->detail_stride[2] != 1) return false;
+  // one image must be addressable with 32-bit byte offsets below 2^31 (buffer-resource loads, out-of-range switch)
+  const int64_t span = (d->sig_extent[0] - 1) * d->sig_stride[1] + d->sig_extent[1];
+  if (d->sig_stride[1] < 0 || span >= (int64_t(1) << 29)) return false;
+  for (int i = 0; i < 2; ++i)
+    if (d->approx_stride[i] < 0 || d->detail_stride[i] < 0) return false;
+  return true;
+}
+
+int dwt2_fwd_tile(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo,
+                  const double* hi, hipStream_t stream) {
+  switch (d->filt_len) {
+    case 18: return dwt2_fwd_tile_long18(d, x, approx, details, lo, hi, stream);
+    case 20: return dwt2_fwd_tile_long20(d, x, approx, details, lo, hi, stream);
+    case 24: return dwt2_fwd_tile_long24(d, x, approx, details, lo, hi, stream);
+    case 32: return dwt2_fwd_tile_long32(d, x, approx, details, lo, hi, stream);
+    default: break;
+  }
+  return d->dtype == MIFWT_F16 ? dwt2_fwd_tile_f16_short(d, x, approx, details, lo, hi, stream)
+                               : dwt2_fwd_tile_f32_short(d, x, approx, details, lo, hi, stream);
+}
+
+// Two fused 2-D analysis kernels.  Measured on MI355X (64-image batches, 128^2 .. 4096^2 planes): the LDS-tile kernel
+// wins for every L <= 14 (by 4-35 %) and for L = 16 up to ~1500^2 planes; only 16-tap filters on big planes favour
+// the streaming kernel (its register ring re-reads no row halo).  f16 storage and 18..32 taps: tile kernel only.
+int dwt2_fwd_choice(const mifwt_level_desc* d) {
+  const int tm = g_options[MIFWT_OPT_TILE_MODE];  // 0 auto, 1 always tile, 2 never tile
+  const bool stream_ok = dwt2_fwd_stream_supported(d), tile_ok = dwt2_fwd_tile_supported(d);
+  if (stream_ok && (tm == 2 || !tile_ok)) return kDwt2FwdStream;
+  if (tile_ok && tm != 2) {
+    const bool big_long = d->filt_len == 16 && d->sig_extent[0] * d->sig_extent[1] >= (int64_t(1) << 21);
+    return (tm == 1 || !stream_ok || !big_long) ? kDwt2FwdTile : kDwt2FwdStream;
+  }
+  return -1;
+}
+
+int dwt2_fwd_fused(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo,
+                   const double* hi, hipStream_t stream) {
+  switch (dwt2_fwd_choice(d)) {
+    case kDwt2FwdTile: return dwt2_fwd_tile(d, x, approx, details, lo, hi, stream);
+    case kDwt2FwdStream: return dwt2_fwd_stream(d, x, approx, details, lo, hi, stream);
+    default: return MIFWT_ERR_UNSUPPORTED;
+  }
+}
+
 bool rows_route_ok(const mifwt_level_desc* d, int direction) {
   (void)direction;
   if (!stream_filter_supported(d->filt_len)) return false;
@@ -107,7 +164,7 @@ bool plane3_route_ok(const mifwt_level_desc* d, int direction) {
   if (d->ndim != 3 || d->dtype != MIFWT_F32 || !rows_route_ok(d, direction)) return false;
   bool foldable;
   const mifwt_level_desc p = plane_desc(d, d->sig_extent[0], &foldable);
-  return direction == 0 ? dwt2_fwd_stream_supported(&p) : dwt2_inv_stream_supported(&p);
+  return direction == 0 ? dwt2_fwd_choice(&p) >= 0 : dwt2_inv_stream_supported(&p);
 }
 
 size_t plane3_ws_bytes(const mifwt_level_desc* d, int direction) {
@@ -148,7 +205,7 @@ int plane3_fwd(const mifwt_level_desc* d, const void* x, void* approx, void* con
     const float* xb = static_cast<const float*>(x) + b * d->sig_stride[0];
     float* sb = scratch + b * D * 4 * plane;
     void* det[3] = {sb + plane, sb + 2 * plane, sb + 3 * plane};
-    const int rc = dwt2_fwd_stream(&p, xb, sb, det, lo, hi, stream);
+    const int rc = dwt2_fwd_fused(&p, xb, sb, det, lo, hi, stream);
     if (rc != MIFWT_OK) return rc;
   }
   StreamJob jobs[4];

@@ -1,246 +1,19 @@
-// mifwt_dwt2_fwd_tile.hip — LDS-tiled 2-D analysis level for SMALL planes (gfx950), kernel id 7.
-//
-// Same maths and the same reference seam as mifwt_dwt2_fwd.hip (F.pad + F.conv2d([4,1,L,L], stride 2) + split,
-// src/ptwt/conv_transform_2.py:142-149), different shape of parallelism.  The streaming kernel walks down
-// 256-column strips with the vertical filter window in registers; its per-wave critical path (ring prefill, then a
-// few row pairs) dominates once a plane is only a few hundred pixels wide — levels 2-3 of a pyramid ran at 3.6 and
-// 2.1 TB/s against 4.7 TB/s on level 1.  Here a 256-thread workgroup owns an output tile of TR x 64 coefficients:
-//   1. all four waves request the (2 TR + L - 2) x (2*64 + L - 2) input tile, boundary extension applied as an
-//      index map per row / column, in ONE burst (every load of the tile is in flight before the first is needed)
-//      and park it in LDS;
-//   2. horizontal pass LDS -> LDS, IN PLACE (row r of the (lo, hi) image overwrites row r of the input tile: it is
-//      shorter, and a row is read and written by one wave only, whose DS operations execute in order): lane = output
-//      column, 8-byte conflict-free reads, (lo, hi) packed v_pk_fma_f32;
-//   3. vertical pass LDS -> registers -> global: lane = output column, wave = a block of output rows, 16 packed
-//      FMAs per coefficient position, one coalesced 256-byte store per band and row.
-// Algorithmic traffic: 4*B*H*W read + 4*4*B*Ho*Wo written; the tile halo ((2 TR + L - 2) / 2 TR rows,
-// (128 + L - 2) / 128 columns) is re-read through L2.
-#include "mifwt_stream.h"
+// mifwt_dwt2_fwd_tile.hip — instantiations of the LDS-tile 2-D analysis kernel (mifwt_dwt2_tile.h): f32 storage, L <= 16.
+#include "mifwt_dwt2_tile.h"
 
 namespace mifwt {
 
-namespace {
-
-constexpr int kTC = 64;  // output columns per tile = lanes
-
-template <int L>
-struct Dwt2TileArgs {
-  const float* x;
-  float* out[4];  // bands aa, ad, da, dd
-  int64_t xs_b, xs_h;
-  int64_t os_b[4], os_h[4];
-  int H, W, Ho, Wo;
-  int tiles_c, tiles_r, ntiles;
-  int mode;
-  f2 tap[L];  // (dec_lo[m], dec_hi[m])
-};
-
-// workgroups per CU that the tile's LDS footprint admits = waves per SIMD to allocate registers for (a 256-thread
-// workgroup puts one wave on each SIMD)
-constexpr int tile_occupancy(int L, int TR) {
-  const int lds = (2 * TR + L - 2) * ((2 * kTC + L - 2 + 1) & ~1) * 4;
-  const int n = (160 * 1024) / lds;
-  return n > 8 ? 8 : (n < 1 ? 1 : n);
-}
-
-template <int L, int TR>
-__global__ void __launch_bounds__(256, tile_occupancy(L, TR)) dwt2_fwd_tile_kernel(const Dwt2TileArgs<L> a) {
-  constexpr int IR = 2 * TR + L - 2;    // input rows of a tile
-  constexpr int IC = 2 * kTC + L - 2;   // input columns of a tile
-  constexpr int XP = (IC + 1) & ~1;     // LDS pitch of the tile (floats, even: 8-byte aligned pairs; >= 2 * kTC)
-  constexpr int NQ = (IC + 63) / 64;    // column loads per lane and row
-  constexpr int RW = TR / 4;            // output rows per wave in the vertical pass
-  __shared__ __attribute__((aligned(16))) float xt[IR * XP];
-  static_assert(XP >= 2 * kTC, "the (lo, hi) row image must fit into the input row it replaces");
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tc = bid % a.tiles_c;
-  const int tr = (bid / a.tiles_c) % a.tiles_r;
-  const int img = bid / (a.tiles_c * a.tiles_r);
-  const int k0 = tc * kTC, j0 = tr * TR;
-
-  // ---- 1. input tile -> LDS ------------------------------------------------------------------------------------------
-  const uint32_t img_bytes = ((uint32_t)(a.H - 1) * (uint32_t)a.xs_h + (uint32_t)a.W) * 4u;
-  const __amdgpu_buffer_rsrc_t xrsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (int64_t)img * a.xs_b), 0, img_bytes, 0x00020000);
-  constexpr uint32_t kOob = 0x80000000u;  // >= num_records: the load returns 0 without a memory request
-  // columns / rows the tile's real outputs need (ragged last tiles request nothing beyond them)
-  const int nc_need = 2 * (min(k0 + kTC, a.Wo) - k0) + L - 2;
-  const int nr_need = 2 * (min(j0 + TR, a.Ho) - j0) + L - 2;
-  const int c_first = 2 * k0 - (L - 2), r_first = 2 * j0 - (L - 2);
-  // a tile whose window lies inside the image along an axis needs no boundary map there: the index arithmetic of the
-  // map (once per row and wave on the scalar unit, once per column and lane) otherwise rivals the filter's issue time
-  const bool cols_inside = c_first >= 0 && c_first + IC <= a.W;
-  const bool rows_inside = r_first >= 0 && r_first + IR <= a.H;
-  const uint32_t row_bytes = (uint32_t)a.xs_h * 4u;
-  constexpr int RPW = (IR + 3) / 4;  // rows per wave
-  uint32_t coff[NQ];
-  if (cols_inside) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) coff[q] = lane + 64 * q < IC ? 4u * (uint32_t)(c_first + lane + 64 * q) : kOob;
-  } else {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int c = lane + 64 * q;
-      const int m = c < nc_need ? ext_index_near(c_first + c, a.W, a.mode) : -1;
-      coff[q] = m < 0 ? kOob : 4u * (uint32_t)m;
-    }
-  }
-  float v[RPW][NQ];
-  if (rows_inside) {
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const int r = wave + 4 * i;  // wave-uniform
-      const uint32_t soff = (uint32_t)(r_first + (r < IR ? r : IR - 1)) * row_bytes;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        v[i][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, coff[q], soff, 0));
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const int r = wave + 4 * i;  // wave-uniform
-      const int m = r < nr_need ? ext_index_near(r_first + r, a.H, a.mode) : -1;
-      const uint32_t soff = m < 0 ? 0u : (uint32_t)m * row_bytes;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        v[i][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, m < 0 ? kOob : coff[q], soff, 0));
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int r = wave + 4 * i;
-    if (r < IR) {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        if (lane + 64 * q < XP) xt[r * XP + lane + 64 * q] = v[i][q];
-    }
-  }
-  __syncthreads();
-
-  // ---- 2. horizontal pass, in place: row r becomes (lo, hi)[k] of output column k0 + k ---------------------------------
-  // c[k] = sum_m h[m] x_ext[2k + 1 - m]; tile column of x_ext[2k + 1 - m] is 2k + (L - 1) - m
-#pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int r = wave + 4 * i;
-    if (r < IR) {
-      const f2* row = reinterpret_cast<const f2*>(&xt[r * XP + 2 * lane]);
-      f2 acc;
-#pragma unroll
-      for (int p = 0; p < L / 2; ++p) {
-        const f2 xx = row[p];  // tile columns 2k + 2p, 2k + 2p + 1  <->  taps L-1-2p, L-2-2p
-        if (p == 0) {
-          acc = pkmul_lo(a.tap[L - 1], xx);
-        } else {
-          pkfma_lo(acc, a.tap[L - 1 - 2 * p], xx);
-        }
-        pkfma_hi(acc, a.tap[L - 2 - 2 * p], xx);
-      }
-      wave_lds_fence();  // every lane's reads of row r are issued (DS ops of a wave run in order) before its overwrite
-      *reinterpret_cast<f2*>(&xt[r * XP + 2 * lane]) = acc;
-    }
-  }
-  __syncthreads();
-
-  // ---- 3. vertical pass + stores: wave w owns output rows j0 + w*RW .. + RW - 1 ----------------------------------------
-  const int k = k0 + lane;
-  f2 win[2 * RW + L - 2];
-#pragma unroll
-  for (int t = 0; t < 2 * RW + L - 2; ++t) win[t] = *reinterpret_cast<const f2*>(&xt[(2 * wave * RW + t) * XP + 2 * lane]);
-#pragma unroll
-  for (int i = 0; i < RW; ++i) {
-    const int j = j0 + wave * RW + i;
-    f2 lo2, hi2;  // lo2 = (aa, da), hi2 = (ad, dd)
-#pragma unroll
-    for (int m = 0; m < L; ++m) {
-      const f2 hv = win[2 * i + (L - 1) - m];  // row 2j + 1 - m of the extended plane
-      if (m == 0) {
-        lo2 = pkmul_lo(a.tap[0], hv);
-        hi2 = pkmul_hi(a.tap[0], hv);
-      } else {
-        pkfma_lo(lo2, a.tap[m], hv);
-        pkfma_hi(hi2, a.tap[m], hv);
-      }
-    }
-    if (j < a.Ho && k < a.Wo) {
-      a.out[0][(int64_t)img * a.os_b[0] + (int64_t)j * a.os_h[0] + k] = lo2.x;
-      a.out[1][(int64_t)img * a.os_b[1] + (int64_t)j * a.os_h[1] + k] = hi2.x;
-      a.out[2][(int64_t)img * a.os_b[2] + (int64_t)j * a.os_h[2] + k] = lo2.y;
-      a.out[3][(int64_t)img * a.os_b[3] + (int64_t)j * a.os_h[3] + k] = hi2.y;
-    }
-  }
-}
-
-template <int L, int TR>
-int launch_tile(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo,
-                const double* hi, hipStream_t stream) {
-  Dwt2TileArgs<L> a;
-  a.x = static_cast<const float*>(x);
-  a.out[0] = static_cast<float*>(approx);
-  for (int s = 1; s < 4; ++s) a.out[s] = static_cast<float*>(details[s - 1]);
-  a.xs_b = d->sig_stride[0];
-  a.xs_h = d->sig_stride[1];
-  for (int s = 0; s < 4; ++s) {
-    a.os_b[s] = s == 0 ? d->approx_stride[0] : d->detail_stride[0];
-    a.os_h[s] = s == 0 ? d->approx_stride[1] : d->detail_stride[1];
-  }
-  a.H = (int)d->sig_extent[0];
-  a.W = (int)d->sig_extent[1];
-  a.Ho = (int)d->coef_extent[0];
-  a.Wo = (int)d->coef_extent[1];
-  a.mode = d->mode;
-  for (int m = 0; m < L; ++m) a.tap[m] = (f2){(float)lo[m], (float)hi[m]};
-  a.tiles_c = (a.Wo + kTC - 1) / kTC;
-  a.tiles_r = (a.Ho + TR - 1) / TR;
-  const int64_t ntiles = (int64_t)d->batch * a.tiles_c * a.tiles_r;
-  if (ntiles > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
-  a.ntiles = (int)ntiles;
-  hipLaunchKernelGGL((dwt2_fwd_tile_kernel<L, TR>), dim3((unsigned)ntiles), dim3(256), 0, stream, a);
-  return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
-}
-
-template <int L>
-int launch_tr(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo,
-              const double* hi, hipStream_t stream) {
-  int tr = g_options[MIFWT_OPT_TILE_ROWS];
-  if (tr <= 0) {
-    // Tile height: the smallest one whose grid is resident at once (one "round" of workgroups: a second round costs
-    // a full tile latency again); taller tiles also carry less row halo.  Residency estimate: LDS-limited.
-    const int64_t tiles_c = (d->coef_extent[1] + kTC - 1) / kTC;
-    tr = 12;  // several rounds anyway: 12 rows measured best on 1024^2 and 515^2 planes (vs 8 / 16 / 20 / 24)
-    for (int cand = 8; cand <= 24; cand += 4) {
-      const int64_t blocks = d->batch * tiles_c * ((d->coef_extent[0] + cand - 1) / cand);
-      const int64_t lds = (int64_t)(2 * cand + L - 2) * (2 * kTC + L - 2) * 4;
-      int64_t per_cu = (160 * 1024) / lds;
-      if (per_cu > 8) per_cu = 8;
-      if (blocks <= 256 * per_cu) {
-        tr = cand;
-        break;
-      }
-    }
-  }
-  if (tr <= 8) return launch_tile<L, 8>(d, x, approx, details, lo, hi, stream);
-  if (tr <= 12) return launch_tile<L, 12>(d, x, approx, details, lo, hi, stream);
-  if (tr <= 16) return launch_tile<L, 16>(d, x, approx, details, lo, hi, stream);
-  if (tr <= 20) return launch_tile<L, 20>(d, x, approx, details, lo, hi, stream);
-  return launch_tile<L, 24>(d, x, approx, details, lo, hi, stream);
-}
-
-}  // namespace
-
-int dwt2_fwd_tile(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo,
-                  const double* hi, hipStream_t stream) {
+int dwt2_fwd_tile_f32_short(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
+                            const double* lo, const double* hi, hipStream_t stream) {
   switch (d->filt_len) {
-    case 2: return launch_tr<2>(d, x, approx, details, lo, hi, stream);
-    case 4: return launch_tr<4>(d, x, approx, details, lo, hi, stream);
-    case 6: return launch_tr<6>(d, x, approx, details, lo, hi, stream);
-    case 8: return launch_tr<8>(d, x, approx, details, lo, hi, stream);
-    case 10: return launch_tr<10>(d, x, approx, details, lo, hi, stream);
-    case 12: return launch_tr<12>(d, x, approx, details, lo, hi, stream);
-    case 14: return launch_tr<14>(d, x, approx, details, lo, hi, stream);
-    case 16: return launch_tr<16>(d, x, approx, details, lo, hi, stream);
+    case 2: return launch_tr<float, 2>(d, x, approx, details, lo, hi, stream);
+    case 4: return launch_tr<float, 4>(d, x, approx, details, lo, hi, stream);
+    case 6: return launch_tr<float, 6>(d, x, approx, details, lo, hi, stream);
+    case 8: return launch_tr<float, 8>(d, x, approx, details, lo, hi, stream);
+    case 10: return launch_tr<float, 10>(d, x, approx, details, lo, hi, stream);
+    case 12: return launch_tr<float, 12>(d, x, approx, details, lo, hi, stream);
+    case 14: return launch_tr<float, 14>(d, x, approx, details, lo, hi, stream);
+    case 16: return launch_tr<float, 16>(d, x, approx, details, lo, hi, stream);
     default: return MIFWT_ERR_UNSUPPORTED;
   }
 }

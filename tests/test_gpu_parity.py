@@ -300,7 +300,8 @@ def test_stream_routes_selected():
     assert kid(3, torch.float32, "zero", 4, 8, (256, 256, 256)) == 5 and kid(3, torch.float32, "zero", 4, 8, (256, 256, 256), direction=1) == 6
     assert kid(3, torch.float64, "zero", 4, 2, (33, 34, 35)) == 3  # f64: inner pass + two outer passes
     assert kid(2, torch.float64, "reflect", 8, 2, (64, 64)) == 3
-    assert kid(2, torch.float32, "symmetric", 32, 2, (300, 300)) == 3  # sym16: beyond the fused 2-D envelope
+    assert kid(2, torch.float32, "symmetric", 32, 2, (300, 300)) == 7  # sym16 analysis: LDS-tile kernel
+    assert kid(2, torch.float32, "symmetric", 32, 2, (300, 300), direction=1) == 4  # sym16 synthesis: axis passes
     assert kid(2, torch.float32, "symmetric", 102, 2, (300, 300)) == 0  # coif17: generic passes
 
 
@@ -372,6 +373,37 @@ def test_half_storage_extension():
         y = ptwt_amd.waverec(c, "db4")
         assert G.relerr(to_np(y[..., :1001].double()), x1.double().numpy()) < 2e-3
     finally:
+        ptwt_amd.set_half_storage(False)
+
+
+@pytest.mark.parametrize("wavelet", ["db9", "db10", "db12", "sym16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_tile_dwt2_long_filters_and_half(wavelet, dtype):
+    """18 / 20 / 24 / 32-tap filters and f16 storage on the LDS-tile kernel (kernel id 7) vs the fp64 oracle of the
+    (quantised) input; f16 tolerance = output rounding, 5e-4 norm-wise."""
+    rng = np.random.default_rng(len(wavelet) + 100)
+    flen = len(O.filter_bank(wavelet)[0])
+    tol = TOL32 if dtype == torch.float32 else 5e-4
+    if dtype == torch.float16:
+        ptwt_amd.set_half_storage(True)
+    try:
+        for tr in (0, 8, 24):
+            _engine.set_option(6, tr)
+            for shape in [(2, 131, 3 * flen + 70), (1, 2 * flen, 2 * flen + 1)]:
+                assert _engine.kernel_id(2, dtype, "symmetric", flen, shape[0], shape[1:]) == 7
+                xq = torch.from_numpy(rng.standard_normal(shape)).to(dtype)
+                for mode in MODES:
+                    level = 2 if min(shape[1:]) > 4 * flen else 1
+                    try:
+                        want = O.wavedec2(xq.double().numpy(), wavelet, mode=mode, level=level)
+                    except RuntimeError:
+                        continue
+                    got = ptwt_amd.wavedec2(xq.to(dev()), wavelet, mode=mode, level=level)
+                    for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(want)):
+                        assert a.dtype == dtype
+                        assert G.relerr(to_np(a.double()), b) < tol, (wavelet, mode, shape, n, tr)
+    finally:
+        _engine.set_option(6, 0)
         ptwt_amd.set_half_storage(False)
 
 
