@@ -216,6 +216,7 @@ size_t route_ws(const mifwt_level_desc* d, int direction, int kid) {
   switch (kid) {
     case kDwt2FwdStream:
     case kDwt2FwdTile:
+    case kDwt2InvTile:
     case kDwt2InvStream: return 0;
     case kDwt3FwdStream:
     case kDwt3InvStream: return plane3_ws_bytes(d, direction);
@@ -235,7 +236,10 @@ int pick_kernel(const mifwt_level_desc* d, int direction) {
     if (plane3_route_ok(d, 0)) return kDwt3FwdStream;
     if (rows_route_ok(d, 0)) return kDwt1FwdRow;
   } else {
-    if (dwt2_inv_stream_supported(d)) return kDwt2InvStream;
+    {
+      const int k2 = dwt2_inv_choice(d);
+      if (k2 >= 0) return k2;
+    }
     if (plane3_route_ok(d, 1)) return kDwt3InvStream;
     if (rows_route_ok(d, 1)) return kDwt1InvRow;
   }
@@ -350,6 +354,7 @@ static int run_inv(const mifwt_level_desc* desc, const void* approx, const void*
   if (need > 0 && (!workspace || workspace_bytes < need)) return MIFWT_ERR_WORKSPACE;
   switch (kid) {
     case kDwt2InvStream: return dwt2_inv_stream(desc, approx, details, y, rec_lo, rec_hi, st);
+    case kDwt2InvTile: return dwt2_inv_tile(desc, approx, details, y, rec_lo, rec_hi, st);
     case kDwt3InvStream: return plane3_inv(desc, approx, details, y, rec_lo, rec_hi, workspace, st);
     case kDwt1InvRow: return rows_inv(desc, approx, details, y, rec_lo, rec_hi, workspace, st);
     default: break;

@@ -116,7 +116,7 @@ int stream_call(int dtype, int kind, const StreamCall& c);  // dispatches on dty
 // ---- fused fast paths --------------------------------------------------------------------------------
 // Each returns MIFWT_ERR_UNSUPPORTED when the descriptor is outside its envelope (the dispatcher then
 // falls back to the generic passes) and never touches the workspace.
-enum KernelId { kGeneric = 0, kDwt2FwdStream = 1, kDwt2InvStream = 2, kDwt1FwdRow = 3, kDwt1InvRow = 4, kDwt3FwdStream = 5, kDwt3InvStream = 6, kDwt2FwdTile = 7 };
+enum KernelId { kGeneric = 0, kDwt2FwdStream = 1, kDwt2InvStream = 2, kDwt1FwdRow = 3, kDwt1InvRow = 4, kDwt3FwdStream = 5, kDwt3InvStream = 6, kDwt2FwdTile = 7, kDwt2InvTile = 8 };
 
 bool dwt2_fwd_stream_supported(const mifwt_level_desc* d);
 int dwt2_fwd_stream(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
@@ -131,6 +131,14 @@ int dwt2_fwd_tile(const mifwt_level_desc* d, const void* x, void* approx, void* 
 int dwt2_fwd_choice(const mifwt_level_desc* d);
 int dwt2_fwd_fused(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
                    const double* dec_lo, const double* dec_hi, hipStream_t stream);  // runs that choice
+
+// LDS-tile fused 2-D synthesis level (mifwt_idwt2_tile.h): f32 / f16, even L <= 16 and L in {18, 20, 24, 32}
+bool dwt2_inv_tile_supported(const mifwt_level_desc* d);
+int dwt2_inv_tile(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y,
+                  const double* rec_lo, const double* rec_hi, hipStream_t stream);
+int dwt2_inv_choice(const mifwt_level_desc* d);  // kDwt2InvTile, kDwt2InvStream, or -1
+int dwt2_inv_fused(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y,
+                   const double* rec_lo, const double* rec_hi, hipStream_t stream);
 
 bool dwt2_inv_stream_supported(const mifwt_level_desc* d);
 int dwt2_inv_stream(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y,

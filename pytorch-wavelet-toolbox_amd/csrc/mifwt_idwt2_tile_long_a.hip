@@ -1,0 +1,19 @@
+// mifwt_idwt2_tile_long_a.hip — LDS-tile 2-D synthesis kernel (mifwt_idwt2_tile.h): 18- and 20-tap filters, f32 / f16.
+#include "mifwt_idwt2_tile.h"
+
+namespace mifwt {
+
+int idwt2_tile_long_a(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y,
+                          const double* lo, const double* hi, hipStream_t stream) {
+  switch (d->filt_len) {
+    case 18:
+      return d->dtype == MIFWT_F16 ? launch_idwt_tr<_Float16, 18>(d, approx, details, y, lo, hi, stream)
+                                   : launch_idwt_tr<float, 18>(d, approx, details, y, lo, hi, stream);
+    case 20:
+      return d->dtype == MIFWT_F16 ? launch_idwt_tr<_Float16, 20>(d, approx, details, y, lo, hi, stream)
+                                   : launch_idwt_tr<float, 20>(d, approx, details, y, lo, hi, stream);
+    default: return MIFWT_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace mifwt

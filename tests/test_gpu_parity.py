@@ -193,7 +193,31 @@ def test_fused_idwt2_vs_oracle(wavelet):
     several strips / chunks and coefficient tensors that are views of the analysis buffers."""
     rng = np.random.default_rng(len(wavelet) * 7 + 1)
     flen = len(O.filter_bank(wavelet)[0])
-    assert _engine.kernel_id(2, torch.float32, "zero", flen, 4, (300, 1101), direction=1) == 2
+    _engine.set_option(5, 2)  # tile mode 2: the streaming kernels
+    try:
+        assert _engine.kernel_id(2, torch.float32, "zero", flen, 4, (300, 1101), direction=1) == 2
+        _check_idwt2(wavelet, rng, flen)
+    finally:
+        _engine.set_option(5, 0)
+
+
+@pytest.mark.parametrize("wavelet", FUSED_WAVELETS + ["db10", "sym16"])
+@pytest.mark.parametrize("tile_rows", [0, 8, 16, 24, 32])
+def test_tile_idwt2_vs_oracle(wavelet, tile_rows):
+    """The LDS-tile synthesis kernel (kernel id 8, forced) against the fp64 oracle."""
+    rng = np.random.default_rng(len(wavelet) * 7 + tile_rows)
+    flen = len(O.filter_bank(wavelet)[0])
+    _engine.set_option(5, 1)
+    _engine.set_option(6, tile_rows)
+    try:
+        assert _engine.kernel_id(2, torch.float32, "zero", flen, 4, (300, 1101), direction=1) == 8
+        _check_idwt2(wavelet, rng, flen)
+    finally:
+        _engine.set_option(5, 0)
+        _engine.set_option(6, 0)
+
+
+def _check_idwt2(wavelet, rng, flen):
     for shape in [(3, 70, 530), (2, 131, 257), (1, 300, 1101), (2, 40, 36)]:
         x = rng.standard_normal(shape)
         level = 3 if min(shape[1:]) > 4 * flen else 1
@@ -301,7 +325,7 @@ def test_stream_routes_selected():
     assert kid(3, torch.float64, "zero", 4, 2, (33, 34, 35)) == 3  # f64: inner pass + two outer passes
     assert kid(2, torch.float64, "reflect", 8, 2, (64, 64)) == 3
     assert kid(2, torch.float32, "symmetric", 32, 2, (300, 300)) == 7  # sym16 analysis: LDS-tile kernel
-    assert kid(2, torch.float32, "symmetric", 32, 2, (300, 300), direction=1) == 4  # sym16 synthesis: axis passes
+    assert kid(2, torch.float32, "symmetric", 32, 2, (300, 300), direction=1) == 8  # sym16 synthesis: LDS tiles
     assert kid(2, torch.float32, "symmetric", 102, 2, (300, 300)) == 0  # coif17: generic passes
 
 
