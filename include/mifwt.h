@@ -146,7 +146,8 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  *   3 / 4  streaming axis passes, analysis / synthesis: inner-axis kernel (+ one outer-axis pass per further
  *          axis); unit innermost stride, f32 / f64 / f16, L in {2..20 even, 24, 32}
  *   5 / 6  3-D analysis / synthesis (f32, even L <= 16): fused 2-D kernel over every depth slice + one
- *          streaming pass along depth */
+ *          streaming pass along depth
+ *   9      fully fused 3-D analysis level, LDS bricks (f32, L in {2, 4, 6}) */
 int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 
 /* Library-wide diagnostic switches (process-global, meant for tests and A/B measurements).

@@ -217,6 +217,7 @@ size_t route_ws(const mifwt_level_desc* d, int direction, int kid) {
     case kDwt2FwdStream:
     case kDwt2FwdTile:
     case kDwt2InvTile:
+    case kDwt3FwdTile:
     case kDwt2InvStream: return 0;
     case kDwt3FwdStream:
     case kDwt3InvStream: return plane3_ws_bytes(d, direction);
@@ -233,6 +234,7 @@ int pick_kernel(const mifwt_level_desc* d, int direction) {
       const int k2 = dwt2_fwd_choice(d);
       if (k2 >= 0) return k2;
     }
+    if (g_options[MIFWT_OPT_TILE_MODE] != 2 && dwt3_fwd_tile_supported(d)) return kDwt3FwdTile;
     if (plane3_route_ok(d, 0)) return kDwt3FwdStream;
     if (rows_route_ok(d, 0)) return kDwt1FwdRow;
   } else {
@@ -331,6 +333,7 @@ static int run_fwd(const mifwt_level_desc* desc, const void* x, void* approx, vo
   switch (kid) {
     case kDwt2FwdStream: return dwt2_fwd_stream(desc, x, approx, details, dec_lo, dec_hi, st);
     case kDwt2FwdTile: return dwt2_fwd_tile(desc, x, approx, details, dec_lo, dec_hi, st);
+    case kDwt3FwdTile: return dwt3_fwd_tile(desc, x, approx, details, dec_lo, dec_hi, st);
     case kDwt3FwdStream: return plane3_fwd(desc, x, approx, details, dec_lo, dec_hi, workspace, st);
     case kDwt1FwdRow: return rows_fwd(desc, x, approx, details, dec_lo, dec_hi, workspace, st);
     default: break;

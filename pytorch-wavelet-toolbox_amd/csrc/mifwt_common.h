@@ -116,7 +116,7 @@ int stream_call(int dtype, int kind, const StreamCall& c);  // dispatches on dty
 // ---- fused fast paths --------------------------------------------------------------------------------
 // Each returns MIFWT_ERR_UNSUPPORTED when the descriptor is outside its envelope (the dispatcher then
 // falls back to the generic passes) and never touches the workspace.
-enum KernelId { kGeneric = 0, kDwt2FwdStream = 1, kDwt2InvStream = 2, kDwt1FwdRow = 3, kDwt1InvRow = 4, kDwt3FwdStream = 5, kDwt3InvStream = 6, kDwt2FwdTile = 7, kDwt2InvTile = 8 };
+enum KernelId { kGeneric = 0, kDwt2FwdStream = 1, kDwt2InvStream = 2, kDwt1FwdRow = 3, kDwt1InvRow = 4, kDwt3FwdStream = 5, kDwt3InvStream = 6, kDwt2FwdTile = 7, kDwt2InvTile = 8, kDwt3FwdTile = 9, kDwt3InvTile = 10 };
 
 bool dwt2_fwd_stream_supported(const mifwt_level_desc* d);
 int dwt2_fwd_stream(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
@@ -143,6 +143,11 @@ int dwt2_inv_fused(const mifwt_level_desc* d, const void* approx, const void* co
 bool dwt2_inv_stream_supported(const mifwt_level_desc* d);
 int dwt2_inv_stream(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y,
                     const double* rec_lo, const double* rec_hi, hipStream_t stream);
+
+// fully fused LDS-tile 3-D analysis level (mifwt_dwt3_fwd_tile.hip): f32, L in {2, 4, 6}
+bool dwt3_fwd_tile_supported(const mifwt_level_desc* d);
+int dwt3_fwd_tile(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
+                  const double* dec_lo, const double* dec_hi, hipStream_t stream);
 
 // ---- composed routes (mifwt_compose.hip) --------------------------------------------------------------------
 bool plane3_route_ok(const mifwt_level_desc* d, int direction);  // ndim 3 f32: fused 2-D planes + depth pass

@@ -1,0 +1,353 @@
+// mifwt_dwt3_fwd_tile.hip — fully fused LDS-tile 3-D analysis level for short filters (gfx950), kernel id 9.
+//
+// Replaces, for one level of wavedec3 / fswavedec3: F.pad + F.conv3d([8,1,L,L,L], stride 2) + split (reference
+// src/ptwt/conv_transform_3.py:121-141) — separably, reading the volume once and writing the eight sub-band volumes
+// once (the composed route of mifwt_compose.hip moves 2x the algorithmic bytes through scratch).
+//
+// A 256-thread workgroup owns TD x TR x 64 coefficients (depth x rows x columns) of all eight bands:
+//   1. the (2 TD + L - 2) x (2 TR + L - 2) x (128 + L - 2) input brick, boundary extension as index maps per slice /
+//      row / column, requested in ONE burst and parked in LDS;
+//   2. W pass in place: every brick row becomes 64 (lo, hi) pairs (one wave per row, DS operations in order);
+//   3. H pass in place: every brick slice becomes TR x 64 x (aa, da, ad, dd) — one wave per slice, all of the slice
+//      read into registers before the first overwrite;
+//   4. D pass LDS -> registers -> global: lane = output column, 4 packed accumulators = 8 bands, coalesced 256-byte
+//      stores per band, row and slice.
+// LDS per workgroup = the brick (L = 4, TD = 2, TR = 4: 31 KB, 5 workgroups per CU); the row / slice halo
+// ((2T + L - 2) / 2T per axis) is re-read through L2.  Envelope: f32, L in {2, 4, 6}; longer filters use the composed
+// route (the brick would no longer allow two workgroups per CU).
+// Algorithmic traffic: 4*B*D*H*W read + 8*4*B*Do*Ho*Wo written.
+#include "mifwt_stream.h"
+
+namespace mifwt {
+
+namespace {
+
+constexpr int kTC3 = 64;
+
+template <int L>
+struct Dwt3TileArgs {
+  const float* x;
+  float* out[8];  // band s: bit 2 = depth high, bit 1 = row high, bit 0 = column high
+  int64_t xs_b, xs_d, xs_h;
+  int64_t os_b[8], os_d[8], os_h[8];
+  int D, H, W, Do, Ho, Wo;
+  int tiles_c, tiles_r, tiles_d;
+  int k_limit;  // the brick kernel stores columns < k_limit; the direct kernel the few beyond (see launch3)
+  int mode;
+  f2 tap[L];  // (dec_lo[m], dec_hi[m])
+};
+
+template <int L, int TD, int TR>
+__global__ void __launch_bounds__(256, 2) dwt3_fwd_tile_kernel(const Dwt3TileArgs<L> a) {
+  constexpr int ID = 2 * TD + L - 2, IR = 2 * TR + L - 2, IC = 2 * kTC3 + L - 2;
+  constexpr int XP = (IC + 1) & ~1;   // row pitch (floats)
+  constexpr int SP = IR * XP;         // slice pitch (floats); >= TR * 256 (the slice's H-pass image)
+  constexpr int NQ = (IC + 63) / 64;
+  constexpr int NROWS = ID * IR;
+  constexpr int RPW = (NROWS + 3) / 4;
+  static_assert(SP >= TR * 4 * kTC3, "the H-pass image of a slice must fit into the slice it replaces");
+  static_assert(XP >= 2 * kTC3, "the W-pass image of a row must fit into the row it replaces");
+  static_assert((TD * TR) % 4 == 0, "output (slice, row) pairs are dealt to four waves");
+  extern __shared__ __attribute__((aligned(16))) float brick[];  // [ID][IR][XP]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tc = bid % a.tiles_c;
+  bid /= a.tiles_c;
+  const int tr = bid % a.tiles_r;
+  bid /= a.tiles_r;
+  const int td = bid % a.tiles_d;
+  const int img = bid / a.tiles_d;
+  const int k0 = tc * kTC3, j0 = tr * TR, z0 = td * TD;
+
+  // ---- 1. input brick -> LDS ---------------------------------------------------------------------------------------------
+  // buffer resource over one batch element (32-bit offsets; the host checks the volume fits)
+  const uint32_t vol_bytes =
+      (uint32_t)(((int64_t)(a.D - 1) * a.xs_d + (int64_t)(a.H - 1) * a.xs_h + a.W) * 4);
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (int64_t)img * a.xs_b), 0, vol_bytes, 0x00020000);
+  constexpr uint32_t kOob = 0x80000000u;
+  const int nc_need = 2 * (min(k0 + kTC3, a.k_limit) - k0) + L - 2;
+  const int nr_need = 2 * (min(j0 + TR, a.Ho) - j0) + L - 2;
+  const int nd_need = 2 * (min(z0 + TD, a.Do) - z0) + L - 2;
+  const int c_first = 2 * k0 - (L - 2), r_first = 2 * j0 - (L - 2), d_first = 2 * z0 - (L - 2);
+  uint32_t coff[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int c = lane + 64 * q;
+    const int m = c < nc_need ? ext_index_near(c_first + c, a.W, a.mode) : -1;
+    coff[q] = m < 0 ? kOob : 4u * (uint32_t)m;
+  }
+  const uint32_t row_bytes = (uint32_t)a.xs_h * 4u, slice_bytes = (uint32_t)a.xs_d * 4u;
+  // bricks whose slices and rows lie inside the volume need no per-row boundary maps (scalar-unit work per brick row)
+  const bool inside = d_first >= 0 && d_first + ID <= a.D && r_first >= 0 && r_first + IR <= a.H;
+  float v[RPW][NQ];
+  if (inside) {
+    const uint32_t base = (uint32_t)d_first * slice_bytes + (uint32_t)r_first * row_bytes;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int rid = min(wave + 4 * i, NROWS - 1);  // wave-uniform brick row id = d * IR + r
+      const int d = rid / IR, r = rid - d * IR;
+      const uint32_t soff = base + (uint32_t)d * slice_bytes + (uint32_t)r * row_bytes;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        v[i][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, coff[q], soff, 0));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int rid = wave + 4 * i;
+      const int d = rid / IR, r = rid - d * IR;
+      const int md = (rid < NROWS && d < nd_need) ? ext_index_near(d_first + d, a.D, a.mode) : -1;
+      const int mr = r < nr_need ? ext_index_near(r_first + r, a.H, a.mode) : -1;
+      const bool on = md >= 0 && mr >= 0;
+      const uint32_t soff = on ? (uint32_t)md * slice_bytes + (uint32_t)mr * row_bytes : 0u;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        v[i][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, on ? coff[q] : kOob, soff, 0));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int rid = wave + 4 * i;
+    if (rid < NROWS) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        if (lane + 64 * q < XP) brick[rid * XP + lane + 64 * q] = v[i][q];
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. W pass, in place: brick row -> (lo, hi)[k] -----------------------------------------------------------------------
+  // rows are wave-private (row id = wave mod 4), so a wave may overwrite a row as soon as ITS reads of that row are
+  // issued; rows go in batches of WB (reads of a batch, then its writes) to keep the dependent read -> write chains few
+  constexpr int WB = 5;
+#pragma unroll
+  for (int i0 = 0; i0 < RPW; i0 += WB) {
+    f2 acc[WB];
+#pragma unroll
+    for (int ib = 0; ib < WB; ++ib) {
+      const int rid = wave + 4 * (i0 + ib);
+      if (i0 + ib < RPW && rid < NROWS) {
+        const f2* row = reinterpret_cast<const f2*>(&brick[rid * XP + 2 * lane]);
+#pragma unroll
+        for (int p = 0; p < L / 2; ++p) {
+          const f2 xx = row[p];  // tile columns 2k + 2p, 2k + 2p + 1  <->  taps L-1-2p, L-2-2p
+          if (p == 0) {
+            acc[ib] = pkmul_lo(a.tap[L - 1], xx);
+          } else {
+            pkfma_lo(acc[ib], a.tap[L - 1 - 2 * p], xx);
+          }
+          pkfma_hi(acc[ib], a.tap[L - 2 - 2 * p], xx);
+        }
+      }
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int ib = 0; ib < WB; ++ib) {
+      const int rid = wave + 4 * (i0 + ib);
+      if (i0 + ib < RPW && rid < NROWS) *reinterpret_cast<f2*>(&brick[rid * XP + 2 * lane]) = acc[ib];
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. H pass, in place: slice d -> [j][k] x (aa, da, ad, dd) ---------------------------------------------------------
+  for (int d = wave; d < ID; d += 4) {
+    float* slice = &brick[d * SP];
+    f2 rowv[IR];
+#pragma unroll
+    for (int r = 0; r < IR; ++r) rowv[r] = *reinterpret_cast<const f2*>(&slice[r * XP + 2 * lane]);
+    wave_lds_fence();  // the whole slice is in registers before its image overwrites it
+#pragma unroll
+    for (int j = 0; j < TR; ++j) {
+      f2 lo2, hi2;  // lo2 = (row-low, row-high) of the column-low value; hi2 of the column-high value
+#pragma unroll
+      for (int m = 0; m < L; ++m) {
+        const f2 hv = rowv[2 * j + (L - 1) - m];
+        if (m == 0) {
+          lo2 = pkmul_lo(a.tap[0], hv);
+          hi2 = pkmul_hi(a.tap[0], hv);
+        } else {
+          pkfma_lo(lo2, a.tap[m], hv);
+          pkfma_hi(hi2, a.tap[m], hv);
+        }
+      }
+      // components: .x = (H a, W a), .y = (H d, W a), .z = (H a, W d), .w = (H d, W d)
+      *reinterpret_cast<f4*>(&slice[(j * kTC3 + lane) * 4]) = (f4){lo2.x, lo2.y, hi2.x, hi2.y};
+    }
+  }
+  __syncthreads();
+
+  // ---- 4. D pass + stores: (slice, row) pairs dealt to the waves; lane = output column ------------------------------------------
+  const int k = k0 + lane;
+#pragma unroll
+  for (int i = 0; i < (TD * TR) / 4; ++i) {
+    const int pr = wave * ((TD * TR) / 4) + i;
+    const int dz = pr / TR, j = pr - dz * TR;
+    f2 acc[4];  // acc[c] = (depth-low, depth-high) of component c
+#pragma unroll
+    for (int m = 0; m < L; ++m) {
+      const f4 hv = *reinterpret_cast<const f4*>(&brick[(2 * dz + (L - 1) - m) * SP + (j * kTC3 + lane) * 4]);
+      const f2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
+      if (m == 0) {
+        acc[0] = pkmul_lo(a.tap[0], h01);
+        acc[1] = pkmul_hi(a.tap[0], h01);
+        acc[2] = pkmul_lo(a.tap[0], h23);
+        acc[3] = pkmul_hi(a.tap[0], h23);
+      } else {
+        pkfma_lo(acc[0], a.tap[m], h01);
+        pkfma_hi(acc[1], a.tap[m], h01);
+        pkfma_lo(acc[2], a.tap[m], h23);
+        pkfma_hi(acc[3], a.tap[m], h23);
+      }
+    }
+    const int z = z0 + dz, y = j0 + j;
+    if (z < a.Do && y < a.Ho && k < a.k_limit) {
+      // component c = (H bit = c & 1, W bit = c >> 1)  ->  band = 4 * depth + 2 * H + W
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int hw = 2 * (c & 1) + (c >> 1);
+        const int b0 = hw, b1 = 4 + hw;
+        a.out[b0][(int64_t)img * a.os_b[b0] + (int64_t)z * a.os_d[b0] + (int64_t)y * a.os_h[b0] + k] = acc[c].x;
+        a.out[b1][(int64_t)img * a.os_b[b1] + (int64_t)z * a.os_d[b1] + (int64_t)y * a.os_h[b1] + k] = acc[c].y;
+      }
+    }
+  }
+}
+
+// The last few columns of a plane whose width is just over a multiple of 64 (129 = 2 * 64 + 1 for 256^3 with db2)
+// would cost a whole extra column of bricks with one active lane in 64.  They go to this direct kernel instead: one
+// thread per (batch, slice, row, column) position, L^3 mapped loads (L1 / L2 hits), all eight bands.
+template <int L>
+__global__ void __launch_bounds__(256) dwt3_fwd_cols_kernel(const Dwt3TileArgs<L> a, const int k_begin, const int64_t total) {
+  const int ncol = a.Wo - k_begin;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = idx;
+    const int k = k_begin + (int)(t % ncol);
+    t /= ncol;
+    const int y = (int)(t % a.Ho);
+    t /= a.Ho;
+    const int z = (int)(t % a.Do);
+    const int img = (int)(t / a.Do);
+    const float* xb = a.x + (int64_t)img * a.xs_b;
+    float acc[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc[s] = 0.f;
+#pragma unroll
+    for (int md = 0; md < L; ++md) {
+      const int sd = ext_index_near(2 * z + 1 - md, a.D, a.mode);
+      if (sd < 0) continue;
+      float pl[4] = {0.f, 0.f, 0.f, 0.f};  // (row band, column band) partial sums of this slice: index 2 * H + W
+#pragma unroll
+      for (int mh = 0; mh < L; ++mh) {
+        const int sh = ext_index_near(2 * y + 1 - mh, a.H, a.mode);
+        if (sh < 0) continue;
+        const float* row = xb + (int64_t)sd * a.xs_d + (int64_t)sh * a.xs_h;
+        float wl = 0.f, wh = 0.f;
+#pragma unroll
+        for (int mw = 0; mw < L; ++mw) {
+          const int sw = ext_index_near(2 * k + 1 - mw, a.W, a.mode);
+          const float xv = sw < 0 ? 0.f : row[sw];
+          wl = fmaf(a.tap[mw].x, xv, wl);
+          wh = fmaf(a.tap[mw].y, xv, wh);
+        }
+        pl[0] = fmaf(a.tap[mh].x, wl, pl[0]);
+        pl[1] = fmaf(a.tap[mh].x, wh, pl[1]);
+        pl[2] = fmaf(a.tap[mh].y, wl, pl[2]);
+        pl[3] = fmaf(a.tap[mh].y, wh, pl[3]);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc[c] = fmaf(a.tap[md].x, pl[c], acc[c]);
+        acc[4 + c] = fmaf(a.tap[md].y, pl[c], acc[4 + c]);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+      a.out[s][(int64_t)img * a.os_b[s] + (int64_t)z * a.os_d[s] + (int64_t)y * a.os_h[s] + k] = acc[s];
+  }
+}
+
+template <int L, int TD, int TR>
+int launch3(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo,
+            const double* hi, hipStream_t stream) {
+  constexpr int ID = 2 * TD + L - 2, IR = 2 * TR + L - 2, XP = (2 * kTC3 + L - 2 + 1) & ~1;
+  constexpr size_t lds_bytes = (size_t)ID * IR * XP * sizeof(float);
+  Dwt3TileArgs<L> a;
+  a.x = static_cast<const float*>(x);
+  for (int s = 0; s < 8; ++s) {
+    a.out[s] = static_cast<float*>(s == 0 ? approx : details[s - 1]);
+    const int64_t* st = s == 0 ? d->approx_stride : d->detail_stride;
+    a.os_b[s] = st[0];
+    a.os_d[s] = st[1];
+    a.os_h[s] = st[2];
+  }
+  a.xs_b = d->sig_stride[0];
+  a.xs_d = d->sig_stride[1];
+  a.xs_h = d->sig_stride[2];
+  a.D = (int)d->sig_extent[0];
+  a.H = (int)d->sig_extent[1];
+  a.W = (int)d->sig_extent[2];
+  a.Do = (int)d->coef_extent[0];
+  a.Ho = (int)d->coef_extent[1];
+  a.Wo = (int)d->coef_extent[2];
+  a.mode = d->mode;
+  for (int m = 0; m < L; ++m) a.tap[m] = (f2){(float)lo[m], (float)hi[m]};
+  // columns: whole bricks of 64; a remainder of at most 8 columns behind at least one full brick goes to the direct
+  // kernel (a brick column for it would run with <= 8 of 64 lanes)
+  const int rem = a.Wo % kTC3;
+  const bool split = a.Wo > kTC3 && rem > 0 && rem <= 8;
+  a.k_limit = split ? a.Wo - rem : a.Wo;
+  a.tiles_c = (a.k_limit + kTC3 - 1) / kTC3;
+  a.tiles_r = (a.Ho + TR - 1) / TR;
+  a.tiles_d = (a.Do + TD - 1) / TD;
+  const int64_t ntiles = (int64_t)d->batch * a.tiles_c * a.tiles_r * a.tiles_d;
+  if (ntiles > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
+  if (split) {
+    const int64_t total = (int64_t)d->batch * a.Do * a.Ho * rem;
+    const int64_t want = (total + 255) / 256;
+    hipLaunchKernelGGL((dwt3_fwd_cols_kernel<L>), dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, stream, a,
+                       a.k_limit, total);
+    if (hipGetLastError() != hipSuccess) return MIFWT_ERR_LAUNCH;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt3_fwd_tile_kernel<L, TD, TR>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((dwt3_fwd_tile_kernel<L, TD, TR>), dim3((unsigned)ntiles), dim3(256), lds_bytes, stream, a);
+  return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
+}
+
+}  // namespace
+
+bool dwt3_fwd_tile_supported(const mifwt_level_desc* d) {
+  if (d->ndim != 3 || d->dtype != MIFWT_F32) return false;
+  const int L = d->filt_len;
+  if (L != 2 && L != 4 && L != 6) return false;
+  if (d->sig_stride[3] != 1 || d->approx_stride[3] != 1 || d->detail_stride[3] != 1) return false;
+  for (int i = 0; i < 3; ++i)
+    if (d->sig_stride[i] < 0 || d->approx_stride[i] < 0 || d->detail_stride[i] < 0) return false;
+  // one batch element must be addressable with 32-bit byte offsets below 2^31 (buffer-resource loads)
+  const int64_t span = (d->sig_extent[0] - 1) * d->sig_stride[1] + (d->sig_extent[1] - 1) * d->sig_stride[2] + d->sig_extent[2];
+  return span < (int64_t(1) << 29);
+}
+
+int dwt3_fwd_tile(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo,
+                  const double* hi, hipStream_t stream) {
+  switch (d->filt_len) {
+    // brick = 2 slices x 4 rows x 64 columns of coefficients: measured best on 8 x 256^3 db2 (0.38 ms per level-1 call vs
+    // 0.46 for 4 x 4 x 64, 0.39 for 4 x 2 x 64, 0.44 for 2 x 2 x 64, 0.53 for 2 x 8 x 64; composed route 0.48)
+    case 2: return g_options[MIFWT_OPT_TILE_ROWS] == 1 ? launch3<2, 4, 4>(d, x, approx, details, lo, hi, stream)
+                                                         : launch3<2, 2, 4>(d, x, approx, details, lo, hi, stream);
+    case 4: return g_options[MIFWT_OPT_TILE_ROWS] == 1 ? launch3<4, 4, 4>(d, x, approx, details, lo, hi, stream)
+                                                         : launch3<4, 2, 4>(d, x, approx, details, lo, hi, stream);
+    case 6: return g_options[MIFWT_OPT_TILE_ROWS] == 1 ? launch3<6, 4, 4>(d, x, approx, details, lo, hi, stream)
+                                                         : launch3<6, 2, 4>(d, x, approx, details, lo, hi, stream);
+    default: return MIFWT_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace mifwt

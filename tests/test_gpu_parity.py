@@ -321,7 +321,8 @@ def test_stream_routes_selected():
     kid = _engine.kernel_id
     assert kid(1, torch.float32, "reflect", 8, 4, (1000,)) == 3 and kid(1, torch.float32, "zero", 8, 4, (1000,), direction=1) == 4
     assert kid(1, torch.float64, "reflect", 2, 1, (4096,)) == 3
-    assert kid(3, torch.float32, "zero", 4, 8, (256, 256, 256)) == 5 and kid(3, torch.float32, "zero", 4, 8, (256, 256, 256), direction=1) == 6
+    assert kid(3, torch.float32, "zero", 4, 8, (256, 256, 256)) == 9  # fully fused LDS-brick 3-D analysis
+    assert kid(3, torch.float32, "zero", 8, 8, (256, 256, 256)) == 5 and kid(3, torch.float32, "zero", 4, 8, (256, 256, 256), direction=1) == 6
     assert kid(3, torch.float64, "zero", 4, 2, (33, 34, 35)) == 3  # f64: inner pass + two outer passes
     assert kid(2, torch.float64, "reflect", 8, 2, (64, 64)) == 3
     assert kid(2, torch.float32, "symmetric", 32, 2, (300, 300)) == 7  # sym16 analysis: LDS-tile kernel
@@ -455,3 +456,35 @@ def test_tile_dwt2_vs_oracle(wavelet, tile_rows):
     finally:
         _engine.set_option(5, 0)
         _engine.set_option(6, 0)
+
+
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3"])
+def test_fused_dwt3_tile_vs_oracle_and_composed(wavelet):
+    """The fully fused LDS-brick 3-D analysis kernel (kernel id 9) against the fp64 oracle (all modes, ragged bricks on
+    every axis, tiny volumes) and against the composed route (fused 2-D planes + depth pass, tile mode 2)."""
+    rng = np.random.default_rng(len(wavelet) + 5)
+    flen = len(O.filter_bank(wavelet)[0])
+    for shape in [(2, 21, 37, 141), (1, 2 * flen + 1, 2 * flen, 2 * flen + 3), (3, 9, 70, 66)]:
+        assert _engine.kernel_id(3, torch.float32, "reflect", flen, shape[0], shape[1:]) == 9
+        x = rng.standard_normal(shape)
+        xg = torch.from_numpy(x).float().to(dev())
+        for mode in MODES:
+            level = 2 if min(shape[1:]) >= 3 * flen else 1
+            try:
+                want = O.wavedec3(x, wavelet, mode=mode, level=level)
+            except RuntimeError:
+                continue
+            got = ptwt_amd.wavedec3(xg, wavelet, mode=mode, level=level)
+            check_tree(got, want, TOL32, f"dwt3 tile {wavelet} {mode} {shape}")
+            _engine.set_option(6, 1)  # the 4 x 4 x 64 brick instantiation
+            try:
+                check_tree(ptwt_amd.wavedec3(xg, wavelet, mode=mode, level=level), want, TOL32, f"dwt3 tile 4x4 {wavelet} {mode}")
+            finally:
+                _engine.set_option(6, 0)
+            _engine.set_option(5, 2)
+            try:
+                comp = ptwt_amd.wavedec3(xg, wavelet, mode=mode, level=level)
+            finally:
+                _engine.set_option(5, 0)
+            for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(comp)):
+                assert G.relerr(to_np(a), to_np(b)) < 5e-7, (wavelet, mode, shape, n)
