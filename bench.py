@@ -123,7 +123,7 @@ def profiled_traffic(workload):
     if workload != "wavedec2_db4_L3_64x1024x1024_f32":
         return None
     for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
-        if name.endswith("_pmc_level1.json"):
+        if name.endswith("_pmc_level1.json") and not name.startswith("r01a"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     return json.load(f).get("hbm_traffic_bytes")
@@ -216,6 +216,24 @@ def main():
     torch.cuda.synchronize()
     events, _engine.level_events = _engine.level_events, None
 
+    # Dominant-kernel leg: the same K level-1 launches once more, back to back on the launch stream between ONE pair
+    # of HIP events (the per-launch event pairs above add a barrier packet on each side of every kernel: +5-8 % on a
+    # 100 us kernel), so that the figure is comparable with the rocprofv3 kernel-trace average under profiles/.
+    lvl1_b2b_ms = None
+    if fn_name in ("wavedec2", "fswavedec2", "wavedec3", "wavedec"):
+        taps = ptwt_amd._wavelets.host_taps(wavelet)
+        mode_id = _engine.MODE_IDS[mode]
+        for i in range(3):
+            _engine.ENGINE.analysis(bufs[i % len(bufs)], taps[0], taps[1], mode_id)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(args.steps):
+            _engine.ENGINE.analysis(bufs[i % len(bufs)], taps[0], taps[1], mode_id)
+        e1.record()
+        torch.cuda.synchronize()
+        lvl1_b2b_ms = e0.elapsed_time(e1) / args.steps
+
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -233,7 +251,8 @@ def main():
         for tag, kid, ext, s, e in events:
             per_level_ms.setdefault("x".join(map(str, ext)), []).append(s.elapsed_time(e))
         kid1 = next((kid for (tag, kid, ext, s, e) in events if tuple(ext) == tuple(shape[1:])), -1)
-        avg_ms = sum(lvl1) / max(1, len(lvl1))
+        per_launch_event_ms = sum(lvl1) / max(1, len(lvl1))
+        avg_ms = lvl1_b2b_ms if lvl1_b2b_ms else per_launch_event_ms
         achieved = lvl1_b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         result = {
             "metric": "Msamples/s",
@@ -271,7 +290,8 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes_per_launch": lvl1_b,
                 "avg_launch_ms": round(avg_ms, 4),
-                "timing": f"HIP events around each of the {len(lvl1)} level-1 launches of a second pass of the same {args.steps} steps",
+                "timing": f"one HIP event pair around {args.steps} back-to-back level-1 launches on the launch stream (same rotating inputs); "
+                          f"with an event pair around every launch inside whole calls: {per_launch_event_ms:.4f} ms",
                 "traffic": profiled_traffic(args.workload),
             },
         }

@@ -30,7 +30,7 @@ ap.add_argument("--generic", action="store_true", help="also time the generic ax
 ap.add_argument("--inverse", action="store_true", help="time the synthesis level that reconstructs --shape instead")
 ap.add_argument("--coop", default="0", help="comma list: 1 = cooperative full-line writer, 0 = independent waves")
 ap.add_argument("--nt", default="0", help="comma list: 1 = nontemporal stores")
-ap.add_argument("--tile", default="2", help="comma list: tile mode (1 = LDS-tile kernel, 2 = streaming kernel, 0 = auto)")
+ap.add_argument("--tile", default="0", help="comma list: tile mode (1 = LDS-tile kernel, 2 = streaming kernel, 0 = auto)")
 ap.add_argument("--tr", default="0", help="comma list: tile rows override (8 / 16)")
 args = ap.parse_args()
 
