@@ -147,7 +147,8 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  *          axis); unit innermost stride, f32 / f64 / f16, L in {2..20 even, 24, 32}
  *   5 / 6  3-D analysis / synthesis (f32, even L <= 16): fused 2-D kernel over every depth slice + one
  *          streaming pass along depth
- *   9      fully fused 3-D analysis level, LDS bricks (f32, L in {2, 4, 6}) */
+ *   9      fully fused 3-D analysis level, LDS bricks (f32, L in {2, 4, 6})
+ *   11     fused 2-D analysis level on the matrix cores (banded-Toeplitz MFMA; f16 storage, even L in [18, 32]) */
 int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 
 /* Library-wide diagnostic switches (process-global, meant for tests and A/B measurements).
@@ -160,7 +161,8 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 #define MIFWT_OPT_COOP 3           /* non-zero selects the workgroup-cooperative full-line output writer */
 #define MIFWT_OPT_NT_STORE 4       /* non-zero: nontemporal stores for the sub-band planes */
 #define MIFWT_OPT_TILE_MODE 5      /* 2-D analysis: 0 = auto (LDS-tile kernel on small planes), 1 = always tile, 2 = never */
-#define MIFWT_OPT_TILE_ROWS 6      /* >0 overrides the tile kernel's output rows per tile (8 or 16) */
+#define MIFWT_OPT_TILE_ROWS 6      /* >0 overrides the tile kernels' output rows per tile */
+#define MIFWT_OPT_MFMA_MODE 7      /* 2-D analysis, f16 storage, 18..32 taps: 0 = matrix-core kernel, 2 = vector tile kernel */
 int mifwt_set_option(int key, int value);
 
 const char* mifwt_strerror(int code);

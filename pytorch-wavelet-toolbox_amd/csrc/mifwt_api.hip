@@ -216,6 +216,7 @@ size_t route_ws(const mifwt_level_desc* d, int direction, int kid) {
   switch (kid) {
     case kDwt2FwdStream:
     case kDwt2FwdTile:
+    case kDwt2FwdMfma:
     case kDwt2InvTile:
     case kDwt3FwdTile:
     case kDwt2InvStream: return 0;
@@ -333,6 +334,7 @@ static int run_fwd(const mifwt_level_desc* desc, const void* x, void* approx, vo
   switch (kid) {
     case kDwt2FwdStream: return dwt2_fwd_stream(desc, x, approx, details, dec_lo, dec_hi, st);
     case kDwt2FwdTile: return dwt2_fwd_tile(desc, x, approx, details, dec_lo, dec_hi, st);
+    case kDwt2FwdMfma: return dwt2_fwd_mfma(desc, x, approx, details, dec_lo, dec_hi, st);
     case kDwt3FwdTile: return dwt3_fwd_tile(desc, x, approx, details, dec_lo, dec_hi, st);
     case kDwt3FwdStream: return plane3_fwd(desc, x, approx, details, dec_lo, dec_hi, workspace, st);
     case kDwt1FwdRow: return rows_fwd(desc, x, approx, details, dec_lo, dec_hi, workspace, st);

@@ -116,7 +116,7 @@ int stream_call(int dtype, int kind, const StreamCall& c);  // dispatches on dty
 // ---- fused fast paths --------------------------------------------------------------------------------
 // Each returns MIFWT_ERR_UNSUPPORTED when the descriptor is outside its envelope (the dispatcher then
 // falls back to the generic passes) and never touches the workspace.
-enum KernelId { kGeneric = 0, kDwt2FwdStream = 1, kDwt2InvStream = 2, kDwt1FwdRow = 3, kDwt1InvRow = 4, kDwt3FwdStream = 5, kDwt3InvStream = 6, kDwt2FwdTile = 7, kDwt2InvTile = 8, kDwt3FwdTile = 9, kDwt3InvTile = 10 };
+enum KernelId { kGeneric = 0, kDwt2FwdStream = 1, kDwt2InvStream = 2, kDwt1FwdRow = 3, kDwt1InvRow = 4, kDwt3FwdStream = 5, kDwt3InvStream = 6, kDwt2FwdTile = 7, kDwt2InvTile = 8, kDwt3FwdTile = 9, kDwt3InvTile = 10, kDwt2FwdMfma = 11 };
 
 bool dwt2_fwd_stream_supported(const mifwt_level_desc* d);
 int dwt2_fwd_stream(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
@@ -125,6 +125,11 @@ int dwt2_fwd_stream(const mifwt_level_desc* d, const void* x, void* approx, void
 // LDS-tile fused 2-D analysis level (mifwt_dwt2_tile.h): f32 / f16 storage, even L <= 16 and L in {18, 20, 24, 32}
 bool dwt2_fwd_tile_supported(const mifwt_level_desc* d);
 int dwt2_fwd_tile(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
+                  const double* dec_lo, const double* dec_hi, hipStream_t stream);
+
+// matrix-core (banded-Toeplitz MFMA) fused 2-D analysis level: f16 storage, even L in [18, 32]
+bool dwt2_fwd_mfma_supported(const mifwt_level_desc* d);
+int dwt2_fwd_mfma(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
                   const double* dec_lo, const double* dec_hi, hipStream_t stream);
 
 // which fused 2-D analysis kernel serves this descriptor: kDwt2FwdTile, kDwt2FwdStream, or -1 (neither)

@@ -125,6 +125,7 @@ int dwt2_fwd_tile(const mifwt_level_desc* d, const void* x, void* approx, void* 
 // the streaming kernel (its register ring re-reads no row halo).  f16 storage and 18..32 taps: tile kernel only.
 int dwt2_fwd_choice(const mifwt_level_desc* d) {
   const int tm = g_options[MIFWT_OPT_TILE_MODE];  // 0 auto, 1 always tile, 2 never tile
+  if (g_options[MIFWT_OPT_MFMA_MODE] != 2 && dwt2_fwd_mfma_supported(d)) return kDwt2FwdMfma;
   const bool stream_ok = dwt2_fwd_stream_supported(d), tile_ok = dwt2_fwd_tile_supported(d);
   if (stream_ok && (tm == 2 || !tile_ok)) return kDwt2FwdStream;
   if (tile_ok && tm != 2) {

@@ -1,0 +1,308 @@
+// mifwt_dwt2_fwd_mfma.hip — fused 2-D analysis level for LONG filters on f16 data with the matrix cores (gfx950), id 11.
+//
+// Same seam as the other fused 2-D analysis kernels (F.pad + F.conv2d + split, reference
+// src/ptwt/conv_transform_2.py:142-149; separable form: separable_conv_transform.py:38-72).  With 18..32 taps the
+// level is no longer HBM- but FMA-bound on the vector ALUs (64 FMA per input sample; the vector LDS-tile kernel spends
+// 6.0 ms on level 1 of BASELINE config 5's 32-image slice against 1.9 ms of HBM time).  A stride-2 filter bank over a
+// block of 16 outputs is a banded-Toeplitz product:
+//     [lo[0..16), hi[0..16)] (32)  =  T (32 x 64)  .  x_window (64),      T[(band, k), j] = h_band[2k + L - 1 - j]
+// (zero outside 0 <= 2k + L - 1 - j < L; half of T is structural zeros — the price of the stride), i.e. a GEMM
+// with M = 32, K = 64 and N = as many independent rows / columns as one likes: v_mfma_f32_32x32x16_f16, four K-steps.
+//
+// A 256-thread workgroup owns 16 x 64 coefficients (all four bands) of one image:
+//   1. the 64 x 160 input tile (f16; boundary extension as index maps, out-of-range = 0) -> LDS, one burst;
+//   2. horizontal pass on the matrix cores: B = 16-byte row fragments of the tile straight from LDS (row pitch chosen
+//      conflict-free), A = T from registers, f32 accumulate; result written TRANSPOSED as f16 ([band][column][row]) so
+//      that
+//   3. the vertical pass is the same GEMM with the same T: B = 16-byte column fragments, D -> global stores.
+// Taps enter the matrix cores as f16 PAIRS (t = t_hi + t_lo, two MFMAs per K-step): f32-accurate filters; the data are
+// f16 by definition of this storage type, the intermediate (lo, hi) image is rounded to f16 once.
+// Envelope: f16 storage, even L in [18, 32] (shorter filters are HBM-bound in the vector kernels already).
+#include "mifwt_stream.h"
+
+namespace mifwt {
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16x __attribute__((ext_vector_type(16)));
+
+constexpr int kMR = 16;    // output rows per tile
+constexpr int kMC = 64;    // output columns per tile
+constexpr int kIR = 64;    // input rows of a tile (>= 2 * 16 + L - 2)
+constexpr int kIC = 160;   // input columns of a tile (>= 2 * 64 + L - 2)
+constexpr int kXP = 168;   // LDS pitch of the input tile in halfs: 336 B, conflict-free 16-byte row fragments
+constexpr int kHP = 72;    // LDS pitch of the transposed (lo, hi) image in halfs: 144 B, conflict-free as well
+
+struct MfmaArgs {
+  const _Float16* x;
+  _Float16* out[4];  // bands aa, ad, da, dd
+  int64_t xs_b, xs_h;
+  int64_t os_b[4], os_h[4];
+  int H, W, Ho, Wo;
+  int tiles_c, tiles_r, ntiles;
+  int mode, L;
+  float lo[32], hi[32];  // dec taps, zero-padded to 32
+};
+
+__global__ void __launch_bounds__(256, 4) dwt2_fwd_mfma_kernel(const MfmaArgs a) {
+  __shared__ __attribute__((aligned(16))) _Float16 xt[kIR * kXP];
+  __shared__ __attribute__((aligned(16))) _Float16 ht[2 * kMC * kHP];
+  __shared__ float taps[64];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int L = a.L;
+  const int n = lane & 31, half = lane >> 5;
+
+  // ---- T fragments, once per (persistent) workgroup: T[i][j] = h_band(i)[2 (i & 15) + L - 1 - j] with i = l & 31,
+  // j = 16 c + 8 (l >> 5) + e; f16 pairs (t = t_hi + t_lo)
+  if (threadIdx.x < 64) taps[threadIdx.x] = threadIdx.x < 32 ? a.lo[threadIdx.x] : a.hi[threadIdx.x - 32];
+  __syncthreads();
+  h8 ahi[4], alo[4];
+  {
+    const int band = n >> 4, kq = n & 15;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = 16 * c + 8 * half + e;
+        const int m = 2 * kq + L - 1 - j;
+        const float t = (m >= 0 && m < L) ? taps[32 * band + m] : 0.f;
+        const _Float16 th = (_Float16)t;
+        ahi[c][e] = th;
+        alo[c][e] = (_Float16)(t - (float)th);
+      }
+    }
+  }
+
+  // Persistent workgroups (the T fragments above cost about as much as one tile's MFMAs).  Block b runs on XCD b % 8;
+  // every XCD gets one contiguous eighth of the (image, tile row, tile column) sequence and its blocks walk through it
+  // together, so that tiles stacked vertically — which share half of their input rows — meet in one L2.
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, nq = gridDim.x >> 3;  // the grid is a multiple of 8
+  const int t_begin = (int)(((int64_t)a.ntiles * xcd) >> 3), t_end = (int)(((int64_t)a.ntiles * (xcd + 1)) >> 3);
+  // Each XCD starts an eighth further into its panel: with one image per panel (8 images) all XCDs would otherwise sit
+  // at the same tile of their image, i.e. at addresses a whole image stride (a power of two) apart — measured 15x
+  // slower (every access of the chip lands in the same few memory channels).
+  const int panel = t_end - t_begin, rot = (int)(((int64_t)panel * xcd) >> 3);
+  constexpr uint32_t kOob = 0x80000000u;
+  const uint32_t row_bytes = (uint32_t)a.xs_h * 2u;
+  const uint32_t img_bytes = ((uint32_t)(a.H - 1) * (uint32_t)a.xs_h + (uint32_t)a.W) * 2u;
+  const bool aligned4 = (a.xs_h & 1) == 0 && (a.xs_b & 1) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 3) == 0;
+
+  struct Tile {
+    int img, k0, j0;
+    bool pairs;  // staged as column pairs (dwords) instead of single halfs
+  };
+  auto locate = [&](int it) -> Tile {
+    int pos = it + rot;
+    if (pos >= panel) pos -= panel;
+    const int tile = t_begin + pos;
+    const int trow = tile / a.tiles_c, tc = tile - trow * a.tiles_c;  // trow = img * tiles_r + tr
+    Tile t;
+    t.img = trow / a.tiles_r;
+    t.k0 = tc * kMC;
+    t.j0 = (trow - t.img * a.tiles_r) * kMR;
+    const int c_first = 2 * t.k0 - (L - 2);
+    // column pairs as dwords when the tile's columns lie inside the image and every row starts 4-byte aligned
+    t.pairs = aligned4 && c_first >= 0 && c_first + kIC <= a.W;
+    return t;
+  };
+  // stage 1a: request a tile's 64 x 160 input window into registers (boundary extension as index maps; everything
+  // outside the needed window and all implicit zeros are out-of-range offsets of the buffer resource)
+  auto request = [&](const Tile& t, uint32_t (&v)[16][3]) {
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.x + (int64_t)t.img * a.xs_b), 0, img_bytes, 0x00020000);
+    const int nc_need = 2 * (min(t.k0 + kMC, a.Wo) - t.k0) + L - 2;
+    const int nr_need = 2 * (min(t.j0 + kMR, a.Ho) - t.j0) + L - 2;
+    const int c_first = 2 * t.k0 - (L - 2), r_first = 2 * t.j0 - (L - 2);
+    if (t.pairs) {
+      uint32_t poff[2];
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) poff[qq] = lane + 64 * qq < kIC / 2 ? 2u * (uint32_t)(c_first + 2 * (lane + 64 * qq)) : kOob;
+      if (r_first >= 0 && r_first + kIR <= a.H) {  // rows inside the image: no map, one add per row
+        uint32_t soff = (uint32_t)(r_first + wave) * row_bytes;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) v[i][qq] = __builtin_amdgcn_raw_buffer_load_b32(xrsrc, poff[qq], soff, 0);
+          soff += 4u * row_bytes;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int r = wave + 4 * i;  // wave-uniform
+          const int m = r < nr_need ? ext_index_near(r_first + r, a.H, a.mode) : -1;
+          const uint32_t soff = m < 0 ? 0u : (uint32_t)m * row_bytes;
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) v[i][qq] = __builtin_amdgcn_raw_buffer_load_b32(xrsrc, m < 0 ? kOob : poff[qq], soff, 0);
+        }
+      }
+    } else {
+      uint32_t coff[3];
+#pragma unroll
+      for (int qq = 0; qq < 3; ++qq) {
+        const int c = lane + 64 * qq;
+        const int m = c < nc_need ? ext_index_near(c_first + c, a.W, a.mode) : -1;
+        coff[qq] = m < 0 ? kOob : 2u * (uint32_t)m;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = wave + 4 * i;  // wave-uniform
+        const int m = r < nr_need ? ext_index_near(r_first + r, a.H, a.mode) : -1;
+        const uint32_t soff = m < 0 ? 0u : (uint32_t)m * row_bytes;
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq) v[i][qq] = __builtin_amdgcn_raw_buffer_load_b16(xrsrc, m < 0 ? kOob : coff[qq], soff, 0);
+      }
+    }
+  };
+  // stage 1b: park the requested window in LDS
+  auto commit = [&](const Tile& t, const uint32_t (&v)[16][3]) {
+    if (t.pairs) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = wave + 4 * i;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+          if (lane + 64 * qq < kXP / 2) *reinterpret_cast<uint32_t*>(&xt[r * kXP + 2 * (lane + 64 * qq)]) = v[i][qq];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = wave + 4 * i;
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq)
+          if (lane + 64 * qq < kXP) xt[r * kXP + lane + 64 * qq] = __builtin_bit_cast(_Float16, (unsigned short)v[i][qq]);
+      }
+    }
+  };
+
+  // Software pipeline over this block's tiles: the NEXT tile's window is requested into registers before the matrix
+  // work of the current one and parked in LDS once the horizontal pass has released the tile buffer.
+  uint32_t stage[16][3];
+  if (q >= panel) return;
+  Tile cur = locate(q);
+  request(cur, stage);
+  commit(cur, stage);
+  __syncthreads();
+  for (int it = q; it < panel; it += nq) {
+    const bool has_next = it + nq < panel;
+    Tile nxt = cur;
+    if (has_next) {
+      nxt = locate(it + nq);
+      request(nxt, stage);
+    }
+
+    // ---- 2. horizontal pass: (row group rg, output block kb) jobs, two per wave.  D[r][(band, kq)] = X[r][j] . T^T: the
+    // tile rows are the A operand, T the B operand, so that a lane ends up with ONE output column and four consecutive rows
+    // per register quad — the transposed (lo, hi) image is written with 8-byte stores
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int job = wave * 2 + jj;
+      const int rg = job >> 2, kb = job & 3;
+      f16x acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const h8 xf = *reinterpret_cast<const h8*>(&xt[(rg * 32 + n) * kXP + 32 * kb + 16 * c + 8 * half]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, ahi[c], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, alo[c], acc, 0, 0, 0);
+      }
+      // D[i][col]: col = n -> (band, kq);  i = (e & 3) + 8 (e >> 2) + 4 half -> tile row rg * 32 + i
+      const int band = n >> 4, kq = n & 15;
+      _Float16* hrow = &ht[(band * kMC + kb * 16 + kq) * kHP + rg * 32 + 4 * half];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<h4*>(hrow + 8 * g) =
+            (h4){(_Float16)acc[4 * g], (_Float16)acc[4 * g + 1], (_Float16)acc[4 * g + 2], (_Float16)acc[4 * g + 3]};
+      }
+    }
+    __syncthreads();  // ht complete, xt released
+
+    if (has_next) commit(nxt, stage);
+
+    // ---- 3. vertical pass: one (horizontal band, column group) job per wave -------------------------------------------------
+    {
+      const int bh = wave >> 1, cg = wave & 1;
+      f16x acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const h8 b = *reinterpret_cast<const h8*>(&ht[(bh * kMC + cg * 32 + n) * kHP + 16 * c + 8 * half]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[c], b, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[c], b, acc, 0, 0, 0);
+      }
+      // D[i][col]: i = (e & 3) + 8 (e >> 2) + 4 half -> vertical band bv = e >> 3, output row jr + 4 half with
+      // jr = (e & 3) + 8 ((e >> 2) & 1);  one per-lane base pointer per vertical band, the rest is wave-uniform
+      const int k = cur.k0 + cg * 32 + n;
+      if (k < a.Wo) {
+#pragma unroll
+        for (int bv = 0; bv < 2; ++bv) {
+          const int s = 2 * bv + bh;  // band: bit 1 = vertical (axis -2) high, bit 0 = horizontal high
+          _Float16* base = a.out[s] + (int64_t)cur.img * a.os_b[s] + (int64_t)(cur.j0 + 4 * half) * a.os_h[s] + k;
+          const int jlim = a.Ho - cur.j0 - 4 * half;  // rows jr of this lane with jr < jlim exist
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            const int jr = (g & 3) + 8 * (g >> 2);
+            if (jr < jlim) base[(int64_t)jr * a.os_h[s]] = (_Float16)acc[8 * bv + g];
+          }
+        }
+      }
+    }
+    __syncthreads();  // next tile's window parked, ht released
+    cur = nxt;
+  }
+}
+
+}  // namespace
+
+bool dwt2_fwd_mfma_supported(const mifwt_level_desc* d) {
+  if (d->ndim != 2 || d->dtype != MIFWT_F16) return false;
+  const int L = d->filt_len;
+  if (L < 18 || L > 32 || (L & 1)) return false;
+  if (d->sig_stride[2] != 1 || d->approx_stride[2] != 1 || d->detail_stride[2] != 1) return false;
+  const int64_t span = (d->sig_extent[0] - 1) * d->sig_stride[1] + d->sig_extent[1];
+  if (d->sig_stride[1] < 0 || span >= (int64_t(1) << 29)) return false;
+  for (int i = 0; i < 2; ++i)
+    if (d->approx_stride[i] < 0 || d->detail_stride[i] < 0) return false;
+  return true;
+}
+
+int dwt2_fwd_mfma(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo,
+                  const double* hi, hipStream_t stream) {
+  MfmaArgs a;
+  a.x = static_cast<const _Float16*>(x);
+  a.out[0] = static_cast<_Float16*>(approx);
+  for (int s = 1; s < 4; ++s) a.out[s] = static_cast<_Float16*>(details[s - 1]);
+  a.xs_b = d->sig_stride[0];
+  a.xs_h = d->sig_stride[1];
+  for (int s = 0; s < 4; ++s) {
+    a.os_b[s] = s == 0 ? d->approx_stride[0] : d->detail_stride[0];
+    a.os_h[s] = s == 0 ? d->approx_stride[1] : d->detail_stride[1];
+  }
+  a.H = (int)d->sig_extent[0];
+  a.W = (int)d->sig_extent[1];
+  a.Ho = (int)d->coef_extent[0];
+  a.Wo = (int)d->coef_extent[1];
+  a.mode = d->mode;
+  a.L = d->filt_len;
+  for (int m = 0; m < 32; ++m) {
+    a.lo[m] = m < d->filt_len ? (float)lo[m] : 0.f;
+    a.hi[m] = m < d->filt_len ? (float)hi[m] : 0.f;
+  }
+  a.tiles_c = (a.Wo + kMC - 1) / kMC;
+  a.tiles_r = (a.Ho + kMR - 1) / kMR;
+  const int64_t ntiles = (int64_t)d->batch * a.tiles_c * a.tiles_r;
+  if (ntiles > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
+  a.ntiles = (int)ntiles;
+  // 4 workgroups per CU (LDS) on 256 CUs; the grid is a multiple of 8 (one contiguous panel of tiles per XCD)
+  int64_t grid = 256 * 4;
+  if (ntiles < grid) grid = (ntiles + 7) & ~int64_t(7);
+  hipLaunchKernelGGL(dwt2_fwd_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
+  return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
+}
+
+}  // namespace mifwt

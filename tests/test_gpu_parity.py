@@ -411,6 +411,7 @@ def test_tile_dwt2_long_filters_and_half(wavelet, dtype):
     tol = TOL32 if dtype == torch.float32 else 5e-4
     if dtype == torch.float16:
         ptwt_amd.set_half_storage(True)
+    _engine.set_option(7, 2)  # MFMA mode 2: the vector tile kernel also for f16 long filters
     try:
         for tr in (0, 8, 24):
             _engine.set_option(6, tr)
@@ -429,6 +430,46 @@ def test_tile_dwt2_long_filters_and_half(wavelet, dtype):
                         assert G.relerr(to_np(a.double()), b) < tol, (wavelet, mode, shape, n, tr)
     finally:
         _engine.set_option(6, 0)
+        _engine.set_option(7, 0)
+        ptwt_amd.set_half_storage(False)
+
+
+@pytest.mark.parametrize("wavelet", ["db9", "db10", "db12", "db14", "sym16"])
+def test_mfma_dwt2_long_filters_half(wavelet):
+    """The matrix-core (banded-Toeplitz MFMA) analysis kernel (kernel id 11; f16 storage, 18..32 taps) against the fp64
+    oracle of the quantised input: every mode, ragged tiles, odd pitches (2-byte-aligned rows -> per-element staging),
+    even pitches (dword staging), several tiles per persistent workgroup; and against the vector tile kernel.
+    Tolerance 5e-4 norm-wise (f16 output rounding 2.1e-4 + one f16 rounding of the intermediate image)."""
+    rng = np.random.default_rng(len(wavelet) + 200)
+    flen = len(O.filter_bank(wavelet)[0])
+    ptwt_amd.set_half_storage(True)
+    try:
+        for shape in [(2, 131, 3 * flen + 70), (1, 2 * flen, 2 * flen + 1), (3, 300, 402), (40, 96, 200)]:
+            assert _engine.kernel_id(2, torch.float16, "symmetric", flen, shape[0], shape[1:]) == 11
+            xq = torch.from_numpy(rng.standard_normal(shape)).to(torch.float16)
+            for mode in MODES:
+                level = 2 if min(shape[1:]) > 4 * flen else 1
+                try:
+                    want = O.wavedec2(xq.double().numpy(), wavelet, mode=mode, level=level)
+                except RuntimeError:
+                    continue
+                got = ptwt_amd.wavedec2(xq.to(dev()), wavelet, mode=mode, level=level)
+                vec = got
+                if flen in (18, 20, 24, 32):  # lengths the vector tile kernel is instantiated for
+                    _engine.set_option(7, 2)
+                    try:
+                        vec = ptwt_amd.wavedec2(xq.to(dev()), wavelet, mode=mode, level=level)
+                    finally:
+                        _engine.set_option(7, 0)
+                # one f16 rounding of the intermediate + one of the output per level: 5e-4 for a single level; every further
+                # level starts from an f16-rounded approximation (the oracle's is exact), so the bound grows with the depth
+                tol = 5e-4 if level == 1 else 1e-3
+                for (n, a), (_, b), (_, c) in zip(G.flatten_coeffs(got), G.flatten_coeffs(want), G.flatten_coeffs(vec)):
+                    assert a.dtype == torch.float16
+                    assert G.relerr(to_np(a.double()), b) < tol, (wavelet, mode, shape, n)
+                    assert G.relerr(to_np(a.double()), to_np(c.double())) < tol + 1e-4, (wavelet, mode, shape, n)
+    finally:
+        _engine.set_option(7, 0)
         ptwt_amd.set_half_storage(False)
 
 

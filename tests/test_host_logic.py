@@ -216,7 +216,8 @@ def test_cabi_descriptor_validation_and_dispatch():
     assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (1024, 1024), direction=1) == 2  # fused 2-D synthesis
     assert _engine.kernel_id(2, torch.float64, "reflect", 8, 64, (1024, 1024)) == 3  # f64 -> streaming axis passes
     assert _engine.kernel_id(2, torch.float32, "reflect", 32, 4, (512, 512)) == 7    # L = 32 analysis -> LDS-tile kernel
-    assert _engine.kernel_id(2, torch.float16, "reflect", 32, 4, (512, 512)) == 7    # f16 storage, too
+    assert _engine.kernel_id(2, torch.float16, "reflect", 32, 4, (512, 512)) == 11   # f16 + long filter: matrix cores
+    assert _engine.kernel_id(2, torch.float16, "reflect", 8, 4, (512, 512)) == 7     # f16, short filter: LDS tiles
     assert _engine.kernel_id(2, torch.float32, "reflect", 32, 4, (512, 512), direction=1) == 8  # synthesis: LDS tiles
     assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (515, 515), direction=1) == 8   # small plane: tiles
     assert _engine.kernel_id(1, torch.float64, "zero", 2, 1, (4096,)) == 3
