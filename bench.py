@@ -158,13 +158,20 @@ def main():
 
     if rank == 0:
         entry.build(verbose=False)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # MIFWT_BENCH_BACKEND=gloo + MIFWT_BENCH_SAME_DEVICE=1: dry run of the N > 1 control flow on a one-GPU box
+    # (all ranks on cuda:0, collectives over gloo on host tensors); the real runs use RCCL, one GPU per rank.
+    backend = os.environ.get("MIFWT_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("MIFWT_BENCH_SAME_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         dist.barrier()
     if rank != 0:
         entry.build(verbose=False)
@@ -235,7 +242,7 @@ def main():
         lvl1_b2b_ms = e0.elapsed_time(e1) / args.steps
 
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
