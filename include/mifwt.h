@@ -158,7 +158,7 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 #define MIFWT_OPT_FORCE_GENERIC 0
 #define MIFWT_OPT_ROWS_PER_CHUNK 1
 #define MIFWT_OPT_PREFETCH_PAIRS 2 /* >0 overrides the fused kernels' prefetch depth (row pairs in flight) */
-#define MIFWT_OPT_COOP 3           /* non-zero selects the workgroup-cooperative full-line output writer */
+#define MIFWT_OPT_RESERVED3 3      /* unused (was: cooperative full-line writer, removed after measurement) */
 #define MIFWT_OPT_NT_STORE 4       /* non-zero: nontemporal stores for the sub-band planes */
 #define MIFWT_OPT_TILE_MODE 5      /* 2-D analysis: 0 = auto (LDS-tile kernel on small planes), 1 = always tile, 2 = never */
 #define MIFWT_OPT_TILE_ROWS 6      /* >0 overrides the tile kernels' output rows per tile */

@@ -105,8 +105,10 @@ ROW_ALIGN = int(os.environ.get("MIFWT_ROW_ALIGN", "1"))  # bytes; 1 = dense rows
 OPT_FORCE_GENERIC = 0
 OPT_ROWS_PER_CHUNK = 1
 OPT_PREFETCH_PAIRS = 2
-OPT_COOP = 3
 OPT_NT_STORE = 4
+OPT_TILE_MODE = 5
+OPT_TILE_ROWS = 6
+OPT_MFMA_MODE = 7
 
 
 def set_option(key: int, value: int) -> None:

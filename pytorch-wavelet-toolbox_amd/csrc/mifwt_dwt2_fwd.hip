@@ -1,4 +1,8 @@
-// mifwt_dwt2_fwd.hip — fused single-launch 2-D analysis level for gfx950 (the north-star kernel).
+// mifwt_dwt2_fwd.hip — fused single-launch 2-D analysis level for gfx950, streaming wave strips (kernel id 1).
+//
+// The first design of the north-star kernel.  The LDS-tile kernel (mifwt_dwt2_tile.h, kernel id 7) has since overtaken
+// it for every filter up to 14 taps and for 16 taps below ~1500^2 planes; this one stays the choice for 16-tap filters
+// on big planes, where its register ring re-reads no row halo (dispatch: dwt2_fwd_choice in mifwt_compose.hip).
 //
 // Replaces, for one level of wavedec2 / fswavedec2:  F.pad + F.conv2d([4,1,L,L], stride 2) + split
 // (reference src/ptwt/conv_transform_2.py:142-149) — separably, with the boundary extension as an index
@@ -84,35 +88,10 @@ struct Cfg {
 // bank-conflict-free and the read offsets are compile-time constants relative to one per-lane base.
 constexpr int kLdsRowFloats = 168 * 4;
 
-// Workgroup-cooperative full-line writer (COOP kernels).  The waves of one workgroup cover ALL column strips
-// of a chunk of rows, so for every band the two output rows of an iteration, and the rows of consecutive
-// iterations, are one contiguous byte stream in memory (dense planes: row pitch == Wo).  Waves deposit their
-// results into a per-band LDS stage laid out like that stream; after one s_barrier the whole workgroup
-// writes out every COMPLETE 128-byte line with 16-byte-aligned stores (each wave store = 8 full lines) and
-// carries the sub-line tail over to the next iteration's stage buffer (double-buffered: one barrier per
-// iteration).  Partial lines remain only at the first and last line of a chunk.  Motivation (tools/
-// membench.hip, MI355X): the same bytes written as 496-byte runs at 4-byte-aligned 2060-byte-pitch addresses
-// stream at 4.3 TB/s, as 128-byte-aligned runs at 5.2-5.4 TB/s.
-struct CoopSink {
-  float* stage;     // [2][4][cap] floats (LDS)
-  int cap;          // floats per band buffer (multiple of 4)
-  int nthreads;     // workgroup size
-  int tid;          // thread index in the workgroup (per lane)
-  float* gptr[4];   // global address of stage index 0 of the current buffer (128-byte aligned)
-  int fill[4];      // floats already in the current buffer = where this iteration's deposit starts
-  int head[4];      // indices below head[s] belong to the previous chunk (first line of the chunk only)
-};
-
-__device__ __forceinline__ void wg_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS traffic only: prefetched buffer loads stay in flight
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
-template <int L, int D, bool EDGE, bool COOP>
+template <int L, int D, bool EDGE>
 __device__ __forceinline__ void strip_body(const Dwt2FwdArgs<L>& a, float (*lds)[kLdsRowFloats], int* rowtab,
                                            const int lane, const int img, const int k_base, const int k_end,
-                                           const int j0, const int j1, CoopSink& sink) {
+                                           const int j0, const int j1) {
   using C = Cfg<L, D>;
   constexpr int R4 = C::R4, KS = C::KS, NCH = C::NCH, RING = C::RING, U = C::U;
 
@@ -293,68 +272,20 @@ __device__ __forceinline__ void strip_body(const Dwt2FwdArgs<L>& a, float (*lds)
                        {ol[0].y, ol[1].y, ol[2].y, ol[3].y},
                        {oh[0].x, oh[1].x, oh[2].x, oh[3].x},
                        {oh[0].y, oh[1].y, oh[2].y, oh[3].y}};
-      if (!COOP) {
-        if (hactive && j0 + 2 * p + hrow < j1) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            char* __restrict__ op = obase[s] + (int64_t)p * opair_bytes[s];
-            if (!EDGE || full4) {
-              if (a.nt_store)
-                __builtin_nontemporal_store(o[s], reinterpret_cast<f4u*>(op + ooff[s]));
-              else
-                *reinterpret_cast<f4u*>(op + ooff[s]) = o[s];
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (kcol + e < k_end) *reinterpret_cast<float*>(op + ooff[s] + 4 * e) = o[s][e];
-            }
-          }
-        }
-      } else {
-        // ---- deposit into the stream-ordered stage, then drain complete lines cooperatively ------------
-        float* const st = sink.stage + (p & 1) * 4 * sink.cap;
-        float* const st_next = sink.stage + ((p & 1) ^ 1) * 4 * sink.cap;
-        if (hactive && j0 + 2 * p + hrow < j1) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            float* dp = st + s * sink.cap + sink.fill[s] + hrow * a.Wo + kcol;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (!EDGE || kcol + e < k_end) dp[e] = o[s][e];
-          }
-        }
-        wg_barrier();
-        const int nrows = min(2, j1 - (j0 + 2 * p));
-        const bool last = p == npairs - 1;
+      if (hactive && j0 + 2 * p + hrow < j1) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const int nf = sink.fill[s] + nrows * a.Wo;  // floats in the buffer
-          const int nl = nf >> 5;                      // complete 128-byte lines
-          const float* sb = st + s * sink.cap;
-          float* gp = sink.gptr[s];
-          const int hd = sink.head[s];
-          for (int u = sink.tid; u < nl * 8; u += sink.nthreads) {
-            const f4 v = *reinterpret_cast<const f4*>(sb + 4 * u);
-            if (4 * u >= hd) {
-              *reinterpret_cast<f4*>(gp + 4 * u) = v;
-            } else {
+          char* __restrict__ op = obase[s] + (int64_t)p * opair_bytes[s];
+          if (!EDGE || full4) {
+            if (a.nt_store)
+              __builtin_nontemporal_store(o[s], reinterpret_cast<f4u*>(op + ooff[s]));
+            else
+              *reinterpret_cast<f4u*>(op + ooff[s]) = o[s];
+          } else {
 #pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (4 * u + e >= hd) gp[4 * u + e] = v[e];
-            }
+            for (int e = 0; e < 4; ++e)
+              if (kcol + e < k_end) *reinterpret_cast<float*>(op + ooff[s] + 4 * e) = o[s][e];
           }
-          const int rem = nf - 32 * nl;
-          if (sink.tid < rem) {
-            const int idx = 32 * nl + sink.tid;
-            if (last) {
-              if (idx >= hd) gp[idx] = sb[idx];  // last (partial) line of the chunk
-            } else {
-              st_next[s * sink.cap + sink.tid] = sb[idx];  // carry the sub-line tail over
-            }
-          }
-          sink.gptr[s] = gp + 32 * nl;
-          sink.fill[s] = rem;
-          if (nl > 0) sink.head[s] = 0;
         }
       }
     }
@@ -373,7 +304,6 @@ __global__ void __launch_bounds__(256, (L <= 8 && D <= 2) ? 3 : 2) dwt2_fwd_stre
   // XCD-aware block remap (block b runs on XCD b % 8): give each XCD a contiguous range of tasks so that
   // strips / chunks that share halo columns / rows meet in the same L2.
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  CoopSink nosink;
   const int task = bid * 4 + wave;
   if (task >= a.ntasks) return;
   const int strip = task % a.nstrips;
@@ -388,7 +318,7 @@ __global__ void __launch_bounds__(256, (L <= 8 && D <= 2) ? 3 : 2) dwt2_fwd_stre
   if (strip < a.n_int) {
     const int k_base = a.kl + strip * C::KS;
     const int k_end = min(k_base + C::KS, a.ke);
-    strip_body<L, D, false, false>(a, lds, rowtab, lane, img, k_base, k_end, j0, j1, nosink);
+    strip_body<L, D, false>(a, lds, rowtab, lane, img, k_base, k_end, j0, j1);
   } else {
     const int e = strip - a.n_int;  // right edge strips first, the left edge strip (if any) last
     int k_base, k_end;
@@ -399,56 +329,7 @@ __global__ void __launch_bounds__(256, (L <= 8 && D <= 2) ? 3 : 2) dwt2_fwd_stre
       k_base = 0;
       k_end = a.kl;
     }
-    strip_body<L, D, true, false>(a, lds, rowtab, lane, img, k_base, k_end, j0, j1, nosink);
-  }
-}
-
-// Cooperative variant: one workgroup = all nstrips column strips (one wave each, left to right) of one chunk
-// of rows of one image; dynamic LDS = nstrips per-wave slabs + the double-buffered 4-band output stage.
-constexpr int kWaveLdsFloats = 2 * kLdsRowFloats + 2 * kRowTab;
-constexpr int kCoopMaxWaves = 8;
-
-template <int L, int D>
-__global__ void __launch_bounds__(64 * kCoopMaxWaves, (L <= 8 && D <= 2) ? 3 : 2) dwt2_fwd_coop_kernel(const Dwt2FwdArgs<L> a, const int stage_cap) {
-  using C = Cfg<L, D>;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int chunk = bid % a.nchunks;
-  const int img = bid / a.nchunks;
-  const int j0 = chunk * a.rows_per_chunk;
-  const int j1 = min(j0 + a.rows_per_chunk, a.Ho);
-
-  float* wave_lds = smem + wave * kWaveLdsFloats;
-  float(*lds)[kLdsRowFloats] = reinterpret_cast<float(*)[kLdsRowFloats]>(wave_lds);
-  int* rowtab = reinterpret_cast<int*>(wave_lds + 2 * kLdsRowFloats);
-
-  CoopSink sink;
-  sink.stage = smem + a.nstrips * kWaveLdsFloats;
-  sink.cap = stage_cap;
-  sink.nthreads = a.nstrips * 64;
-  sink.tid = threadIdx.x;
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    float* first = a.out[s] + (int64_t)img * a.os_b[s] + (int64_t)j0 * a.os_h[s];  // first float of the chunk
-    const int phase = (int)((reinterpret_cast<uintptr_t>(first) >> 2) & 31);       // position inside its line
-    sink.gptr[s] = first - phase;
-    sink.fill[s] = phase;
-    sink.head[s] = phase;
-  }
-
-  // strips left to right: [left edge] interior ... [right edge ...]
-  const int has_left = a.kl > 0 ? 1 : 0;
-  if (wave < has_left) {
-    strip_body<L, D, true, true>(a, lds, rowtab, lane, img, 0, a.kl, j0, j1, sink);
-  } else if (wave < has_left + a.n_int) {
-    const int k_base = a.kl + (wave - has_left) * C::KS;
-    strip_body<L, D, false, true>(a, lds, rowtab, lane, img, k_base, min(k_base + C::KS, a.ke), j0, j1, sink);
-  } else {
-    const int k_base = a.ke + (wave - has_left - a.n_int) * C::KS;
-    strip_body<L, D, true, true>(a, lds, rowtab, lane, img, k_base, min(k_base + C::KS, a.Wo), j0, j1, sink);
+    strip_body<L, D, true>(a, lds, rowtab, lane, img, k_base, k_end, j0, j1);
   }
 }
 
@@ -494,51 +375,9 @@ int launch(const mifwt_level_desc* d, const void* x, void* approx, void* const* 
   a.n_int = (ke - kl + C::KS - 1) / C::KS;
   a.n_edge_r = (a.Wo - ke + C::KS - 1) / C::KS;
   a.nstrips = a.n_int + a.n_edge_r + (kl > 0 ? 1 : 0);
-  // Cooperative full-line writer (opt-in, MIFWT_OPT_COOP): needs one workgroup to span the row and dense
-  // output planes.  Measured on MI355X it LOSES to the independent-wave kernel (0.139 vs 0.117 ms on config 2
-  // level 1): the per-iteration workgroup barrier and the lower count of streaming waves per CU cost more
-  // than the full-line stores gain.  Kept for A/B work on the store pattern.
-  bool coop = g_options[MIFWT_OPT_COOP] != 0 && a.nstrips <= kCoopMaxWaves && a.Wo >= 16;
-  for (int s = 0; s < 4; ++s) coop = coop && a.os_h[s] == a.Wo;
-  if (coop) {
-    const int cap = (2 * a.Wo + 32 + 3) & ~3;
-    const size_t lds_bytes = ((size_t)a.nstrips * kWaveLdsFloats + (size_t)2 * 4 * cap) * sizeof(float);
-    if (lds_bytes <= 160 * 1024) {
-      // workgroups resident per CU: LDS- and wave-limited (3 waves per SIMD = 12 waves per CU)
-      const int waves_per_cu = (L <= 8 && D <= 2) ? 12 : 8;
-      int wg_per_cu = (int)((160 * 1024) / lds_bytes);
-      if (wg_per_cu > waves_per_cu / a.nstrips) wg_per_cu = waves_per_cu / a.nstrips;
-      if (wg_per_cu < 1) wg_per_cu = 1;
-      const double slots = 256.0 * wg_per_cu;
-      // rows per chunk: the largest even value whose task count fills whole rounds of the resident slots
-      int rpc = 8;
-      double best = -1.0;
-      for (int r = kMaxRowsPerChunk; r >= 8; r -= 2) {
-        const double rounds = (double)d->batch * ((a.Ho + r - 1) / r) / slots;
-        const double full = rounds < 1.0 ? rounds : rounds / (double)(int64_t)(rounds + 0.999999);
-        if (full > best + 0.03) {
-          best = full;
-          rpc = r;
-        }
-      }
-      if (g_options[MIFWT_OPT_ROWS_PER_CHUNK] > 0) rpc = (g_options[MIFWT_OPT_ROWS_PER_CHUNK] + 1) & ~1;
-      if (rpc > kMaxRowsPerChunk) rpc = kMaxRowsPerChunk;
-      a.rows_per_chunk = rpc;
-      a.nchunks = (a.Ho + rpc - 1) / rpc;
-      const int64_t nblk64 = (int64_t)d->batch * a.nchunks;
-      if (nblk64 > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
-      a.ntasks = (int)nblk64;
-      static bool attr_set = false;
-      if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt2_fwd_coop_kernel<L, D>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-      }
-      hipLaunchKernelGGL((dwt2_fwd_coop_kernel<L, D>), dim3((unsigned)nblk64), dim3(64 * a.nstrips), lds_bytes, stream, a,
-                         cap);
-      return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
-    }
-  }
+  // (A workgroup-cooperative full-line output writer — one workgroup spanning the row, per-band LDS stage, only complete
+  // 128-byte lines stored — was built and measured: 0.139 vs 0.117 ms on config 2 level 1; the per-iteration workgroup
+  // barrier and the lower count of streaming waves per CU cost more than full-line stores gain.  Removed.)
   // Independent-wave kernel.  Rows per chunk: short chunks win on MI355X (8 rows beats 16/32/64 by 10-30 %):
   // the L-2 halo rows are re-read from L2, not HBM, while many short tasks keep every CU's wave slots
   // refilled and balanced.

@@ -28,7 +28,6 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--generic", action="store_true", help="also time the generic axis-pass path")
 ap.add_argument("--inverse", action="store_true", help="time the synthesis level that reconstructs --shape instead")
-ap.add_argument("--coop", default="0", help="comma list: 1 = cooperative full-line writer, 0 = independent waves")
 ap.add_argument("--nt", default="0", help="comma list: 1 = nontemporal stores")
 ap.add_argument("--tile", default="0", help="comma list: tile mode (1 = LDS-tile kernel, 2 = streaming kernel, 0 = auto)")
 ap.add_argument("--tr", default="0", help="comma list: tile rows override (8 / 16)")
