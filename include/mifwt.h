@@ -133,6 +133,18 @@ int mifwt_swt_inv(int dtype, int filt_len, int64_t rows, int64_t n, int64_t dila
                   int64_t a_row_stride, int64_t d_row_stride, void* y, int64_t y_row_stride, const double* rec_lo,
                   const double* rec_hi, double scale, void* stream);
 
+/* Reduction behind the gradients w.r.t. the FILTER TAPS (learnable wavelets: src/ptwt/wavelets_learnable.py; the reference
+ * gets them from ATen's conv backward because its taps stay in the autograd graph, src/ptwt/_util.py:132):
+ *     out[t] += sum_{row < rows} sum_{k < m_len} a[row, k] * b_ext[row, 2k + c0 + sgn * t],     t in [0, filt_len)
+ * a: rows x m_len, b: rows x n_len (contiguous samples, row strides in elements), b extended by `mode` (enum mifwt_mode);
+ * out: DEVICE array of filt_len doubles, accumulated into (zero it first).  f32 / f64.
+ *   analysis level,  dL/d dec[m]:  a = upstream gradient of the band, b = level input, c0 = 1,        sgn = -1, mode = level's
+ *   synthesis level, dL/d rec[t]:  a = the band,                     b = upstream gradient of y, c0 = -(L-2), sgn = +1, zero mode
+ * (for N-D levels a / b are taken after the other axes have been transformed; the host layer composes that). */
+int mifwt_tap_correlate(int dtype, int64_t rows, int64_t m_len, int64_t n_len, const void* a, int64_t a_row_stride,
+                        const void* b, int64_t b_row_stride, int filt_len, int c0, int sgn, int mode, double* out,
+                        void* stream);
+
 /* Scratch bytes one call needs (0 on the fused paths).  direction: 0 = analysis, 1 = synthesis,
  * 2 = mifwt_dwt_fwd_adjoint, 3 = mifwt_dwt_inv_adjoint (same numbering for mifwt_kernel_id). */
 size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);

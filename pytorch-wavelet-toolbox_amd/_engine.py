@@ -74,6 +74,9 @@ def load_library() -> ctypes.CDLL:
     lib.mifwt_dwt_fwd_adjoint.argtypes = [desc_p, vp, ctypes.POINTER(vp), vp, dbl_p, dbl_p, vp, ctypes.c_size_t, vp]
     lib.mifwt_dwt_inv_adjoint.restype = ctypes.c_int
     lib.mifwt_dwt_inv_adjoint.argtypes = [desc_p, vp, vp, ctypes.POINTER(vp), dbl_p, dbl_p, vp, ctypes.c_size_t, vp]
+    lib.mifwt_tap_correlate.restype = ctypes.c_int
+    lib.mifwt_tap_correlate.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, vp,
+                                        ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
     lib.mifwt_set_option.restype = ctypes.c_int
     lib.mifwt_set_option.argtypes = [ctypes.c_int, ctypes.c_int]
     if lib.mifwt_abi_version() != ABI_VERSION:
@@ -341,6 +344,23 @@ class HipLevelEngine:
         yp = g_y.data_ptr()
         self._run(p, 3, g_y, lambda ws, wsb, stream: lib.mifwt_dwt_inv_adjoint(p.ref, yp, base, ptrs, lo, hi, ws, wsb, stream))
         return g_buf
+
+    def tap_correlate(self, a: torch.Tensor, b: torch.Tensor, filt_len: int, c0: int, sgn: int, mode_id: int,
+                      out: torch.Tensor) -> None:
+        """``out[t] += sum_{row, k} a[row, k] * b_ext[row, 2k + c0 + sgn t]`` (C ABI ``mifwt_tap_correlate``): ``a`` [rows, M],
+        ``b`` [rows, N] (contiguous samples), ``out`` float64 [filt_len] on the same device, accumulated into."""
+        _require_gpu(a)
+        lib = load_library()
+        if a.stride(-1) != 1:
+            a = a.contiguous()
+        if b.stride(-1) != 1:
+            b = b.contiguous()
+        assert a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0] and out.dtype == torch.float64
+        with torch.cuda.device(a.device):
+            rc = lib.mifwt_tap_correlate(_DTYPE_IDS[a.dtype], a.shape[0], a.shape[1], b.shape[1], a.data_ptr(), a.stride(0),
+                                         b.data_ptr(), b.stride(0), filt_len, c0, sgn, mode_id, out.data_ptr(),
+                                         _raw_stream(a.device.index if a.device.index is not None else torch.cuda.current_device()))
+        _check(rc)
 
     @staticmethod
     def _run(p: _Plan, direction: int, anchor: torch.Tensor, call) -> None:

@@ -21,55 +21,169 @@ AxisHint = Union[int, Sequence[int], None]
 
 
 # ------------------------------------------------------------------------------------------ autograd
+def _rows_last(t: torch.Tensor, axis: int) -> torch.Tensor:
+    """[B, e_0.., e_{n-1}] -> 2-D [rows, e_axis] with ``axis`` (0-based among the trailing dims) innermost."""
+    t = t.movedim(1 + axis, -1)
+    return t.reshape(-1, t.shape[-1])
+
+
+def _band_index(ndim: int, axis: int, sigma: int, rest: int) -> int:
+    """Band index of the level buffer: bit (ndim-1-a) <=> axis a high-pass; ``rest`` enumerates the other axes' bits in
+    axis order (most significant first)."""
+    s, r = 0, rest
+    for a in reversed(range(ndim)):
+        if a == axis:
+            bit = sigma
+        else:
+            bit = r & 1
+            r >>= 1
+        s |= bit << (ndim - 1 - a)
+    return s
+
+
+def _analysis_tap_grads(x, g_buf, dec_lo, dec_hi, mode_id):
+    """d loss / d (dec_lo, dec_hi) of one analysis level (float64 [L] each).  Along axis a the level is
+    c[k] = sum_m h[m] z_ext[2k+1-m] with z = the input transformed over the OTHER axes (ordinary level calls with axis a
+    folded into the batch); the reduction is ``mifwt_tap_correlate`` (reference: ATen conv backward w.r.t. the weight)."""
+    nd = x.dim() - 1
+    flen = len(dec_lo)
+    g_lo = torch.zeros(flen, dtype=torch.float64, device=x.device)
+    g_hi = torch.zeros_like(g_lo)
+    eng = _engine.ENGINE
+    for a in range(nd):
+        if nd == 1:
+            parts = [x]  # [B, N]
+            part_axis = 0
+        else:
+            xa = x.movedim(1 + a, 1)  # [B, N_a, others..]
+            flat = xa.reshape(-1, *xa.shape[2:])
+            pb = eng.analysis(flat, dec_lo, dec_hi, mode_id)  # [B * N_a, 2^(nd-1), M_others..]
+            pb = pb.reshape(xa.shape[0], xa.shape[1], *pb.shape[1:])  # [B, N_a, 2^(nd-1), M_others..]
+            parts = [pb[:, :, r] for r in range(1 << (nd - 1))]  # each [B, N_a, M_others..]
+            part_axis = 0
+        for r, z in enumerate(parts):
+            z2 = _rows_last(z, part_axis) if nd > 1 else z
+            for sigma, out in ((0, g_lo), (1, g_hi)):
+                band = _band_index(nd, a, sigma, r)
+                g2 = _rows_last(g_buf[:, band], a)
+                eng.tap_correlate(g2, z2, flen, 1, -1, mode_id, out)
+    return g_lo, g_hi
+
+
+def _synthesis_tap_grads(g_y, approx, details, rec_lo, rec_hi):
+    """d loss / d (rec_lo, rec_hi) of one synthesis level.  Along axis a: y[n] = sum_k u[k] g[n+L-2-2k] with u = the
+    bands whose axis-a letter is lo / hi, synthesised over the OTHER axes."""
+    nd = approx.dim() - 1
+    flen = len(rec_lo)
+    g_lo = torch.zeros(flen, dtype=torch.float64, device=g_y.device)
+    g_hi = torch.zeros_like(g_lo)
+    eng = _engine.ENGINE
+    bands = [approx] + list(details)
+    for a in range(nd):
+        gy2 = _rows_last(g_y, a)
+        for sigma, out in ((0, g_lo), (1, g_hi)):
+            if nd == 1:
+                u2 = bands[sigma]
+            else:
+                sel = [bands[_band_index(nd, a, sigma, r)].movedim(1 + a, 1) for r in range(1 << (nd - 1))]  # [B, M_a, M_others..]
+                flat = [t.reshape(-1, *t.shape[2:]).contiguous() for t in sel]
+                out_ext = [g_y.shape[1 + o] for o in range(nd) if o != a]
+                u = eng.synthesis(flat[0], flat[1:], rec_lo, rec_hi, out_ext)  # [B * M_a, N_others..]
+                u = u.reshape(sel[0].shape[0], sel[0].shape[1], *u.shape[1:])  # [B, M_a, N_others..]
+                u2 = _rows_last(u, 0)
+            eng.tap_correlate(u2, gy2, flen, -(flen - 2), 1, 0, out)
+    return g_lo, g_hi
+
+
+def _like(grad64: torch.Tensor, ref: Optional[torch.Tensor]):
+    return None if ref is None else grad64.to(device=ref.device, dtype=ref.dtype).reshape(ref.shape)
+
+
 class _AnalysisLevel(torch.autograd.Function):
-    """One analysis level as a differentiable op w.r.t. its input.  The reference is differentiable because it is
-    built from ATen ops (F.pad + F.conv*d, src/ptwt/conv_transform.py:135-139 and the 2-D / 3-D twins); here the
-    backward is the explicit adjoint kernel (C ABI ``mifwt_dwt_fwd_adjoint``).  Filter taps are constants."""
+    """One analysis level as a differentiable op w.r.t. its input and (optionally) the dec taps.  The reference is
+    differentiable because it is built from ATen ops (F.pad + F.conv*d, src/ptwt/conv_transform.py:135-139 and the
+    2-D / 3-D twins); here the backward is the explicit adjoint kernel (C ABI ``mifwt_dwt_fwd_adjoint``) and, for
+    learnable filter banks, the tap correlation (``mifwt_tap_correlate``).  ``lo_t`` / ``hi_t`` are the tap TENSORS (or
+    None): they only tie the op into the graph, the kernels take the host copies ``dec_lo`` / ``dec_hi``."""
 
     @staticmethod
-    def forward(ctx, x, dec_lo, dec_hi, mode_id):
+    def forward(ctx, x, dec_lo, dec_hi, mode_id, lo_t=None, hi_t=None):
         ctx.meta = (tuple(x.shape[1:]), dec_lo, dec_hi, mode_id)
+        ctx.taps = (lo_t, hi_t)
+        need_taps = any(t is not None and t.requires_grad for t in (lo_t, hi_t))
+        ctx.save_for_backward(x if need_taps else None)
         return _engine.ENGINE.analysis(x, dec_lo, dec_hi, mode_id)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_buf):
         sig_shape, dec_lo, dec_hi, mode_id = ctx.meta
-        return _engine.ENGINE.analysis_adjoint(g_buf, sig_shape, dec_lo, dec_hi, mode_id), None, None, None
+        (x,) = ctx.saved_tensors
+        g_x = _engine.ENGINE.analysis_adjoint(g_buf, sig_shape, dec_lo, dec_hi, mode_id) if ctx.needs_input_grad[0] else None
+        g_lo = g_hi = None
+        if x is not None and (ctx.needs_input_grad[4] or ctx.needs_input_grad[5]):
+            g_lo, g_hi = _analysis_tap_grads(x, g_buf, dec_lo, dec_hi, mode_id)
+            g_lo, g_hi = _like(g_lo, ctx.taps[0]), _like(g_hi, ctx.taps[1])
+        return g_x, None, None, None, g_lo, g_hi
 
 
 class _SynthesisLevel(torch.autograd.Function):
-    """One synthesis level, differentiable w.r.t. the approximation and every detail band (backward:
-    ``mifwt_dwt_inv_adjoint``; reference: autograd through torch.stack + F.conv_transpose*d + crop)."""
+    """One synthesis level, differentiable w.r.t. the approximation, every detail band and (optionally) the rec taps
+    (backward: ``mifwt_dwt_inv_adjoint`` + ``mifwt_tap_correlate``; reference: autograd through torch.stack +
+    F.conv_transpose*d + crop)."""
 
     @staticmethod
-    def forward(ctx, rec_lo, rec_hi, out_ext, approx, *details):
+    def forward(ctx, rec_lo, rec_hi, out_ext, lo_t, hi_t, approx, *details):
         ctx.meta = (tuple(approx.shape[1:]), rec_lo, rec_hi, len(details))
+        ctx.taps = (lo_t, hi_t)
+        need_taps = any(t is not None and t.requires_grad for t in (lo_t, hi_t))
+        if need_taps:
+            ctx.save_for_backward(approx, *details)
+        else:
+            ctx.save_for_backward()
         return _engine.ENGINE.synthesis(approx, list(details), rec_lo, rec_hi, out_ext)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_y):
         coef_shape, rec_lo, rec_hi, ndet = ctx.meta
-        g = _engine.ENGINE.synthesis_adjoint(g_y, coef_shape, rec_lo, rec_hi)
-        return (None, None, None) + tuple(g[:, s] for s in range(ndet + 1))
+        g_bands = (None,) * (ndet + 1)
+        if any(ctx.needs_input_grad[5:]):
+            g = _engine.ENGINE.synthesis_adjoint(g_y, coef_shape, rec_lo, rec_hi)
+            g_bands = tuple(g[:, s] for s in range(ndet + 1))
+        g_lo = g_hi = None
+        saved = ctx.saved_tensors
+        if saved and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
+            g_lo, g_hi = _synthesis_tap_grads(g_y, saved[0], saved[1:], rec_lo, rec_hi)
+            g_lo, g_hi = _like(g_lo, ctx.taps[0]), _like(g_hi, ctx.taps[1])
+        return (None, None, None, g_lo, g_hi) + g_bands
 
 
 _warned_tap_grad = False
 
 
 def _warn_tap_grad(wavelet) -> None:
-    """Taps travel by value in the kernel arguments: gradients w.r.t. learnable filter taps are not propagated."""
+    """For the transforms whose taps are constants to autograd (swt / iswt, packet trees): say so once."""
     global _warned_tap_grad
-    if _warned_tap_grad or isinstance(wavelet, str) or not torch.is_grad_enabled():
+    if _warned_tap_grad or _tap_tensors(wavelet) is None:
         return
-    bank = wavelet if isinstance(wavelet, tuple) else getattr(wavelet, "filter_bank", ())
-    if any(isinstance(t, torch.Tensor) and t.requires_grad for t in bank):
-        import warnings
+    import warnings
 
-        _warned_tap_grad = True
-        warnings.warn("ptwt_amd: filter taps are treated as constants; gradients w.r.t. learnable wavelet taps are not "
-                      "propagated (gradients w.r.t. the data are).", stacklevel=3)
+    _warned_tap_grad = True
+    warnings.warn("ptwt_amd: this transform treats the filter taps as constants; gradients w.r.t. learnable wavelet taps are "
+                  "propagated by wavedec/waverec{,2,3} and fswavedec/fswaverec{2,3} only.", stacklevel=3)
+
+
+def _tap_tensors(wavelet):
+    """(dec_lo, dec_hi, rec_lo, rec_hi) as the caller's TENSORS when the filter bank is learnable (any of them requires
+    grad and grad mode is on), else None.  src/ptwt/_util.py:115-132 keeps such taps in the graph with torch.as_tensor."""
+    if isinstance(wavelet, str) or not torch.is_grad_enabled():
+        return None
+    bank = wavelet if isinstance(wavelet, tuple) else getattr(wavelet, "filter_bank", ())
+    if len(bank) == 4 and all(isinstance(t, torch.Tensor) for t in bank) and any(t.requires_grad for t in bank):
+        return tuple(bank)
+    return None
+
 
 # detail-band order of each public container, as band indices of the engine (bit (n-1-a) <=> axis a high-pass)
 _KEYS_ND = {
@@ -189,7 +303,7 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
     layout = _Layout(data, ndim, axes)
     x = layout.fold(data)
     dec_lo, dec_hi, _, _ = host_taps(wavelet)
-    _warn_tap_grad(wavelet)
+    tap_t = _tap_tensors(wavelet)
     flen = len(dec_lo)
     if level is None:
         level = dwtn_max_level(x.shape[1:], flen)
@@ -198,8 +312,8 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
     for _ in range(level):
         mode_id = _mode_id(mode)
         _check_pad(cur.shape[1:], flen, "reflect" if mode is None else mode)
-        if cur.requires_grad and torch.is_grad_enabled():
-            buf = _AnalysisLevel.apply(cur, dec_lo, dec_hi, mode_id)
+        if torch.is_grad_enabled() and (cur.requires_grad or tap_t is not None):
+            buf = _AnalysisLevel.apply(cur, dec_lo, dec_hi, mode_id, *((tap_t[0], tap_t[1]) if tap_t else (None, None)))
         else:
             buf = _engine.ENGINE.analysis(cur, dec_lo, dec_hi, mode_id)
         bufs.append(buf)
@@ -240,7 +354,7 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
             raise ValueError(f"Unexpected input type {type(t)}")
     _check_same_device_dtype(flat)
     _, _, rec_lo, rec_hi = host_taps(wavelet)
-    _warn_tap_grad(wavelet)
+    tap_t = _tap_tensors(wavelet)
     flen = len(rec_lo)
     cur = layout.fold(approx)
     folded = [[layout.fold(t) for t in lvl] for lvl in levels]
@@ -263,8 +377,8 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
         out_ext = [2 * cur.shape[1 + a] - flen + 2 - trims[a] for a in range(ndim)]
         if min(out_ext) < 1:
             raise ValueError("coefficients too short for this wavelet")
-        if torch.is_grad_enabled() and (cur.requires_grad or any(t.requires_grad for t in det)):
-            cur = _SynthesisLevel.apply(rec_lo, rec_hi, tuple(out_ext), cur, *det)
+        if torch.is_grad_enabled() and (cur.requires_grad or any(t.requires_grad for t in det) or tap_t is not None):
+            cur = _SynthesisLevel.apply(rec_lo, rec_hi, tuple(out_ext), *((tap_t[2], tap_t[3]) if tap_t else (None, None)), cur, *det)
         else:
             cur = _engine.ENGINE.synthesis(cur, det, rec_lo, rec_hi, out_ext)
     return layout.unfold(cur)

@@ -123,7 +123,7 @@ class _PacketTree(collections.UserDict):
         mode_id = _fwt._mode_id(self.mode)
         _fwt._check_pad(flat.shape[1:], len(dec_lo), "reflect" if self.mode is None else self.mode)
         if flat.requires_grad and torch.is_grad_enabled():
-            out = _fwt._AnalysisLevel.apply(flat, dec_lo, dec_hi, mode_id)
+            out = _fwt._AnalysisLevel.apply(flat, dec_lo, dec_hi, mode_id, None, None)
         else:
             out = _engine.ENGINE.analysis(flat, dec_lo, dec_hi, mode_id)  # [B * nb^level, nb, M..]
         nxt = out.reshape(src.shape[0], *([nb] * (level + 1)), *out.shape[2:])
@@ -197,7 +197,7 @@ class _PacketTree(collections.UserDict):
                         out_ext[a] = target[a]
             approx, details = flat[:, 0], [flat[:, s] for s in range(1, nb)]
             if torch.is_grad_enabled() and flat.requires_grad:
-                rec = _fwt._SynthesisLevel.apply(rec_lo, rec_hi, tuple(out_ext), approx, *details)
+                rec = _fwt._SynthesisLevel.apply(rec_lo, rec_hi, tuple(out_ext), None, None, approx, *details)
             else:
                 rec = _engine.ENGINE.synthesis(approx, details, rec_lo, rec_hi, out_ext)
             buf = rec.reshape(children.shape[0], *([nb] * level), *rec.shape[1:])
