@@ -529,3 +529,87 @@ def test_fused_dwt3_tile_vs_oracle_and_composed(wavelet):
                 _engine.set_option(5, 0)
             for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(comp)):
                 assert G.relerr(to_np(a), to_np(b)) < 5e-7, (wavelet, mode, shape, n)
+
+
+# ------------------------------------------------------------------ edge cases and the other BASELINE configs at full size
+def test_empty_batch_tiny_and_level0():
+    """Empty batches, one-sample signals and level 0 go through without touching a kernel's bounds."""
+    for fn, rec, shape in [("wavedec", "waverec", (0, 64)), ("wavedec2", "waverec2", (0, 32, 32)), ("wavedec3", "waverec3", (0, 16, 16, 16))]:
+        x = torch.zeros(*shape, device=dev())
+        c = getattr(ptwt_amd, fn)(x, "db2", mode="symmetric", level=2)
+        assert c[0].shape[0] == 0
+        y = getattr(ptwt_amd, rec)(c, "db2")
+        assert y.shape[0] == 0
+    x = torch.randn(3, 1, device=dev(), dtype=torch.float64)  # N = 1
+    check_tree(ptwt_amd.wavedec(x, "db4", mode="zero", level=1), O.wavedec(x.cpu().numpy(), "db4", mode="zero", level=1), TOL64, "N=1")
+    x = torch.randn(3, 3, device=dev(), dtype=torch.float64)  # N = 3 < pad: the symmetric extension folds repeatedly
+    check_tree(ptwt_amd.wavedec(x, "db4", mode="symmetric", level=1), O.wavedec(x.cpu().numpy(), "db4", mode="symmetric", level=1),
+               TOL64, "N=3")
+    x = torch.randn(2, 5, 7, device=dev())
+    c = ptwt_amd.wavedec2(x, "haar", level=0)
+    assert len(c) == 1 and torch.equal(c[0], x)
+    x1 = torch.randn(1, 2, 3, device=dev())  # planes smaller than the filter
+    check_tree(ptwt_amd.wavedec2(x1, "db3", mode="symmetric", level=1), O.wavedec2(x1.cpu().double().numpy(), "db3", mode="symmetric", level=1), TOL32, "2x3 db3")
+
+
+def test_full_size_config3_properties():
+    """BASELINE configs[2] at full size (8 x 256^3 fp32, db2, level 3, mode zero): oracle check on a sub-volume's worth of
+    coefficients (first batch element vs the fp64 oracle), linearity, round trip."""
+    torch.manual_seed(3)
+    x = torch.randn(8, 256, 256, 256, device=dev())
+    c = ptwt_amd.wavedec3(x, "db2", level=3)
+    assert tuple(c[0].shape[-3:]) == (34, 34, 34) and tuple(c[-1]["ddd"].shape[-3:]) == (129, 129, 129)
+    want = O.wavedec3(to_np(x[0]).astype(np.float64), "db2", level=3)
+    got = tuple([c[0][0]] + [{k: v[0] for k, v in d.items()} for d in c[1:]])
+    check_tree(got, want, TOL32, "config 3, batch element 0")
+    y = torch.randn_like(x)
+    cz = ptwt_amd.wavedec3(2 * x + y, "db2", level=3)
+    cy = ptwt_amd.wavedec3(y, "db2", level=3)
+    for (n, a), (_, b), (_, d) in zip(G.flatten_coeffs(cz), G.flatten_coeffs(c), G.flatten_coeffs(cy)):
+        assert G.relerr(to_np(a[:2]), to_np((2 * b + d)[:2])) < 2e-6, n
+    rec = ptwt_amd.waverec3(c, "db2")
+    assert rec.shape == x.shape and (rec - x).abs().max().item() < 1e-5
+
+
+def test_full_size_config4_slice_properties():
+    """BASELINE configs[3], one GPU's 64-image shard (64 x 4096^2 fp32, db8, level 4): oracle check on one image, round trip."""
+    torch.manual_seed(4)
+    x = torch.randn(64, 4096, 4096, device=dev())
+    c = ptwt_amd.wavedec2(x, "db8", level=4)
+    assert [tuple(t.shape[-2:]) for t in (c[0], c[1][0], c[2][0], c[3][0], c[4][0])] == [(270, 270), (270, 270), (525, 525), (1035, 1035), (2055, 2055)]
+    want = O.wavedec2(to_np(x[63]).astype(np.float64), "db8", level=4)
+    got = tuple([c[0][63]] + [tuple(t[63] for t in det) for det in c[1:]])
+    check_tree(got, want, TOL32, "config 4, image 63")
+    rec = ptwt_amd.waverec2(c, "db8")
+    assert rec.shape == x.shape
+    assert G.relerr(to_np(rec[:2]), to_np(x[:2])) < 2e-6 and (rec[60:] - x[60:]).abs().max().item() < 2e-5
+
+
+def test_full_size_config5_slice_properties():
+    """BASELINE configs[4], a 16-image slice (16 x 8192^2 fp16, sym16, level 5, fswavedec2; matrix-core kernel): oracle
+    check on the finest level of a crop-independent image (whole image 0 through the fp64 oracle would take minutes:
+    the check uses level 1 of image 0 and the deeper levels of a 1024^2 image), sizes, linearity in fp16 tolerance."""
+    ptwt_amd.set_half_storage(True)
+    try:
+        torch.manual_seed(5)
+        x = torch.randn(16, 8192, 8192, device=dev()).half()
+        c = ptwt_amd.fswavedec2(x, "sym16", level=5)
+        assert [tuple(d["dd"].shape[-2:]) for d in c[1:]] == [(286, 286), (541, 541), (1051, 1051), (2071, 2071), (4111, 4111)]
+        assert c[0].dtype == torch.float16 and _engine.kernel_id(2, torch.float16, "reflect", 32, 16, (8192, 8192)) == 11
+        # level 1 of a 2048-row band of image 0 against the oracle (rows are independent of the rest only through the
+        # vertical filter: compare the interior rows of the band)
+        band = x[0, 1024:3072].double().cpu().numpy()
+        want = O.fswavedec2(band, "sym16", level=1)
+        got_dd = c[-1]["dd"][0].double().cpu().numpy()
+        # rows 1024..3071 of the image <-> coefficient rows (1024 + 30)/2 .. : interior rows of the band's transform
+        lo = 60
+        w = want[1]["dd"][lo:-lo]
+        g = got_dd[512 + lo: 512 + lo + w.shape[0]]
+        assert G.relerr(g, w) < 5e-4
+        small = x[1, :1024, :1024].contiguous()
+        check = ptwt_amd.fswavedec2(small, "sym16", level=5)
+        want = O.fswavedec2(small.double().cpu().numpy(), "sym16", level=5)
+        for (n, a), (_, b) in zip(G.flatten_coeffs(check), G.flatten_coeffs(want)):
+            assert G.relerr(to_np(a.double()), b) < 2e-3, n  # five levels of f16 storage
+    finally:
+        ptwt_amd.set_half_storage(False)
