@@ -180,7 +180,13 @@ __global__ void __launch_bounds__(256, 2) dwt3_fwd_tile_kernel(const Dwt3TileArg
   __syncthreads();
 
   // ---- 4. D pass + stores: (slice, row) pairs dealt to the waves; lane = output column ------------------------------------------
+  // The scalar unit is shared by the whole CU and was this kernel's busiest resource (934 scalar instructions per wave, most of
+  // them 64-bit address arithmetic per band and store): band bases are formed once per workgroup, the (slice, row) offset once
+  // per pair and stride set (band 0 = approximation strides, bands 1..7 share the detail strides).
   const int k = k0 + lane;
+  float* obase[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) obase[b] = a.out[b] + (int64_t)img * a.os_b[b] + k;
 #pragma unroll
   for (int i = 0; i < (TD * TR) / 4; ++i) {
     const int pr = wave * ((TD * TR) / 4) + i;
@@ -204,13 +210,14 @@ __global__ void __launch_bounds__(256, 2) dwt3_fwd_tile_kernel(const Dwt3TileArg
     }
     const int z = z0 + dz, y = j0 + j;
     if (z < a.Do && y < a.Ho && k < a.k_limit) {
+      const int64_t off_a = (int64_t)z * a.os_d[0] + (int64_t)y * a.os_h[0];  // approximation strides
+      const int64_t off_d = (int64_t)z * a.os_d[1] + (int64_t)y * a.os_h[1];  // detail strides (bands 1..7)
       // component c = (H bit = c & 1, W bit = c >> 1)  ->  band = 4 * depth + 2 * H + W
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int hw = 2 * (c & 1) + (c >> 1);
-        const int b0 = hw, b1 = 4 + hw;
-        a.out[b0][(int64_t)img * a.os_b[b0] + (int64_t)z * a.os_d[b0] + (int64_t)y * a.os_h[b0] + k] = acc[c].x;
-        a.out[b1][(int64_t)img * a.os_b[b1] + (int64_t)z * a.os_d[b1] + (int64_t)y * a.os_h[b1] + k] = acc[c].y;
+        obase[hw][hw == 0 ? off_a : off_d] = acc[c].x;
+        obase[4 + hw][off_d] = acc[c].y;
       }
     }
   }
