@@ -158,6 +158,11 @@ __global__ void __launch_bounds__(256, tile_occupancy(L, TR)) dwt2_fwd_tile_kern
 
   // ---- 3. vertical pass + stores: wave w owns output rows j0 + w*RW .. + RW - 1 ----------------------------------------
   const int k = k0 + lane;
+  // band bases once per workgroup, row offsets once per row and stride set (bands 1..3 share the detail strides): the
+  // scalar unit is shared by the CU, per-store 64-bit address arithmetic was a third of its load on small planes
+  T* obase[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) obase[s] = a.out[s] + (int64_t)img * a.os_b[s] + k;
   f2 win[2 * RW + L - 2];
 #pragma unroll
   for (int t = 0; t < 2 * RW + L - 2; ++t) win[t] = *reinterpret_cast<const f2*>(&xt[(2 * wave * RW + t) * XP + 2 * lane]);
@@ -177,10 +182,11 @@ __global__ void __launch_bounds__(256, tile_occupancy(L, TR)) dwt2_fwd_tile_kern
       }
     }
     if (j < a.Ho && k < a.Wo) {
-      a.out[0][(int64_t)img * a.os_b[0] + (int64_t)j * a.os_h[0] + k] = (T)lo2.x;
-      a.out[1][(int64_t)img * a.os_b[1] + (int64_t)j * a.os_h[1] + k] = (T)hi2.x;
-      a.out[2][(int64_t)img * a.os_b[2] + (int64_t)j * a.os_h[2] + k] = (T)lo2.y;
-      a.out[3][(int64_t)img * a.os_b[3] + (int64_t)j * a.os_h[3] + k] = (T)hi2.y;
+      const int64_t off_a = (int64_t)j * a.os_h[0], off_d = (int64_t)j * a.os_h[1];
+      obase[0][off_a] = (T)lo2.x;
+      obase[1][off_d] = (T)hi2.x;
+      obase[2][off_d] = (T)lo2.y;
+      obase[3][off_d] = (T)hi2.y;
     }
   }
 }
