@@ -76,6 +76,18 @@ def algorithmic_bytes(batch, sig, flen, level, esize):
     return (esize * batch * compulsory, esize * batch * per_level, esize * batch * level1)
 
 
+def _flatten(coeffs):
+    out = []
+    for i, c in enumerate(coeffs):
+        if isinstance(c, torch.Tensor):
+            out.append((str(i), c))
+        elif isinstance(c, dict):
+            out.extend((f"{i}_{k}", v) for k, v in c.items())
+        else:
+            out.extend((f"{i}_{j}", v) for j, v in enumerate(c))
+    return out
+
+
 def cpu_baseline(fn, shape, wavelet, level, mode, dtype):
     """The reference's CPU op sequence on this host's cores, on a bounded sample of the same workload."""
     if fn != "wavedec2":
@@ -143,6 +155,7 @@ def main():
     ap.add_argument("--workload", default="wavedec2_db4_L3_64x1024x1024_f32", choices=sorted(WORKLOADS))
     ap.add_argument("--buffers", type=int, default=3, help="distinct input buffers rotated to defeat the 256 MiB Infinity Cache")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the (untimed, reported) coefficient all-gather leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -241,6 +254,32 @@ def main():
         torch.cuda.synchronize()
         lvl1_b2b_ms = e0.elapsed_time(e1) / args.steps
 
+    # Optional, outside the timed region (N > 1): what replicating the coefficients on every rank would cost — one
+    # all_gather_into_tensor per level buffer over RCCL / xGMI (ptwt_amd.distributed.gather_coeffs).  Reported, never part
+    # of `value`: the transform itself needs no collective.
+    gather_info = None
+    if distributed and backend == "nccl" and not args.no_gather:
+        try:
+            from ptwt_amd import distributed as D
+
+            coeffs = step(0)
+            D.gather_coeffs(coeffs)  # warm-up (communicator set-up)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tg = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                full = D.gather_coeffs(coeffs)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tg = (time.perf_counter() - tg) / reps
+            nbytes = sum(v.numel() * v.element_size() for _, v in _flatten(coeffs))
+            gather_info = {"ms": round(tg * 1e3, 3), "bytes_per_rank": nbytes, "collectives": "one all_gather_into_tensor per level buffer",
+                           "GBps_per_rank_in": round(nbytes * (world - 1) / tg / 1e9, 1)}
+            del full
+        except Exception as exc:  # never let the optional leg break the benchmark line
+            gather_info = {"error": repr(exc)[:200]}
+
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -302,6 +341,8 @@ def main():
                 "traffic": profiled_traffic(args.workload),
             },
         }
+        if gather_info is not None:
+            result["coefficient_gather"] = gather_info
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(fn_name, shape, wavelet, level, mode, dtype)
         print(json.dumps(result), flush=True)
