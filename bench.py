@@ -155,7 +155,9 @@ def main():
     ap.add_argument("--workload", default="wavedec2_db4_L3_64x1024x1024_f32", choices=sorted(WORKLOADS))
     ap.add_argument("--buffers", type=int, default=3, help="distinct input buffers rotated to defeat the 256 MiB Infinity Cache")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the (untimed, reported) coefficient all-gather leg")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: also time (outside the timed region) the all-gather that would replicate the coefficients on "
+                         "every rank; opt-in because it cannot be exercised on the one-GPU development boxes")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -258,7 +260,7 @@ def main():
     # all_gather_into_tensor per level buffer over RCCL / xGMI (ptwt_amd.distributed.gather_coeffs).  Reported, never part
     # of `value`: the transform itself needs no collective.
     gather_info = None
-    if distributed and backend == "nccl" and not args.no_gather:
+    if distributed and backend == "nccl" and args.gather:
         try:
             from ptwt_amd import distributed as D
 
