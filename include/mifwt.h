@@ -103,6 +103,19 @@ int mifwt_dwt_inv(const mifwt_level_desc* desc, const void* approx, const void* 
                   const double* rec_lo, const double* rec_hi, void* workspace, size_t workspace_bytes,
                   void* stream);
 
+/* TWO consecutive 2-D analysis levels in one launch — two trips of the reference's level loop
+ * (src/ptwt/conv_transform_2.py:142-149) whose intermediate approximation never reaches HBM: a pyramid returns only the
+ * detail bands of a level that is not the last (conv_transform_2.py:150-156), so the write + re-read of that
+ * approximation is traffic the per-level seam cannot avoid.  d1 / d2 describe the two levels exactly as two
+ * mifwt_dwt_fwd calls would (d2->sig_extent == d1->coef_extent; d1's approx_stride and d2's sig_stride are ignored).
+ *   details1  HOST array of 3 device ptrs: level-1 bands ad, da, dd     approx2 / details2: the level-2 bands
+ * Results are bit-identical to the two per-level calls.  mifwt_dwt2_fwd_pair_supported() says (1 / 0) whether this
+ * build serves the pair (f32, even L <= 8, any mode but periodic, unit innermost strides, level-1 plane at least
+ * 64 columns x L + 6 rows); the call itself returns MIFWT_ERR_UNSUPPORTED otherwise and launches nothing. */
+int mifwt_dwt2_fwd_pair_supported(const mifwt_level_desc* d1, const mifwt_level_desc* d2);
+int mifwt_dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, const void* x, void* const* details1,
+                        void* approx2, void* const* details2, const double* dec_lo, const double* dec_hi, void* stream);
+
 /* Adjoints (transposes) of the two level maps, for reverse-mode differentiation.  The reference gets them from
  * ATen autograd through F.pad / _pad_symmetric + F.conv{1,2,3}d and torch.stack + F.conv_transpose{1,2,3}d
  * (same call sites as above); here they are explicit entry points that take the SAME descriptor as the
@@ -160,7 +173,9 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  *   5 / 6  3-D analysis / synthesis (f32, even L <= 16): fused 2-D kernel over every depth slice + one
  *          streaming pass along depth
  *   9      fully fused 3-D analysis level, LDS bricks (f32, L in {2, 4, 6})
- *   11     fused 2-D analysis level on the matrix cores (banded-Toeplitz MFMA; f16 storage, even L in [18, 32]) */
+ *   11     fused 2-D analysis level on the matrix cores (banded-Toeplitz MFMA; f16 storage, even L in [18, 32])
+ *   12     two fused 2-D analysis levels per launch (mifwt_dwt2_fwd_pair; never returned by mifwt_kernel_id, which
+ *          describes single-level calls) */
 int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 
 /* Library-wide diagnostic switches (process-global, meant for tests and A/B measurements).
@@ -175,6 +190,8 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 #define MIFWT_OPT_TILE_MODE 5      /* 2-D analysis: 0 = auto (LDS-tile kernel on small planes), 1 = always tile, 2 = never */
 #define MIFWT_OPT_TILE_ROWS 6      /* >0 overrides the tile kernels' output rows per tile */
 #define MIFWT_OPT_MFMA_MODE 7      /* 2-D analysis, f16 storage, 18..32 taps: 0 = matrix-core kernel, 2 = vector tile kernel */
+#define MIFWT_OPT_PAIR_MODE 8      /* two-level analysis launches: 0 = auto, 2 = never (mifwt_dwt2_fwd_pair_supported says 0) */
+#define MIFWT_OPT_PAIR_ROWS 9      /* >0 overrides the pair kernel's level-2 rows per tile (4, 6, 8, 12) */
 int mifwt_set_option(int key, int value);
 
 const char* mifwt_strerror(int code);

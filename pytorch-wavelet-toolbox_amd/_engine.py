@@ -77,6 +77,10 @@ def load_library() -> ctypes.CDLL:
     lib.mifwt_tap_correlate.restype = ctypes.c_int
     lib.mifwt_tap_correlate.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, vp,
                                         ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
+    lib.mifwt_dwt2_fwd_pair_supported.restype = ctypes.c_int
+    lib.mifwt_dwt2_fwd_pair_supported.argtypes = [desc_p, desc_p]
+    lib.mifwt_dwt2_fwd_pair.restype = ctypes.c_int
+    lib.mifwt_dwt2_fwd_pair.argtypes = [desc_p, desc_p, vp, ctypes.POINTER(vp), vp, ctypes.POINTER(vp), dbl_p, dbl_p, vp]
     lib.mifwt_set_option.restype = ctypes.c_int
     lib.mifwt_set_option.argtypes = [ctypes.c_int, ctypes.c_int]
     if lib.mifwt_abi_version() != ABI_VERSION:
@@ -112,6 +116,9 @@ OPT_NT_STORE = 4
 OPT_TILE_MODE = 5
 OPT_TILE_ROWS = 6
 OPT_MFMA_MODE = 7
+OPT_PAIR_MODE = 8
+OPT_PAIR_ROWS = 9
+KID_PAIR = 12
 
 
 def set_option(key: int, value: int) -> None:
@@ -212,6 +219,52 @@ class HipLevelEngine:
         xp = x.data_ptr()
         self._run(p, 0, x, lambda ws, wsb, stream: lib.mifwt_dwt_fwd(p.ref, xp, base, ptrs, lo, hi, ws, wsb, stream))
         return buf
+
+    def analysis_pair(self, x: torch.Tensor, dec_lo: Sequence[float], dec_hi: Sequence[float], mode_id: int):
+        """TWO consecutive 2-D analysis levels in one launch (C ABI ``mifwt_dwt2_fwd_pair``): ``x`` [B, H, W] ->
+        ``(buf1, buf2)`` laid out like two :meth:`analysis` calls, except that plane 0 of ``buf1`` (the intermediate
+        approximation, which a pyramid does not return) is left unwritten.  Returns None when the library does not
+        serve this geometry as a pair; the caller then runs the levels one by one."""
+        _require_gpu(x)
+        if x.dim() != 3:
+            return None
+        flen = len(dec_lo)
+        key = ("pair", x.shape, x.stride(), x.dtype, mode_id, flen, ROW_ALIGN)
+        plan = _plans.get(key)
+        if plan is None:
+            if len(_plans) > 4096:
+                _plans.clear()
+            lib = load_library()
+            p1 = self._analysis_plan(x, flen, mode_id)
+            ok = False
+            p2 = None
+            if not p1.empty:
+                # geometry of the level-2 call: its input is plane 0 of the level-1 buffer (strides only, no memory)
+                lvl1 = torch.empty(p1.alloc_shape, dtype=x.dtype, device="meta")
+                if p1.view_last is not None:
+                    lvl1 = lvl1[..., : p1.view_last]
+                p2 = self._analysis_plan(lvl1[:, 0], flen, mode_id)
+                ok = (not p2.empty) and bool(lib.mifwt_dwt2_fwd_pair_supported(p1.ref, p2.ref))
+            plan = _plans[key] = (p1, p2, ok)
+        p1, p2, ok = plan
+        if not ok:
+            return None
+        buf1 = torch.empty(p1.alloc_shape, dtype=x.dtype, device=x.device)
+        buf2 = torch.empty(p2.alloc_shape, dtype=x.dtype, device=x.device)
+        if p1.view_last is not None:
+            buf1 = buf1[..., : p1.view_last]
+        if p2.view_last is not None:
+            buf2 = buf2[..., : p2.view_last]
+        b1, b2 = buf1.data_ptr(), buf2.data_ptr()
+        for s in range(1, 4):
+            p1.ptrs[s - 1] = b1 + s * p1.plane_bytes
+            p2.ptrs[s - 1] = b2 + s * p2.plane_bytes
+        lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
+        lib = _lib
+        xp = x.data_ptr()
+        self._run(p1, 0, x, lambda ws, wsb, stream: lib.mifwt_dwt2_fwd_pair(p1.ref, p2.ref, xp, p1.ptrs, b2, p2.ptrs, lo, hi, stream),
+                  kid=KID_PAIR)
+        return buf1, buf2
 
     def synthesis(self, approx: torch.Tensor, details: List[torch.Tensor], rec_lo: Sequence[float],
                   rec_hi: Sequence[float], out_extent: Sequence[int]) -> torch.Tensor:
@@ -363,11 +416,11 @@ class HipLevelEngine:
         _check(rc)
 
     @staticmethod
-    def _run(p: _Plan, direction: int, anchor: torch.Tensor, call) -> None:
+    def _run(p: _Plan, direction: int, anchor: torch.Tensor, call, kid: Optional[int] = None) -> None:
         dev = anchor.device
         if dev.index is not None and dev.index != torch.cuda.current_device():
             with torch.cuda.device(dev):
-                return HipLevelEngine._run(p, direction, anchor, call)
+                return HipLevelEngine._run(p, direction, anchor, call, kid)
         wsb = p.ws_bytes
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
         if level_events is None:
@@ -379,7 +432,7 @@ class HipLevelEngine:
             rc = call(ws.data_ptr() if ws is not None else None, wsb, stream.cuda_stream)
             ev[1].record(stream)
             d = p.desc
-            level_events.append((("fwd", "inv", "fwd_adj", "inv_adj")[direction], p.kid, tuple(d.sig_extent[: d.ndim]), ev[0], ev[1]))
+            level_events.append((("fwd", "inv", "fwd_adj", "inv_adj")[direction], p.kid if kid is None else kid, tuple(d.sig_extent[: d.ndim]), ev[0], ev[1]))
         if rc != 0:
             _check(rc)
         # the scratch block returns to the caching allocator when `ws` dies; the allocator only hands it to

@@ -309,10 +309,24 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
         level = dwtn_max_level(x.shape[1:], flen)
     bufs: List[torch.Tensor] = []
     cur = x
-    for _ in range(level):
+    done = 0
+    while done < level:
         mode_id = _mode_id(mode)
         _check_pad(cur.shape[1:], flen, "reflect" if mode is None else mode)
-        if torch.is_grad_enabled() and (cur.requires_grad or tap_t is not None):
+        differentiable = torch.is_grad_enabled() and (cur.requires_grad or tap_t is not None)
+        if ndim == 2 and level - done >= 2 and not differentiable:
+            # two levels per launch, the approximation between them kept on chip (mifwt_dwt2_fwd_pair); the second
+            # level's reflect / periodic pad check is the reference's own (it would raise inside the next trip)
+            n1 = [(n + flen - 1) // 2 for n in cur.shape[1:]]
+            _check_pad(n1, flen, "reflect" if mode is None else mode)
+            pair = _engine.ENGINE.analysis_pair(cur, dec_lo, dec_hi, mode_id)
+            if pair is not None:
+                bufs.extend(pair)
+                cur = pair[1][:, 0]
+                done += 2
+                continue
+        done += 1
+        if differentiable:
             buf = _AnalysisLevel.apply(cur, dec_lo, dec_hi, mode_id, *((tap_t[0], tap_t[1]) if tap_t else (None, None)))
         else:
             buf = _engine.ENGINE.analysis(cur, dec_lo, dec_hi, mode_id)

@@ -252,13 +252,13 @@ int pick_kernel(const mifwt_level_desc* d, int direction) {
 }  // namespace
 
 namespace mifwt {
-int g_options[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+int g_options[16] = {0};
 }
 
 extern "C" {
 
 int mifwt_set_option(int key, int value) {
-  if (key < 0 || key >= 8) return MIFWT_ERR_BADARG;
+  if (key < 0 || key >= 16) return MIFWT_ERR_BADARG;
   g_options[key] = value;
   return MIFWT_OK;
 }
@@ -423,4 +423,24 @@ int mifwt_dwt_inv_adjoint(const mifwt_level_desc* desc, const void* g_y, void* g
   return run_fwd(&z, g_y, g_approx, g_details, lo, hi, workspace, workspace_bytes, stream);
 }
 
+// Two consecutive 2-D analysis levels in one launch (mifwt_dwt2_fwd_pair.hip); d2 describes the second level, whose
+// input is the (never materialised) approximation of d1.
+int mifwt_dwt2_fwd_pair_supported(const mifwt_level_desc* d1, const mifwt_level_desc* d2) {
+  if (!d1 || !d2 || validate(d1, 0) != MIFWT_OK || validate(d2, 0) != MIFWT_OK) return 0;
+  return dwt2_fwd_pair_supported(d1, d2) ? 1 : 0;
+}
+
+int mifwt_dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, const void* x, void* const* details1,
+                        void* approx2, void* const* details2, const double* dec_lo, const double* dec_hi, void* stream) {
+  if (!d1 || !d2) return MIFWT_ERR_BADARG;
+  int rc = validate(d1, 0);
+  if (rc == MIFWT_OK) rc = validate(d2, 0);
+  if (rc != MIFWT_OK) return rc;
+  if (!x || !details1 || !approx2 || !details2 || !dec_lo || !dec_hi) return MIFWT_ERR_BADARG;
+  for (int s = 0; s < 3; ++s)
+    if (!details1[s] || !details2[s]) return MIFWT_ERR_BADARG;
+  if (!dwt2_fwd_pair_supported(d1, d2)) return MIFWT_ERR_UNSUPPORTED;
+  if (d1->batch == 0) return MIFWT_OK;
+  return dwt2_fwd_pair(d1, d2, x, details1, approx2, details2, dec_lo, dec_hi, static_cast<hipStream_t>(stream));
+}
 }  // extern "C"

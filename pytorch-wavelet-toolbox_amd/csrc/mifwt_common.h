@@ -8,7 +8,7 @@
 namespace mifwt {
 
 constexpr int kMaxFilt = MIFWT_MAX_FILT;
-extern int g_options[8];  // mifwt_set_option() switches
+extern int g_options[16];  // mifwt_set_option() switches
 
 // Boundary extension as an index map (replaces F.pad / _pad_symmetric of the reference:
 // src/ptwt/conv_transform.py:59-66, src/ptwt/_util.py:163-195).  Returns the source index in [0, n) of
@@ -116,7 +116,7 @@ int stream_call(int dtype, int kind, const StreamCall& c);  // dispatches on dty
 // ---- fused fast paths --------------------------------------------------------------------------------
 // Each returns MIFWT_ERR_UNSUPPORTED when the descriptor is outside its envelope (the dispatcher then
 // falls back to the generic passes) and never touches the workspace.
-enum KernelId { kGeneric = 0, kDwt2FwdStream = 1, kDwt2InvStream = 2, kDwt1FwdRow = 3, kDwt1InvRow = 4, kDwt3FwdStream = 5, kDwt3InvStream = 6, kDwt2FwdTile = 7, kDwt2InvTile = 8, kDwt3FwdTile = 9, kDwt3InvTile = 10, kDwt2FwdMfma = 11 };
+enum KernelId { kGeneric = 0, kDwt2FwdStream = 1, kDwt2InvStream = 2, kDwt1FwdRow = 3, kDwt1InvRow = 4, kDwt3FwdStream = 5, kDwt3InvStream = 6, kDwt2FwdTile = 7, kDwt2InvTile = 8, kDwt3FwdTile = 9, kDwt3InvTile = 10, kDwt2FwdMfma = 11, kDwt2FwdPair = 12 };
 
 bool dwt2_fwd_stream_supported(const mifwt_level_desc* d);
 int dwt2_fwd_stream(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
@@ -131,6 +131,12 @@ int dwt2_fwd_tile(const mifwt_level_desc* d, const void* x, void* approx, void* 
 bool dwt2_fwd_mfma_supported(const mifwt_level_desc* d);
 int dwt2_fwd_mfma(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
                   const double* dec_lo, const double* dec_hi, hipStream_t stream);
+
+// two consecutive 2-D analysis levels in one launch, the intermediate approximation kept in LDS
+// (mifwt_dwt2_fwd_pair.hip): f32, even L <= 8, every mode but periodic
+bool dwt2_fwd_pair_supported(const mifwt_level_desc* d1, const mifwt_level_desc* d2);
+int dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, const void* x, void* const* details1,
+                  void* approx2, void* const* details2, const double* dec_lo, const double* dec_hi, hipStream_t stream);
 
 // which fused 2-D analysis kernel serves this descriptor: kDwt2FwdTile, kDwt2FwdStream, or -1 (neither)
 int dwt2_fwd_choice(const mifwt_level_desc* d);

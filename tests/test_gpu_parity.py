@@ -613,3 +613,85 @@ def test_full_size_config5_slice_properties():
             assert G.relerr(to_np(a.double()), b) < 2e-3, n  # five levels of f16 storage
     finally:
         ptwt_amd.set_half_storage(False)
+
+
+# ---- two analysis levels per launch (mifwt_dwt2_fwd_pair, kernel id 12) ----------------------------------------------
+def _pair_vs_single(x, wavelet, mode, level):
+    """wavedec2 with the pair kernel against the per-level kernels on the same input: bit-identical."""
+    _engine.level_events = []
+    try:
+        got = ptwt_amd.wavedec2(x, wavelet, mode=mode, level=level)
+        kids = [e[1] for e in _engine.level_events]
+    finally:
+        _engine.level_events = None
+    _engine.set_option(_engine.OPT_PAIR_MODE, 2)
+    try:
+        want = ptwt_amd.wavedec2(x, wavelet, mode=mode, level=level)
+    finally:
+        _engine.set_option(_engine.OPT_PAIR_MODE, 0)
+    gf, wf = G.flatten_coeffs(got), G.flatten_coeffs(want)
+    assert [n for n, _ in gf] == [n for n, _ in wf]
+    for (n, a), (_, b) in zip(gf, wf):
+        assert a.shape == b.shape, (n, a.shape, b.shape)
+        assert torch.equal(a, b), f"{wavelet} {mode} L{level} {tuple(x.shape)} {n}: max diff {(a - b).abs().max().item():.3e}"
+    return kids
+
+
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4"])
+@pytest.mark.parametrize("mode", ["reflect", "zero", "constant", "symmetric"])
+def test_pair_kernel_bit_identical_to_per_level(wavelet, mode):
+    g = torch.Generator().manual_seed(11)
+    for shape, level in [((3, 200, 300), 2), ((2, 257, 131), 2), ((2, 333, 517), 3), ((1, 1024, 1024), 4), ((5, 128, 136), 2)]:
+        x = torch.randn(*shape, generator=g, dtype=torch.float32).to(dev())
+        kids = _pair_vs_single(x, wavelet, mode, level)
+        assert kids[0] == _engine.KID_PAIR, (shape, kids)
+
+
+@pytest.mark.parametrize("rows", [4, 6, 8, 12])
+def test_pair_kernel_tile_heights(rows):
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 389, 611, generator=g, dtype=torch.float32).to(dev())
+    _engine.set_option(_engine.OPT_PAIR_ROWS, rows)
+    try:
+        for wavelet in ("db1", "db4"):
+            for mode in ("reflect", "symmetric", "zero"):
+                kids = _pair_vs_single(x, wavelet, mode, 2)
+                assert kids == [_engine.KID_PAIR]
+    finally:
+        _engine.set_option(_engine.OPT_PAIR_ROWS, 0)
+
+
+def test_pair_kernel_vs_oracle_and_fallbacks():
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(2, 300, 260, generator=g, dtype=torch.float32)
+    got = ptwt_amd.wavedec2(x.to(dev()), "db4", mode="symmetric", level=3)
+    want = O.wavedec2(x.numpy().astype(np.float64), "db4", mode="symmetric", level=3)
+    check_tree(got, want, TOL32, "pair db4 symmetric")
+    # periodic extension, long filters, narrow planes and f64 are served level by level
+    for xx, wavelet, mode in [(x, "db4", "periodic"), (x, "db8", "reflect"), (x[..., :100], "db2", "reflect"), (x.double(), "db2", "zero")]:
+        _engine.level_events = []
+        try:
+            ptwt_amd.wavedec2(xx.to(dev()), wavelet, mode=mode, level=2)
+            kids = [e[1] for e in _engine.level_events]
+        finally:
+            _engine.level_events = None
+        assert _engine.KID_PAIR not in kids and len(kids) == 2, (wavelet, mode, kids)
+    # non-contiguous rows (a column slice of a wider image) and a strided batch
+    wide = torch.randn(4, 300, 700, generator=g, dtype=torch.float32).to(dev())
+    view = wide[::2, :, 100:500]
+    kids = _pair_vs_single(view, "db3", "reflect", 2)
+    assert kids == [_engine.KID_PAIR]
+    check_tree(ptwt_amd.wavedec2(view, "db3", level=2), O.wavedec2(view.cpu().numpy().astype(np.float64), "db3", mode="reflect", level=2), TOL32)
+
+
+def test_pair_kernel_full_size_config2_round_trip():
+    x = torch.randn(64, 1024, 1024, dtype=torch.float32, device=dev())
+    _engine.level_events = []
+    try:
+        c = ptwt_amd.wavedec2(x, "db4", level=3)
+        kids = [e[1] for e in _engine.level_events]
+    finally:
+        _engine.level_events = None
+    assert kids == [_engine.KID_PAIR, 7], kids
+    rec = ptwt_amd.waverec2(c, "db4")
+    assert (rec - x).abs().max().item() < 5e-6
