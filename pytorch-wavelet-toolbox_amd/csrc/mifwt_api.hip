@@ -441,6 +441,9 @@ int mifwt_dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, 
     if (!details1[s] || !details2[s]) return MIFWT_ERR_BADARG;
   if (!dwt2_fwd_pair_supported(d1, d2)) return MIFWT_ERR_UNSUPPORTED;
   if (d1->batch == 0) return MIFWT_OK;
-  return dwt2_fwd_pair(d1, d2, x, details1, approx2, details2, dec_lo, dec_hi, static_cast<hipStream_t>(stream));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (g_options[MIFWT_OPT_PAIR_MODE] != 1 && dwt2_fwd_roll_supported(d1, d2))
+    return dwt2_fwd_roll(d1, d2, x, details1, approx2, details2, dec_lo, dec_hi, st);
+  return dwt2_fwd_pair(d1, d2, x, details1, approx2, details2, dec_lo, dec_hi, st);
 }
 }  // extern "C"

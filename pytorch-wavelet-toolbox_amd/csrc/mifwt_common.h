@@ -138,6 +138,11 @@ bool dwt2_fwd_pair_supported(const mifwt_level_desc* d1, const mifwt_level_desc*
 int dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, const void* x, void* const* details1,
                   void* approx2, void* const* details2, const double* dec_lo, const double* dec_hi, hipStream_t stream);
 
+// the same two levels as rolling column strips (mifwt_dwt2_fwd_roll.hip): needs a level-1 plane of >= 32 rows
+bool dwt2_fwd_roll_supported(const mifwt_level_desc* d1, const mifwt_level_desc* d2);
+int dwt2_fwd_roll(const mifwt_level_desc* d1, const mifwt_level_desc* d2, const void* x, void* const* details1,
+                  void* approx2, void* const* details2, const double* dec_lo, const double* dec_hi, hipStream_t stream);
+
 // which fused 2-D analysis kernel serves this descriptor: kDwt2FwdTile, kDwt2FwdStream, or -1 (neither)
 int dwt2_fwd_choice(const mifwt_level_desc* d);
 int dwt2_fwd_fused(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,

@@ -616,14 +616,17 @@ def test_full_size_config5_slice_properties():
 
 
 # ---- two analysis levels per launch (mifwt_dwt2_fwd_pair, kernel id 12) ----------------------------------------------
-def _pair_vs_single(x, wavelet, mode, level):
-    """wavedec2 with the pair kernel against the per-level kernels on the same input: bit-identical."""
+def _pair_vs_single(x, wavelet, mode, level, pair_mode=0):
+    """wavedec2 with a pair kernel (pair_mode 0: rolling strips where they apply, 1: tiles) against the per-level
+    kernels on the same input: bit-identical."""
+    _engine.set_option(_engine.OPT_PAIR_MODE, pair_mode)
     _engine.level_events = []
     try:
         got = ptwt_amd.wavedec2(x, wavelet, mode=mode, level=level)
         kids = [e[1] for e in _engine.level_events]
     finally:
         _engine.level_events = None
+        _engine.set_option(_engine.OPT_PAIR_MODE, 0)
     _engine.set_option(_engine.OPT_PAIR_MODE, 2)
     try:
         want = ptwt_amd.wavedec2(x, wavelet, mode=mode, level=level)
@@ -637,25 +640,29 @@ def _pair_vs_single(x, wavelet, mode, level):
     return kids
 
 
+@pytest.mark.parametrize("pair_mode", [0, 1])
 @pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4"])
 @pytest.mark.parametrize("mode", ["reflect", "zero", "constant", "symmetric"])
-def test_pair_kernel_bit_identical_to_per_level(wavelet, mode):
+def test_pair_kernel_bit_identical_to_per_level(wavelet, mode, pair_mode):
     g = torch.Generator().manual_seed(11)
-    for shape, level in [((3, 200, 300), 2), ((2, 257, 131), 2), ((2, 333, 517), 3), ((1, 1024, 1024), 4), ((5, 128, 136), 2)]:
+    for shape, level in [((3, 200, 300), 2), ((2, 257, 131), 2), ((2, 333, 517), 3), ((1, 1024, 1024), 4), ((5, 128, 136), 2),
+                         ((2, 61, 140), 2), ((1, 1030, 129), 2)]:
         x = torch.randn(*shape, generator=g, dtype=torch.float32).to(dev())
-        kids = _pair_vs_single(x, wavelet, mode, level)
+        kids = _pair_vs_single(x, wavelet, mode, level, pair_mode)
         assert kids[0] == _engine.KID_PAIR, (shape, kids)
 
 
-@pytest.mark.parametrize("rows", [4, 6, 8, 12])
-def test_pair_kernel_tile_heights(rows):
+@pytest.mark.parametrize("pair_mode", [0, 1])
+@pytest.mark.parametrize("rows", [4, 6, 8, 12, 16, 40, 64])
+def test_pair_kernel_tile_heights(rows, pair_mode):
+    """OPT_PAIR_ROWS: level-2 rows per tile (tile kernel) / per strip segment (rolling kernel, rounded up to 8)."""
     g = torch.Generator().manual_seed(12)
     x = torch.randn(2, 389, 611, generator=g, dtype=torch.float32).to(dev())
     _engine.set_option(_engine.OPT_PAIR_ROWS, rows)
     try:
         for wavelet in ("db1", "db4"):
             for mode in ("reflect", "symmetric", "zero"):
-                kids = _pair_vs_single(x, wavelet, mode, 2)
+                kids = _pair_vs_single(x, wavelet, mode, 2, pair_mode)
                 assert kids == [_engine.KID_PAIR]
     finally:
         _engine.set_option(_engine.OPT_PAIR_ROWS, 0)

@@ -25,7 +25,8 @@ ap.add_argument("--shape", default="64,1024,1024")
 ap.add_argument("--wavelet", default="db4")
 ap.add_argument("--mode", default="reflect")
 ap.add_argument("--level", type=int, default=3)
-ap.add_argument("--rows", default="8")
+ap.add_argument("--rows", default="8", help="tile-pair kernel: level-2 rows per tile")
+ap.add_argument("--seg", default="32", help="rolling kernel: level-2 rows per segment")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=20)
 args = ap.parse_args()
@@ -33,7 +34,8 @@ args = ap.parse_args()
 shape = tuple(int(v) for v in args.shape.split(","))
 dev = torch.device("cuda:0")
 bufs = [torch.randn(*shape, device=dev) for _ in range(3)]
-variants = [("single", 2, 0)] + [(f"pair rows={r}", 0, int(r)) for r in args.rows.split(",")]
+variants = [("single", 2, 0)] + [(f"tile-pair rows={r}", 1, int(r)) for r in args.rows.split(",") if r] + \
+    [(f"roll seg={r}", 0, int(r)) for r in args.seg.split(",") if r]
 times = {v[0]: [] for v in variants}
 kids = {}
 
