@@ -15,15 +15,17 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_
 done
 python - <<PY
 import csv, glob, collections
-for p in sorted(glob.glob("$OUT/p*/*_counter_collection.csv")):
-    per = collections.defaultdict(list)
-    g = v = l = None
-    for r in csv.DictReader(open(p)):
-        if "$KERNEL" in r["Kernel_Name"]:
-            per[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            g = r["Grid_Size"]; v = r["VGPR_Count"]; l = r.get("LDS_Block_Size")
-    print(p.split("/")[-2], "grid", g, "vgpr", v, "lds", l, {k: round(sum(x)/len(x)) for k, x in per.items()})
-for p in sorted(glob.glob("$OUT/p1/*_kernel_trace.csv")):
-    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(p)) if "$KERNEL" in r["Kernel_Name"]]
-    print("durations ns", d[:12])
+for kern in "$KERNEL".split(","):  # comma list of kernel-name substrings; the first dispatch of each is dropped (cold)
+    print("==", kern)
+    for p in sorted(glob.glob("$OUT/p*/*_counter_collection.csv")):
+        per = collections.defaultdict(list)
+        g = v = l = None
+        for r in csv.DictReader(open(p)):
+            if kern in r["Kernel_Name"]:
+                per[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                g = r["Grid_Size"]; v = r["VGPR_Count"]; l = r.get("LDS_Block_Size")
+        print(p.split("/")[-2], "grid", g, "vgpr", v, "lds", l, {k: round(sum(x[1:]) / max(1, len(x) - 1)) for k, x in per.items()})
+    for p in sorted(glob.glob("$OUT/p1/*_kernel_trace.csv")):
+        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(p)) if kern in r["Kernel_Name"]]
+        print("durations ns", d[:12])
 PY
