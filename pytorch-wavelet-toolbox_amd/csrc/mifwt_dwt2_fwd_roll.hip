@@ -5,12 +5,13 @@
 // 3 (L-2) level-0 halo rows under a level-2 tile: with 8 level-2 rows per tile that is 50 input rows loaded,
 // staged and filtered for every 32 it owns.  Here a 256-thread workgroup owns a column strip (64 level-1 columns: 64 -
 // (L-2) owned + L-2 halo) of one SEGMENT of level-2 rows and walks down it in steps of 8 level-2 rows = 16 level-1 rows
-// = 32 level-0 rows; the horizontally filtered rows and the level-1 approximation live in two LDS rings that keep
-// the last L-2 rows of the previous step, so inside a segment nothing is loaded or filtered twice:
-//   per step   wave w:  its 8 prefetched level-0 rows -> h-ring slots; request the NEXT step's rows (in flight
+// = 32 level-0 rows; the horizontally filtered rows and the level-1 approximation live in two LDS windows whose
+// last L-2 rows are copied to the top for the next step (fixed slots: no ring arithmetic), so inside a segment nothing is
+// loaded or filtered twice:
+//   per step   wave w:  its 8 prefetched level-0 rows -> h-window; request the NEXT step's rows (in flight
 //                       during everything below); level-1 horizontal pass over its own rows, in place
 //              barrier  level-1 vertical pass, 4 rows per wave from a register window: details -> HBM, approximation
-//                       -> a-ring; level-2 horizontal pass over the rows it just produced, in place
+//                       -> a-window; level-2 horizontal pass over the rows it just produced, in place
 //              barrier  level-2 vertical pass, one row per half-wave -> the four level-2 bands to HBM.
 // A segment starts with a prologue of 3 (L-2) level-0 rows that fills the rings.  The first segment of a plane is
 // aligned to its top, all others to its bottom (the boundary extension of level 2 reads ACTUAL level-1 rows through
@@ -28,9 +29,8 @@ struct Dwt2RollArgs {
   const float* x;
   float* d1[3];  // level-1 bands ad, da, dd
   float* o2[4];  // level-2 bands aa, ad, da, dd
-  int64_t xs_b, xs_h;
-  int64_t d1s_b, d1s_h;
-  int64_t a2s_b, a2s_h, d2s_b, d2s_h;
+  int64_t xs_b, d1s_b, a2s_b, d2s_b;  // image strides (elements)
+  int xs_h, d1s_h, a2s_h, d2s_h;      // row strides (elements; one image spans < 2^31 elements)
   int H0, W0, H1, W1, H2, W2;
   int strips, nseg, seg;  // column strips per plane, row segments per plane, level-2 rows per segment (multiple of 8)
   int mode;
@@ -39,10 +39,22 @@ struct Dwt2RollArgs {
 
 constexpr int roll_lds_bytes(int L) { return ((32 + L - 2) * (128 + L - 2) + (16 + L - 2) * 64) * 4; }
 constexpr int roll_occupancy(int L) {
-  // 6 workgroups' rings fit; the prefetch registers of the 6- and 8-tap instances need the 5-wave register budget
+  // 6 workgroups' windows fit; the prefetch registers of the 6- and 8-tap instances need the 5-wave register budget
   const int n = (160 * 1024) / roll_lds_bytes(L), cap = L <= 4 ? 6 : 5;
   return n > cap ? cap : (n < 1 ? 1 : n);
 }
+
+// Boundary extension for an index at most one period outside [0, n), branch-free and without the general
+// fallback of ext_index_near (whose integer division, inlined at every use, tripled this kernel's code): mode is
+// folded into (k, lo_add, hi_add) once per workgroup.  Zero mode: the caller tests (unsigned)i >= n itself.
+struct Fold1 {
+  int k, lo_add, sym;  // k = 0 (constant) or -1 (mirror modes)
+  __device__ __forceinline__ int operator()(int i, int n) const {
+    const int mi = i & k;  // i for the mirror modes, 0 for constant
+    const int hi_add = k ? 2 * n - 2 + sym : n - 1;
+    return i < 0 ? lo_add - mi : (i >= n ? hi_add - mi : i);
+  }
+};
 
 template <int L>
 __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(const Dwt2RollArgs<L> a) {
@@ -51,16 +63,16 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
   constexpr int T2C = (C1 - HL) / 2;  // level-2 columns of a strip
   constexpr int OC1 = 2 * T2C;        // level-1 columns a strip owns
   constexpr int C0 = 2 * C1 + HL;     // level-0 columns
-  constexpr int XP = C0;              // pitch of the h-ring (floats, even)
+  constexpr int XP = C0;              // pitch of the h-window (floats, even)
   constexpr int NQ = (C0 + 63) / 64;
   constexpr int S2 = 8, S1 = 16, S0 = 32;  // rows per step at levels 2 / 1 / 0
-  constexpr int RH = S0 + HL;              // h-ring rows (level-0 row index space, horizontally filtered)
-  constexpr int RL = S1 + HL;              // a-ring rows (level-1 approximation, then its horizontal (lo, hi) image)
+  constexpr int RH = S0 + HL;  // h-window: slot t < HL = level-0 row 4 j - HL + t (kept from the previous step), then the step's 32
+  constexpr int RL = S1 + HL;  // a-window: slot t < HL = level-1 row 2 j - HL + t, then the step's 16
   constexpr int LP = 64;
-  constexpr int PR0 = 3 * HL;              // prologue: level-0 rows
-  constexpr int PW0 = (PR0 + 3) / 4;       //           per wave
-  constexpr int PW1 = (HL + 3) / 4;        // prologue: level-1 rows per wave
-  static_assert(T2C <= 32 && T2C >= 1 && PR0 <= RH, "ring geometry");
+  constexpr int PR0 = 3 * HL;         // prologue: level-0 rows
+  constexpr int PW0 = (PR0 + 3) / 4;  //           per wave
+  constexpr int PW1 = (HL + 3) / 4;   // prologue: level-1 rows per wave
+  static_assert(T2C <= 32 && T2C >= 1 && PR0 <= RH, "window geometry");
   __shared__ __attribute__((aligned(16))) float hr[RH * XP];
   __shared__ __attribute__((aligned(16))) float lr[RL * LP + 8];
 
@@ -80,80 +92,76 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
   const int k2_0 = tc * T2C;
   const int s1c = min(max(2 * k2_0 - HL, 0), a.W1 - C1);
   const int c_first = 2 * s1c - HL;
+  const bool zero_mode = a.mode == MIFWT_MODE_ZERO;
+  Fold1 fold;
+  fold.k = a.mode == MIFWT_MODE_CONSTANT ? 0 : -1;
+  fold.sym = a.mode == MIFWT_MODE_SYMMETRIC ? 1 : 0;
+  fold.lo_add = -fold.sym;
 
   // ---- level-0 column offsets, once per workgroup ---------------------------------------------------------------------
   const uint32_t img_bytes = ((uint32_t)(a.H0 - 1) * (uint32_t)a.xs_h + (uint32_t)a.W0) * 4u;
   const __amdgpu_buffer_rsrc_t xrsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (int64_t)img * a.xs_b), 0, img_bytes, 0x00020000);
-  constexpr uint32_t kOob = 0x80000000u;
+  constexpr uint32_t kOob = 0x80000000u;  // >= num_records: the load returns 0 without a memory request
   const uint32_t row_bytes = (uint32_t)a.xs_h * 4u;
   uint32_t coff[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const int c = lane + 64 * q;
-    const int m = c < C0 ? ext_index_near(c_first + c, a.W0, a.mode) : -1;
-    coff[q] = m < 0 ? kOob : 4u * (uint32_t)m;
+    const int c = c_first + lane + 64 * q;
+    const bool dead = lane + 64 * q >= C0 || (zero_mode && (unsigned)c >= (unsigned)a.W0);
+    coff[q] = dead ? kOob : 4u * (uint32_t)fold(c, a.W0);
   }
 
-  // level-0 rows r_first + wave + 4 i (i < N) of the extended plane -> registers
+  // level-0 rows r_first + wave + 4 i (i < N, row < r_end) of the extended plane -> registers.  Rows the level-1 plane
+  // does not need (above -HL: segment 0's prologue; below 2 H1 - 1: the bottom-aligned last step) request nothing.
+  const int r_valid_hi = 2 * a.H1;
   auto request = [&](auto n_tag, float (&v)[decltype(n_tag)::value][NQ], int r_first, int r_end) {
     constexpr int N = decltype(n_tag)::value;
-    if (r_first >= 0 && r_first + 4 * N <= a.H0 && r_first + 4 * N <= r_end) {
+    if (r_first >= 0 && r_first + 4 * N <= min(a.H0, r_end)) {  // interior: no map, one scalar add per row
+      uint32_t soff = (uint32_t)(r_first + wave) * row_bytes;
 #pragma unroll
       for (int i = 0; i < N; ++i) {
-        const uint32_t soff = (uint32_t)(r_first + wave + 4 * i) * row_bytes;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) v[i][q] = tile_load<float>(xrsrc, coff[q], soff);
+        soff += 4u * row_bytes;
       }
     } else {
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         const int r = r_first + wave + 4 * i;
-        const int m = r < r_end ? ext_index_near(r, a.H0, a.mode) : -1;
-        const uint32_t soff = m < 0 ? 0u : (uint32_t)m * row_bytes;
+        const bool dead = r >= r_end || r < -HL || r >= r_valid_hi || (zero_mode && (unsigned)r >= (unsigned)a.H0);
+        // a dead row reads beyond the buffer's num_records through the scalar offset: no branch, no memory request
+        const uint32_t soff = dead ? kOob : (uint32_t)fold(r, a.H0) * row_bytes;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) v[i][q] = tile_load<float>(xrsrc, m < 0 ? kOob : coff[q], soff);
+        for (int q = 0; q < NQ; ++q) v[i][q] = tile_load<float>(xrsrc, coff[q], soff);
       }
     }
   };
 
-  // registers -> ring slots slot0 + wave + 4 i (mod RH), then the level-1 horizontal pass over the same rows, in place
-  // (a row is staged, read and overwritten by ONE wave, whose DS operations execute in order: no barrier in between)
-  auto stage_h1 = [&](auto n_tag, float (&v)[decltype(n_tag)::value][NQ], int slot0, int nrows) {
-    constexpr int N = decltype(n_tag)::value;
+  // level-1 horizontal pass over h-window slots s0 and s1, in place (two rows at once: two independent accumulation
+  // chains, back-to-back dependent v_pk_fma_f32 cost a wait state each)
+  auto h1_rows = [&](int s0, int s1) {
+    const f2* row0 = reinterpret_cast<const f2*>(&hr[s0 * XP + 2 * lane]);
+    const f2* row1 = reinterpret_cast<const f2*>(&hr[s1 * XP + 2 * lane]);
+    f2 acc0, acc1;
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      if (wave + 4 * i < nrows) {
-        int s = slot0 + wave + 4 * i;
-        s = s >= RH ? s - RH : s;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-          if (lane + 64 * q < XP) hr[s * XP + lane + 64 * q] = v[i][q];
+    for (int p = 0; p < L / 2; ++p) {
+      const f2 x0 = row0[p], x1 = row1[p];
+      if (p == 0) {
+        acc0 = pkmul_lo(a.tap[L - 1], x0);
+        acc1 = pkmul_lo(a.tap[L - 1], x1);
+      } else {
+        pkfma_lo(acc0, a.tap[L - 1 - 2 * p], x0);
+        pkfma_lo(acc1, a.tap[L - 1 - 2 * p], x1);
       }
+      pkfma_hi(acc0, a.tap[L - 2 - 2 * p], x0);
+      pkfma_hi(acc1, a.tap[L - 2 - 2 * p], x1);
     }
     wave_lds_fence();
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      if (wave + 4 * i < nrows) {
-        int s = slot0 + wave + 4 * i;
-        s = s >= RH ? s - RH : s;
-        const f2* row = reinterpret_cast<const f2*>(&hr[s * XP + 2 * lane]);
-        f2 acc;
-#pragma unroll
-        for (int p = 0; p < L / 2; ++p) {
-          const f2 xx = row[p];
-          if (p == 0) {
-            acc = pkmul_lo(a.tap[L - 1], xx);
-          } else {
-            pkfma_lo(acc, a.tap[L - 1 - 2 * p], xx);
-          }
-          pkfma_hi(acc, a.tap[L - 2 - 2 * p], xx);
-        }
-        wave_lds_fence();
-        *reinterpret_cast<f2*>(&hr[s * XP + 2 * lane]) = acc;
-      }
-    }
+    *reinterpret_cast<f2*>(&hr[s0 * XP + 2 * lane]) = acc0;
+    *reinterpret_cast<f2*>(&hr[s1 * XP + 2 * lane]) = acc1;
   };
+  auto h1_row = [&](int s) { h1_rows(s, s); };
 
   // level-2 column map (edge strips only), once per workgroup
   const int half = lane >> 5, kk = lane & 31;
@@ -163,11 +171,12 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
   int cidx[L];
 #pragma unroll
   for (int p = 0; p < L; ++p) {
-    const int m = col_live ? ext_index_near(2 * k2 - HL + p, a.W1, a.mode) : -1;
-    cidx[p] = cols_in2 ? 2 * kk + p : (m < 0 ? -1 : m - s1c);
+    const int e = 2 * k2 - HL + p;
+    const bool dead = !col_live || (zero_mode && (unsigned)e >= (unsigned)a.W1);
+    cidx[p] = dead ? -1 : fold(e, a.W1) - s1c;
   }
-  // level-2 horizontal pass over a-ring row `s` for the lanes of one half-wave (or all lanes with both = true), in place
-  auto h2_row = [&](int s, bool active) {
+  // level-2 horizontal pass over a-window slot `s` (lanes 0-31 and 32-63 may be given different slots), in place
+  auto h2_row = [&](int s, bool store) {
     f2 acc;
     if (cols_in2) {
       const f2* row = reinterpret_cast<const f2*>(&lr[s * LP + 2 * kk]);
@@ -185,8 +194,10 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
 #pragma unroll
       for (int p = 0; p < L / 2; ++p) {
         f2 xx;
-        xx.x = cidx[2 * p] >= 0 ? lr[s * LP + cidx[2 * p]] : 0.0f;
-        xx.y = cidx[2 * p + 1] >= 0 ? lr[s * LP + cidx[2 * p + 1]] : 0.0f;
+        xx.x = lr[s * LP + max(cidx[2 * p], 0)];
+        xx.y = lr[s * LP + max(cidx[2 * p + 1], 0)];
+        xx.x = cidx[2 * p] >= 0 ? xx.x : 0.0f;
+        xx.y = cidx[2 * p + 1] >= 0 ? xx.y : 0.0f;
         if (p == 0) {
           acc = pkmul_lo(a.tap[L - 1], xx);
         } else {
@@ -196,43 +207,59 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
       }
     }
     wave_lds_fence();
-    if (active && kk < T2C) *reinterpret_cast<f2*>(&lr[s * LP + 2 * kk]) = acc;
+    if (store && kk < T2C) *reinterpret_cast<f2*>(&lr[s * LP + 2 * kk]) = acc;
   };
 
   const int m1c = s1c + lane;
   const bool own_c = m1c >= 2 * k2_0 && m1c < 2 * k2_0 + OC1;
-  // band bases stay on the scalar unit (wave-uniform); the lanes add their column
-  const int64_t d1_img = (int64_t)img * a.d1s_b, a2_img = (int64_t)img * a.a2s_b, d2_img = (int64_t)img * a.d2s_b;
+  // band bases stay on the scalar unit; lanes add 32-bit element offsets
+  float* const d1b0 = a.d1[0] + (int64_t)img * a.d1s_b;
+  float* const d1b1 = a.d1[1] + (int64_t)img * a.d1s_b;
+  float* const d1b2 = a.d1[2] + (int64_t)img * a.d1s_b;
+  float* const o2b0 = a.o2[0] + (int64_t)img * a.a2s_b;
+  float* const o2b1 = a.o2[1] + (int64_t)img * a.d2s_b;
+  float* const o2b2 = a.o2[2] + (int64_t)img * a.d2s_b;
+  float* const o2b3 = a.o2[3] + (int64_t)img * a.d2s_b;
 
-  // ---- prologue: level-0 rows [4 ja - 3 HL, 4 ja) -> h-ring slots [0, 3 HL); level-1 rows [2 ja - HL, 2 ja) -> a-ring
-  // slots [0, HL).  (For segment 0 those level-1 rows lie above the plane and are never read; their level-0 rows are
-  // real: the level-0 extension.)
+  // ---- prologue: level-0 rows [4 ja - 3 HL, 4 ja): the last HL of them -> h-window slots [0, HL) (where step 0 expects the
+  // rows kept from "the previous step"), the first 2 HL -> slots [HL, 3 HL); level-1 rows [2 ja - HL, 2 ja) -> a-window
+  // slots [0, HL).  (For segment 0 those level-1 rows lie above the plane and are never read.)
   float pv[S0 / 4][NQ];
-  int hs = PR0 % RH;  // h-ring slot of the first row of the coming step
-  int ls = HL;        // a-ring slot of the first level-1 row of the coming step
   if constexpr (HL > 0) {
     float pp[PW0][NQ];
     request(std::integral_constant<int, PW0>{}, pp, 4 * ja - PR0, 4 * ja);
     request(std::integral_constant<int, S0 / 4>{}, pv, 4 * ja, 4 * ja + S0);
-    stage_h1(std::integral_constant<int, PW0>{}, pp, 0, PR0);
+#pragma unroll
+    for (int i = 0; i < PW0; ++i) {
+      const int q = wave + 4 * i;  // prologue row index
+      if (q < PR0) {
+        const int s = q < 2 * HL ? q + HL : q - 2 * HL;
+#pragma unroll
+        for (int u = 0; u < NQ; ++u)
+          if (lane + 64 * u < XP) hr[s * XP + lane + 64 * u] = pp[i][u];
+        wave_lds_fence();
+        h1_row(s);
+      }
+    }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < PW1; ++i) {
-      const int il = wave + 4 * i;  // level-1 row 2 ja - HL + il, a-ring slot il; its h-rows: slots 2 il .. 2 il + L - 1
+      const int il = wave + 4 * i;  // level-1 row 2 ja - HL + il -> a-window slot il; its h-rows: prologue rows 2 il .. 2 il + L - 1
       if (il < HL) {
         float aa;
 #pragma unroll
         for (int m = 0; m < L; ++m) {
-          const float hv = hr[(2 * il + (L - 1) - m) * XP + 2 * lane];
-          // same operation as the low half of the packed vertical pass
-          aa = m == 0 ? a.tap[0].x * hv : __builtin_fmaf(a.tap[m].x, hv, aa);
+          const int q = 2 * il + (L - 1) - m;
+          const int s = q < 2 * HL ? q + HL : q - 2 * HL;
+          const float hv = hr[s * XP + 2 * lane];
+          aa = m == 0 ? a.tap[0].x * hv : __builtin_fmaf(a.tap[m].x, hv, aa);  // the low half of the packed vertical pass
         }
         lr[il * LP + lane] = aa;
         wave_lds_fence();
         h2_row(il, half == 0);
       }
     }
-    __syncthreads();  // the prologue's h-rows are dead: step 0 may overwrite their slots
+    __syncthreads();  // the prologue's first 2 HL h-rows are dead: step 0 overwrites their slots
   } else {
     request(std::integral_constant<int, S0 / 4>{}, pv, 4 * ja, 4 * ja + S0);
   }
@@ -241,90 +268,110 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
 #pragma unroll 1
   for (int st = 0; st < nsteps; ++st) {
     const int j = ja + S2 * st;
-    stage_h1(std::integral_constant<int, S0 / 4>{}, pv, hs, S0);
+    // this wave's 8 level-0 rows -> slots HL + wave + 4 i, then their horizontal pass (same wave: DS order suffices)
+#pragma unroll
+    for (int i = 0; i < S0 / 4; ++i) {
+      const int s = HL + wave + 4 * i;
+#pragma unroll
+      for (int u = 0; u < NQ; ++u)
+        if (lane + 64 * u < XP) hr[s * XP + lane + 64 * u] = pv[i][u];
+    }
+    wave_lds_fence();
     if (st + 1 < nsteps) request(std::integral_constant<int, S0 / 4>{}, pv, 4 * (j + S2), 4 * (j + S2) + S0);
+#pragma unroll
+    for (int i = 0; i < S0 / 4; i += 2) h1_rows(HL + wave + 4 * i, HL + wave + 4 * i + 4);
     __syncthreads();
 
-    // level-1 vertical pass: wave w -> level-1 rows 2 j + 4 w + i, i < 4; h-rows 4 j + 8 w - HL + t, t < HL + 8
+    // level-1 vertical pass: wave w -> level-1 rows 2 j + 4 w + i (i < 4) from h-window slots 8 w + t, t < HL + 8
     {
-      f2 win[HL + 8];
-      int base = hs + 8 * wave - HL;
-      base = base < 0 ? base + RH : base;
+      if (st > 0) {
+        // keep the last HL rows of the previous step's a-window: slot S1 + t -> slot t, by the wave that is about to
+        // overwrite slot S1 + t (every wave finished reading the old window before the barrier above)
 #pragma unroll
-      for (int t = 0; t < HL + 8; ++t) {
-        int s = base + t;
-        s = s >= RH ? s - RH : s;
-        s = s >= RH ? s - RH : s;
-        win[t] = *reinterpret_cast<const f2*>(&hr[s * XP + 2 * lane]);
+        for (int t = 0; t < HL; ++t) {
+          if (((S1 + t - HL) >> 2) == wave) {
+            const float keep = lr[(S1 + t) * LP + lane];
+            wave_lds_fence();
+            lr[t * LP + lane] = keep;
+          }
+        }
+        wave_lds_fence();
       }
+      f2 win[HL + 8];
+      const float* wbase = &hr[(8 * wave) * XP + 2 * lane];
+#pragma unroll
+      for (int t = 0; t < HL + 8; ++t) win[t] = *reinterpret_cast<const f2*>(wbase + t * XP);
+      float* lrow = &lr[(HL + 4 * wave) * LP + lane];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m1r = 2 * j + 4 * wave + i;
-        int sl = ls + 4 * wave + i;
-        sl = sl >= RL ? sl - RL : sl;
         const bool own_r = m1r >= own_lo && m1r < own_hi;
-        f2 lo2;  // (aa, da)
-#pragma unroll
-        for (int m = 0; m < L; ++m) {
-          const f2 hv = win[2 * i + (L - 1) - m];
-          if (m == 0) {
-            lo2 = pkmul_lo(a.tap[0], hv);
-          } else {
-            pkfma_lo(lo2, a.tap[m], hv);
-          }
-        }
-        lr[sl * LP + lane] = lo2.x;
+        f2 lo2, hi2;  // (aa, da), (ad, dd)
         if (own_r) {
-          f2 hi2;  // (ad, dd)
 #pragma unroll
           for (int m = 0; m < L; ++m) {
             const f2 hv = win[2 * i + (L - 1) - m];
             if (m == 0) {
+              lo2 = pkmul_lo(a.tap[0], hv);
               hi2 = pkmul_hi(a.tap[0], hv);
             } else {
+              pkfma_lo(lo2, a.tap[m], hv);
               pkfma_hi(hi2, a.tap[m], hv);
             }
           }
           if (own_c) {
-            const int64_t off = d1_img + (int64_t)m1r * a.d1s_h;
-            (a.d1[0] + off)[m1c] = hi2.x;
-            (a.d1[1] + off)[m1c] = lo2.y;
-            (a.d1[2] + off)[m1c] = hi2.y;
+            const int off = m1r * a.d1s_h + m1c;
+            d1b0[off] = hi2.x;
+            d1b1[off] = lo2.y;
+            d1b2[off] = hi2.y;
+          }
+        } else {  // halo / out-of-plane row: only its approximation is needed
+#pragma unroll
+          for (int m = 0; m < L; ++m) {
+            const f2 hv = win[2 * i + (L - 1) - m];
+            if (m == 0) {
+              lo2 = pkmul_lo(a.tap[0], hv);
+            } else {
+              pkfma_lo(lo2, a.tap[m], hv);
+            }
           }
         }
+        lrow[i * LP] = lo2.x;
       }
-      // level-2 horizontal pass over the four rows this wave just wrote: half-wave h takes rows (h, 2 + h)
+      // level-2 horizontal pass over the four rows this wave just wrote: half-wave h takes rows h and 2 + h
       wave_lds_fence();
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        int sl = ls + 4 * wave + 2 * i + half;
-        sl = sl >= RL ? sl - RL : sl;
-        h2_row(sl, true);
-      }
+      for (int i = 0; i < 2; ++i) h2_row(HL + 4 * wave + 2 * i + half, true);
     }
     __syncthreads();
+
+    // keep the last HL rows of the h-window for the next step: slot S0 + t -> slot t, by the wave whose next staging
+    // overwrites slot S0 + t (all waves are past the vertical pass)
+#pragma unroll
+    for (int t = 0; t < HL; ++t) {
+      if (((S0 + t - HL) & 3) == wave) {
+        const f2 keep = *reinterpret_cast<const f2*>(&hr[(S0 + t) * XP + 2 * lane]);
+        wave_lds_fence();
+        *reinterpret_cast<f2*>(&hr[t * XP + 2 * lane]) = keep;
+      }
+    }
 
     // level-2 vertical pass: half-wave (2 wave + half) -> level-2 row j + 2 wave + half
     {
       const int j2 = j + 2 * wave + half;
       const bool live = col_live && j2 < jb;
-      const bool rows_in2 = 2 * j - HL >= 0 && 2 * j + S1 <= a.H1;
+      const bool rows_in2 = 2 * j - HL >= 0 && 2 * j + S1 <= a.H1;  // no extension anywhere in this step
       f2 lo2, hi2;
 #pragma unroll
       for (int m = 0; m < L; ++m) {
-        const int t = (L - 1) - m;  // extended level-1 row 2 j2 - HL + t
-        int rel;                    // relative to the first level-1 row of this step, in [-HL, 16)
+        const int t = (L - 1) - m;  // extended level-1 row e = 2 j2 - HL + t; a-window slot = (actual row) - (2 j - HL)
+        int sl = 2 * (2 * wave + half) + t;
         bool zero = false;
-        if (rows_in2) {
-          rel = 2 * (2 * wave + half) - HL + t;
-        } else {
-          const int e = live ? ext_index_near(2 * j2 - HL + t, a.H1, a.mode) : -1;
-          zero = e < 0;
-          rel = zero ? 0 : e - 2 * j;
+        if (!rows_in2) {
+          const int e = 2 * j2 - HL + t;
+          zero = !live || (zero_mode && (unsigned)e >= (unsigned)a.H1);
+          sl = zero ? 0 : fold(e, a.H1) - (2 * j - HL);
         }
-        int sl = ls + rel;
-        sl = sl < 0 ? sl + RL : sl;
-        sl = sl >= RL ? sl - RL : sl;
         f2 hv = *reinterpret_cast<const f2*>(&lr[sl * LP + 2 * kk]);
         if (zero) hv = (f2){0.0f, 0.0f};
         if (m == 0) {
@@ -336,18 +383,13 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
         }
       }
       if (live) {
-        // j2 differs between the half-waves: 32-bit per-lane offsets onto scalar bases (planes < 2^31 elements)
-        const int off_a = j2 * (int)a.a2s_h + k2, off_d = j2 * (int)a.d2s_h + k2;
-        (a.o2[0] + a2_img)[off_a] = lo2.x;
-        (a.o2[1] + d2_img)[off_d] = hi2.x;
-        (a.o2[2] + d2_img)[off_d] = lo2.y;
-        (a.o2[3] + d2_img)[off_d] = hi2.y;
+        const int off_a = j2 * a.a2s_h + k2, off_d = j2 * a.d2s_h + k2;
+        o2b0[off_a] = lo2.x;
+        o2b1[off_d] = hi2.x;
+        o2b2[off_d] = lo2.y;
+        o2b3[off_d] = hi2.y;
       }
     }
-    hs += S0;
-    hs = hs >= RH ? hs - RH : hs;
-    ls += S1;
-    ls = ls >= RL ? ls - RL : ls;
   }
 }
 
@@ -362,7 +404,12 @@ static int roll_segment(const mifwt_level_desc* d2) {
 
 bool dwt2_fwd_roll_supported(const mifwt_level_desc* d1, const mifwt_level_desc* d2) {
   if (!dwt2_fwd_pair_supported(d1, d2)) return false;
-  // rings: one step is 16 level-1 rows; the bottom-aligned last step must find its mirrored rows in the ring
+  // one step is 16 level-1 rows and the bottom-aligned last step must find its mirrored rows in the window; 32-bit
+  // element offsets inside one image of every band
+  const int64_t lim = int64_t(1) << 31;
+  if (d1->coef_extent[0] * d1->detail_stride[1] >= lim || d2->coef_extent[0] * d2->approx_stride[1] >= lim ||
+      d2->coef_extent[0] * d2->detail_stride[1] >= lim)
+    return false;
   return d1->coef_extent[0] >= 32 && d2->coef_extent[0] >= 9;
 }
 
@@ -376,13 +423,13 @@ static int launch_roll(const mifwt_level_desc* d1, const mifwt_level_desc* d2, c
   a.o2[0] = static_cast<float*>(approx2);
   for (int s = 1; s < 4; ++s) a.o2[s] = static_cast<float*>(details2[s - 1]);
   a.xs_b = d1->sig_stride[0];
-  a.xs_h = d1->sig_stride[1];
+  a.xs_h = (int)d1->sig_stride[1];
   a.d1s_b = d1->detail_stride[0];
-  a.d1s_h = d1->detail_stride[1];
+  a.d1s_h = (int)d1->detail_stride[1];
   a.a2s_b = d2->approx_stride[0];
-  a.a2s_h = d2->approx_stride[1];
+  a.a2s_h = (int)d2->approx_stride[1];
   a.d2s_b = d2->detail_stride[0];
-  a.d2s_h = d2->detail_stride[1];
+  a.d2s_h = (int)d2->detail_stride[1];
   a.H0 = (int)d1->sig_extent[0];
   a.W0 = (int)d1->sig_extent[1];
   a.H1 = (int)d1->coef_extent[0];
