@@ -104,12 +104,21 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (int64_t)img * a.xs_b), 0, img_bytes, 0x00020000);
   constexpr uint32_t kOob = 0x80000000u;  // >= num_records: the load returns 0 without a memory request
   const uint32_t row_bytes = (uint32_t)a.xs_h * 4u;
-  uint32_t coff[NQ];
+  // Interior strips (no boundary map along the columns) fetch a row as ONE 8-byte load per lane (columns 2 lane,
+  // 2 lane + 1) plus one 4-byte load for the HL columns beyond 128; edge strips map every column and use 4-byte loads.
+  // Lanes with no column of their own in the last load repeat an element they already fetch (and store it to the same
+  // LDS word again): every load and LDS store below is unconditional.
+  const bool pairs = c_first >= 0 && c_first + C0 <= a.W0;
+  uint32_t coff[NQ];  // byte offset of this lane's column in load q (pairs: q = 0 is the 8-byte load, q = NQ - 1 the tail)
+  int ltail = 0;      // h-window column the tail load's value is stored to
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const int c = c_first + lane + 64 * q;
-    const bool dead = lane + 64 * q >= C0 || (zero_mode && (unsigned)c >= (unsigned)a.W0);
+    int col = pairs ? (q == 0 ? 2 * lane : 128 + lane) : lane + 64 * q;
+    if (col >= C0) col = pairs ? 2 * lane : lane + 64 * (q - 1);  // repeat (only the tail load has such lanes)
+    const int c = c_first + col;
+    const bool dead = zero_mode && (unsigned)c >= (unsigned)a.W0;
     coff[q] = dead ? kOob : 4u * (uint32_t)fold(c, a.W0);
+    if (q == NQ - 1) ltail = col;
   }
 
   // level-0 rows r_first + wave + 4 i (i < N, row < r_end) of the extended plane -> registers.  Rows the level-1 plane
@@ -117,24 +126,57 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
   const int r_valid_hi = 2 * a.H1;
   auto request = [&](auto n_tag, float (&v)[decltype(n_tag)::value][NQ], int r_first, int r_end) {
     constexpr int N = decltype(n_tag)::value;
-    if (r_first >= 0 && r_first + 4 * N <= min(a.H0, r_end)) {  // interior: no map, one scalar add per row
-      uint32_t soff = (uint32_t)(r_first + wave) * row_bytes;
+    const bool fast = r_first >= 0 && r_first + 4 * N <= min(a.H0, r_end);  // interior: no map, one scalar add per row
+    uint32_t soffs[N];
+    bool deads[N];
+    if (fast) {
 #pragma unroll
       for (int i = 0; i < N; ++i) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) v[i][q] = tile_load<float>(xrsrc, coff[q], soff);
-        soff += 4u * row_bytes;
+        soffs[i] = (uint32_t)(r_first + wave + 4 * i) * row_bytes;
+        deads[i] = false;
       }
     } else {
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         const int r = r_first + wave + 4 * i;
-        const bool dead = r >= r_end || r < -HL || r >= r_valid_hi || (zero_mode && (unsigned)r >= (unsigned)a.H0);
-        // a dead row reads beyond the buffer's num_records through the scalar offset: no branch, no memory request
-        const uint32_t soff = dead ? kOob : (uint32_t)fold(r, a.H0) * row_bytes;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) v[i][q] = tile_load<float>(xrsrc, coff[q], soff);
+        deads[i] = r >= r_end || r < -HL || r >= r_valid_hi || (zero_mode && (unsigned)r >= (unsigned)a.H0);
+        soffs[i] = __builtin_amdgcn_readfirstlane(deads[i] ? 0u : (uint32_t)fold(r, a.H0) * row_bytes);
       }
+    }
+    // a dead row is requested at a per-lane offset beyond num_records: nothing is fetched, zeros come back
+    if (pairs) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const u2 w = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, deads[i] ? kOob : coff[0], soffs[i], 0);
+        v[i][0] = __builtin_bit_cast(float, w.x);
+        v[i][1] = __builtin_bit_cast(float, w.y);
+        if constexpr (NQ > 2) v[i][2] = tile_load<float>(xrsrc, deads[i] ? kOob : coff[2], soffs[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v[i][q] = tile_load<float>(xrsrc, deads[i] ? kOob : coff[q], soffs[i]);
+    }
+  };
+  // registers of N rows -> h-window slots slot(i)
+  auto stage = [&](auto n_tag, const float (&v)[decltype(n_tag)::value][NQ], auto slot, int nrows) {
+    constexpr int N = decltype(n_tag)::value;
+    if (pairs) {
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        if (wave + 4 * i < nrows) {
+          *reinterpret_cast<f2*>(&hr[slot(i) * XP + 2 * lane]) = (f2){v[i][0], v[i][1]};
+          if constexpr (NQ > 2) hr[slot(i) * XP + ltail] = v[i][2];
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        if (wave + 4 * i < nrows) {
+          hr[slot(i) * XP + lane] = v[i][0];
+          hr[slot(i) * XP + (NQ > 2 ? 64 + lane : ltail)] = v[i][1];
+          if constexpr (NQ > 2) hr[slot(i) * XP + ltail] = v[i][2];
+        }
     }
   };
 
@@ -176,7 +218,7 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
     cidx[p] = dead ? -1 : fold(e, a.W1) - s1c;
   }
   // level-2 horizontal pass over a-window slot `s` (lanes 0-31 and 32-63 may be given different slots), in place
-  auto h2_row = [&](int s, bool store) {
+  auto h2_row = [&](int s) {
     f2 acc;
     if (cols_in2) {
       const f2* row = reinterpret_cast<const f2*>(&lr[s * LP + 2 * kk]);
@@ -207,7 +249,8 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
       }
     }
     wave_lds_fence();
-    if (store && kk < T2C) *reinterpret_cast<f2*>(&lr[s * LP + 2 * kk]) = acc;
+    // lanes beyond the strip's T2C columns store too: columns 2 T2C .. 63 of the row are dead once it has been read
+    *reinterpret_cast<f2*>(&lr[s * LP + 2 * kk]) = acc;
   };
 
   const int m1c = s1c + lane;
@@ -229,18 +272,15 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
     float pp[PW0][NQ];
     request(std::integral_constant<int, PW0>{}, pp, 4 * ja - PR0, 4 * ja);
     request(std::integral_constant<int, S0 / 4>{}, pv, 4 * ja, 4 * ja + S0);
-#pragma unroll
-    for (int i = 0; i < PW0; ++i) {
+    auto pslot = [&](int i) {
       const int q = wave + 4 * i;  // prologue row index
-      if (q < PR0) {
-        const int s = q < 2 * HL ? q + HL : q - 2 * HL;
+      return q < 2 * HL ? q + HL : q - 2 * HL;
+    };
+    stage(std::integral_constant<int, PW0>{}, pp, pslot, PR0);
+    wave_lds_fence();
 #pragma unroll
-        for (int u = 0; u < NQ; ++u)
-          if (lane + 64 * u < XP) hr[s * XP + lane + 64 * u] = pp[i][u];
-        wave_lds_fence();
-        h1_row(s);
-      }
-    }
+    for (int i = 0; i < PW0; ++i)
+      if (wave + 4 * i < PR0) h1_row(pslot(i));
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < PW1; ++i) {
@@ -256,7 +296,7 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
         }
         lr[il * LP + lane] = aa;
         wave_lds_fence();
-        h2_row(il, half == 0);
+        h2_row(il);  // both half-waves compute and store the same row
       }
     }
     __syncthreads();  // the prologue's first 2 HL h-rows are dead: step 0 overwrites their slots
@@ -269,13 +309,7 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
   for (int st = 0; st < nsteps; ++st) {
     const int j = ja + S2 * st;
     // this wave's 8 level-0 rows -> slots HL + wave + 4 i, then their horizontal pass (same wave: DS order suffices)
-#pragma unroll
-    for (int i = 0; i < S0 / 4; ++i) {
-      const int s = HL + wave + 4 * i;
-#pragma unroll
-      for (int u = 0; u < NQ; ++u)
-        if (lane + 64 * u < XP) hr[s * XP + lane + 64 * u] = pv[i][u];
-    }
+    stage(std::integral_constant<int, S0 / 4>{}, pv, [&](int i) { return HL + wave + 4 * i; }, S0);
     wave_lds_fence();
     if (st + 1 < nsteps) request(std::integral_constant<int, S0 / 4>{}, pv, 4 * (j + S2), 4 * (j + S2) + S0);
 #pragma unroll
@@ -288,11 +322,15 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
         // keep the last HL rows of the previous step's a-window: slot S1 + t -> slot t, by the wave that is about to
         // overwrite slot S1 + t (every wave finished reading the old window before the barrier above)
 #pragma unroll
-        for (int t = 0; t < HL; ++t) {
-          if (((S1 + t - HL) >> 2) == wave) {
-            const float keep = lr[(S1 + t) * LP + lane];
-            wave_lds_fence();
-            lr[t * LP + lane] = keep;
+        for (int w = 0; w < 4; ++w) {
+          if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < HL; ++t)
+              if (((S1 + t - HL) >> 2) == w) {
+                const float keep = lr[(S1 + t) * LP + lane];
+                wave_lds_fence();
+                lr[t * LP + lane] = keep;
+              }
           }
         }
         wave_lds_fence();
@@ -307,52 +345,44 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
         const int m1r = 2 * j + 4 * wave + i;
         const bool own_r = m1r >= own_lo && m1r < own_hi;
         f2 lo2, hi2;  // (aa, da), (ad, dd)
-        if (own_r) {
 #pragma unroll
-          for (int m = 0; m < L; ++m) {
-            const f2 hv = win[2 * i + (L - 1) - m];
-            if (m == 0) {
-              lo2 = pkmul_lo(a.tap[0], hv);
-              hi2 = pkmul_hi(a.tap[0], hv);
-            } else {
-              pkfma_lo(lo2, a.tap[m], hv);
-              pkfma_hi(hi2, a.tap[m], hv);
-            }
+        for (int m = 0; m < L; ++m) {
+          const f2 hv = win[2 * i + (L - 1) - m];
+          if (m == 0) {
+            lo2 = pkmul_lo(a.tap[0], hv);
+            hi2 = pkmul_hi(a.tap[0], hv);
+          } else {
+            pkfma_lo(lo2, a.tap[m], hv);
+            pkfma_hi(hi2, a.tap[m], hv);
           }
-          if (own_c) {
-            const int off = m1r * a.d1s_h + m1c;
-            d1b0[off] = hi2.x;
-            d1b1[off] = lo2.y;
-            d1b2[off] = hi2.y;
-          }
-        } else {  // halo / out-of-plane row: only its approximation is needed
-#pragma unroll
-          for (int m = 0; m < L; ++m) {
-            const f2 hv = win[2 * i + (L - 1) - m];
-            if (m == 0) {
-              lo2 = pkmul_lo(a.tap[0], hv);
-            } else {
-              pkfma_lo(lo2, a.tap[m], hv);
-            }
-          }
+        }
+        if (own_r && own_c) {  // own_r fails only on rows beyond the plane / beyond this segment
+          const int off = m1r * a.d1s_h + m1c;
+          d1b0[off] = hi2.x;
+          d1b1[off] = lo2.y;
+          d1b2[off] = hi2.y;
         }
         lrow[i * LP] = lo2.x;
       }
       // level-2 horizontal pass over the four rows this wave just wrote: half-wave h takes rows h and 2 + h
       wave_lds_fence();
 #pragma unroll
-      for (int i = 0; i < 2; ++i) h2_row(HL + 4 * wave + 2 * i + half, true);
+      for (int i = 0; i < 2; ++i) h2_row(HL + 4 * wave + 2 * i + half);
     }
     __syncthreads();
 
     // keep the last HL rows of the h-window for the next step: slot S0 + t -> slot t, by the wave whose next staging
     // overwrites slot S0 + t (all waves are past the vertical pass)
 #pragma unroll
-    for (int t = 0; t < HL; ++t) {
-      if (((S0 + t - HL) & 3) == wave) {
-        const f2 keep = *reinterpret_cast<const f2*>(&hr[(S0 + t) * XP + 2 * lane]);
-        wave_lds_fence();
-        *reinterpret_cast<f2*>(&hr[t * XP + 2 * lane]) = keep;
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int t = 0; t < HL; ++t)
+          if (((S0 + t - HL) & 3) == w) {
+            const f2 keep = *reinterpret_cast<const f2*>(&hr[(S0 + t) * XP + 2 * lane]);
+            wave_lds_fence();
+            *reinterpret_cast<f2*>(&hr[t * XP + 2 * lane]) = keep;
+          }
       }
     }
 
