@@ -32,6 +32,7 @@ struct Dwt2PairArgs {
   int H0, W0, H1, W1, H2, W2;
   int tiles_c, tiles_r;
   int mode;
+  int sync_stage;
   f2 tap[L];  // (dec_lo[m], dec_hi[m])
 };
 
@@ -121,7 +122,9 @@ __global__ void __launch_bounds__(256, pair_occupancy(L, T2R)) dwt2_fwd_pair_ker
         if (lane + 64 * q < XP) xt[r * XP + lane + 64 * q] = v[i][q];
     }
   }
-  __syncthreads();
+  // no workgroup barrier here: row r is staged, filtered and overwritten by the same wave (rows wave + 4 i), whose DS
+  // operations execute in order; the option keeps the barrier for A/B measurements
+  if (a.sync_stage) __syncthreads(); else wave_lds_fence();
 
   // ---- 2. level-1 horizontal pass, in place: row r becomes (lo, hi)[c] of level-1 column s1c + c --------------------
 #pragma unroll
@@ -324,6 +327,7 @@ static int launch_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, c
   a.H2 = (int)d2->coef_extent[0];
   a.W2 = (int)d2->coef_extent[1];
   a.mode = d1->mode;
+  a.sync_stage = g_options[MIFWT_OPT_SYNC_STAGE];
   for (int m = 0; m < L; ++m) a.tap[m] = (f2){(float)lo[m], (float)hi[m]};
   a.tiles_c = (a.W2 + T2C - 1) / T2C;
   a.tiles_r = (a.H2 + T2R - 1) / T2R;

@@ -104,79 +104,57 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (int64_t)img * a.xs_b), 0, img_bytes, 0x00020000);
   constexpr uint32_t kOob = 0x80000000u;  // >= num_records: the load returns 0 without a memory request
   const uint32_t row_bytes = (uint32_t)a.xs_h * 4u;
-  // Interior strips (no boundary map along the columns) fetch a row as ONE 8-byte load per lane (columns 2 lane,
-  // 2 lane + 1) plus one 4-byte load for the HL columns beyond 128; edge strips map every column and use 4-byte loads.
-  // Lanes with no column of their own in the last load repeat an element they already fetch (and store it to the same
-  // LDS word again): every load and LDS store below is unconditional.
-  const bool pairs = c_first >= 0 && c_first + C0 <= a.W0;
-  uint32_t coff[NQ];  // byte offset of this lane's column in load q (pairs: q = 0 is the 8-byte load, q = NQ - 1 the tail)
-  int ltail = 0;      // h-window column the tail load's value is stored to
+  uint32_t coff[NQ];  // byte offset of this lane's column in load q; lanes beyond the window's C0 columns request nothing
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    int col = pairs ? (q == 0 ? 2 * lane : 128 + lane) : lane + 64 * q;
-    if (col >= C0) col = pairs ? 2 * lane : lane + 64 * (q - 1);  // repeat (only the tail load has such lanes)
-    const int c = c_first + col;
-    const bool dead = zero_mode && (unsigned)c >= (unsigned)a.W0;
+    const int c = c_first + lane + 64 * q;
+    const bool dead = lane + 64 * q >= C0 || (zero_mode && (unsigned)c >= (unsigned)a.W0);
     coff[q] = dead ? kOob : 4u * (uint32_t)fold(c, a.W0);
-    if (q == NQ - 1) ltail = col;
   }
+  constexpr bool kTail = (C0 & 63) != 0;  // the last load covers only C0 - 64 (NQ - 1) columns
+  const bool tail_lane = lane + 64 * (NQ - 1) < C0;
 
   // level-0 rows r_first + wave + 4 i (i < N, row < r_end) of the extended plane -> registers.  Rows the level-1 plane
   // does not need (above -HL: segment 0's prologue; below 2 H1 - 1: the bottom-aligned last step) request nothing.
   const int r_valid_hi = 2 * a.H1;
   auto request = [&](auto n_tag, float (&v)[decltype(n_tag)::value][NQ], int r_first, int r_end) {
     constexpr int N = decltype(n_tag)::value;
-    const bool fast = r_first >= 0 && r_first + 4 * N <= min(a.H0, r_end);  // interior: no map, one scalar add per row
-    uint32_t soffs[N];
-    bool deads[N];
-    if (fast) {
+    if (r_first >= 0 && r_first + 4 * N <= min(a.H0, r_end)) {  // interior: no map, one scalar add per row
+      uint32_t soff = (uint32_t)(r_first + wave) * row_bytes;
 #pragma unroll
       for (int i = 0; i < N; ++i) {
-        soffs[i] = (uint32_t)(r_first + wave + 4 * i) * row_bytes;
-        deads[i] = false;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v[i][q] = tile_load<float>(xrsrc, coff[q], soff);
+        soff += 4u * row_bytes;
       }
     } else {
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         const int r = r_first + wave + 4 * i;
-        deads[i] = r >= r_end || r < -HL || r >= r_valid_hi || (zero_mode && (unsigned)r >= (unsigned)a.H0);
-        soffs[i] = __builtin_amdgcn_readfirstlane(deads[i] ? 0u : (uint32_t)fold(r, a.H0) * row_bytes);
+        const bool dead = r >= r_end || r < -HL || r >= r_valid_hi || (zero_mode && (unsigned)r >= (unsigned)a.H0);
+        const uint32_t soff = __builtin_amdgcn_readfirstlane(dead ? 0u : (uint32_t)fold(r, a.H0) * row_bytes);
+        // a dead row is requested at per-lane offsets beyond num_records: nothing is fetched, zeros come back
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v[i][q] = tile_load<float>(xrsrc, dead ? kOob : coff[q], soff);
       }
-    }
-    // a dead row is requested at a per-lane offset beyond num_records: nothing is fetched, zeros come back
-    if (pairs) {
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        const u2 w = __builtin_amdgcn_raw_buffer_load_b64(xrsrc, deads[i] ? kOob : coff[0], soffs[i], 0);
-        v[i][0] = __builtin_bit_cast(float, w.x);
-        v[i][1] = __builtin_bit_cast(float, w.y);
-        if constexpr (NQ > 2) v[i][2] = tile_load<float>(xrsrc, deads[i] ? kOob : coff[2], soffs[i]);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < N; ++i)
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) v[i][q] = tile_load<float>(xrsrc, deads[i] ? kOob : coff[q], soffs[i]);
     }
   };
-  // registers of N rows -> h-window slots slot(i)
+  // registers of N rows -> h-window slots slot(i); the partial last load is stored under one exec mask for all rows
   auto stage = [&](auto n_tag, const float (&v)[decltype(n_tag)::value][NQ], auto slot, int nrows) {
     constexpr int N = decltype(n_tag)::value;
-    if (pairs) {
+    constexpr int NF = kTail ? NQ - 1 : NQ;
 #pragma unroll
-      for (int i = 0; i < N; ++i)
-        if (wave + 4 * i < nrows) {
-          *reinterpret_cast<f2*>(&hr[slot(i) * XP + 2 * lane]) = (f2){v[i][0], v[i][1]};
-          if constexpr (NQ > 2) hr[slot(i) * XP + ltail] = v[i][2];
-        }
-    } else {
+    for (int i = 0; i < N; ++i)
+      if (wave + 4 * i < nrows) {
 #pragma unroll
-      for (int i = 0; i < N; ++i)
-        if (wave + 4 * i < nrows) {
-          hr[slot(i) * XP + lane] = v[i][0];
-          hr[slot(i) * XP + (NQ > 2 ? 64 + lane : ltail)] = v[i][1];
-          if constexpr (NQ > 2) hr[slot(i) * XP + ltail] = v[i][2];
-        }
+        for (int q = 0; q < NF; ++q) hr[slot(i) * XP + lane + 64 * q] = v[i][q];
+      }
+    if constexpr (kTail) {
+      if (tail_lane) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          if (wave + 4 * i < nrows) hr[slot(i) * XP + lane + 64 * (NQ - 1)] = v[i][NQ - 1];
+      }
     }
   };
 
@@ -426,7 +404,7 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
 // level-2 rows per segment: the option's value, else 32; always a multiple of 8 that leaves at least two segments
 static int roll_segment(const mifwt_level_desc* d2) {
   int seg = g_options[MIFWT_OPT_PAIR_ROWS];
-  if (seg <= 0) seg = 32;
+  if (seg <= 0) seg = 24;  // measured best on 1024^2 planes (16 .. 64 tried): more, shorter segments balance the chip better than they cost in prologues
   seg = (seg + 7) / 8 * 8;
   const int cap = (int)((d2->coef_extent[0] - 1) / 8 * 8);
   return seg < cap ? seg : cap;

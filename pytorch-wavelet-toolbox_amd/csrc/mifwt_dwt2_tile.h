@@ -31,6 +31,7 @@ struct Dwt2TileArgs {
   int H, W, Ho, Wo;
   int tiles_c, tiles_r, ntiles;
   int mode;
+  int sync_stage;
   f2 tap[L];  // (dec_lo[m], dec_hi[m])
 };
 
@@ -130,7 +131,9 @@ __global__ void __launch_bounds__(256, tile_occupancy(L, TR)) dwt2_fwd_tile_kern
         if (lane + 64 * q < XP) xt[r * XP + lane + 64 * q] = v[i][q];
     }
   }
-  __syncthreads();
+  // no workgroup barrier here: row r is staged, filtered and overwritten by the same wave (rows wave + 4 i), whose DS
+  // operations execute in order; the option keeps the barrier for A/B measurements
+  if (a.sync_stage) __syncthreads(); else wave_lds_fence();
 
   // ---- 2. horizontal pass, in place: row r becomes (lo, hi)[k] of output column k0 + k ---------------------------------
   // c[k] = sum_m h[m] x_ext[2k + 1 - m]; tile column of x_ext[2k + 1 - m] is 2k + (L - 1) - m
@@ -209,6 +212,7 @@ int launch_tile(const mifwt_level_desc* d, const void* x, void* approx, void* co
   a.Ho = (int)d->coef_extent[0];
   a.Wo = (int)d->coef_extent[1];
   a.mode = d->mode;
+  a.sync_stage = g_options[MIFWT_OPT_SYNC_STAGE];
   for (int m = 0; m < L; ++m) a.tap[m] = (f2){(float)lo[m], (float)hi[m]};
   a.tiles_c = (a.Wo + kTC - 1) / kTC;
   a.tiles_r = (a.Ho + TR - 1) / TR;

@@ -617,8 +617,8 @@ def test_full_size_config5_slice_properties():
 
 # ---- two analysis levels per launch (mifwt_dwt2_fwd_pair, kernel id 12) ----------------------------------------------
 def _pair_vs_single(x, wavelet, mode, level, pair_mode=0):
-    """wavedec2 with a pair kernel (pair_mode 0: rolling strips where they apply, 1: tiles) against the per-level
-    kernels on the same input: bit-identical."""
+    """wavedec2 with a pair kernel (pair_mode 0: the library's choice, 1: tiles, 3: rolling strips where they apply)
+    against the per-level kernels on the same input: bit-identical."""
     _engine.set_option(_engine.OPT_PAIR_MODE, pair_mode)
     _engine.level_events = []
     try:
@@ -640,7 +640,7 @@ def _pair_vs_single(x, wavelet, mode, level, pair_mode=0):
     return kids
 
 
-@pytest.mark.parametrize("pair_mode", [0, 1])
+@pytest.mark.parametrize("pair_mode", [0, 1, 3])
 @pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4"])
 @pytest.mark.parametrize("mode", ["reflect", "zero", "constant", "symmetric"])
 def test_pair_kernel_bit_identical_to_per_level(wavelet, mode, pair_mode):
@@ -652,7 +652,7 @@ def test_pair_kernel_bit_identical_to_per_level(wavelet, mode, pair_mode):
         assert kids[0] == _engine.KID_PAIR, (shape, kids)
 
 
-@pytest.mark.parametrize("pair_mode", [0, 1])
+@pytest.mark.parametrize("pair_mode", [1, 3])
 @pytest.mark.parametrize("rows", [4, 6, 8, 12, 16, 40, 64])
 def test_pair_kernel_tile_heights(rows, pair_mode):
     """OPT_PAIR_ROWS: level-2 rows per tile (tile kernel) / per strip segment (rolling kernel, rounded up to 8)."""

@@ -29,13 +29,14 @@ ap.add_argument("--rows", default="8", help="tile-pair kernel: level-2 rows per 
 ap.add_argument("--seg", default="32", help="rolling kernel: level-2 rows per segment")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--sync-stage", type=int, default=0, help="1: keep the staging barrier of the tile kernels (A/B)")
 args = ap.parse_args()
 
 shape = tuple(int(v) for v in args.shape.split(","))
 dev = torch.device("cuda:0")
 bufs = [torch.randn(*shape, device=dev) for _ in range(3)]
 variants = [("single", 2, 0)] + [(f"tile-pair rows={r}", 1, int(r)) for r in args.rows.split(",") if r] + \
-    [(f"roll seg={r}", 0, int(r)) for r in args.seg.split(",") if r]
+    [(f"roll seg={r}", 3, int(r)) for r in args.seg.split(",") if r] + [("auto", 0, 0)]
 times = {v[0]: [] for v in variants}
 kids = {}
 
@@ -48,6 +49,7 @@ for rnd in range(args.rounds + 1):
     for name, pm, rows in variants:
         _engine.set_option(_engine.OPT_PAIR_MODE, pm)
         _engine.set_option(_engine.OPT_PAIR_ROWS, rows)
+        _engine.set_option(10, args.sync_stage)
         if rnd == 0:
             _engine.level_events = []
             run(0)
@@ -67,6 +69,7 @@ for rnd in range(args.rounds + 1):
         times[name].append(e0.elapsed_time(e1) * 1e3 / args.iters)
 _engine.set_option(_engine.OPT_PAIR_MODE, 0)
 _engine.set_option(_engine.OPT_PAIR_ROWS, 0)
+_engine.set_option(10, 0)
 n = 1
 for v in shape:
     n *= v
