@@ -73,7 +73,9 @@ def algorithmic_bytes(batch, sig, flen, level, esize):
         per_level += prod(cur) + nb * prod(e)
         cur = e
     level1 = prod(sig) + nb * prod(exts[0])
-    return (esize * batch * compulsory, esize * batch * per_level, esize * batch * level1)
+    # two-levels-per-launch kernel (mifwt_dwt2_fwd_pair): input + level-1 details + all four level-2 bands
+    pair12 = prod(sig) + (nb - 1) * prod(exts[0]) + nb * prod(exts[1]) if len(exts) > 1 else level1
+    return (esize * batch * compulsory, esize * batch * per_level, esize * batch * level1, esize * batch * pair12)
 
 
 def _flatten(coeffs):
@@ -127,7 +129,7 @@ def cpu_baseline(fn, shape, wavelet, level, mode, dtype):
     }
 
 
-def profiled_traffic(workload):
+def profiled_traffic(workload, kernel_label=""):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate passes, FETCH_SIZE x2 gfx950 correction; tools/gpu_pmc.sh + tools/summarize_prof.py).
     PMC counters cannot be collected from inside this process, so the value is the one measured when the
@@ -138,7 +140,12 @@ def profiled_traffic(workload):
         if name.endswith("_pmc_level1.json") and not name.startswith("r01a"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
-                    return json.load(f).get("hbm_traffic_bytes")
+                    prof = json.load(f)
+                # only a profile of the SAME kernel family counts (the committed file names its kernel)
+                fam = "roll" if "roll" in kernel_label else ("pair" if "pair" in kernel_label else "tile")
+                if fam not in prof.get("kernel", ""):
+                    continue
+                return prof.get("hbm_traffic_bytes")
             except Exception:
                 return None
     return None
@@ -242,16 +249,22 @@ def main():
     # of HIP events (the per-launch event pairs above add a barrier packet on each side of every kernel: +5-8 % on a
     # 100 us kernel), so that the figure is comparable with the rocprofv3 kernel-trace average under profiles/.
     lvl1_b2b_ms = None
+    first_kid = events[0][1] if events else -1
     if fn_name in ("wavedec2", "fswavedec2", "wavedec3", "wavedec"):
         taps = ptwt_amd._wavelets.host_taps(wavelet)
         mode_id = _engine.MODE_IDS[mode]
+        # the first launch of a call: one level, or levels 1+2 where the two-level kernel serves the call
+        if first_kid == _engine.KID_PAIR:
+            launch = lambda b: _engine.ENGINE.analysis_pair(b, taps[0], taps[1], mode_id)  # noqa: E731
+        else:
+            launch = lambda b: _engine.ENGINE.analysis(b, taps[0], taps[1], mode_id)  # noqa: E731
         for i in range(3):
-            _engine.ENGINE.analysis(bufs[i % len(bufs)], taps[0], taps[1], mode_id)
+            launch(bufs[i % len(bufs)])
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(args.steps):
-            _engine.ENGINE.analysis(bufs[i % len(bufs)], taps[0], taps[1], mode_id)
+            launch(bufs[i % len(bufs)])
         e1.record()
         torch.cuda.synchronize()
         lvl1_b2b_ms = e0.elapsed_time(e1) / args.steps
@@ -291,7 +304,7 @@ def main():
         samples_per_step = prod(shape) * world
         ms_per_step = elapsed / args.steps * 1e3
         esize = torch.empty(0, dtype=dtype).element_size()
-        comp_b, perlvl_b, lvl1_b = algorithmic_bytes(shape[0], shape[1:], flen, level, esize)
+        comp_b, perlvl_b, lvl1_b, pair_b = algorithmic_bytes(shape[0], shape[1:], flen, level, esize)
         # dominant kernel = the level-1 analysis launch (largest signal extent); durations from HIP events
         # recorded on the launch stream inside the timed region
         lvl1 = [s.elapsed_time(e) for (tag, kid, ext, s, e) in events if tag == "fwd" and tuple(ext) == tuple(shape[1:])]
@@ -299,6 +312,12 @@ def main():
         for tag, kid, ext, s, e in events:
             per_level_ms.setdefault("x".join(map(str, ext)), []).append(s.elapsed_time(e))
         kid1 = next((kid for (tag, kid, ext, s, e) in events if tuple(ext) == tuple(shape[1:])), -1)
+        if kid1 == _engine.KID_PAIR:
+            lvl1_b = pair_b
+        klabel = {1: "dwt2_fwd_stream_kernel (level 1)", 7: "dwt2_fwd_tile_kernel (level 1)", 0: "generic axis kernels (level 1)",
+                  3: "streaming axis kernels (level 1)", 5: "fused 2-D planes + depth pass (level 1)", 9: "dwt3_fwd_tile_kernel (level 1)",
+                  11: "dwt2_fwd_mfma_kernel (level 1)",
+                  12: ("dwt2_fwd_roll_kernel" if flen >= 6 else "dwt2_fwd_pair_kernel") + " (levels 1+2 in one launch)"}.get(kid1, f"kernel id {kid1} (level 1)")
         per_launch_event_ms = sum(lvl1) / max(1, len(lvl1))
         avg_ms = lvl1_b2b_ms if lvl1_b2b_ms else per_launch_event_ms
         achieved = lvl1_b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -330,7 +349,7 @@ def main():
                 "level_kernel_ms": {k: round(sum(v) / len(v), 4) for k, v in per_level_ms.items()},
             },
             "roofline": {
-                "kernel": {1: "dwt2_fwd_stream_kernel (level 1)", 7: "dwt2_fwd_tile_kernel (level 1)", 0: "generic axis kernels (level 1)", 3: "streaming axis kernels (level 1)", 5: "fused 2-D planes + depth pass (level 1)"}.get(kid1, f"kernel id {kid1} (level 1)"),
+                "kernel": klabel,
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
@@ -338,9 +357,9 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes_per_launch": lvl1_b,
                 "avg_launch_ms": round(avg_ms, 4),
-                "timing": f"one HIP event pair around {args.steps} back-to-back level-1 launches on the launch stream (same rotating inputs); "
+                "timing": f"one HIP event pair around {args.steps} back-to-back launches of that kernel on the launch stream (same rotating inputs); "
                           f"with an event pair around every launch inside whole calls: {per_launch_event_ms:.4f} ms",
-                "traffic": profiled_traffic(args.workload),
+                "traffic": profiled_traffic(args.workload, klabel),
             },
         }
         if gather_info is not None:

@@ -15,7 +15,7 @@
 //              barrier  level-2 vertical pass, one row per half-wave -> the four level-2 bands to HBM.
 // A segment starts with a prologue of 3 (L-2) level-0 rows that fills the rings.  The first segment of a plane is
 // aligned to its top, all others to its bottom (the boundary extension of level 2 reads ACTUAL level-1 rows through
-// the index map, and those must still be in the ring: oracle-checked in tests/test_host_logic.py's numpy model).
+// the index map, and those must still be in the window: tests/test_roll_model.py models exactly this bookkeeping).
 // Column handling (shifted window at the plane's edges, per-lane index map for the extension) is the tile version's.
 // Bit-identical to the per-level kernels.  Algorithmic traffic: 4 B H W read + 4 B (3 H1 W1 + 4 H2 W2) written.
 #include <type_traits>

@@ -20,6 +20,16 @@ class OracleLevelEngine:
         keys = [format(s, f"0{ndim}b").replace("0", "a").replace("1", "d") for s in range(1 << ndim)]
         return torch.from_numpy(np.stack([bands[k] for k in keys], axis=1))
 
+    def analysis_pair(self, x, dec_lo, dec_hi, mode_id):
+        """Stand-in for the two-levels-per-launch call: same return contract as HipLevelEngine.analysis_pair — plane 0
+        of the first buffer (the intermediate approximation) is NOT part of it, so it is poisoned here."""
+        if x.dim() != 3 or min(x.shape[1:]) < 16:
+            return None
+        buf1 = self.analysis(x, dec_lo, dec_hi, mode_id)
+        buf2 = self.analysis(buf1[:, 0], dec_lo, dec_hi, mode_id)
+        buf1[:, 0] = float("nan")
+        return buf1, buf2
+
     def synthesis(self, approx, details, rec_lo, rec_hi, out_extent):
         ndim = approx.dim() - 1
         flen = len(rec_lo)

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc
 cd /tmp
 rocprofv3 -L > $OUT/counters_list.txt 2>&1
-CMD="python $GRAFT_REPO_ROOT/tools/level_bench.py --tile ${TILE:-0} --rpc ${RPC:-0} --depth ${DEPTH:-0} --rounds 1 --iters 4"
+CMD="python $GRAFT_REPO_ROOT/tools/level_bench.py ${PAIR:+--pair} --tile ${TILE:-0} --rpc ${RPC:-0} --depth ${DEPTH:-0} --rounds 1 --iters 4"
 i=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" \
            "FETCH_SIZE GRBM_GUI_ACTIVE" \

@@ -31,6 +31,7 @@ ap.add_argument("--inverse", action="store_true", help="time the synthesis level
 ap.add_argument("--nt", default="0", help="comma list: 1 = nontemporal stores")
 ap.add_argument("--tile", default="0", help="comma list: tile mode (1 = LDS-tile kernel, 2 = streaming kernel, 0 = auto)")
 ap.add_argument("--tr", default="0", help="comma list: tile rows override (8 / 16)")
+ap.add_argument("--pair", action="store_true", help="time the two-levels-per-launch kernel (levels 1+2) instead of one level")
 args = ap.parse_args()
 
 shape = tuple(int(v) for v in args.shape.split(","))
@@ -50,6 +51,14 @@ if args.inverse:
     def run(i):
         cb = cbufs[i % 3]
         return eng.synthesis(cb[:, 0], [cb[:, s] for s in range(1, nb)], taps[2], taps[3], out_ext)
+elif args.pair:
+    coef2 = [(n + flen - 1) // 2 for n in coef]
+    bytes_algo = 4 * shape[0] * (torch.Size(shape[1:]).numel() + (nb - 1) * torch.Size(coef).numel() + nb * torch.Size(coef2).numel())
+
+    def run(i):
+        out = eng.analysis_pair(bufs[i % 3], taps[0], taps[1], mode_id)
+        assert out is not None, "the library does not serve this geometry as a pair"
+        return out
 else:
     def run(i):
         return eng.analysis(bufs[i % 3], taps[0], taps[1], mode_id)
