@@ -39,8 +39,8 @@ struct Dwt2RollArgs {
 
 constexpr int roll_lds_bytes(int L) { return ((32 + L - 2) * (128 + L - 2) + (16 + L - 2) * 64) * 4; }
 constexpr int roll_occupancy(int L) {
-  // 6 workgroups' windows fit; the prefetch registers of the 6- and 8-tap instances need the 5-wave register budget
-  const int n = (160 * 1024) / roll_lds_bytes(L), cap = L <= 4 ? 6 : 5;
+  // 6 workgroups' windows fit; the prefetch registers of the longer instances need the 5-wave register budget
+  const int n = (160 * 1024) / roll_lds_bytes(L), cap = L <= 2 ? 6 : 5;
   return n > cap ? cap : (n < 1 ? 1 : n);
 }
 
@@ -139,13 +139,16 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
       }
     }
   };
-  // registers of N rows -> h-window slots slot(i); the partial last load is stored under one exec mask for all rows
-  auto stage = [&](auto n_tag, const float (&v)[decltype(n_tag)::value][NQ], auto slot, int nrows) {
-    constexpr int N = decltype(n_tag)::value;
+  // registers of N rows -> h-window slots slot(i); the partial last load is stored under one exec mask for all rows.
+  // nrows_tag: rows that exist (compile time; when it equals 4 N every wave owns N rows and no row test is emitted —
+  // the compiler cannot know that wave < 4)
+  auto stage = [&](auto n_tag, auto nrows_tag, const float (&v)[decltype(n_tag)::value][NQ], auto slot) {
+    constexpr int N = decltype(n_tag)::value, NROWS = decltype(nrows_tag)::value;
+    constexpr bool kAll = NROWS == 4 * N;
     constexpr int NF = kTail ? NQ - 1 : NQ;
 #pragma unroll
     for (int i = 0; i < N; ++i)
-      if (wave + 4 * i < nrows) {
+      if (kAll || wave + 4 * i < NROWS) {
 #pragma unroll
         for (int q = 0; q < NF; ++q) hr[slot(i) * XP + lane + 64 * q] = v[i][q];
       }
@@ -153,7 +156,7 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
       if (tail_lane) {
 #pragma unroll
         for (int i = 0; i < N; ++i)
-          if (wave + 4 * i < nrows) hr[slot(i) * XP + lane + 64 * (NQ - 1)] = v[i][NQ - 1];
+          if (kAll || wave + 4 * i < NROWS) hr[slot(i) * XP + lane + 64 * (NQ - 1)] = v[i][NQ - 1];
       }
     }
   };
@@ -254,7 +257,7 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
       const int q = wave + 4 * i;  // prologue row index
       return q < 2 * HL ? q + HL : q - 2 * HL;
     };
-    stage(std::integral_constant<int, PW0>{}, pp, pslot, PR0);
+    stage(std::integral_constant<int, PW0>{}, std::integral_constant<int, PR0>{}, pp, pslot);
     wave_lds_fence();
 #pragma unroll
     for (int i = 0; i < PW0; ++i)
@@ -287,7 +290,7 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
   for (int st = 0; st < nsteps; ++st) {
     const int j = ja + S2 * st;
     // this wave's 8 level-0 rows -> slots HL + wave + 4 i, then their horizontal pass (same wave: DS order suffices)
-    stage(std::integral_constant<int, S0 / 4>{}, pv, [&](int i) { return HL + wave + 4 * i; }, S0);
+    stage(std::integral_constant<int, S0 / 4>{}, std::integral_constant<int, S0>{}, pv, [&](int i) { return HL + wave + 4 * i; });
     wave_lds_fence();
     if (st + 1 < nsteps) request(std::integral_constant<int, S0 / 4>{}, pv, 4 * (j + S2), 4 * (j + S2) + S0);
 #pragma unroll
