@@ -104,6 +104,12 @@ bool dwt2_fwd_tile_supported(const mifwt_level_desc* d) {
   if (d->sig_stride[1] < 0 || span >= (int64_t(1) << 29)) return false;
   for (int i = 0; i < 2; ++i)
     if (d->approx_stride[i] < 0 || d->detail_stride[i] < 0) return false;
+  // the kernel maps the boundary with ONE fold (mifwt_stream.h: Fold1): every requested index lies within one period
+  // of the plane once the plane is at least as long as the filter; shorter planes take the streaming / generic routes
+  if (d->sig_extent[0] < L || d->sig_extent[1] < L) return false;
+  // 32-bit element offsets inside one image of a band
+  const int64_t lim = int64_t(1) << 31;
+  if (d->coef_extent[0] * d->approx_stride[1] >= lim || d->coef_extent[0] * d->detail_stride[1] >= lim) return false;
   return true;
 }
 

@@ -44,18 +44,6 @@ constexpr int roll_occupancy(int L) {
   return n > cap ? cap : (n < 1 ? 1 : n);
 }
 
-// Boundary extension for an index at most one period outside [0, n), branch-free and without the general
-// fallback of ext_index_near (whose integer division, inlined at every use, tripled this kernel's code): mode is
-// folded into (k, lo_add, hi_add) once per workgroup.  Zero mode: the caller tests (unsigned)i >= n itself.
-struct Fold1 {
-  int k, lo_add, sym;  // k = 0 (constant) or -1 (mirror modes)
-  __device__ __forceinline__ int operator()(int i, int n) const {
-    const int mi = i & k;  // i for the mirror modes, 0 for constant
-    const int hi_add = k ? 2 * n - 2 + sym : n - 1;
-    return i < 0 ? lo_add - mi : (i >= n ? hi_add - mi : i);
-  }
-};
-
 template <int L>
 __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(const Dwt2RollArgs<L> a) {
   constexpr int HL = L - 2;
@@ -93,10 +81,9 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
   const int s1c = min(max(2 * k2_0 - HL, 0), a.W1 - C1);
   const int c_first = 2 * s1c - HL;
   const bool zero_mode = a.mode == MIFWT_MODE_ZERO;
-  Fold1 fold;
-  fold.k = a.mode == MIFWT_MODE_CONSTANT ? 0 : -1;
-  fold.sym = a.mode == MIFWT_MODE_SYMMETRIC ? 1 : 0;
-  fold.lo_add = -fold.sym;
+  Fold1 fold;  // mifwt_stream.h
+  fold.set(a.mode);
+  __builtin_assume(wave >= 0 && wave < 4);
 
   // ---- level-0 column offsets, once per workgroup ---------------------------------------------------------------------
   const uint32_t img_bytes = ((uint32_t)(a.H0 - 1) * (uint32_t)a.xs_h + (uint32_t)a.W0) * 4u;

@@ -83,52 +83,50 @@ __global__ void __launch_bounds__(256, tile_occupancy(L, TR)) dwt2_fwd_tile_kern
   const int nc_need = 2 * (min(k0 + kTC, a.Wo) - k0) + L - 2;
   const int nr_need = 2 * (min(j0 + TR, a.Ho) - j0) + L - 2;
   const int c_first = 2 * k0 - (L - 2), r_first = 2 * j0 - (L - 2);
-  // a tile whose window lies inside the image along an axis needs no boundary map there: the index arithmetic of the
-  // map (once per row and wave on the scalar unit, once per column and lane) otherwise rivals the filter's issue time
-  const bool cols_inside = c_first >= 0 && c_first + IC <= a.W;
+  // Boundary extension = the branch-free single-fold map (the launcher routes planes shorter than the filter elsewhere).
+  // A tile whose rows lie inside the image skips the per-row map: one scalar add per row.
+  __builtin_assume(wave >= 0 && wave < 4);
+  const bool zero_mode = a.mode == MIFWT_MODE_ZERO;
+  Fold1 fold;
+  fold.set(a.mode);
   const bool rows_inside = r_first >= 0 && r_first + IR <= a.H;
   const uint32_t row_bytes = (uint32_t)a.xs_h * ES;
   constexpr int RPW = (IR + 3) / 4;  // rows per wave
   uint32_t coff[NQ];
-  if (cols_inside) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) coff[q] = lane + 64 * q < IC ? ES * (uint32_t)(c_first + lane + 64 * q) : kOob;
-  } else {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int c = lane + 64 * q;
-      const int m = c < nc_need ? ext_index_near(c_first + c, a.W, a.mode) : -1;
-      coff[q] = m < 0 ? kOob : ES * (uint32_t)m;
-    }
+  for (int q = 0; q < NQ; ++q) {
+    const int c = lane + 64 * q, ci = c_first + c;
+    const bool dead = c >= nc_need || (zero_mode && (unsigned)ci >= (unsigned)a.W);
+    coff[q] = dead ? kOob : ES * (uint32_t)fold(ci, a.W);
   }
   float v[RPW][NQ];
   if (rows_inside) {
+    uint32_t soff = (uint32_t)(r_first + wave) * row_bytes;
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
-      const int r = wave + 4 * i;  // wave-uniform
-      const uint32_t soff = (uint32_t)(r_first + (r < IR ? r : IR - 1)) * row_bytes;
+      // rows beyond the tile (wave + 4 i >= IR, last i only) re-read the tile's last row: in range, never used
+      const uint32_t so = (4 * i + 3 < IR || wave + 4 * i < IR) ? soff : (uint32_t)(r_first + IR - 1) * row_bytes;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        v[i][q] = tile_load<T>(xrsrc, coff[q], soff);
+      for (int q = 0; q < NQ; ++q) v[i][q] = tile_load<T>(xrsrc, coff[q], so);
+      soff += 4u * row_bytes;
     }
   } else {
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
-      const int r = wave + 4 * i;  // wave-uniform
-      const int m = r < nr_need ? ext_index_near(r_first + r, a.H, a.mode) : -1;
-      const uint32_t soff = m < 0 ? 0u : (uint32_t)m * row_bytes;
+      const int r = wave + 4 * i, ri = r_first + r;
+      const bool dead = r >= nr_need || (zero_mode && (unsigned)ri >= (unsigned)a.H);
+      const uint32_t soff = __builtin_amdgcn_readfirstlane(dead ? 0u : (uint32_t)fold(ri, a.H) * row_bytes);
 #pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        v[i][q] = tile_load<T>(xrsrc, m < 0 ? kOob : coff[q], soff);
+      for (int q = 0; q < NQ; ++q) v[i][q] = tile_load<T>(xrsrc, dead ? kOob : coff[q], soff);
     }
   }
 #pragma unroll
   for (int i = 0; i < RPW; ++i) {
     const int r = wave + 4 * i;
-    if (r < IR) {
+    if (4 * i + 3 < IR || r < IR) {  // first clause: compile time, true for every i but possibly the last
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
-        if (lane + 64 * q < XP) xt[r * XP + lane + 64 * q] = v[i][q];
+        if (64 * q + 63 < XP || lane + 64 * q < XP) xt[r * XP + lane + 64 * q] = v[i][q];
     }
   }
   // no workgroup barrier here: row r is staged, filtered and overwritten by the same wave (rows wave + 4 i), whose DS
@@ -140,7 +138,7 @@ __global__ void __launch_bounds__(256, tile_occupancy(L, TR)) dwt2_fwd_tile_kern
 #pragma unroll
   for (int i = 0; i < RPW; ++i) {
     const int r = wave + 4 * i;
-    if (r < IR) {
+    if (4 * i + 3 < IR || r < IR) {
       const f2* row = reinterpret_cast<const f2*>(&xt[r * XP + 2 * lane]);
       f2 acc;
 #pragma unroll
@@ -163,9 +161,9 @@ __global__ void __launch_bounds__(256, tile_occupancy(L, TR)) dwt2_fwd_tile_kern
   const int k = k0 + lane;
   // band bases once per workgroup, row offsets once per row and stride set (bands 1..3 share the detail strides): the
   // scalar unit is shared by the CU, per-store 64-bit address arithmetic was a third of its load on small planes
-  T* obase[4];
+  T* obase[4];  // wave-uniform (scalar registers); lanes add a 32-bit element offset
 #pragma unroll
-  for (int s = 0; s < 4; ++s) obase[s] = a.out[s] + (int64_t)img * a.os_b[s] + k;
+  for (int s = 0; s < 4; ++s) obase[s] = a.out[s] + (int64_t)img * a.os_b[s];
   f2 win[2 * RW + L - 2];
 #pragma unroll
   for (int t = 0; t < 2 * RW + L - 2; ++t) win[t] = *reinterpret_cast<const f2*>(&xt[(2 * wave * RW + t) * XP + 2 * lane]);
@@ -185,7 +183,7 @@ __global__ void __launch_bounds__(256, tile_occupancy(L, TR)) dwt2_fwd_tile_kern
       }
     }
     if (j < a.Ho && k < a.Wo) {
-      const int64_t off_a = (int64_t)j * a.os_h[0], off_d = (int64_t)j * a.os_h[1];
+      const int off_a = j * (int)a.os_h[0] + k, off_d = j * (int)a.os_h[1] + k;
       obase[0][off_a] = (T)lo2.x;
       obase[1][off_d] = (T)hi2.x;
       obase[2][off_d] = (T)lo2.y;

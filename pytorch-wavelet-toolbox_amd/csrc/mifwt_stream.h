@@ -40,6 +40,27 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Boundary extension for an index at most ONE period outside [0, n) (what a level's pads of L-2 / L-1 samples need once
+// n >= L), branch-free and without the general fallback of ext_index_near, whose integer division — inlined at every
+// use — dominated the code size and the scalar-unit time of the tile kernels.  The mode is folded into three integers
+// once per workgroup:  i < 0 -> lo_add + k i,  i >= n -> hi_add(n) + k i,  k = -1 (mirror modes), 0 (constant), +1 (periodic).
+// Zero mode: the caller tests (unsigned)i >= n itself and requests nothing.
+struct Fold1 {
+  int kneg, kpos, sym, per;  // bit masks (0 / -1): mirror, periodic; sym = 1 for the half-sample mirror
+  __device__ __forceinline__ void set(int mode) {
+    kneg = (mode == MIFWT_MODE_REFLECT || mode == MIFWT_MODE_SYMMETRIC || mode == MIFWT_MODE_ZERO) ? -1 : 0;
+    kpos = mode == MIFWT_MODE_PERIODIC ? -1 : 0;
+    sym = mode == MIFWT_MODE_SYMMETRIC ? 1 : 0;
+    per = kpos;
+  }
+  __device__ __forceinline__ int operator()(int i, int n) const {
+    const int ki = (i & kpos) - (i & kneg);                                      // k * i
+    const int lo_add = (n & per) - sym;                                           // n (periodic), -1 (symmetric), 0
+    const int hi_add = kneg ? 2 * n - 2 + sym : ((n - 1) & ~per) - (n & per);     // 2n-2(+1) | n-1 (constant) | -n (periodic)
+    return i < 0 ? lo_add + ki : (i >= n ? hi_add + ki : i);
+  }
+};
+
 // XCD-aware block remap (block b runs on XCD b % 8): every XCD gets a contiguous range of logical blocks so
 // that tasks sharing halo rows / columns meet in one L2.  Bijective for any grid size.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
