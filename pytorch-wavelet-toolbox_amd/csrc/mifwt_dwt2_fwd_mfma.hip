@@ -52,6 +52,11 @@ __global__ void __launch_bounds__(256, 4) dwt2_fwd_mfma_kernel(const MfmaArgs a)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  __builtin_assume(wave >= 0 && wave < 4);
+  // boundary extension = the branch-free single-fold map (Fold1, mifwt_stream.h; the launcher requires extents >= L)
+  const bool zero_mode = a.mode == MIFWT_MODE_ZERO;
+  Fold1 fold;
+  fold.set(a.mode);
   const int L = a.L;
   const int n = lane & 31, half = lane >> 5;
 
@@ -132,10 +137,11 @@ __global__ void __launch_bounds__(256, 4) dwt2_fwd_mfma_kernel(const MfmaArgs a)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int r = wave + 4 * i;  // wave-uniform
-          const int m = r < nr_need ? ext_index_near(r_first + r, a.H, a.mode) : -1;
-          const uint32_t soff = m < 0 ? 0u : (uint32_t)m * row_bytes;
+          const int ri = r_first + r;
+          const bool dead = r >= nr_need || (zero_mode && (unsigned)ri >= (unsigned)a.H);
+          const uint32_t soff = __builtin_amdgcn_readfirstlane(dead ? 0u : (uint32_t)fold(ri, a.H) * row_bytes);
 #pragma unroll
-          for (int qq = 0; qq < 2; ++qq) v[i][qq] = __builtin_amdgcn_raw_buffer_load_b32(xrsrc, m < 0 ? kOob : poff[qq], soff, 0);
+          for (int qq = 0; qq < 2; ++qq) v[i][qq] = __builtin_amdgcn_raw_buffer_load_b32(xrsrc, dead ? kOob : poff[qq], soff, 0);
         }
       }
     } else {
@@ -143,16 +149,18 @@ __global__ void __launch_bounds__(256, 4) dwt2_fwd_mfma_kernel(const MfmaArgs a)
 #pragma unroll
       for (int qq = 0; qq < 3; ++qq) {
         const int c = lane + 64 * qq;
-        const int m = c < nc_need ? ext_index_near(c_first + c, a.W, a.mode) : -1;
-        coff[qq] = m < 0 ? kOob : 2u * (uint32_t)m;
+        const int ci = c_first + c;
+        const bool dead = c >= nc_need || (zero_mode && (unsigned)ci >= (unsigned)a.W);
+        coff[qq] = dead ? kOob : 2u * (uint32_t)fold(ci, a.W);
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int r = wave + 4 * i;  // wave-uniform
-        const int m = r < nr_need ? ext_index_near(r_first + r, a.H, a.mode) : -1;
-        const uint32_t soff = m < 0 ? 0u : (uint32_t)m * row_bytes;
+        const int ri = r_first + r;
+        const bool dead = r >= nr_need || (zero_mode && (unsigned)ri >= (unsigned)a.H);
+        const uint32_t soff = __builtin_amdgcn_readfirstlane(dead ? 0u : (uint32_t)fold(ri, a.H) * row_bytes);
 #pragma unroll
-        for (int qq = 0; qq < 3; ++qq) v[i][qq] = __builtin_amdgcn_raw_buffer_load_b16(xrsrc, m < 0 ? kOob : coff[qq], soff, 0);
+        for (int qq = 0; qq < 3; ++qq) v[i][qq] = __builtin_amdgcn_raw_buffer_load_b16(xrsrc, dead ? kOob : coff[qq], soff, 0);
       }
     }
   };
@@ -268,6 +276,7 @@ bool dwt2_fwd_mfma_supported(const mifwt_level_desc* d) {
   if (d->sig_stride[1] < 0 || span >= (int64_t(1) << 29)) return false;
   for (int i = 0; i < 2; ++i)
     if (d->approx_stride[i] < 0 || d->detail_stride[i] < 0) return false;
+  if (d->sig_extent[0] < L || d->sig_extent[1] < L) return false;  // single-fold boundary map
   return true;
 }
 

@@ -79,47 +79,48 @@ __global__ void __launch_bounds__(256, pair_occupancy(L, T2R)) dwt2_fwd_pair_ker
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (int64_t)img * a.xs_b), 0, img_bytes, 0x00020000);
   constexpr uint32_t kOob = 0x80000000u;
   const int c_first = 2 * s1c - HL, r_first = 2 * s1r - HL;
-  const bool cols_inside = c_first >= 0 && c_first + C0 <= a.W0;
+  // boundary extension = the branch-free single-fold map (Fold1, mifwt_stream.h): the window of actual level-1 rows /
+  // columns keeps every requested level-0 index within one period of the plane
+  __builtin_assume(wave >= 0 && wave < 4);
+  const bool zero_mode = a.mode == MIFWT_MODE_ZERO;
+  Fold1 fold;
+  fold.set(a.mode);
   const bool rows_inside = r_first >= 0 && r_first + R0 <= a.H0;
   const uint32_t row_bytes = (uint32_t)a.xs_h * 4u;
   uint32_t coff[NQ];
-  if (cols_inside) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) coff[q] = lane + 64 * q < C0 ? 4u * (uint32_t)(c_first + lane + 64 * q) : kOob;
-  } else {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int c = lane + 64 * q;
-      const int m = c < C0 ? ext_index_near(c_first + c, a.W0, a.mode) : -1;
-      coff[q] = m < 0 ? kOob : 4u * (uint32_t)m;
-    }
+  for (int q = 0; q < NQ; ++q) {
+    const int c = lane + 64 * q, ci = c_first + c;
+    const bool dead = c >= C0 || (zero_mode && (unsigned)ci >= (unsigned)a.W0);
+    coff[q] = dead ? kOob : 4u * (uint32_t)fold(ci, a.W0);
   }
   float v[RPW0][NQ];
   if (rows_inside) {
+    uint32_t soff = (uint32_t)(r_first + wave) * row_bytes;
 #pragma unroll
     for (int i = 0; i < RPW0; ++i) {
-      const int r = wave + 4 * i;
-      const uint32_t soff = (uint32_t)(r_first + (r < R0 ? r : R0 - 1)) * row_bytes;
+      const uint32_t so = (4 * i + 3 < R0 || wave + 4 * i < R0) ? soff : (uint32_t)(r_first + R0 - 1) * row_bytes;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) v[i][q] = tile_load<float>(xrsrc, coff[q], soff);
+      for (int q = 0; q < NQ; ++q) v[i][q] = tile_load<float>(xrsrc, coff[q], so);
+      soff += 4u * row_bytes;
     }
   } else {
 #pragma unroll
     for (int i = 0; i < RPW0; ++i) {
-      const int r = wave + 4 * i;
-      const int m = r < R0 ? ext_index_near(r_first + r, a.H0, a.mode) : -1;
-      const uint32_t soff = m < 0 ? 0u : (uint32_t)m * row_bytes;
+      const int r = wave + 4 * i, ri = r_first + r;
+      const bool dead = r >= R0 || (zero_mode && (unsigned)ri >= (unsigned)a.H0);
+      const uint32_t soff = __builtin_amdgcn_readfirstlane(dead ? 0u : (uint32_t)fold(ri, a.H0) * row_bytes);
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) v[i][q] = tile_load<float>(xrsrc, m < 0 ? kOob : coff[q], soff);
+      for (int q = 0; q < NQ; ++q) v[i][q] = tile_load<float>(xrsrc, dead ? kOob : coff[q], soff);
     }
   }
 #pragma unroll
   for (int i = 0; i < RPW0; ++i) {
     const int r = wave + 4 * i;
-    if (r < R0) {
+    if (4 * i + 3 < R0 || r < R0) {  // first clause: compile time
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
-        if (lane + 64 * q < XP) xt[r * XP + lane + 64 * q] = v[i][q];
+        if (64 * q + 63 < XP || lane + 64 * q < XP) xt[r * XP + lane + 64 * q] = v[i][q];
     }
   }
   // no workgroup barrier here: row r is staged, filtered and overwritten by the same wave (rows wave + 4 i), whose DS
@@ -130,7 +131,7 @@ __global__ void __launch_bounds__(256, pair_occupancy(L, T2R)) dwt2_fwd_pair_ker
 #pragma unroll
   for (int i = 0; i < RPW0; ++i) {
     const int r = wave + 4 * i;
-    if (r < R0) {
+    if (4 * i + 3 < R0 || r < R0) {
       const f2* row = reinterpret_cast<const f2*>(&xt[r * XP + 2 * lane]);
       f2 acc;
 #pragma unroll
@@ -161,9 +162,9 @@ __global__ void __launch_bounds__(256, pair_occupancy(L, T2R)) dwt2_fwd_pair_ker
     __syncthreads();  // every wave holds its rows: the window storage is free for the approximation tile
     const int m1c = s1c + lane;
     const bool own_c = m1c >= 2 * k2_0 && m1c < 2 * k2_0 + OC1;
-    float* db[3];
+    float* db[3];  // wave-uniform bases; lanes add 32-bit element offsets
 #pragma unroll
-    for (int s = 0; s < 3; ++s) db[s] = a.d1[s] + (int64_t)img * a.d1s_b + m1c;
+    for (int s = 0; s < 3; ++s) db[s] = a.d1[s] + (int64_t)img * a.d1s_b;
 #pragma unroll
     for (int i = 0; i < RW1; ++i) {
       const int i1 = i1b + i;  // wave-uniform
@@ -193,7 +194,7 @@ __global__ void __launch_bounds__(256, pair_occupancy(L, T2R)) dwt2_fwd_pair_ker
             }
           }
           if (own_c) {
-            const int64_t off = (int64_t)m1r * a.d1s_h;
+            const int off = m1r * (int)a.d1s_h + m1c;
             db[0][off] = hi2.x;
             db[1][off] = lo2.y;
             db[2][off] = hi2.y;
@@ -233,8 +234,9 @@ __global__ void __launch_bounds__(256, pair_occupancy(L, T2R)) dwt2_fwd_pair_ker
       int cidx[L];
 #pragma unroll
       for (int p = 0; p < L; ++p) {
-        const int m = col_live ? ext_index_near(2 * k2 - HL + p, a.W1, a.mode) : -1;
-        cidx[p] = m < 0 ? -1 : m - s1c;
+        const int e = 2 * k2 - HL + p;
+        const bool dead = !col_live || (zero_mode && (unsigned)e >= (unsigned)a.W1);
+        cidx[p] = dead ? -1 : fold(e, a.W1) - s1c;
       }
 #pragma unroll 1
       for (int q = wave; q < R1 / 2; q += 4) {
@@ -263,9 +265,9 @@ __global__ void __launch_bounds__(256, pair_occupancy(L, T2R)) dwt2_fwd_pair_ker
   {
     const bool rows_in2 = 2 * j2_0 - HL >= 0 && 2 * j2_0 + 2 * T2R <= a.H1;  // then s1r == 2 j2_0 - HL
     float* ob[4];
-    ob[0] = a.o2[0] + (int64_t)img * a.a2s_b + k2;
+    ob[0] = a.o2[0] + (int64_t)img * a.a2s_b;
 #pragma unroll
-    for (int s = 1; s < 4; ++s) ob[s] = a.o2[s] + (int64_t)img * a.d2s_b + k2;
+    for (int s = 1; s < 4; ++s) ob[s] = a.o2[s] + (int64_t)img * a.d2s_b;
 #pragma unroll
     for (int i = 0; i < RW2; ++i) {
       const int j2l = (2 * wave + half) * RW2 + i;
@@ -279,8 +281,9 @@ __global__ void __launch_bounds__(256, pair_occupancy(L, T2R)) dwt2_fwd_pair_ker
         if (rows_in2) {
           local = min(2 * j2l + t, R1 - 1);
         } else {
-          const int e = live ? ext_index_near(2 * j2 - HL + t, a.H1, a.mode) : -1;
-          local = e < 0 ? -1 : e - s1r;
+          const int e = 2 * j2 - HL + t;
+          const bool dead = !live || (zero_mode && (unsigned)e >= (unsigned)a.H1);
+          local = dead ? -1 : fold(e, a.H1) - s1r;
         }
         f2 hv = (f2){0.0f, 0.0f};
         if (local >= 0) hv = *reinterpret_cast<const f2*>(&ll[local * LP + 2 * kk]);
@@ -293,7 +296,7 @@ __global__ void __launch_bounds__(256, pair_occupancy(L, T2R)) dwt2_fwd_pair_ker
         }
       }
       if (live) {
-        const int64_t off_a = (int64_t)j2 * a.a2s_h, off_d = (int64_t)j2 * a.d2s_h;
+        const int off_a = j2 * (int)a.a2s_h + k2, off_d = j2 * (int)a.d2s_h + k2;
         ob[0][off_a] = lo2.x;
         ob[1][off_d] = hi2.x;
         ob[2][off_d] = lo2.y;
@@ -363,6 +366,10 @@ bool dwt2_fwd_pair_supported(const mifwt_level_desc* d1, const mifwt_level_desc*
   if (d1->detail_stride[0] < 0 || d1->detail_stride[1] < 0) return false;
   for (int i = 0; i < 2; ++i)
     if (d2->approx_stride[i] < 0 || d2->detail_stride[i] < 0) return false;
+  const int64_t lim = int64_t(1) << 31;  // 32-bit element offsets inside one image of a band
+  if (d1->coef_extent[0] * d1->detail_stride[1] >= lim || d2->coef_extent[0] * d2->approx_stride[1] >= lim ||
+      d2->coef_extent[0] * d2->detail_stride[1] >= lim)
+    return false;
   // the level-1 window of a tile (halo included) must fit into the level-1 plane
   if (d1->coef_extent[1] < 64 || d1->coef_extent[0] < 2 * 4 + (L - 2)) return false;
   return true;

@@ -72,12 +72,18 @@ __global__ void __launch_bounds__(256, 2) dwt3_fwd_tile_kernel(const Dwt3TileArg
   const int nr_need = 2 * (min(j0 + TR, a.Ho) - j0) + L - 2;
   const int nd_need = 2 * (min(z0 + TD, a.Do) - z0) + L - 2;
   const int c_first = 2 * k0 - (L - 2), r_first = 2 * j0 - (L - 2), d_first = 2 * z0 - (L - 2);
+  // boundary extension = the branch-free single-fold map (Fold1, mifwt_stream.h; the launcher requires extents >= L)
+  __builtin_assume(wave >= 0 && wave < 4);
+  const bool zero_mode = a.mode == MIFWT_MODE_ZERO;
+  Fold1 fold;
+  fold.set(a.mode);
   uint32_t coff[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int c = lane + 64 * q;
-    const int m = c < nc_need ? ext_index_near(c_first + c, a.W, a.mode) : -1;
-    coff[q] = m < 0 ? kOob : 4u * (uint32_t)m;
+    const int ci = c_first + c;
+    const bool dead = c >= nc_need || (zero_mode && (unsigned)ci >= (unsigned)a.W);
+    coff[q] = dead ? kOob : 4u * (uint32_t)fold(ci, a.W);
   }
   const uint32_t row_bytes = (uint32_t)a.xs_h * 4u, slice_bytes = (uint32_t)a.xs_d * 4u;
   // bricks whose slices and rows lie inside the volume need no per-row boundary maps (scalar-unit work per brick row)
@@ -99,10 +105,11 @@ __global__ void __launch_bounds__(256, 2) dwt3_fwd_tile_kernel(const Dwt3TileArg
     for (int i = 0; i < RPW; ++i) {
       const int rid = wave + 4 * i;
       const int d = rid / IR, r = rid - d * IR;
-      const int md = (rid < NROWS && d < nd_need) ? ext_index_near(d_first + d, a.D, a.mode) : -1;
-      const int mr = r < nr_need ? ext_index_near(r_first + r, a.H, a.mode) : -1;
-      const bool on = md >= 0 && mr >= 0;
-      const uint32_t soff = on ? (uint32_t)md * slice_bytes + (uint32_t)mr * row_bytes : 0u;
+      const int di = d_first + d, ri = r_first + r;
+      const bool on = rid < NROWS && d < nd_need && r < nr_need &&
+                      !(zero_mode && ((unsigned)di >= (unsigned)a.D || (unsigned)ri >= (unsigned)a.H));
+      const uint32_t soff = __builtin_amdgcn_readfirstlane(
+          on ? (uint32_t)fold(di, a.D) * slice_bytes + (uint32_t)fold(ri, a.H) * row_bytes : 0u);
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
         v[i][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, on ? coff[q] : kOob, soff, 0));
@@ -229,6 +236,9 @@ __global__ void __launch_bounds__(256, 2) dwt3_fwd_tile_kernel(const Dwt3TileArg
 template <int L>
 __global__ void __launch_bounds__(256) dwt3_fwd_cols_kernel(const Dwt3TileArgs<L> a, const int k_begin, const int64_t total) {
   const int ncol = a.Wo - k_begin;
+  const bool zero_mode = a.mode == MIFWT_MODE_ZERO;
+  Fold1 fold;
+  fold.set(a.mode);
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     int64_t t = idx;
     const int k = k_begin + (int)(t % ncol);
@@ -243,19 +253,22 @@ __global__ void __launch_bounds__(256) dwt3_fwd_cols_kernel(const Dwt3TileArgs<L
     for (int s = 0; s < 8; ++s) acc[s] = 0.f;
 #pragma unroll
     for (int md = 0; md < L; ++md) {
-      const int sd = ext_index_near(2 * z + 1 - md, a.D, a.mode);
-      if (sd < 0) continue;
+      const int ed = 2 * z + 1 - md;
+      if (zero_mode && (unsigned)ed >= (unsigned)a.D) continue;
+      const int sd = fold(ed, a.D);
       float pl[4] = {0.f, 0.f, 0.f, 0.f};  // (row band, column band) partial sums of this slice: index 2 * H + W
 #pragma unroll
       for (int mh = 0; mh < L; ++mh) {
-        const int sh = ext_index_near(2 * y + 1 - mh, a.H, a.mode);
-        if (sh < 0) continue;
+        const int eh = 2 * y + 1 - mh;
+        if (zero_mode && (unsigned)eh >= (unsigned)a.H) continue;
+        const int sh = fold(eh, a.H);
         const float* row = xb + (int64_t)sd * a.xs_d + (int64_t)sh * a.xs_h;
         float wl = 0.f, wh = 0.f;
 #pragma unroll
         for (int mw = 0; mw < L; ++mw) {
-          const int sw = ext_index_near(2 * k + 1 - mw, a.W, a.mode);
-          const float xv = sw < 0 ? 0.f : row[sw];
+          const int ew = 2 * k + 1 - mw;
+          const bool zw = zero_mode && (unsigned)ew >= (unsigned)a.W;
+          const float xv = zw ? 0.f : row[zw ? 0 : fold(ew, a.W)];
           wl = fmaf(a.tap[mw].x, xv, wl);
           wh = fmaf(a.tap[mw].y, xv, wh);
         }
@@ -339,6 +352,9 @@ bool dwt3_fwd_tile_supported(const mifwt_level_desc* d) {
     if (d->sig_stride[i] < 0 || d->approx_stride[i] < 0 || d->detail_stride[i] < 0) return false;
   // one batch element must be addressable with 32-bit byte offsets below 2^31 (buffer-resource loads)
   const int64_t span = (d->sig_extent[0] - 1) * d->sig_stride[1] + (d->sig_extent[1] - 1) * d->sig_stride[2] + d->sig_extent[2];
+  // single-fold boundary map: every extent at least as long as the filter
+  for (int i = 0; i < 3; ++i)
+    if (d->sig_extent[i] < L) return false;
   return span < (int64_t(1) << 29);
 }
 
