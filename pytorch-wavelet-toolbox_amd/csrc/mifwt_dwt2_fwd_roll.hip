@@ -52,6 +52,7 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
   constexpr int OC1 = 2 * T2C;        // level-1 columns a strip owns
   constexpr int C0 = 2 * C1 + HL;     // level-0 columns
   constexpr int XP = C0;              // pitch of the h-window (floats, even)
+  constexpr int NQ = (C0 + 63) / 64;
   constexpr int S2 = 8, S1 = 16, S0 = 32;  // rows per step at levels 2 / 1 / 0
   constexpr int RH = S0 + HL;  // h-window: slot t < HL = level-0 row 4 j - HL + t (kept from the previous step), then the step's 32
   constexpr int RL = S1 + HL;  // a-window: slot t < HL = level-1 row 2 j - HL + t, then the step's 16
@@ -90,49 +91,30 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (int64_t)img * a.xs_b), 0, img_bytes, 0x00020000);
   constexpr uint32_t kOob = 0x80000000u;  // >= num_records: the load returns 0 without a memory request
   const uint32_t row_bytes = (uint32_t)a.xs_h * 4u;
-  uint32_t coff[2];  // byte offsets of this lane's columns lane, 64 + lane
+  uint32_t coff[NQ];  // byte offset of this lane's column in load q; lanes beyond the window's C0 columns request nothing
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     const int c = c_first + lane + 64 * q;
-    coff[q] = (zero_mode && (unsigned)c >= (unsigned)a.W0) ? kOob : 4u * (uint32_t)fold(c, a.W0);
+    const bool dead = lane + 64 * q >= C0 || (zero_mode && (unsigned)c >= (unsigned)a.W0);
+    coff[q] = dead ? kOob : 4u * (uint32_t)fold(c, a.W0);
   }
-  // The window is C0 = 128 + HL columns wide: two full loads per row, and the HL tail columns of ALL rows a wave owns in a
-  // step travel in ONE load (lane = (row i, tail column c), i = lane / HL) and one LDS store, instead of an almost
-  // empty third load + store per row (measured: the per-row tail cost 4 % of the kernel).
-  constexpr bool kTail = HL > 0;
-  constexpr int NF = 2;  // full loads per row
-  static_assert(C0 == 128 + HL && (S0 / 4) * (HL > 0 ? HL : 1) <= 64, "tail layout");
-  const int ti = kTail ? lane / (kTail ? HL : 1) : 0, tcol = lane - ti * HL;
-  uint32_t tcoff = kOob;
-  if constexpr (kTail) {
-    const int c = c_first + 128 + tcol;
-    if (!(zero_mode && (unsigned)c >= (unsigned)a.W0)) tcoff = 4u * (uint32_t)fold(c, a.W0);
-  }
+  constexpr bool kTail = (C0 & 63) != 0;  // the last load covers only C0 - 64 (NQ - 1) columns
+  const bool tail_lane = lane + 64 * (NQ - 1) < C0;
 
   // level-0 rows r_first + wave + 4 i (i < N, row < r_end) of the extended plane -> registers.  Rows the level-1 plane
   // does not need (above -HL: segment 0's prologue; below 2 H1 - 1: the bottom-aligned last step) request nothing.
   const int r_valid_hi = 2 * a.H1;
-  auto request = [&](auto n_tag, float (&v)[decltype(n_tag)::value][NF], float& vt, int r_first, int r_end) {
+  auto request = [&](auto n_tag, float (&v)[decltype(n_tag)::value][NQ], int r_first, int r_end) {
     constexpr int N = decltype(n_tag)::value;
     if (r_first >= 0 && r_first + 4 * N <= min(a.H0, r_end)) {  // interior: no map, one scalar add per row
       uint32_t soff = (uint32_t)(r_first + wave) * row_bytes;
-      if constexpr (kTail) {
-        const uint32_t tv = ti < N ? tcoff + (uint32_t)(4 * ti) * row_bytes : kOob;  // an out-of-range tcoff stays out of range
-        vt = tile_load<float>(xrsrc, tv, soff);
-      }
 #pragma unroll
       for (int i = 0; i < N; ++i) {
 #pragma unroll
-        for (int q = 0; q < NF; ++q) v[i][q] = tile_load<float>(xrsrc, coff[q], soff);
+        for (int q = 0; q < NQ; ++q) v[i][q] = tile_load<float>(xrsrc, coff[q], soff);
         soff += 4u * row_bytes;
       }
     } else {
-      if constexpr (kTail) {
-        const int r = r_first + wave + 4 * ti;  // per lane
-        const bool dead = ti >= N || r >= r_end || r < -HL || r >= r_valid_hi || (zero_mode && (unsigned)r >= (unsigned)a.H0);
-        const uint32_t tv = dead ? kOob : tcoff + (uint32_t)fold(r, a.H0) * row_bytes;
-        vt = tile_load<float>(xrsrc, tv, 0u);
-      }
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         const int r = r_first + wave + 4 * i;
@@ -140,15 +122,17 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
         const uint32_t soff = __builtin_amdgcn_readfirstlane(dead ? 0u : (uint32_t)fold(r, a.H0) * row_bytes);
         // a dead row is requested at per-lane offsets beyond num_records: nothing is fetched, zeros come back
 #pragma unroll
-        for (int q = 0; q < NF; ++q) v[i][q] = tile_load<float>(xrsrc, dead ? kOob : coff[q], soff);
+        for (int q = 0; q < NQ; ++q) v[i][q] = tile_load<float>(xrsrc, dead ? kOob : coff[q], soff);
       }
     }
   };
-  // registers of N rows -> h-window slots slot(i).  nrows_tag: rows that exist (compile time; when it equals 4 N every
-  // wave owns N rows and no row test is emitted — the compiler cannot know that wave < 4)
-  auto stage = [&](auto n_tag, auto nrows_tag, const float (&v)[decltype(n_tag)::value][NF], float vt, auto slot) {
+  // registers of N rows -> h-window slots slot(i); the partial last load is stored under one exec mask for all rows.
+  // nrows_tag: rows that exist (compile time; when it equals 4 N every wave owns N rows and no row test is emitted —
+  // the compiler cannot know that wave < 4)
+  auto stage = [&](auto n_tag, auto nrows_tag, const float (&v)[decltype(n_tag)::value][NQ], auto slot) {
     constexpr int N = decltype(n_tag)::value, NROWS = decltype(nrows_tag)::value;
     constexpr bool kAll = NROWS == 4 * N;
+    constexpr int NF = kTail ? NQ - 1 : NQ;
 #pragma unroll
     for (int i = 0; i < N; ++i)
       if (kAll || wave + 4 * i < NROWS) {
@@ -156,7 +140,11 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
         for (int q = 0; q < NF; ++q) hr[slot(i) * XP + lane + 64 * q] = v[i][q];
       }
     if constexpr (kTail) {
-      if (ti < N && (kAll || wave + 4 * ti < NROWS)) hr[slot(ti) * XP + 128 + tcol] = vt;
+      if (tail_lane) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          if (kAll || wave + 4 * i < NROWS) hr[slot(i) * XP + lane + 64 * (NQ - 1)] = v[i][NQ - 1];
+      }
     }
   };
 
@@ -190,61 +178,47 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
   const int k2 = k2_0 + kk;
   const bool col_live = kk < T2C && k2 < a.W2;
   const bool cols_in2 = 2 * k2_0 - HL >= 0 && 2 * k2_0 + OC1 <= a.W1;  // then s1c == 2 k2_0 - HL, no extension
-  // (edge strips) a-window column of extended level-1 column 2 k2 - HL + p, or -1 for an implicit zero; recomputed where
-  // used: eight more live registers per lane would cost the kernel its fifth wave per SIMD
-  auto cidx = [&](int p) {
+  int cidx[L];
+#pragma unroll
+  for (int p = 0; p < L; ++p) {
     const int e = 2 * k2 - HL + p;
     const bool dead = !col_live || (zero_mode && (unsigned)e >= (unsigned)a.W1);
-    return dead ? -1 : fold(e, a.W1) - s1c;
-  };
-  // level-2 horizontal pass over a-window slots s0 and s1, in place; the half-waves (lanes 0-31 / 32-63) may be given
-  // different slots.  Two rows at once: two accumulation chains and one LDS round trip instead of two (the pass sits
-  // on the critical path between the vertical pass and the barrier: measured 10 % of the kernel row by row)
-  auto h2_rows = [&](int s0, int s1) {
-    f2 acc0, acc1;
+    cidx[p] = dead ? -1 : fold(e, a.W1) - s1c;
+  }
+  // level-2 horizontal pass over a-window slot `s` (lanes 0-31 and 32-63 may be given different slots), in place
+  auto h2_row = [&](int s) {
+    f2 acc;
     if (cols_in2) {
-      const f2* row0 = reinterpret_cast<const f2*>(&lr[s0 * LP + 2 * kk]);
-      const f2* row1 = reinterpret_cast<const f2*>(&lr[s1 * LP + 2 * kk]);
+      const f2* row = reinterpret_cast<const f2*>(&lr[s * LP + 2 * kk]);
 #pragma unroll
       for (int p = 0; p < L / 2; ++p) {
-        const f2 x0 = row0[p], x1 = row1[p];
+        const f2 xx = row[p];
         if (p == 0) {
-          acc0 = pkmul_lo(a.tap[L - 1], x0);
-          acc1 = pkmul_lo(a.tap[L - 1], x1);
+          acc = pkmul_lo(a.tap[L - 1], xx);
         } else {
-          pkfma_lo(acc0, a.tap[L - 1 - 2 * p], x0);
-          pkfma_lo(acc1, a.tap[L - 1 - 2 * p], x1);
+          pkfma_lo(acc, a.tap[L - 1 - 2 * p], xx);
         }
-        pkfma_hi(acc0, a.tap[L - 2 - 2 * p], x0);
-        pkfma_hi(acc1, a.tap[L - 2 - 2 * p], x1);
+        pkfma_hi(acc, a.tap[L - 2 - 2 * p], xx);
       }
     } else {
 #pragma unroll
       for (int p = 0; p < L / 2; ++p) {
-        f2 x0, x1;
-        const int ca = cidx(2 * p), cb = cidx(2 * p + 1);
-        const int ia = max(ca, 0), ib = max(cb, 0);
-        x0.x = lr[s0 * LP + ia];
-        x0.y = lr[s0 * LP + ib];
-        x1.x = lr[s1 * LP + ia];
-        x1.y = lr[s1 * LP + ib];
-        if (ca < 0) x0.x = x1.x = 0.0f;
-        if (cb < 0) x0.y = x1.y = 0.0f;
+        f2 xx;
+        xx.x = lr[s * LP + max(cidx[2 * p], 0)];
+        xx.y = lr[s * LP + max(cidx[2 * p + 1], 0)];
+        xx.x = cidx[2 * p] >= 0 ? xx.x : 0.0f;
+        xx.y = cidx[2 * p + 1] >= 0 ? xx.y : 0.0f;
         if (p == 0) {
-          acc0 = pkmul_lo(a.tap[L - 1], x0);
-          acc1 = pkmul_lo(a.tap[L - 1], x1);
+          acc = pkmul_lo(a.tap[L - 1], xx);
         } else {
-          pkfma_lo(acc0, a.tap[L - 1 - 2 * p], x0);
-          pkfma_lo(acc1, a.tap[L - 1 - 2 * p], x1);
+          pkfma_lo(acc, a.tap[L - 1 - 2 * p], xx);
         }
-        pkfma_hi(acc0, a.tap[L - 2 - 2 * p], x0);
-        pkfma_hi(acc1, a.tap[L - 2 - 2 * p], x1);
+        pkfma_hi(acc, a.tap[L - 2 - 2 * p], xx);
       }
     }
     wave_lds_fence();
     // lanes beyond the strip's T2C columns store too: columns 2 T2C .. 63 of the row are dead once it has been read
-    *reinterpret_cast<f2*>(&lr[s0 * LP + 2 * kk]) = acc0;
-    if (s1 != s0) *reinterpret_cast<f2*>(&lr[s1 * LP + 2 * kk]) = acc1;
+    *reinterpret_cast<f2*>(&lr[s * LP + 2 * kk]) = acc;
   };
 
   const int m1c = s1c + lane;
@@ -261,16 +235,16 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
   // ---- prologue: level-0 rows [4 ja - 3 HL, 4 ja): the last HL of them -> h-window slots [0, HL) (where step 0 expects the
   // rows kept from "the previous step"), the first 2 HL -> slots [HL, 3 HL); level-1 rows [2 ja - HL, 2 ja) -> a-window
   // slots [0, HL).  (For segment 0 those level-1 rows lie above the plane and are never read.)
-  float pv[S0 / 4][NF], pvt = 0.0f;
+  float pv[S0 / 4][NQ];
   if constexpr (HL > 0) {
-    float pp[PW0][NF], ppt = 0.0f;
-    request(std::integral_constant<int, PW0>{}, pp, ppt, 4 * ja - PR0, 4 * ja);
-    request(std::integral_constant<int, S0 / 4>{}, pv, pvt, 4 * ja, 4 * ja + S0);
+    float pp[PW0][NQ];
+    request(std::integral_constant<int, PW0>{}, pp, 4 * ja - PR0, 4 * ja);
+    request(std::integral_constant<int, S0 / 4>{}, pv, 4 * ja, 4 * ja + S0);
     auto pslot = [&](int i) {
       const int q = wave + 4 * i;  // prologue row index
       return q < 2 * HL ? q + HL : q - 2 * HL;
     };
-    stage(std::integral_constant<int, PW0>{}, std::integral_constant<int, PR0>{}, pp, ppt, pslot);
+    stage(std::integral_constant<int, PW0>{}, std::integral_constant<int, PR0>{}, pp, pslot);
     wave_lds_fence();
 #pragma unroll
     for (int i = 0; i < PW0; ++i)
@@ -290,12 +264,12 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
         }
         lr[il * LP + lane] = aa;
         wave_lds_fence();
-        h2_rows(il, il);  // both half-waves compute and store the same row
+        h2_row(il);  // both half-waves compute and store the same row
       }
     }
     __syncthreads();  // the prologue's first 2 HL h-rows are dead: step 0 overwrites their slots
   } else {
-    request(std::integral_constant<int, S0 / 4>{}, pv, pvt, 4 * ja, 4 * ja + S0);
+    request(std::integral_constant<int, S0 / 4>{}, pv, 4 * ja, 4 * ja + S0);
   }
 
   // ---- steps ------------------------------------------------------------------------------------------------------------
@@ -303,9 +277,9 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
   for (int st = 0; st < nsteps; ++st) {
     const int j = ja + S2 * st;
     // this wave's 8 level-0 rows -> slots HL + wave + 4 i, then their horizontal pass (same wave: DS order suffices)
-    stage(std::integral_constant<int, S0 / 4>{}, std::integral_constant<int, S0>{}, pv, pvt, [&](int i) { return HL + wave + 4 * i; });
+    stage(std::integral_constant<int, S0 / 4>{}, std::integral_constant<int, S0>{}, pv, [&](int i) { return HL + wave + 4 * i; });
     wave_lds_fence();
-    if (st + 1 < nsteps) request(std::integral_constant<int, S0 / 4>{}, pv, pvt, 4 * (j + S2), 4 * (j + S2) + S0);
+    if (st + 1 < nsteps) request(std::integral_constant<int, S0 / 4>{}, pv, 4 * (j + S2), 4 * (j + S2) + S0);
 #pragma unroll
     for (int i = 0; i < S0 / 4; i += 2) h1_rows(HL + wave + 4 * i, HL + wave + 4 * i + 4);
     __syncthreads();
@@ -329,21 +303,13 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
         }
         wave_lds_fence();
       }
-      // sliding register window over h-window slots 8 w + t: L rows for the first output row, two more per further row
-      // (loaded one row ahead; the scheduling barrier keeps the compiler from hoisting all HL + 8 loads to the top,
-      // which costs 8 live registers the kernel does not have)
       f2 win[HL + 8];
       const float* wbase = &hr[(8 * wave) * XP + 2 * lane];
 #pragma unroll
-      for (int t = 0; t < L + 2; ++t) win[t] = *reinterpret_cast<const f2*>(wbase + t * XP);
+      for (int t = 0; t < HL + 8; ++t) win[t] = *reinterpret_cast<const f2*>(wbase + t * XP);
       float* lrow = &lr[(HL + 4 * wave) * LP + lane];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if (i >= 1 && i < 3) {
-          win[L + 2 * i] = *reinterpret_cast<const f2*>(wbase + (L + 2 * i) * XP);
-          win[L + 2 * i + 1] = *reinterpret_cast<const f2*>(wbase + (L + 2 * i + 1) * XP);
-        }
-        __builtin_amdgcn_sched_barrier(0);
         const int m1r = 2 * j + 4 * wave + i;
         const bool own_r = m1r >= own_lo && m1r < own_hi;
         f2 lo2, hi2;  // (aa, da), (ad, dd)
@@ -368,7 +334,8 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
       }
       // level-2 horizontal pass over the four rows this wave just wrote: half-wave h takes rows h and 2 + h
       wave_lds_fence();
-      h2_rows(HL + 4 * wave + half, HL + 4 * wave + 2 + half);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) h2_row(HL + 4 * wave + 2 * i + half);
     }
     __syncthreads();
 
