@@ -124,7 +124,8 @@ __global__ void __launch_bounds__(256, 2) dwt3_fwd_tile_kernel(const Dwt3TileArg
         if (lane + 64 * q < XP) brick[rid * XP + lane + 64 * q] = v[i][q];
     }
   }
-  __syncthreads();
+  // no workgroup barrier: a brick row is staged and then filtered by the same wave (rows wave + 4 i), DS order suffices
+  wave_lds_fence();
 
   // ---- 2. W pass, in place: brick row -> (lo, hi)[k] -----------------------------------------------------------------------
   // rows are wave-private (row id = wave mod 4), so a wave may overwrite a row as soon as ITS reads of that row are
