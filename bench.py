@@ -317,7 +317,7 @@ def main():
         klabel = {1: "dwt2_fwd_stream_kernel (level 1)", 7: "dwt2_fwd_tile_kernel (level 1)", 0: "generic axis kernels (level 1)",
                   3: "streaming axis kernels (level 1)", 5: "fused 2-D planes + depth pass (level 1)", 9: "dwt3_fwd_tile_kernel (level 1)",
                   11: "dwt2_fwd_mfma_kernel (level 1)",
-                  12: ("dwt2_fwd_roll_kernel" if flen >= 6 else "dwt2_fwd_pair_kernel") + " (levels 1+2 in one launch)"}.get(kid1, f"kernel id {kid1} (level 1)")
+                  12: ("dwt2_fwd_roll_kernel" if flen >= 8 else "dwt2_fwd_pair_kernel") + " (levels 1+2 in one launch)"}.get(kid1, f"kernel id {kid1} (level 1)")
         per_launch_event_ms = sum(lvl1) / max(1, len(lvl1))
         avg_ms = lvl1_b2b_ms if lvl1_b2b_ms else per_launch_event_ms
         achieved = lvl1_b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0

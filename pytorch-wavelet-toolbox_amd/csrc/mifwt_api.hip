@@ -442,10 +442,11 @@ int mifwt_dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, 
   if (!dwt2_fwd_pair_supported(d1, d2)) return MIFWT_ERR_UNSUPPORTED;
   if (d1->batch == 0) return MIFWT_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // rolling strips carry no row halo but more bookkeeping per row: measured ahead of the tile version from 6 taps on
-  // (1024^2 planes: db4 140 vs 150 us; db2 134 vs 119 us, haar 103 vs 99 us), so auto mode picks by filter length
+  // rolling strips carry no row halo but more bookkeeping per row: measured ahead of the tile version only for 8 taps
+  // (64 x 1024^2, 3 levels, same runs: db4 131 vs 139 us; db3 124-139 vs 119-127 us, db2 121 vs 113 us, haar 110 vs
+  // 101 us), so auto mode picks by filter length
   const int pm = g_options[MIFWT_OPT_PAIR_MODE];
-  if (pm != 1 && (pm == 3 || d1->filt_len >= 6) && dwt2_fwd_roll_supported(d1, d2))
+  if (pm != 1 && (pm == 3 || d1->filt_len >= 8) && dwt2_fwd_roll_supported(d1, d2))
     return dwt2_fwd_roll(d1, d2, x, details1, approx2, details2, dec_lo, dec_hi, st);
   return dwt2_fwd_pair(d1, d2, x, details1, approx2, details2, dec_lo, dec_hi, st);
 }

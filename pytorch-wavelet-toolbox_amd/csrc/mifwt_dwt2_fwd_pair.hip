@@ -343,7 +343,9 @@ static int launch_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, c
 // level-2 rows per tile: 8 unless the option overrides (A/B) or the level-1 plane is too short for that window
 static int pair_rows(const mifwt_level_desc* d1) {
   int t = g_options[MIFWT_OPT_PAIR_ROWS];
-  if (t <= 0) t = 8;
+  // measured on 64 x 1024^2 (4 / 6 / 8 / 12 rows): haar 101 / 104 / 106 / 107 us, db2 121 / 113 / 116 / 116, db3 135 / 128 /
+  // 127 / 129, db4 170 / 150 / 143 / 153 — the longer the filter, the more rows amortise the 3 (L - 2)-row halo
+  if (t <= 0) t = d1->filt_len <= 2 ? 4 : (d1->filt_len <= 4 ? 6 : 8);
   t = t <= 4 ? 4 : (t <= 6 ? 6 : (t <= 8 ? 8 : 12));
   const int64_t h1 = d1->coef_extent[0];
   const int hl = d1->filt_len - 2;
