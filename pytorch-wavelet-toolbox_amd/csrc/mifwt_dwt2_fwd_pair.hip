@@ -31,6 +31,7 @@ struct Dwt2PairArgs {
   int64_t a2s_b, a2s_h, d2s_b, d2s_h;
   int H0, W0, H1, W1, H2, W2;
   int tiles_c, tiles_r;
+  FastDiv div_c, div_r;  // by tiles_c, tiles_r
   int mode;
   int sync_stage;
   f2 tap[L];  // (dec_lo[m], dec_hi[m])
@@ -65,9 +66,9 @@ __global__ void __launch_bounds__(256, pair_occupancy(L, T2R)) dwt2_fwd_pair_ker
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tc = bid % a.tiles_c;
-  const int tr = (bid / a.tiles_c) % a.tiles_r;
-  const int img = bid / (a.tiles_c * a.tiles_r);
+  uint32_t utc, utr;
+  const int img = (int)a.div_r.divmod(a.div_c.divmod((uint32_t)bid, utc), utr);
+  const int tc = (int)utc, tr = (int)utr;
   const int k2_0 = tc * T2C, j2_0 = tr * T2R;
   // window of actual level-1 rows / columns: nominal [2 j2_0 - HL, 2 j2_0 + 2 T2R), shifted into [0, H1)
   const int s1r = min(max(2 * j2_0 - HL, 0), a.H1 - R1);
@@ -334,6 +335,8 @@ static int launch_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, c
   for (int m = 0; m < L; ++m) a.tap[m] = (f2){(float)lo[m], (float)hi[m]};
   a.tiles_c = (a.W2 + T2C - 1) / T2C;
   a.tiles_r = (a.H2 + T2R - 1) / T2R;
+  a.div_c = make_fastdiv((uint32_t)a.tiles_c);
+  a.div_r = make_fastdiv((uint32_t)a.tiles_r);
   const int64_t ntiles = (int64_t)d1->batch * a.tiles_c * a.tiles_r;
   if (ntiles > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
   hipLaunchKernelGGL((dwt2_fwd_pair_kernel<L, T2R>), dim3((unsigned)ntiles), dim3(256), 0, stream, a);

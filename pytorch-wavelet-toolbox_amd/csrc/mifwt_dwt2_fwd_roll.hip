@@ -33,6 +33,7 @@ struct Dwt2RollArgs {
   int xs_h, d1s_h, a2s_h, d2s_h;      // row strides (elements; one image spans < 2^31 elements)
   int H0, W0, H1, W1, H2, W2;
   int strips, nseg, seg;  // column strips per plane, row segments per plane, level-2 rows per segment (multiple of 8)
+  FastDiv div_s, div_g;   // by strips, nseg
   int mode;
   f2 tap[L];  // (dec_lo[m], dec_hi[m])
 };
@@ -67,9 +68,9 @@ __global__ void __launch_bounds__(256, roll_occupancy(L)) dwt2_fwd_roll_kernel(c
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tc = bid % a.strips;
-  const int sg = (bid / a.strips) % a.nseg;
-  const int img = bid / (a.strips * a.nseg);
+  uint32_t utc, usg;
+  const int img = (int)a.div_g.divmod(a.div_s.divmod((uint32_t)bid, utc), usg);
+  const int tc = (int)utc, sg = (int)usg;
   // level-2 rows [ja, jb) of this segment; segment 0 is top-aligned (its last step is masked beyond jb), the others
   // end exactly at jb
   const int jb = a.H2 - (a.nseg - 1 - sg) * a.seg;
@@ -439,6 +440,8 @@ static int launch_roll(const mifwt_level_desc* d1, const mifwt_level_desc* d2, c
   a.strips = (a.W2 + T2C - 1) / T2C;
   a.seg = roll_segment(d2);
   a.nseg = (a.H2 + a.seg - 1) / a.seg;
+  a.div_s = make_fastdiv((uint32_t)a.strips);
+  a.div_g = make_fastdiv((uint32_t)a.nseg);
   const int64_t nwg = (int64_t)d1->batch * a.strips * a.nseg;
   if (nwg > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
   hipLaunchKernelGGL((dwt2_fwd_roll_kernel<L>), dim3((unsigned)nwg), dim3(256), 0, stream, a);

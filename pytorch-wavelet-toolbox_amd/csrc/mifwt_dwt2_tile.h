@@ -30,6 +30,7 @@ struct Dwt2TileArgs {
   int64_t os_b[4], os_h[4];
   int H, W, Ho, Wo;
   int tiles_c, tiles_r, ntiles;
+  FastDiv div_c, div_r;  // by tiles_c, tiles_r
   int mode;
   int sync_stage;
   f2 tap[L];  // (dec_lo[m], dec_hi[m])
@@ -69,9 +70,9 @@ __global__ void __launch_bounds__(256, tile_occupancy(L, TR)) dwt2_fwd_tile_kern
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tc = bid % a.tiles_c;
-  const int tr = (bid / a.tiles_c) % a.tiles_r;
-  const int img = bid / (a.tiles_c * a.tiles_r);
+  uint32_t utc, utr;
+  const int img = (int)a.div_r.divmod(a.div_c.divmod((uint32_t)bid, utc), utr);
+  const int tc = (int)utc, tr = (int)utr;
   const int k0 = tc * kTC, j0 = tr * TR;
 
   // ---- 1. input tile -> LDS ------------------------------------------------------------------------------------------
@@ -214,6 +215,8 @@ int launch_tile(const mifwt_level_desc* d, const void* x, void* approx, void* co
   for (int m = 0; m < L; ++m) a.tap[m] = (f2){(float)lo[m], (float)hi[m]};
   a.tiles_c = (a.Wo + kTC - 1) / kTC;
   a.tiles_r = (a.Ho + TR - 1) / TR;
+  a.div_c = make_fastdiv((uint32_t)a.tiles_c);
+  a.div_r = make_fastdiv((uint32_t)a.tiles_r);
   const int64_t ntiles = (int64_t)d->batch * a.tiles_c * a.tiles_r;
   if (ntiles > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
   a.ntiles = (int)ntiles;

@@ -25,6 +25,7 @@ struct Idwt2TileArgs {
   int Mh, Mw;  // coefficient extents
   int H, W;    // output extents (already trimmed: 2M - L + 2 - t)
   int tiles_c, tiles_r, ntiles;
+  FastDiv div_c, div_r;  // by tiles_c, tiles_r
   f2 tlo[L / 2];  // (rec_lo[2j], rec_lo[2j+1])
   f2 thi[L / 2];  // (rec_hi[2j], rec_hi[2j+1])
 };
@@ -62,9 +63,10 @@ __global__ void __launch_bounds__(256, idwt_tile_occupancy(L, TRO)) idwt2_tile_k
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int tc = bid % a.tiles_c;
-  const int tr = (bid / a.tiles_c) % a.tiles_r;
-  const int img = bid / (a.tiles_c * a.tiles_r);
+  uint32_t utc, utr;
+  const int img = (int)a.div_r.divmod(a.div_c.divmod((uint32_t)bid, utc), utr);
+  const int tc = (int)utc, tr = (int)utr;
+  __builtin_assume(wave >= 0 && wave < 4);
   const int q0 = tc * NQ;        // first coefficient column
   const int y0 = tr * TRO;       // first output row (even)
   const int m0 = y0 >> 1;        // first coefficient row
@@ -171,6 +173,8 @@ int launch_idwt_tile(const mifwt_level_desc* d, const void* approx, const void* 
   }
   a.tiles_c = (a.W + 2 * NQ - 1) / (2 * NQ);
   a.tiles_r = (a.H + TRO - 1) / TRO;
+  a.div_c = make_fastdiv((uint32_t)a.tiles_c);
+  a.div_r = make_fastdiv((uint32_t)a.tiles_r);
   const int64_t ntiles = (int64_t)d->batch * a.tiles_c * a.tiles_r;
   if (ntiles > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
   a.ntiles = (int)ntiles;

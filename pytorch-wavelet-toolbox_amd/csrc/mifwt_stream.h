@@ -61,6 +61,29 @@ struct Fold1 {
   }
 };
 
+// Division of a workgroup index by a launch-time constant without the ~40-instruction software divide (v_rcp_iflag +
+// Newton step + fix-ups) the compiler emits for a runtime divisor — three of them opened every tile kernel.  Round-up
+// method (Granlund & Montgomery): q = (mulhi(m, n) + n) >> s, m = floor(2^32 (2^s - d) / d) + 1, s = ceil(log2 d);
+// exact for n < 2^31 (the sum cannot overflow), any d >= 1.
+struct FastDiv {
+  uint32_t mul, shift, d;
+  __device__ __forceinline__ uint32_t div(uint32_t n) const { return (__umulhi(mul, n) + n) >> shift; }
+  __device__ __forceinline__ uint32_t divmod(uint32_t n, uint32_t& rem) const {
+    const uint32_t q = div(n);
+    rem = n - q * d;
+    return q;
+  }
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint32_t s = 0;
+  while ((uint64_t(1) << s) < d) ++s;
+  f.shift = s;
+  f.mul = (uint32_t)(((uint64_t(1) << 32) * ((uint64_t(1) << s) - d)) / d + 1);
+  return f;
+}
+
 // XCD-aware block remap (block b runs on XCD b % 8): every XCD gets a contiguous range of logical blocks so
 // that tasks sharing halo rows / columns meet in one L2.  Bijective for any grid size.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
