@@ -13,4 +13,4 @@ done
 ( timeout 600 python tools/bench_more.py ) 2>/dev/null > gpurun_out/bench_more.log
 ( timeout 120 python tools/copy_floor.py ) 2>/dev/null > gpurun_out/copy_floor.log
 ( timeout 300 python tools/host_overhead.py ) 2>/dev/null | head -3 > gpurun_out/host_overhead.log
-RPC=0 DEPTH=0 bash tools/gpu_pmc.sh > gpurun_out/pmc.log 2>&1; tail -3 gpurun_out/pmc.log
+PAIR=1 RPC=0 DEPTH=0 bash tools/gpu_pmc.sh > gpurun_out/pmc.log 2>&1; tail -3 gpurun_out/pmc.log
