@@ -32,6 +32,8 @@ struct Dwt3TileArgs {
   int64_t os_b[8], os_d[8], os_h[8];
   int D, H, W, Do, Ho, Wo;
   int tiles_c, tiles_r, tiles_d;
+  int segd;                     // unused
+  FastDiv div_c, div_r, div_d;  // slice-per-wave kernel: by tiles_c, tiles_r, tiles_d
   int k_limit;  // the brick kernel stores columns < k_limit; the direct kernel the few beyond (see launch3)
   int mode;
   f2 tap[L];  // (dec_lo[m], dec_hi[m])
@@ -231,6 +233,181 @@ __global__ void __launch_bounds__(256, 2) dwt3_fwd_tile_kernel(const Dwt3TileArg
   }
 }
 
+// ---- slice-per-wave bricks (the default) ---------------------------------------------------------------------------------
+// Same brick as dwt3_fwd_tile_kernel (TD x 4 x 64 coefficients, all eight bands), different dealing of the work: wave w
+// takes input SLICES w, w + 4, ... whole.  Its rows are staged, filtered along W and then along H without leaving the
+// wave — the W-pass result of row r, column k sits in lane k's registers, which is exactly what the H pass of column k
+// needs — so the W-pass image is never written to LDS and read back, and the barrier between the two passes is gone
+// (dwt3_fwd_tile_kernel deals ROWS to waves and pays both).  One barrier: all slices filtered -> D pass.
+template <int L, int TD>
+__global__ void __launch_bounds__(256, 2) dwt3_fwd_slice_kernel(const Dwt3TileArgs<L> a) {
+  constexpr int TR = 4, HL = L - 2;
+  constexpr int ID = 2 * TD + HL, IR = 2 * TR + HL, IC = 2 * kTC3 + HL;
+  constexpr int XP = (IC + 1) & ~1;  // row pitch (floats)
+  constexpr int SP = IR * XP;        // slice pitch (floats); >= TR * 256 (the slice's (H, W) image)
+  constexpr int NQ = (IC + 63) / 64;
+  constexpr int SPW = (ID + 3) / 4;  // slices per wave
+  static_assert(SP >= TR * 4 * kTC3, "the (H, W) image of a slice must fit into the slice it replaces");
+  static_assert((TD * TR) % 4 == 0, "output (slice, row) pairs are dealt to four waves");
+  extern __shared__ __attribute__((aligned(16))) float ring[];  // [ID][IR][XP]
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  __builtin_assume(wave >= 0 && wave < 4);
+  uint32_t utc, utr, utd;
+  const int img = (int)a.div_d.divmod(a.div_r.divmod(a.div_c.divmod((uint32_t)xcd_remap(blockIdx.x, gridDim.x), utc), utr), utd);
+  const int k0 = (int)utc * kTC3, j0 = (int)utr * TR, z0 = (int)utd * TD;
+  const int zb = min(a.Do, z0 + TD);
+  const uint32_t vol_bytes = (uint32_t)(((int64_t)(a.D - 1) * a.xs_d + (int64_t)(a.H - 1) * a.xs_h + a.W) * 4);
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (int64_t)img * a.xs_b), 0, vol_bytes, 0x00020000);
+  constexpr uint32_t kOob = 0x80000000u;
+  const bool zero_mode = a.mode == MIFWT_MODE_ZERO;
+  Fold1 fold;
+  fold.set(a.mode);
+  const uint32_t row_bytes = (uint32_t)a.xs_h * 4u, slice_bytes = (uint32_t)a.xs_d * 4u;
+  // column and row maps are the same for every slice of the walk: once per workgroup
+  const int nc_need = 2 * (min(k0 + kTC3, a.k_limit) - k0) + HL;
+  const int nr_need = 2 * (min(j0 + TR, a.Ho) - j0) + HL;
+  const int c_first = 2 * k0 - HL, r_first = 2 * j0 - HL;
+  uint32_t coff[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int c = lane + 64 * q, ci = c_first + c;
+    const bool dead = c >= nc_need || (zero_mode && (unsigned)ci >= (unsigned)a.W);
+    coff[q] = dead ? kOob : 4u * (uint32_t)fold(ci, a.W);
+  }
+  uint32_t roff[IR];
+  uint32_t rdead = 0;
+#pragma unroll
+  for (int i = 0; i < IR; ++i) {
+    const int ri = r_first + i;
+    const bool dead = i >= nr_need || (zero_mode && (unsigned)ri >= (unsigned)a.H);
+    roff[i] = dead ? 0u : (uint32_t)fold(ri, a.H) * row_bytes;
+    rdead |= dead ? 1u << i : 0u;
+  }
+
+  // the IR rows of extended input slice e -> registers (nothing is requested for slices no stored output needs)
+  auto request = [&](float (&v)[IR][NQ], int e, bool on) {
+    const bool sdead = !on || e >= 2 * zb || (zero_mode && (unsigned)e >= (unsigned)a.D);  // slices past the brick's last real output: nothing
+    const uint32_t sbase = __builtin_amdgcn_readfirstlane(sdead ? 0u : (uint32_t)fold(e, a.D) * slice_bytes);
+    if (!sdead && rdead == 0) {
+#pragma unroll
+      for (int i = 0; i < IR; ++i)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          v[i][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, coff[q], sbase + roff[i], 0));
+    } else {
+#pragma unroll
+      for (int i = 0; i < IR; ++i) {
+        const bool dead = sdead || ((rdead >> i) & 1u);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          v[i][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrsrc, dead ? kOob : coff[q], sbase + roff[i], 0));
+      }
+    }
+  };
+  // park the raw rows of a slice in ring slot `slot`
+  auto stage = [&](const float (&v)[IR][NQ], int slot) {
+    float* sl = &ring[slot * SP];
+#pragma unroll
+    for (int i = 0; i < IR; ++i)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        if (64 * q + 63 < XP || lane + 64 * q < XP) sl[i * XP + lane + 64 * q] = v[i][q];
+  };
+  // W pass + H pass of the slice in ring slot `slot`, registers in between; the (H, W) image replaces the raw rows
+  auto filter_slice = [&](int slot) {
+    float* sl = &ring[slot * SP];
+    wave_lds_fence();  // this wave staged the slice: its own DS order is all that is needed
+    f2 rowv[IR];       // (W-low, W-high) of column k0 + lane, row i
+#pragma unroll
+    for (int i = 0; i < IR; ++i) {
+      const f2* row = reinterpret_cast<const f2*>(&sl[i * XP + 2 * lane]);
+#pragma unroll
+      for (int p = 0; p < L / 2; ++p) {
+        const f2 xx = row[p];
+        if (p == 0) {
+          rowv[i] = pkmul_lo(a.tap[L - 1], xx);
+        } else {
+          pkfma_lo(rowv[i], a.tap[L - 1 - 2 * p], xx);
+        }
+        pkfma_hi(rowv[i], a.tap[L - 2 - 2 * p], xx);
+      }
+    }
+    wave_lds_fence();  // every raw row has been read before the image overwrites the slot
+#pragma unroll
+    for (int j = 0; j < TR; ++j) {
+      f2 lo2, hi2;
+#pragma unroll
+      for (int m = 0; m < L; ++m) {
+        const f2 hv = rowv[2 * j + (L - 1) - m];
+        if (m == 0) {
+          lo2 = pkmul_lo(a.tap[0], hv);
+          hi2 = pkmul_hi(a.tap[0], hv);
+        } else {
+          pkfma_lo(lo2, a.tap[m], hv);
+          pkfma_hi(hi2, a.tap[m], hv);
+        }
+      }
+      // components: .x = (H a, W a), .y = (H d, W a), .z = (H a, W d), .w = (H d, W d)
+      *reinterpret_cast<f4*>(&sl[(j * kTC3 + lane) * 4]) = (f4){lo2.x, lo2.y, hi2.x, hi2.y};
+    }
+  };
+
+  const int k = k0 + lane;
+  float* obase[8];  // wave-uniform; lanes add 32-bit element offsets
+#pragma unroll
+  for (int b = 0; b < 8; ++b) obase[b] = a.out[b] + (int64_t)img * a.os_b[b];
+
+  // every load of the wave's slices is in flight before the first slice is staged
+  float v[SPW][IR][NQ];
+#pragma unroll
+  for (int t = 0; t < SPW; ++t) request(v[t], 2 * z0 - HL + wave + 4 * t, wave + 4 * t < ID);
+#pragma unroll
+  for (int t = 0; t < SPW; ++t) {
+    if (4 * t + 3 < ID || wave + 4 * t < ID) {
+      stage(v[t], wave + 4 * t);
+      filter_slice(wave + 4 * t);
+    }
+  }
+  __syncthreads();
+
+  // D pass + stores: (output slice, row) pairs dealt to the waves, lane = output column
+#pragma unroll
+  for (int i = 0; i < (TD * TR) / 4; ++i) {
+    const int pr = wave * ((TD * TR) / 4) + i, dz = pr / TR, j = pr - dz * TR;
+    f2 acc[4];  // acc[c] = (depth-low, depth-high) of component c
+#pragma unroll
+    for (int m = 0; m < L; ++m) {
+      const f4 hv = *reinterpret_cast<const f4*>(&ring[(2 * dz + (L - 1) - m) * SP + (j * kTC3 + lane) * 4]);
+      const f2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
+      if (m == 0) {
+        acc[0] = pkmul_lo(a.tap[0], h01);
+        acc[1] = pkmul_hi(a.tap[0], h01);
+        acc[2] = pkmul_lo(a.tap[0], h23);
+        acc[3] = pkmul_hi(a.tap[0], h23);
+      } else {
+        pkfma_lo(acc[0], a.tap[m], h01);
+        pkfma_hi(acc[1], a.tap[m], h01);
+        pkfma_lo(acc[2], a.tap[m], h23);
+        pkfma_hi(acc[3], a.tap[m], h23);
+      }
+    }
+    const int zo = z0 + dz, y = j0 + j;
+    if (zo < zb && y < a.Ho && k < a.k_limit) {
+      const int off_a = zo * (int)a.os_d[0] + y * (int)a.os_h[0] + k;  // approximation strides
+      const int off_d = zo * (int)a.os_d[1] + y * (int)a.os_h[1] + k;  // detail strides (bands 1..7)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int hw = 2 * (c & 1) + (c >> 1);  // component c = (H bit = c & 1, W bit = c >> 1) -> band = 4 depth + 2 H + W
+        obase[hw][hw == 0 ? off_a : off_d] = acc[c].x;
+        obase[4 + hw][off_d] = acc[c].y;
+      }
+    }
+  }
+}
+
 // The last few columns of a plane whose width is just over a multiple of 64 (129 = 2 * 64 + 1 for 256^3 with db2)
 // would cost a whole extra column of bricks with one active lane in 64.  They go to this direct kernel instead: one
 // thread per (batch, slice, row, column) position, L^3 mapped loads (L1 / L2 hits), all eight bands.
@@ -293,7 +470,10 @@ __global__ void __launch_bounds__(256) dwt3_fwd_cols_kernel(const Dwt3TileArgs<L
 template <int L, int TD, int TR>
 int launch3(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo,
             const double* hi, hipStream_t stream) {
-  constexpr int ID = 2 * TD + L - 2, IR = 2 * TR + L - 2, XP = (2 * kTC3 + L - 2 + 1) & ~1;
+  // TD < 0 selects the slice-per-wave kernel with bricks of -TD output slices
+  constexpr bool kRoll = TD < 0;
+  constexpr int TDA = TD < 0 ? -TD : TD;
+  constexpr int ID = 2 * TDA + L - 2, IR = 2 * TR + L - 2, XP = (2 * kTC3 + L - 2 + 1) & ~1;
   constexpr size_t lds_bytes = (size_t)ID * IR * XP * sizeof(float);
   Dwt3TileArgs<L> a;
   a.x = static_cast<const float*>(x);
@@ -322,7 +502,11 @@ int launch3(const mifwt_level_desc* d, const void* x, void* approx, void* const*
   a.k_limit = split ? a.Wo - rem : a.Wo;
   a.tiles_c = (a.k_limit + kTC3 - 1) / kTC3;
   a.tiles_r = (a.Ho + TR - 1) / TR;
-  a.tiles_d = (a.Do + TD - 1) / TD;
+  a.segd = 0;
+  a.tiles_d = (a.Do + TDA - 1) / TDA;
+  a.div_c = make_fastdiv((uint32_t)a.tiles_c);
+  a.div_r = make_fastdiv((uint32_t)a.tiles_r);
+  a.div_d = make_fastdiv((uint32_t)a.tiles_d);
   const int64_t ntiles = (int64_t)d->batch * a.tiles_c * a.tiles_r * a.tiles_d;
   if (ntiles > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
   if (split) {
@@ -333,12 +517,22 @@ int launch3(const mifwt_level_desc* d, const void* x, void* approx, void* const*
     if (hipGetLastError() != hipSuccess) return MIFWT_ERR_LAUNCH;
   }
   static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt3_fwd_tile_kernel<L, TD, TR>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    attr_set = true;
+  if constexpr (kRoll) {
+    static_assert(TR == 4, "the slice-per-wave kernel owns 4 rows");
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt3_fwd_slice_kernel<L, TDA>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((dwt3_fwd_slice_kernel<L, TDA>), dim3((unsigned)ntiles), dim3(256), lds_bytes, stream, a);
+  } else {
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt3_fwd_tile_kernel<L, TD, TR>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((dwt3_fwd_tile_kernel<L, TD, TR>), dim3((unsigned)ntiles), dim3(256), lds_bytes, stream, a);
   }
-  hipLaunchKernelGGL((dwt3_fwd_tile_kernel<L, TD, TR>), dim3((unsigned)ntiles), dim3(256), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 
@@ -356,6 +550,9 @@ bool dwt3_fwd_tile_supported(const mifwt_level_desc* d) {
   // single-fold boundary map: every extent at least as long as the filter
   for (int i = 0; i < 3; ++i)
     if (d->sig_extent[i] < L) return false;
+  // 32-bit element offsets inside one batch element of a band (rolling kernel)
+  if (d->coef_extent[0] * d->approx_stride[1] >= (int64_t(1) << 31) || d->coef_extent[0] * d->detail_stride[1] >= (int64_t(1) << 31))
+    return false;
   return span < (int64_t(1) << 29);
 }
 
@@ -364,12 +561,19 @@ int dwt3_fwd_tile(const mifwt_level_desc* d, const void* x, void* approx, void* 
   switch (d->filt_len) {
     // brick = 2 slices x 4 rows x 64 columns of coefficients: measured best on 8 x 256^3 db2 (0.38 ms per level-1 call vs
     // 0.46 for 4 x 4 x 64, 0.39 for 4 x 2 x 64, 0.44 for 2 x 2 x 64, 0.53 for 2 x 8 x 64; composed route 0.48)
-    case 2: return g_options[MIFWT_OPT_TILE_ROWS] == 1 ? launch3<2, 4, 4>(d, x, approx, details, lo, hi, stream)
-                                                         : launch3<2, 2, 4>(d, x, approx, details, lo, hi, stream);
-    case 4: return g_options[MIFWT_OPT_TILE_ROWS] == 1 ? launch3<4, 4, 4>(d, x, approx, details, lo, hi, stream)
-                                                         : launch3<4, 2, 4>(d, x, approx, details, lo, hi, stream);
-    case 6: return g_options[MIFWT_OPT_TILE_ROWS] == 1 ? launch3<6, 4, 4>(d, x, approx, details, lo, hi, stream)
-                                                         : launch3<6, 2, 4>(d, x, approx, details, lo, hi, stream);
+    // TILE_ROWS option: 0 = slice-per-wave bricks 2 x 4 x 64 (default), 3 = slice-per-wave 3 x 4 x 64; row-dealt bricks: 2 = 2 x 4 x 64, 1 = 4 x 4 x 64
+    case 2: return g_options[MIFWT_OPT_TILE_ROWS] == 1   ? launch3<2, 4, 4>(d, x, approx, details, lo, hi, stream)
+                   : g_options[MIFWT_OPT_TILE_ROWS] == 2 ? launch3<2, 2, 4>(d, x, approx, details, lo, hi, stream)
+                                                         : (g_options[MIFWT_OPT_TILE_ROWS] == 3 ? launch3<2, -3, 4>(d, x, approx, details, lo, hi, stream)
+                                                                                             : launch3<2, -2, 4>(d, x, approx, details, lo, hi, stream));
+    case 4: return g_options[MIFWT_OPT_TILE_ROWS] == 1   ? launch3<4, 4, 4>(d, x, approx, details, lo, hi, stream)
+                   : g_options[MIFWT_OPT_TILE_ROWS] == 2 ? launch3<4, 2, 4>(d, x, approx, details, lo, hi, stream)
+                                                         : (g_options[MIFWT_OPT_TILE_ROWS] == 3 ? launch3<4, -3, 4>(d, x, approx, details, lo, hi, stream)
+                                                                                             : launch3<4, -2, 4>(d, x, approx, details, lo, hi, stream));
+    case 6: return g_options[MIFWT_OPT_TILE_ROWS] == 1   ? launch3<6, 4, 4>(d, x, approx, details, lo, hi, stream)
+                   : g_options[MIFWT_OPT_TILE_ROWS] == 2 ? launch3<6, 2, 4>(d, x, approx, details, lo, hi, stream)
+                                                         : (g_options[MIFWT_OPT_TILE_ROWS] == 3 ? launch3<6, -3, 4>(d, x, approx, details, lo, hi, stream)
+                                                                                             : launch3<6, -2, 4>(d, x, approx, details, lo, hi, stream));
     default: return MIFWT_ERR_UNSUPPORTED;
   }
 }

@@ -517,11 +517,17 @@ def test_fused_dwt3_tile_vs_oracle_and_composed(wavelet):
                 continue
             got = ptwt_amd.wavedec3(xg, wavelet, mode=mode, level=level)
             check_tree(got, want, TOL32, f"dwt3 tile {wavelet} {mode} {shape}")
-            _engine.set_option(6, 1)  # the 4 x 4 x 64 brick instantiation
-            try:
-                check_tree(ptwt_amd.wavedec3(xg, wavelet, mode=mode, level=level), want, TOL32, f"dwt3 tile 4x4 {wavelet} {mode}")
-            finally:
-                _engine.set_option(6, 0)
+            # default = slice-per-wave bricks 2 x 4 x 64; tile-rows option 3: slice-per-wave 3 x 4 x 64, 2 / 1: the row-dealt
+            # bricks 2 x 4 x 64 / 4 x 4 x 64 — all compute the same sums in the same order
+            for opt6, opt1 in [(1, 0), (2, 0), (3, 0)]:
+                _engine.set_option(6, opt6)
+                try:
+                    other = ptwt_amd.wavedec3(xg, wavelet, mode=mode, level=level)
+                finally:
+                    _engine.set_option(6, 0)
+                check_tree(other, want, TOL32, f"dwt3 tile variant {opt6}/{opt1} {wavelet} {mode}")
+                for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(other)):
+                    assert torch.equal(a, b), (wavelet, mode, shape, n, opt6, opt1)
             _engine.set_option(5, 2)
             try:
                 comp = ptwt_amd.wavedec3(xg, wavelet, mode=mode, level=level)
