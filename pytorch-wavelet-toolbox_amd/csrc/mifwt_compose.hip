@@ -89,19 +89,21 @@ mifwt_level_desc plane_desc(const mifwt_level_desc* d, int64_t depth, bool* fold
 // ---- LDS-tile fused 2-D analysis: envelope and per-(type, length) instantiation units ---------------------------
 int dwt2_fwd_tile_f32_short(const mifwt_level_desc*, const void*, void*, void* const*, const double*, const double*, hipStream_t);
 int dwt2_fwd_tile_f16_short(const mifwt_level_desc*, const void*, void*, void* const*, const double*, const double*, hipStream_t);
+int dwt2_fwd_tile_f64_short(const mifwt_level_desc*, const void*, void*, void* const*, const double*, const double*, hipStream_t);
 int dwt2_fwd_tile_long18(const mifwt_level_desc*, const void*, void*, void* const*, const double*, const double*, hipStream_t);
 int dwt2_fwd_tile_long20(const mifwt_level_desc*, const void*, void*, void* const*, const double*, const double*, hipStream_t);
 int dwt2_fwd_tile_long24(const mifwt_level_desc*, const void*, void*, void* const*, const double*, const double*, hipStream_t);
 int dwt2_fwd_tile_long32(const mifwt_level_desc*, const void*, void*, void* const*, const double*, const double*, hipStream_t);
 
 bool dwt2_fwd_tile_supported(const mifwt_level_desc* d) {
-  if (d->ndim != 2 || (d->dtype != MIFWT_F32 && d->dtype != MIFWT_F16)) return false;
+  if (d->ndim != 2 || (d->dtype != MIFWT_F32 && d->dtype != MIFWT_F16 && d->dtype != MIFWT_F64)) return false;
   const int L = d->filt_len;
   if (!((L >= 2 && L <= 20 && (L & 1) == 0) || L == 24 || L == 32)) return false;
+  if (d->dtype == MIFWT_F64 && L > 16) return false;  // f64 instantiations: mifwt_dwt2_fwd_tile_f64.hip
   if (d->sig_stride[2] != 1 || d->approx_stride[2] != 1 || d->detail_stride[2] != 1) return false;
   // one image must be addressable with 32-bit byte offsets below 2^31 (buffer-resource loads, out-of-range switch)
   const int64_t span = (d->sig_extent[0] - 1) * d->sig_stride[1] + d->sig_extent[1];
-  if (d->sig_stride[1] < 0 || span >= (int64_t(1) << 29)) return false;
+  if (d->sig_stride[1] < 0 || span >= (int64_t(1) << (d->dtype == MIFWT_F64 ? 28 : 29))) return false;
   for (int i = 0; i < 2; ++i)
     if (d->approx_stride[i] < 0 || d->detail_stride[i] < 0) return false;
   // the kernel maps the boundary with ONE fold (mifwt_stream.h: Fold1): every requested index lies within one period
@@ -115,6 +117,7 @@ bool dwt2_fwd_tile_supported(const mifwt_level_desc* d) {
 
 int dwt2_fwd_tile(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo,
                   const double* hi, hipStream_t stream) {
+  if (d->dtype == MIFWT_F64) return dwt2_fwd_tile_f64_short(d, x, approx, details, lo, hi, stream);
   switch (d->filt_len) {
     case 18: return dwt2_fwd_tile_long18(d, x, approx, details, lo, hi, stream);
     case 20: return dwt2_fwd_tile_long20(d, x, approx, details, lo, hi, stream);
@@ -153,23 +156,27 @@ int dwt2_fwd_fused(const mifwt_level_desc* d, const void* x, void* approx, void*
 // ---- LDS-tile fused 2-D synthesis -------------------------------------------------------------------------------------
 int idwt2_tile_f32_short(const mifwt_level_desc*, const void*, const void* const*, void*, const double*, const double*, hipStream_t);
 int idwt2_tile_f16_short(const mifwt_level_desc*, const void*, const void* const*, void*, const double*, const double*, hipStream_t);
+int idwt2_tile_f64_short(const mifwt_level_desc*, const void*, const void* const*, void*, const double*, const double*, hipStream_t);
 int idwt2_tile_long_a(const mifwt_level_desc*, const void*, const void* const*, void*, const double*, const double*, hipStream_t);
 int idwt2_tile_long_b(const mifwt_level_desc*, const void*, const void* const*, void*, const double*, const double*, hipStream_t);
 
 bool dwt2_inv_tile_supported(const mifwt_level_desc* d) {
-  if (d->ndim != 2 || (d->dtype != MIFWT_F32 && d->dtype != MIFWT_F16)) return false;
+  if (d->ndim != 2 || (d->dtype != MIFWT_F32 && d->dtype != MIFWT_F16 && d->dtype != MIFWT_F64)) return false;
   const int L = d->filt_len;
   if (!((L >= 2 && L <= 20 && (L & 1) == 0) || L == 24 || L == 32)) return false;
+  if (d->dtype == MIFWT_F64 && L > 16) return false;  // f64 instantiations: mifwt_idwt2_tile_f64.hip
   if (d->sig_stride[2] != 1 || d->approx_stride[2] != 1 || d->detail_stride[2] != 1) return false;
   for (int i = 0; i < 2; ++i)
     if (d->approx_stride[i] < 0 || d->detail_stride[i] < 0 || d->sig_stride[i] < 0) return false;
   const int64_t span_a = (d->coef_extent[0] - 1) * d->approx_stride[1] + d->coef_extent[1];
   const int64_t span_d = (d->coef_extent[0] - 1) * d->detail_stride[1] + d->coef_extent[1];
-  return span_a < (int64_t(1) << 29) && span_d < (int64_t(1) << 29);
+  const int64_t lim = int64_t(1) << (d->dtype == MIFWT_F64 ? 28 : 29);  // 32-bit byte offsets below 2^31
+  return span_a < lim && span_d < lim;
 }
 
 int dwt2_inv_tile(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y, const double* lo,
                   const double* hi, hipStream_t stream) {
+  if (d->dtype == MIFWT_F64) return idwt2_tile_f64_short(d, approx, details, y, lo, hi, stream);
   if (d->filt_len == 18 || d->filt_len == 20) return idwt2_tile_long_a(d, approx, details, y, lo, hi, stream);
   if (d->filt_len == 24 || d->filt_len == 32) return idwt2_tile_long_b(d, approx, details, y, lo, hi, stream);
   return d->dtype == MIFWT_F16 ? idwt2_tile_f16_short(d, approx, details, y, lo, hi, stream)

@@ -33,20 +33,24 @@ struct Dwt2TileArgs {
   FastDiv div_c, div_r;  // by tiles_c, tiles_r
   int mode;
   int sync_stage;
-  f2 tap[L];  // (dec_lo[m], dec_hi[m])
+  typename TileArith<T>::vec2 tap[L];  // (dec_lo[m], dec_hi[m]) in the arithmetic type
 };
 
 // workgroups per CU that the tile's LDS footprint admits = waves per SIMD to allocate registers for (a 256-thread
 // workgroup puts one wave on each SIMD)
-constexpr int tile_occupancy(int L, int TR) {
-  const int lds = (2 * TR + L - 2) * ((2 * kTC + L - 2 + 1) & ~1) * 4;
+constexpr int tile_occupancy(int L, int TR, int esz = 4) {
+  const int lds = (2 * TR + L - 2) * ((2 * kTC + L - 2 + 1) & ~1) * esz;
   const int n = (160 * 1024) / lds;
   return n > 8 ? 8 : (n < 1 ? 1 : n);
 }
 
 // one element of storage type T through the buffer resource (byte offset), widened to float
 template <typename T>
-__device__ __forceinline__ float tile_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff);
+__device__ __forceinline__ typename TileArith<T>::type tile_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff);
+template <>
+__device__ __forceinline__ double tile_load<double>(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0));
+}
 template <>
 __device__ __forceinline__ float tile_load<float>(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
@@ -57,14 +61,16 @@ __device__ __forceinline__ float tile_load<_Float16>(__amdgpu_buffer_rsrc_t rsrc
 }
 
 template <typename T, int L, int TR>
-__global__ void __launch_bounds__(256, tile_occupancy(L, TR)) dwt2_fwd_tile_kernel(const Dwt2TileArgs<T, L> a) {
+__global__ void __launch_bounds__(256, tile_occupancy(L, TR, sizeof(typename TileArith<T>::type))) dwt2_fwd_tile_kernel(const Dwt2TileArgs<T, L> a) {
   constexpr uint32_t ES = sizeof(T);
+  typedef typename TileArith<T>::type A;   // arithmetic / LDS element type
+  typedef typename TileArith<T>::vec2 A2;  // (lo, hi) pair
   constexpr int IR = 2 * TR + L - 2;    // input rows of a tile
   constexpr int IC = 2 * kTC + L - 2;   // input columns of a tile
   constexpr int XP = (IC + 1) & ~1;     // LDS pitch of the tile (floats, even: 8-byte aligned pairs; >= 2 * kTC)
   constexpr int NQ = (IC + 63) / 64;    // column loads per lane and row
   constexpr int RW = TR / 4;            // output rows per wave in the vertical pass
-  __shared__ __attribute__((aligned(16))) float xt[IR * XP];
+  __shared__ __attribute__((aligned(16))) A xt[IR * XP];
   static_assert(XP >= 2 * kTC, "the (lo, hi) row image must fit into the input row it replaces");
 
   const int lane = threadIdx.x & 63;
@@ -100,7 +106,7 @@ __global__ void __launch_bounds__(256, tile_occupancy(L, TR)) dwt2_fwd_tile_kern
     const bool dead = c >= nc_need || (zero_mode && (unsigned)ci >= (unsigned)a.W);
     coff[q] = dead ? kOob : ES * (uint32_t)fold(ci, a.W);
   }
-  float v[RPW][NQ];
+  A v[RPW][NQ];
   if (rows_inside) {
     uint32_t soff = (uint32_t)(r_first + wave) * row_bytes;
 #pragma unroll
@@ -140,20 +146,20 @@ __global__ void __launch_bounds__(256, tile_occupancy(L, TR)) dwt2_fwd_tile_kern
   for (int i = 0; i < RPW; ++i) {
     const int r = wave + 4 * i;
     if (4 * i + 3 < IR || r < IR) {
-      const f2* row = reinterpret_cast<const f2*>(&xt[r * XP + 2 * lane]);
-      f2 acc;
+      const A2* row = reinterpret_cast<const A2*>(&xt[r * XP + 2 * lane]);
+      A2 acc;
 #pragma unroll
       for (int p = 0; p < L / 2; ++p) {
-        const f2 xx = row[p];  // tile columns 2k + 2p, 2k + 2p + 1  <->  taps L-1-2p, L-2-2p
+        const A2 xx = row[p];  // tile columns 2k + 2p, 2k + 2p + 1  <->  taps L-1-2p, L-2-2p
         if (p == 0) {
-          acc = pkmul_lo(a.tap[L - 1], xx);
+          acc = amul_lo(a.tap[L - 1], xx);
         } else {
-          pkfma_lo(acc, a.tap[L - 1 - 2 * p], xx);
+          afma_lo(acc, a.tap[L - 1 - 2 * p], xx);
         }
-        pkfma_hi(acc, a.tap[L - 2 - 2 * p], xx);
+        afma_hi(acc, a.tap[L - 2 - 2 * p], xx);
       }
       wave_lds_fence();  // every lane's reads of row r are issued (DS ops of a wave run in order) before its overwrite
-      *reinterpret_cast<f2*>(&xt[r * XP + 2 * lane]) = acc;
+      *reinterpret_cast<A2*>(&xt[r * XP + 2 * lane]) = acc;
     }
   }
   __syncthreads();
@@ -165,22 +171,22 @@ __global__ void __launch_bounds__(256, tile_occupancy(L, TR)) dwt2_fwd_tile_kern
   T* obase[4];  // wave-uniform (scalar registers); lanes add a 32-bit element offset
 #pragma unroll
   for (int s = 0; s < 4; ++s) obase[s] = a.out[s] + (int64_t)img * a.os_b[s];
-  f2 win[2 * RW + L - 2];
+  A2 win[2 * RW + L - 2];
 #pragma unroll
-  for (int t = 0; t < 2 * RW + L - 2; ++t) win[t] = *reinterpret_cast<const f2*>(&xt[(2 * wave * RW + t) * XP + 2 * lane]);
+  for (int t = 0; t < 2 * RW + L - 2; ++t) win[t] = *reinterpret_cast<const A2*>(&xt[(2 * wave * RW + t) * XP + 2 * lane]);
 #pragma unroll
   for (int i = 0; i < RW; ++i) {
     const int j = j0 + wave * RW + i;
-    f2 lo2, hi2;  // lo2 = (aa, da), hi2 = (ad, dd)
+    A2 lo2, hi2;  // lo2 = (aa, da), hi2 = (ad, dd)
 #pragma unroll
     for (int m = 0; m < L; ++m) {
-      const f2 hv = win[2 * i + (L - 1) - m];  // row 2j + 1 - m of the extended plane
+      const A2 hv = win[2 * i + (L - 1) - m];  // row 2j + 1 - m of the extended plane
       if (m == 0) {
-        lo2 = pkmul_lo(a.tap[0], hv);
-        hi2 = pkmul_hi(a.tap[0], hv);
+        lo2 = amul_lo(a.tap[0], hv);
+        hi2 = amul_hi(a.tap[0], hv);
       } else {
-        pkfma_lo(lo2, a.tap[m], hv);
-        pkfma_hi(hi2, a.tap[m], hv);
+        afma_lo(lo2, a.tap[m], hv);
+        afma_hi(hi2, a.tap[m], hv);
       }
     }
     if (j < a.Ho && k < a.Wo) {
@@ -212,7 +218,8 @@ int launch_tile(const mifwt_level_desc* d, const void* x, void* approx, void* co
   a.Wo = (int)d->coef_extent[1];
   a.mode = d->mode;
   a.sync_stage = g_options[MIFWT_OPT_SYNC_STAGE];
-  for (int m = 0; m < L; ++m) a.tap[m] = (f2){(float)lo[m], (float)hi[m]};
+  for (int m = 0; m < L; ++m)
+    a.tap[m] = (typename TileArith<T>::vec2){(typename TileArith<T>::type)lo[m], (typename TileArith<T>::type)hi[m]};
   a.tiles_c = (a.Wo + kTC - 1) / kTC;
   a.tiles_r = (a.Ho + TR - 1) / TR;
   a.div_c = make_fastdiv((uint32_t)a.tiles_c);
@@ -236,7 +243,7 @@ int launch_tr(const mifwt_level_desc* d, const void* x, void* approx, void* cons
     tr = L <= 10 ? 12 : (L <= 20 ? 16 : 24);
     for (int cand = 8; cand <= 24; cand += 4) {
       const int64_t blocks = d->batch * tiles_c * ((d->coef_extent[0] + cand - 1) / cand);
-      const int64_t lds = (int64_t)(2 * cand + L - 2) * (2 * kTC + L - 2) * 4;
+      const int64_t lds = (int64_t)(2 * cand + L - 2) * (2 * kTC + L - 2) * (int64_t)sizeof(typename TileArith<T>::type);
       int64_t per_cu = (160 * 1024) / lds;
       if (per_cu > 8) per_cu = 8;
       if (blocks <= 256 * per_cu) {

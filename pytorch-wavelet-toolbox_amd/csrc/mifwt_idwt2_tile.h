@@ -26,19 +26,23 @@ struct Idwt2TileArgs {
   int H, W;    // output extents (already trimmed: 2M - L + 2 - t)
   int tiles_c, tiles_r, ntiles;
   FastDiv div_c, div_r;  // by tiles_c, tiles_r
-  f2 tlo[L / 2];  // (rec_lo[2j], rec_lo[2j+1])
-  f2 thi[L / 2];  // (rec_hi[2j], rec_hi[2j+1])
+  typename TileArith<T>::vec2 tlo[L / 2];  // (rec_lo[2j], rec_lo[2j+1]) in the arithmetic type
+  typename TileArith<T>::vec2 thi[L / 2];  // (rec_hi[2j], rec_hi[2j+1])
 };
 
-constexpr int idwt_tile_occupancy(int L, int TRO) {
+constexpr int idwt_tile_occupancy(int L, int TRO, int esz = 4) {
   const int cr = TRO / 2 + L / 2 - 1;
-  const int lds = (4 * cr + 2 * TRO) * 64 * 4;
+  const int lds = (4 * cr + 2 * TRO) * 64 * esz;
   const int n = (160 * 1024) / lds;
   return n > 8 ? 8 : (n < 1 ? 1 : n);
 }
 
 template <typename T>
-__device__ __forceinline__ float idwt_tile_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff);
+__device__ __forceinline__ typename TileArith<T>::type idwt_tile_load(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff);
+template <>
+__device__ __forceinline__ double idwt_tile_load<double>(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0));
+}
 template <>
 __device__ __forceinline__ float idwt_tile_load<float>(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
@@ -49,16 +53,18 @@ __device__ __forceinline__ float idwt_tile_load<_Float16>(__amdgpu_buffer_rsrc_t
 }
 
 template <typename T, int L, int TRO>
-__global__ void __launch_bounds__(256, idwt_tile_occupancy(L, TRO)) idwt2_tile_kernel(const Idwt2TileArgs<T, L> a) {
+__global__ void __launch_bounds__(256, idwt_tile_occupancy(L, TRO, sizeof(typename TileArith<T>::type))) idwt2_tile_kernel(const Idwt2TileArgs<T, L> a) {
   constexpr uint32_t ES = sizeof(T);
+  typedef typename TileArith<T>::type A;   // arithmetic / LDS element type
+  typedef typename TileArith<T>::vec2 A2;
   constexpr int HL = L / 2;
   constexpr int NQ = 64 - (HL - 1);      // coefficient columns whose outputs a tile stores
   constexpr int CR = TRO / 2 + HL - 1;   // coefficient rows of a tile
   constexpr int RPW = (CR + 3) / 4;      // coefficient rows per wave (load phase)
   constexpr int PPW = TRO / 8;           // output row PAIRS per wave (vertical phase): TRO/2 pairs over 4 waves
   static_assert(TRO % 8 == 0, "TRO must be a multiple of 8");
-  __shared__ __attribute__((aligned(16))) float ct[4][CR][64];  // coefficient tiles
-  __shared__ __attribute__((aligned(16))) f2 xt[TRO][64];       // (X_lo, X_hi) per output row and coefficient column
+  __shared__ __attribute__((aligned(16))) A ct[4][CR][64];  // coefficient tiles
+  __shared__ __attribute__((aligned(16))) A2 xt[TRO][64];       // (X_lo, X_hi) per output row and coefficient column
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -75,7 +81,7 @@ __global__ void __launch_bounds__(256, idwt_tile_occupancy(L, TRO)) idwt2_tile_k
   constexpr uint32_t kOob = 0x80000000u;
   const int qc = q0 + lane;
   const uint32_t coff = qc < a.Mw ? ES * (uint32_t)qc : kOob;  // columns past the band read 0 (never used by a stored output)
-  float v[4][RPW];
+  A v[4][RPW];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const uint32_t bytes = ((uint32_t)(a.Mh - 1) * (uint32_t)a.is_h[s] + (uint32_t)a.Mw) * ES;
@@ -99,24 +105,24 @@ __global__ void __launch_bounds__(256, idwt_tile_occupancy(L, TRO)) idwt2_tile_k
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
     const int pp = wave * PPW + j;  // output row pair of the tile; coefficient rows pp .. pp + HL - 1
-    f2 xl, xh;                      // (row 2pp, row 2pp + 1) of X_lo / X_hi
+    A2 xl, xh;                      // (row 2pp, row 2pp + 1) of X_lo / X_hi
 #pragma unroll
     for (int i = 0; i < HL; ++i) {
-      const f2 tl = a.tlo[HL - 1 - i], th = a.thi[HL - 1 - i];
-      const f2 caa = {ct[0][pp + i][lane], ct[1][pp + i][lane]};  // .x = aa, .y = ad
-      const f2 cda = {ct[2][pp + i][lane], ct[3][pp + i][lane]};  // .x = da, .y = dd
+      const A2 tl = a.tlo[HL - 1 - i], th = a.thi[HL - 1 - i];
+      const A2 caa = {ct[0][pp + i][lane], ct[1][pp + i][lane]};  // .x = aa, .y = ad
+      const A2 cda = {ct[2][pp + i][lane], ct[3][pp + i][lane]};  // .x = da, .y = dd
       if (i == 0) {
-        xl = pkmul_lo(tl, caa);
-        xh = pkmul_hi(tl, caa);
+        xl = amul_lo(tl, caa);
+        xh = amul_hi(tl, caa);
       } else {
-        pkfma_lo(xl, tl, caa);
-        pkfma_hi(xh, tl, caa);
+        afma_lo(xl, tl, caa);
+        afma_hi(xh, tl, caa);
       }
-      pkfma_lo(xl, th, cda);
-      pkfma_hi(xh, th, cda);
+      afma_lo(xl, th, cda);
+      afma_hi(xh, th, cda);
     }
-    xt[2 * pp][lane] = (f2){xl.x, xh.x};
-    xt[2 * pp + 1][lane] = (f2){xl.y, xh.y};
+    xt[2 * pp][lane] = (A2){xl.x, xh.x};
+    xt[2 * pp + 1][lane] = (A2){xl.y, xh.y};
   }
   __syncthreads();
 
@@ -126,16 +132,16 @@ __global__ void __launch_bounds__(256, idwt_tile_occupancy(L, TRO)) idwt2_tile_k
 #pragma unroll
   for (int j = 0; j < TRO / 4; ++j) {
     const int r = wave * (TRO / 4) + j;
-    f2 o;  // (y[x], y[x + 1])
+    A2 o;  // (y[x], y[x + 1])
 #pragma unroll
     for (int i = 0; i < HL; ++i) {
-      const f2 w = xt[r][(lane + i) & 63];  // lanes >= NQ wrap harmlessly (not stored)
+      const A2 w = xt[r][(lane + i) & 63];  // lanes >= NQ wrap harmlessly (not stored)
       if (i == 0) {
-        o = pkmul_lo(a.tlo[HL - 1], w);
+        o = amul_lo(a.tlo[HL - 1], w);
       } else {
-        pkfma_lo(o, a.tlo[HL - 1 - i], w);
+        afma_lo(o, a.tlo[HL - 1 - i], w);
       }
-      pkfma_hi(o, a.thi[HL - 1 - i], w);
+      afma_hi(o, a.thi[HL - 1 - i], w);
     }
     const int yr = y0 + r;
     if (lane_on && yr < a.H) {
@@ -168,8 +174,9 @@ int launch_idwt_tile(const mifwt_level_desc* d, const void* approx, const void* 
   a.H = (int)d->sig_extent[0];
   a.W = (int)d->sig_extent[1];
   for (int j = 0; j < L / 2; ++j) {
-    a.tlo[j] = (f2){(float)lo[2 * j], (float)lo[2 * j + 1]};
-    a.thi[j] = (f2){(float)hi[2 * j], (float)hi[2 * j + 1]};
+    typedef typename TileArith<T>::type A;
+    a.tlo[j] = (typename TileArith<T>::vec2){(A)lo[2 * j], (A)lo[2 * j + 1]};
+    a.thi[j] = (typename TileArith<T>::vec2){(A)hi[2 * j], (A)hi[2 * j + 1]};
   }
   a.tiles_c = (a.W + 2 * NQ - 1) / (2 * NQ);
   a.tiles_r = (a.H + TRO - 1) / TRO;
@@ -192,7 +199,7 @@ int launch_idwt_tr(const mifwt_level_desc* d, const void* approx, const void* co
     tro = 32;  // several rounds anyway: taller tiles = longer load bursts (32 rows measured best on 1024^2)
     for (int cand = 8; cand <= 32; cand += 8) {  // smallest tile height whose grid is resident in one round
       const int64_t blocks = d->batch * tiles_c * ((d->sig_extent[0] + cand - 1) / cand);
-      if (blocks <= 256 * idwt_tile_occupancy(L, cand)) {
+      if (blocks <= 256 * idwt_tile_occupancy(L, cand, sizeof(typename TileArith<T>::type))) {
         tro = cand;
         break;
       }

@@ -32,6 +32,27 @@ __device__ __forceinline__ f2 pkmul_hi(const f2 tap, const f2 pair) {
   return r;
 }
 
+// Arithmetic layer of the tile kernels: f32 / f16 storage computes in packed f32 (the four asm helpers above), f64
+// storage in double (no packed f64 FMA on gfx950: two v_fma_f64 per "packed" step).  a*_lo / a*_hi have the meaning of
+// pk*_lo / pk*_hi: (acc.x, acc.y) (+)= (tap.x, tap.y) * pair.x  resp.  * pair.y.
+typedef double d2 __attribute__((ext_vector_type(2)));
+template <typename T> struct TileArith { typedef float type; typedef f2 vec2; };
+template <> struct TileArith<double> { typedef double type; typedef d2 vec2; };
+__device__ __forceinline__ f2 amul_lo(const f2 tap, const f2 pair) { return pkmul_lo(tap, pair); }
+__device__ __forceinline__ f2 amul_hi(const f2 tap, const f2 pair) { return pkmul_hi(tap, pair); }
+__device__ __forceinline__ void afma_lo(f2& acc, const f2 tap, const f2 pair) { pkfma_lo(acc, tap, pair); }
+__device__ __forceinline__ void afma_hi(f2& acc, const f2 tap, const f2 pair) { pkfma_hi(acc, tap, pair); }
+__device__ __forceinline__ d2 amul_lo(const d2 tap, const d2 pair) { return (d2){tap.x * pair.x, tap.y * pair.x}; }
+__device__ __forceinline__ d2 amul_hi(const d2 tap, const d2 pair) { return (d2){tap.x * pair.y, tap.y * pair.y}; }
+__device__ __forceinline__ void afma_lo(d2& acc, const d2 tap, const d2 pair) {
+  acc.x = __builtin_fma(tap.x, pair.x, acc.x);
+  acc.y = __builtin_fma(tap.y, pair.x, acc.y);
+}
+__device__ __forceinline__ void afma_hi(d2& acc, const d2 tap, const d2 pair) {
+  acc.x = __builtin_fma(tap.x, pair.y, acc.x);
+  acc.y = __builtin_fma(tap.y, pair.y, acc.y);
+}
+
 // Ordering of one wave's own LDS traffic (different lanes write and read the same slab): DS operations of a
 // wave execute in order, this only stops the compiler from moving them across.
 __device__ __forceinline__ void wave_lds_fence() {

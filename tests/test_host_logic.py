@@ -214,7 +214,9 @@ def test_cabi_descriptor_validation_and_dispatch():
     assert _engine.kernel_id(2, torch.float32, "reflect", 16, 64, (4096, 4096)) == 1  # fused 2-D analysis, streaming
     assert _engine.kernel_id(2, torch.float32, "reflect", 16, 64, (1035, 1035)) == 7
     assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (1024, 1024), direction=1) == 2  # fused 2-D synthesis
-    assert _engine.kernel_id(2, torch.float64, "reflect", 8, 64, (1024, 1024)) == 3  # f64 -> streaming axis passes
+    assert _engine.kernel_id(2, torch.float64, "reflect", 8, 64, (1024, 1024)) == 7  # f64, L <= 16: LDS tiles in double
+    assert _engine.kernel_id(2, torch.float64, "reflect", 8, 64, (1024, 1024), direction=1) == 8
+    assert _engine.kernel_id(2, torch.float64, "reflect", 20, 4, (512, 512)) == 3    # f64, long filter: streaming axis passes
     assert _engine.kernel_id(2, torch.float32, "reflect", 32, 4, (512, 512)) == 7    # L = 32 analysis -> LDS-tile kernel
     assert _engine.kernel_id(2, torch.float16, "reflect", 32, 4, (512, 512)) == 11   # f16 + long filter: matrix cores
     assert _engine.kernel_id(2, torch.float16, "reflect", 8, 4, (512, 512)) == 7     # f16, short filter: LDS tiles
