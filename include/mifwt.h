@@ -166,7 +166,7 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  * negative = error code.
  *   0  generic per-axis passes (any strides, any L <= 128)
  *   1 / 2  fused single-launch 2-D analysis / synthesis level, streaming wave strips (f32, even L <= 16)
- *   7 / 8  fused single-launch 2-D analysis / synthesis level, LDS tiles (f32 / f16, even L <= 20, 24, 32); the
+ *   7 / 8  fused single-launch 2-D analysis / synthesis level, LDS tiles (f32 / f16, even L <= 20, 24, 32; f64, even L <= 16); the
  *          default 2-D kernels — the streaming analysis kernel is kept for 16-tap filters on planes >= ~1500^2
  *   3 / 4  streaming axis passes, analysis / synthesis: inner-axis kernel (+ one outer-axis pass per further
  *          axis); unit innermost stride, f32 / f64 / f16, L in {2..20 even, 24, 32}

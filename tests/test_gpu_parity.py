@@ -324,7 +324,8 @@ def test_stream_routes_selected():
     assert kid(3, torch.float32, "zero", 4, 8, (256, 256, 256)) == 9  # fully fused LDS-brick 3-D analysis
     assert kid(3, torch.float32, "zero", 8, 8, (256, 256, 256)) == 5 and kid(3, torch.float32, "zero", 4, 8, (256, 256, 256), direction=1) == 6
     assert kid(3, torch.float64, "zero", 4, 2, (33, 34, 35)) == 3  # f64: inner pass + two outer passes
-    assert kid(2, torch.float64, "reflect", 8, 2, (64, 64)) == 3
+    assert kid(2, torch.float64, "reflect", 8, 2, (64, 64)) == 7 and kid(2, torch.float64, "reflect", 8, 2, (64, 64), direction=1) == 8  # f64 tiles
+    assert kid(2, torch.float64, "reflect", 24, 2, (64, 64)) == 3  # f64, long filter: inner + outer pass
     assert kid(2, torch.float32, "symmetric", 32, 2, (300, 300)) == 7  # sym16 analysis: LDS-tile kernel
     assert kid(2, torch.float32, "symmetric", 32, 2, (300, 300), direction=1) == 8  # sym16 synthesis: LDS tiles
     assert kid(2, torch.float32, "symmetric", 102, 2, (300, 300)) == 0  # coif17: generic passes
