@@ -34,7 +34,7 @@ struct Dwt3TileArgs {
   int tiles_c, tiles_r, tiles_d;
   int segd;                     // unused
   FastDiv div_c, div_r, div_d;  // slice-per-wave kernel: by tiles_c, tiles_r, tiles_d
-  int k_limit;  // the brick kernel stores columns < k_limit; the direct kernel the few beyond (see launch3)
+  int k_limit;  // the brick kernels store columns < k_limit; dwt3_fwd_tail_kernel the few beyond (see launch3)
   int mode;
   f2 tap[L];  // (dec_lo[m], dec_hi[m])
 };
@@ -409,61 +409,104 @@ __global__ void __launch_bounds__(256, 2) dwt3_fwd_slice_kernel(const Dwt3TileAr
 }
 
 // The last few columns of a plane whose width is just over a multiple of 64 (129 = 2 * 64 + 1 for 256^3 with db2)
-// would cost a whole extra column of bricks with one active lane in 64.  They go to this direct kernel instead: one
-// thread per (batch, slice, row, column) position, L^3 mapped loads (L1 / L2 hits), all eight bands.
+// would cost a whole extra column of bricks with one active lane in 64.  They go to this kernel instead: a workgroup owns
+// TZ output slices x TY output rows of the `rem` leftover columns and runs the three passes through LDS with work items
+// instead of lanes-as-columns:
+//   1. W pass: item = (input slice, input row): reads the row's last few samples (one cache line) -> (lo, hi) per column
+//   2. H pass: item = (input slice, output row, column) -> the four (H, W) components
+//   3. D pass: item = (output slice, output row, column) -> eight bands, stored.
+// (The first version was one thread per output position with L^3 mapped loads: 16 lines per position instead of the
+// row tails once — 77 us for the one leftover column of config 3, a fifth of the level.)
+constexpr int kTailTZ = 4, kTailTY = 32;
+
 template <int L>
-__global__ void __launch_bounds__(256) dwt3_fwd_cols_kernel(const Dwt3TileArgs<L> a, const int k_begin, const int64_t total) {
-  const int ncol = a.Wo - k_begin;
+__global__ void __launch_bounds__(256) dwt3_fwd_tail_kernel(const Dwt3TileArgs<L> a, const int k_begin, const int rem, const int nzb,
+                                                            const int nyb) {
+  constexpr int HL = L - 2, TZ = kTailTZ, TY = kTailTY;
+  constexpr int ID = 2 * TZ + HL, IRY = 2 * TY + HL;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  f2* const W1 = reinterpret_cast<f2*>(sm);                      // [ID][IRY][rem]: (W-low, W-high)
+  f4* const H1 = reinterpret_cast<f4*>(sm + 2 * ID * IRY * rem);  // [ID][TY][rem]: (Ha Wa, Hd Wa, Ha Wd, Hd Wd)
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int yb = bid % nyb;
+  bid /= nyb;
+  const int zb = bid % nzb;
+  const int img = bid / nzb;
+  const int z0 = zb * TZ, y0 = yb * TY;
+  const int d_first = 2 * z0 - HL, r_first = 2 * y0 - HL;
   const bool zero_mode = a.mode == MIFWT_MODE_ZERO;
   Fold1 fold;
   fold.set(a.mode);
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    int64_t t = idx;
-    const int k = k_begin + (int)(t % ncol);
-    t /= ncol;
-    const int y = (int)(t % a.Ho);
-    t /= a.Ho;
-    const int z = (int)(t % a.Do);
-    const int img = (int)(t / a.Do);
-    const float* xb = a.x + (int64_t)img * a.xs_b;
-    float acc[8];
+  const float* xb = a.x + (int64_t)img * a.xs_b;
+
+  // ---- 1. W pass ---------------------------------------------------------------------------------------------------------
+  for (int item = tid; item < ID * IRY; item += 256) {
+    const int s = item / IRY, r = item - s * IRY;
+    const int ed = d_first + s, eh = r_first + r;
+    // rows / slices no stored output needs (ragged last blocks) and implicit zeros read nothing
+    const bool dead = ed >= 2 * a.Do || eh >= 2 * a.Ho || (zero_mode && ((unsigned)ed >= (unsigned)a.D || (unsigned)eh >= (unsigned)a.H));
+    const float* row = xb + (dead ? 0 : (int64_t)fold(ed, a.D) * a.xs_d + (int64_t)fold(eh, a.H) * a.xs_h);
+    for (int e = 0; e < rem; ++e) {
+      const int k = k_begin + e;
+      float lo = 0.f, hi = 0.f;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) acc[s] = 0.f;
-#pragma unroll
-    for (int md = 0; md < L; ++md) {
-      const int ed = 2 * z + 1 - md;
-      if (zero_mode && (unsigned)ed >= (unsigned)a.D) continue;
-      const int sd = fold(ed, a.D);
-      float pl[4] = {0.f, 0.f, 0.f, 0.f};  // (row band, column band) partial sums of this slice: index 2 * H + W
-#pragma unroll
-      for (int mh = 0; mh < L; ++mh) {
-        const int eh = 2 * y + 1 - mh;
-        if (zero_mode && (unsigned)eh >= (unsigned)a.H) continue;
-        const int sh = fold(eh, a.H);
-        const float* row = xb + (int64_t)sd * a.xs_d + (int64_t)sh * a.xs_h;
-        float wl = 0.f, wh = 0.f;
-#pragma unroll
-        for (int mw = 0; mw < L; ++mw) {
-          const int ew = 2 * k + 1 - mw;
-          const bool zw = zero_mode && (unsigned)ew >= (unsigned)a.W;
-          const float xv = zw ? 0.f : row[zw ? 0 : fold(ew, a.W)];
-          wl = fmaf(a.tap[mw].x, xv, wl);
-          wh = fmaf(a.tap[mw].y, xv, wh);
-        }
-        pl[0] = fmaf(a.tap[mh].x, wl, pl[0]);
-        pl[1] = fmaf(a.tap[mh].x, wh, pl[1]);
-        pl[2] = fmaf(a.tap[mh].y, wl, pl[2]);
-        pl[3] = fmaf(a.tap[mh].y, wh, pl[3]);
+      for (int p = 0; p < L; ++p) {
+        const int m = L - 1 - p, ew = 2 * k + 1 - m;  // same order as the bricks' W pass
+        const bool zw = dead || (zero_mode && (unsigned)ew >= (unsigned)a.W);
+        const float xv = zw ? 0.f : row[fold(ew, a.W)];
+        lo = p == 0 ? a.tap[m].x * xv : __builtin_fmaf(a.tap[m].x, xv, lo);
+        hi = p == 0 ? a.tap[m].y * xv : __builtin_fmaf(a.tap[m].y, xv, hi);
       }
+      W1[item * rem + e] = (f2){lo, hi};
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. H pass ---------------------------------------------------------------------------------------------------------
+  for (int item = tid; item < ID * TY * rem; item += 256) {
+    const int e = item % rem, sj = item / rem;
+    const int s = sj / TY, j = sj - s * TY;
+    f2 lo2, hi2;  // lo2 = (H-low, H-high) of the W-low value, hi2 of the W-high value
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        acc[c] = fmaf(a.tap[md].x, pl[c], acc[c]);
-        acc[4 + c] = fmaf(a.tap[md].y, pl[c], acc[4 + c]);
+    for (int m = 0; m < L; ++m) {
+      const f2 hv = W1[(s * IRY + 2 * j + (L - 1) - m) * rem + e];
+      if (m == 0) {
+        lo2 = (f2){a.tap[0].x * hv.x, a.tap[0].y * hv.x};
+        hi2 = (f2){a.tap[0].x * hv.y, a.tap[0].y * hv.y};
+      } else {
+        lo2 = (f2){__builtin_fmaf(a.tap[m].x, hv.x, lo2.x), __builtin_fmaf(a.tap[m].y, hv.x, lo2.y)};
+        hi2 = (f2){__builtin_fmaf(a.tap[m].x, hv.y, hi2.x), __builtin_fmaf(a.tap[m].y, hv.y, hi2.y)};
       }
     }
+    H1[item] = (f4){lo2.x, lo2.y, hi2.x, hi2.y};  // item == (s * TY + j) * rem + e
+  }
+  __syncthreads();
+
+  // ---- 3. D pass + stores ------------------------------------------------------------------------------------------------
+  for (int item = tid; item < TZ * TY * rem; item += 256) {
+    const int e = item % rem, zj = item / rem;
+    const int dz = zj / TY, j = zj - dz * TY;
+    float lo[4], hi[4];  // depth-low / depth-high of component c
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
-      a.out[s][(int64_t)img * a.os_b[s] + (int64_t)z * a.os_d[s] + (int64_t)y * a.os_h[s] + k] = acc[s];
+    for (int m = 0; m < L; ++m) {
+      const f4 hv = H1[((2 * dz + (L - 1) - m) * TY + j) * rem + e];
+      const float c4[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        lo[c] = m == 0 ? a.tap[0].x * c4[c] : __builtin_fmaf(a.tap[m].x, c4[c], lo[c]);
+        hi[c] = m == 0 ? a.tap[0].y * c4[c] : __builtin_fmaf(a.tap[m].y, c4[c], hi[c]);
+      }
+    }
+    const int z = z0 + dz, y = y0 + j, k = k_begin + e;
+    if (z < a.Do && y < a.Ho) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int hw = 2 * (c & 1) + (c >> 1);  // component c = (H bit = c & 1, W bit = c >> 1) -> band = 4 depth + 2 H + W
+        a.out[hw][(int64_t)img * a.os_b[hw] + (int64_t)z * a.os_d[hw] + (int64_t)y * a.os_h[hw] + k] = lo[c];
+        a.out[4 + hw][(int64_t)img * a.os_b[4 + hw] + (int64_t)z * a.os_d[4 + hw] + (int64_t)y * a.os_h[4 + hw] + k] = hi[c];
+      }
+    }
   }
 }
 
@@ -510,10 +553,18 @@ int launch3(const mifwt_level_desc* d, const void* x, void* approx, void* const*
   const int64_t ntiles = (int64_t)d->batch * a.tiles_c * a.tiles_r * a.tiles_d;
   if (ntiles > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
   if (split) {
-    const int64_t total = (int64_t)d->batch * a.Do * a.Ho * rem;
-    const int64_t want = (total + 255) / 256;
-    hipLaunchKernelGGL((dwt3_fwd_cols_kernel<L>), dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, stream, a,
-                       a.k_limit, total);
+    constexpr int ID = 2 * kTailTZ + L - 2, IRY = 2 * kTailTY + L - 2;
+    const int nzb = (a.Do + kTailTZ - 1) / kTailTZ, nyb = (a.Ho + kTailTY - 1) / kTailTY;
+    const size_t tail_lds = (size_t)(2 * ID * IRY + 4 * ID * kTailTY) * rem * sizeof(float);
+    static bool tail_attr_set = false;
+    if (!tail_attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt3_fwd_tail_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)((size_t)(2 * ID * IRY + 4 * ID * kTailTY) * 8 * sizeof(float)));
+      tail_attr_set = true;
+    }
+    const int64_t nblk = (int64_t)d->batch * nzb * nyb;
+    if (nblk > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((dwt3_fwd_tail_kernel<L>), dim3((unsigned)nblk), dim3(256), tail_lds, stream, a, a.k_limit, rem, nzb, nyb);
     if (hipGetLastError() != hipSuccess) return MIFWT_ERR_LAUNCH;
   }
   static bool attr_set = false;
