@@ -116,6 +116,17 @@ int mifwt_dwt2_fwd_pair_supported(const mifwt_level_desc* d1, const mifwt_level_
 int mifwt_dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, const void* x, void* const* details1,
                         void* approx2, void* const* details2, const double* dec_lo, const double* dec_hi, void* stream);
 
+/* TWO consecutive 2-D synthesis levels in one launch — two trips of waverec2's level loop
+ * (src/ptwt/conv_transform_2.py:222-249); the approximation between them (the coarser level's cropped output) never
+ * reaches HBM.  d2 describes the COARSER level, d1 the finer one, exactly as two mifwt_dwt_inv calls would
+ * (d2->sig_extent == d1->coef_extent; d2's sig_stride and d1's approx_stride are ignored).
+ *   approx2 / details2  the coarser level's bands      details1  HOST array of 3 device ptrs: finer bands ad, da, dd
+ * Results are bit-identical to the two per-level calls.  f32, even L <= 8, unit innermost strides, output plane >= 64 x 64
+ * (mifwt_dwt2_inv_pair_supported says 1 / 0); MIFWT_ERR_UNSUPPORTED otherwise, nothing launched. */
+int mifwt_dwt2_inv_pair_supported(const mifwt_level_desc* d2, const mifwt_level_desc* d1);
+int mifwt_dwt2_inv_pair(const mifwt_level_desc* d2, const mifwt_level_desc* d1, const void* approx2, const void* const* details2,
+                        const void* const* details1, void* y, const double* rec_lo, const double* rec_hi, void* stream);
+
 /* Adjoints (transposes) of the two level maps, for reverse-mode differentiation.  The reference gets them from
  * ATen autograd through F.pad / _pad_symmetric + F.conv{1,2,3}d and torch.stack + F.conv_transpose{1,2,3}d
  * (same call sites as above); here they are explicit entry points that take the SAME descriptor as the
@@ -174,8 +185,8 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  *          streaming pass along depth
  *   9      fully fused 3-D analysis level, LDS bricks (f32, L in {2, 4, 6})
  *   11     fused 2-D analysis level on the matrix cores (banded-Toeplitz MFMA; f16 storage, even L in [18, 32])
- *   12     two fused 2-D analysis levels per launch (mifwt_dwt2_fwd_pair; never returned by mifwt_kernel_id, which
- *          describes single-level calls) */
+ *   12 / 13  two fused 2-D analysis / synthesis levels per launch (mifwt_dwt2_fwd_pair / mifwt_dwt2_inv_pair; never
+ *          returned by mifwt_kernel_id, which describes single-level calls) */
 int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 
 /* Library-wide diagnostic switches (process-global, meant for tests and A/B measurements).

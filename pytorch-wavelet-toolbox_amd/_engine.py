@@ -81,6 +81,10 @@ def load_library() -> ctypes.CDLL:
     lib.mifwt_dwt2_fwd_pair_supported.argtypes = [desc_p, desc_p]
     lib.mifwt_dwt2_fwd_pair.restype = ctypes.c_int
     lib.mifwt_dwt2_fwd_pair.argtypes = [desc_p, desc_p, vp, ctypes.POINTER(vp), vp, ctypes.POINTER(vp), dbl_p, dbl_p, vp]
+    lib.mifwt_dwt2_inv_pair_supported.restype = ctypes.c_int
+    lib.mifwt_dwt2_inv_pair_supported.argtypes = [desc_p, desc_p]
+    lib.mifwt_dwt2_inv_pair.restype = ctypes.c_int
+    lib.mifwt_dwt2_inv_pair.argtypes = [desc_p, desc_p, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, dbl_p, dbl_p, vp]
     lib.mifwt_set_option.restype = ctypes.c_int
     lib.mifwt_set_option.argtypes = [ctypes.c_int, ctypes.c_int]
     if lib.mifwt_abi_version() != ABI_VERSION:
@@ -119,6 +123,7 @@ OPT_MFMA_MODE = 7
 OPT_PAIR_MODE = 8
 OPT_PAIR_ROWS = 9
 KID_PAIR = 12
+KID_INV_PAIR = 13
 
 
 def set_option(key: int, value: int) -> None:
@@ -308,6 +313,68 @@ class HipLevelEngine:
         lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
         ap, yp = approx.data_ptr(), y.data_ptr()
         self._run(p, 1, approx, lambda ws, wsb, stream: lib.mifwt_dwt_inv(p.ref, ap, ptrs, yp, lo, hi, ws, wsb, stream))
+        return y
+
+    def synthesis_pair(self, approx2: torch.Tensor, details2: List[torch.Tensor], details1: List[torch.Tensor],
+                       rec_lo: Sequence[float], rec_hi: Sequence[float], out_extent: Sequence[int]):
+        """TWO consecutive 2-D synthesis levels in one launch (C ABI ``mifwt_dwt2_inv_pair``): the coarser level's bands
+        ``approx2`` / ``details2`` [B, M2h, M2w], the finer level's ``details1`` [B, M1h, M1w] (whose extents are the cropped
+        output extents of the coarser level) -> y [B, *out_extent].  Returns None when the library does not serve this
+        geometry as a pair; the caller then runs the levels one by one."""
+        _require_gpu(approx2)
+        if approx2.dim() != 3 or approx2.dtype != torch.float32:
+            return None
+        lib = load_library()
+        flen = len(rec_lo)
+        batch = approx2.shape[0]
+        st2 = details2[0].stride()
+        if any(t.stride() != st2 for t in details2):
+            details2 = [t.contiguous() for t in details2]
+            st2 = details2[0].stride()
+        st1 = details1[0].stride()
+        if any(t.stride() != st1 for t in details1):
+            details1 = [t.contiguous() for t in details1]
+            st1 = details1[0].stride()
+        m1 = tuple(details1[0].shape[1:])
+        key = ("invpair", approx2.shape, approx2.stride(), st2, m1, st1, flen, tuple(out_extent))
+        plan = _plans.get(key)
+        if plan is None:
+            if len(_plans) > 4096:
+                _plans.clear()
+            d2, d1 = LevelDesc(), LevelDesc()
+            for d in (d1, d2):
+                d.ndim, d.dtype, d.mode, d.filt_len, d.batch = 2, _DTYPE_IDS[approx2.dtype], 0, flen, batch
+            for a in range(2):
+                d2.sig_extent[a] = int(m1[a])
+                d2.coef_extent[a] = int(approx2.shape[1 + a])
+                d1.sig_extent[a] = int(out_extent[a])
+                d1.coef_extent[a] = int(m1[a])
+            ydense = [int(out_extent[0]) * int(out_extent[1]), int(out_extent[1]), 1]
+            lldense = [int(m1[0]) * int(m1[1]), int(m1[1]), 1]
+            for a in range(3):
+                d2.sig_stride[a] = lldense[a]       # never materialised
+                d2.approx_stride[a] = approx2.stride(a)
+                d2.detail_stride[a] = st2[a]
+                d1.sig_stride[a] = ydense[a]
+                d1.approx_stride[a] = lldense[a]    # ignored
+                d1.detail_stride[a] = st1[a]
+            p = _Plan()
+            p.desc = d1
+            p.ref = ctypes.byref(d1)
+            p.ws_bytes = 0
+            p.kid = KID_INV_PAIR
+            ok = bool(lib.mifwt_dwt2_inv_pair_supported(ctypes.byref(d2), p.ref))
+            plan = _plans[key] = (p, d2, ctypes.byref(d2), (ctypes.c_void_p * 3)(), (ctypes.c_void_p * 3)(), ok)
+        p, _d2, ref2, ptrs2, ptrs1, ok = plan
+        if not ok:
+            return None
+        y = torch.empty((batch, *out_extent), dtype=approx2.dtype, device=approx2.device)
+        for i in range(3):
+            ptrs2[i] = details2[i].data_ptr()
+            ptrs1[i] = details1[i].data_ptr()
+        lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
+        ap, yp = approx2.data_ptr(), y.data_ptr()
+        self._run(p, 1, approx2, lambda ws, wsb, stream: lib.mifwt_dwt2_inv_pair(ref2, p.ref, ap, ptrs2, ptrs1, yp, lo, hi, stream))
         return y
 
     # ---- adjoints (reverse-mode differentiation; C ABI mifwt_dwt_fwd_adjoint / mifwt_dwt_inv_adjoint) -------------

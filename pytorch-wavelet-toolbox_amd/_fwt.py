@@ -372,29 +372,51 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
     flen = len(rec_lo)
     cur = layout.fold(approx)
     folded = [[layout.fold(t) for t in lvl] for lvl in levels]
-    for pos, det in enumerate(folded):
+    def level_out_extent(cur_shape, pos):
+        """Checks of one trip of the reference's level loop (shapes, trims) -> output extents of that level."""
+        det = folded[pos]
         if separable:
             # the separable reference crops the running approximation to the detail shape
             # (src/ptwt/separable_conv_transform.py:94-97) and never trims the synthesis output
-            cur = cur[tuple(slice(0, s) for s in det[0].shape)]
+            cur_shape = tuple(min(c, s_) for c, s_ in zip(cur_shape, det[0].shape))
             trims = [0] * ndim
         else:
             trims = [0] * ndim
             if pos + 1 < len(folded):
                 nxt = folded[pos + 1][0].shape
-                trims = [_adjust_trim(2 * cur.shape[1 + a] - flen + 2, nxt[1 + a]) for a in range(ndim)]
+                trims = [_adjust_trim(2 * cur_shape[1 + a] - flen + 2, nxt[1 + a]) for a in range(ndim)]
         for t in det:
-            if t.shape != cur.shape:
+            if tuple(t.shape) != tuple(cur_shape):
                 if ndim == 1:  # torch.stack in the reference (src/ptwt/conv_transform.py:186)
                     raise RuntimeError("stack expects each tensor to be equal size")
                 raise ValueError("All coefficients on each level must have the same shape")
-        out_ext = [2 * cur.shape[1 + a] - flen + 2 - trims[a] for a in range(ndim)]
+        out_ext = [2 * cur_shape[1 + a] - flen + 2 - trims[a] for a in range(ndim)]
         if min(out_ext) < 1:
             raise ValueError("coefficients too short for this wavelet")
-        if torch.is_grad_enabled() and (cur.requires_grad or any(t.requires_grad for t in det) or tap_t is not None):
+        return out_ext
+
+    pos = 0
+    while pos < len(folded):
+        det = folded[pos]
+        if separable:
+            cur = cur[tuple(slice(0, s_) for s_ in det[0].shape)]
+        out_ext = level_out_extent(tuple(cur.shape), pos)
+        differentiable = torch.is_grad_enabled() and (cur.requires_grad or any(t.requires_grad for t in det) or tap_t is not None)
+        if (ndim == 2 and not separable and not differentiable and pos + 1 < len(folded)
+                and not (torch.is_grad_enabled() and any(t.requires_grad for t in folded[pos + 1]))):
+            # two levels per launch, the approximation between them kept on chip (mifwt_dwt2_inv_pair); the checks of the
+            # second trip are the reference's own and run before anything is launched
+            out_ext2 = level_out_extent((cur.shape[0], *out_ext), pos + 1)
+            y = _engine.ENGINE.synthesis_pair(cur, det, folded[pos + 1], rec_lo, rec_hi, out_ext2)
+            if y is not None:
+                cur = y
+                pos += 2
+                continue
+        if differentiable:
             cur = _SynthesisLevel.apply(rec_lo, rec_hi, tuple(out_ext), *((tap_t[2], tap_t[3]) if tap_t else (None, None)), cur, *det)
         else:
             cur = _engine.ENGINE.synthesis(cur, det, rec_lo, rec_hi, out_ext)
+        pos += 1
     return layout.unfold(cur)
 
 

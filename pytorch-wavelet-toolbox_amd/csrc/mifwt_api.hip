@@ -450,4 +450,24 @@ int mifwt_dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, 
     return dwt2_fwd_roll(d1, d2, x, details1, approx2, details2, dec_lo, dec_hi, st);
   return dwt2_fwd_pair(d1, d2, x, details1, approx2, details2, dec_lo, dec_hi, st);
 }
+// Two consecutive 2-D synthesis levels in one launch (mifwt_idwt2_pair.hip); d2 describes the coarser level, whose
+// (cropped) output is the approximation of d1 and is never materialised.
+int mifwt_dwt2_inv_pair_supported(const mifwt_level_desc* d2, const mifwt_level_desc* d1) {
+  if (!d1 || !d2 || validate(d1, 1) != MIFWT_OK || validate(d2, 1) != MIFWT_OK) return 0;
+  return dwt2_inv_pair_supported(d2, d1) ? 1 : 0;
+}
+
+int mifwt_dwt2_inv_pair(const mifwt_level_desc* d2, const mifwt_level_desc* d1, const void* approx2, const void* const* details2,
+                        const void* const* details1, void* y, const double* rec_lo, const double* rec_hi, void* stream) {
+  if (!d1 || !d2) return MIFWT_ERR_BADARG;
+  int rc = validate(d2, 1);
+  if (rc == MIFWT_OK) rc = validate(d1, 1);
+  if (rc != MIFWT_OK) return rc;
+  if (!approx2 || !details2 || !details1 || !y || !rec_lo || !rec_hi) return MIFWT_ERR_BADARG;
+  for (int s = 0; s < 3; ++s)
+    if (!details1[s] || !details2[s]) return MIFWT_ERR_BADARG;
+  if (!dwt2_inv_pair_supported(d2, d1)) return MIFWT_ERR_UNSUPPORTED;
+  if (d1->batch == 0) return MIFWT_OK;
+  return dwt2_inv_pair(d2, d1, approx2, details2, details1, y, rec_lo, rec_hi, static_cast<hipStream_t>(stream));
+}
 }  // extern "C"

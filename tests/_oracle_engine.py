@@ -30,6 +30,13 @@ class OracleLevelEngine:
         buf1[:, 0] = float("nan")
         return buf1, buf2
 
+    def synthesis_pair(self, approx2, details2, details1, rec_lo, rec_hi, out_extent):
+        """Stand-in for the two-levels-per-launch synthesis call (same contract as HipLevelEngine.synthesis_pair)."""
+        if approx2.dim() != 3 or min(out_extent) < 16:
+            return None
+        mid = self.synthesis(approx2, details2, rec_lo, rec_hi, list(details1[0].shape[1:]))
+        return self.synthesis(mid, details1, rec_lo, rec_hi, out_extent)
+
     def synthesis(self, approx, details, rec_lo, rec_hi, out_extent):
         ndim = approx.dim() - 1
         flen = len(rec_lo)

@@ -709,3 +709,56 @@ def test_pair_kernel_full_size_config2_round_trip():
     assert kids == [_engine.KID_PAIR, 7], kids
     rec = ptwt_amd.waverec2(c, "db4")
     assert (rec - x).abs().max().item() < 5e-6
+
+
+# ---- two synthesis levels per launch (mifwt_dwt2_inv_pair, kernel id 13) ---------------------------------------------
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4"])
+def test_idwt_pair_kernel_bit_identical_to_per_level(wavelet):
+    """waverec2 with the two-level synthesis kernel against the per-level kernels on the same coefficients (odd and even
+    extents, i.e. with and without the reference's end-crop between levels; strided batch): bit-identical, and the round
+    trip closes."""
+    g = torch.Generator().manual_seed(21)
+    for shape, level in [((3, 200, 300), 2), ((2, 257, 131), 2), ((2, 333, 517), 3), ((1, 1024, 1024), 4), ((5, 128, 136), 2), ((2, 1030, 129), 3)]:
+        x = torch.randn(*shape, generator=g, dtype=torch.float32).to(dev())
+        for mode in ("reflect", "zero"):
+            c = ptwt_amd.wavedec2(x, wavelet, mode=mode, level=level)
+            _engine.level_events = []
+            try:
+                got = ptwt_amd.waverec2(c, wavelet)
+                kids = [e[1] for e in _engine.level_events]
+            finally:
+                _engine.level_events = None
+            _engine.set_option(_engine.OPT_PAIR_MODE, 2)
+            try:
+                want = ptwt_amd.waverec2(c, wavelet)
+            finally:
+                _engine.set_option(_engine.OPT_PAIR_MODE, 0)
+            assert kids[-1] == _engine.KID_INV_PAIR, (shape, wavelet, kids)  # the finest two levels go as a pair
+            assert got.shape == want.shape and torch.equal(got, want), (shape, wavelet, mode, (got - want).abs().max().item())
+            assert (got[..., : shape[-2], : shape[-1]] - x).abs().max().item() < 5e-6
+
+
+def test_idwt_pair_fallbacks_and_views():
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(2, 300, 260, generator=g, dtype=torch.float32)
+    # f64, long filters and small planes are served level by level
+    for xx, wavelet in [(x.double(), "db2"), (x, "db8"), (x[..., :60, :60], "db2")]:
+        c = ptwt_amd.wavedec2(xx.to(dev()), wavelet, level=2)
+        _engine.level_events = []
+        try:
+            ptwt_amd.waverec2(c, wavelet)
+            kids = [e[1] for e in _engine.level_events]
+        finally:
+            _engine.level_events = None
+        assert _engine.KID_INV_PAIR not in kids and len(kids) == 2, (wavelet, kids)
+    # coefficients that are views with foreign strides (channels-last style batch) still reconstruct exactly as per level
+    c = ptwt_amd.wavedec2(x.to(dev()), "db3", level=2)
+    cv = [c[0].transpose(0, 1).contiguous().transpose(0, 1)] + [type(d)(*(t.clone() for t in d)) for d in c[1:]]
+    got = ptwt_amd.waverec2(cv, "db3")
+    _engine.set_option(_engine.OPT_PAIR_MODE, 2)
+    try:
+        want = ptwt_amd.waverec2(cv, "db3")
+    finally:
+        _engine.set_option(_engine.OPT_PAIR_MODE, 0)
+    assert torch.equal(got, want)
+    check_tree([got], [O.waverec2(O.wavedec2(x.numpy().astype(np.float64), "db3", level=2), "db3")], 2e-6, "idwt pair vs oracle")

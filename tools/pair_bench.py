@@ -29,6 +29,7 @@ ap.add_argument("--rows", default="8", help="tile-pair kernel: level-2 rows per 
 ap.add_argument("--seg", default="32", help="rolling kernel: level-2 rows per segment")
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--inverse", action="store_true", help="time waverec2 of the coefficients instead (single vs auto)")
 ap.add_argument("--sync-stage", type=int, default=0, help="1: keep the staging barrier of the tile kernels (A/B)")
 args = ap.parse_args()
 
@@ -41,8 +42,16 @@ times = {v[0]: [] for v in variants}
 kids = {}
 
 
-def run(i):
-    return ptwt_amd.wavedec2(bufs[i % 3], args.wavelet, mode=args.mode, level=args.level)
+if args.inverse:
+    coefs = [ptwt_amd.wavedec2(b, args.wavelet, mode=args.mode, level=args.level) for b in bufs]
+    variants = [("single", 2, 0), ("auto", 0, 0)]
+    times = {v[0]: [] for v in variants}
+
+    def run(i):
+        return ptwt_amd.waverec2(coefs[i % 3], args.wavelet)
+else:
+    def run(i):
+        return ptwt_amd.wavedec2(bufs[i % 3], args.wavelet, mode=args.mode, level=args.level)
 
 
 for rnd in range(args.rounds + 1):
