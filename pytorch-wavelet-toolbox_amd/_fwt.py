@@ -402,7 +402,8 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
             cur = cur[tuple(slice(0, s_) for s_ in det[0].shape)]
         out_ext = level_out_extent(tuple(cur.shape), pos)
         differentiable = torch.is_grad_enabled() and (cur.requires_grad or any(t.requires_grad for t in det) or tap_t is not None)
-        if (ndim == 2 and not separable and not differentiable and pos + 1 < len(folded)
+        # levels go in pairs counted from the FINEST one (that is where the bytes are): an odd count starts with a single level
+        if (ndim == 2 and not separable and not differentiable and (len(folded) - pos) % 2 == 0
                 and not (torch.is_grad_enabled() and any(t.requires_grad for t in folded[pos + 1]))):
             # two levels per launch, the approximation between them kept on chip (mifwt_dwt2_inv_pair); the checks of the
             # second trip are the reference's own and run before anything is launched
