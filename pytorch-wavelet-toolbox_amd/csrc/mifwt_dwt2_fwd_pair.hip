@@ -15,7 +15,8 @@
 // every workgroup computes a window of ACTUAL level-1 rows / columns (the nominal window shifted into the plane at an
 // edge), and edge tiles read it through the extension index map; periodic extension would need the far side of
 // the plane and is left to the per-level kernels.  Same arithmetic, in the same order, as two calls of the tile
-// kernel (mifwt_dwt2_tile.h): results are bit-identical to the per-level path.
+// kernel (mifwt_dwt2_tile.h): results are bit-identical to the per-level path.  tests/test_pair_model.py models the window
+// bookkeeping on the CPU.
 // Algorithmic traffic: 4 B H W read + 4 B (3 H1 W1 + 4 H2 W2) written.
 #include "mifwt_dwt2_tile.h"
 

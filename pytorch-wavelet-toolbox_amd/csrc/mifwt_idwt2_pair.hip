@@ -13,7 +13,8 @@
 //   C. continues exactly like the level kernel (vertical synthesis, horizontal synthesis, 8-byte stores).
 // Synthesis halos are small (L/2 - 1 coefficients per level and axis), so the approximation tile costs about a quarter of
 // the tile's arithmetic on top; the coarser level's scratch tiles live in the LDS array phase C overwrites later.
-// Results are bit-identical to two per-level launches.  f32, even L <= 8.
+// Results are bit-identical to two per-level launches (tests/test_idwt_pair_model.py models the tile geometry on the CPU).
+// f32, even L <= 8.
 // Algorithmic traffic: 4 B (4 M2h M2w + 3 M1h M1w) read + 4 B H W written.
 #include "mifwt_idwt2_tile.h"
 
