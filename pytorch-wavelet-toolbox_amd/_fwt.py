@@ -403,10 +403,11 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
         out_ext = level_out_extent(tuple(cur.shape), pos)
         differentiable = torch.is_grad_enabled() and (cur.requires_grad or any(t.requires_grad for t in det) or tap_t is not None)
         # levels go in pairs counted from the FINEST one (that is where the bytes are): an odd count starts with a single level
-        if (ndim == 2 and not separable and not differentiable and (len(folded) - pos) % 2 == 0
+        if (ndim == 2 and not differentiable and (len(folded) - pos) % 2 == 0
                 and not (torch.is_grad_enabled() and any(t.requires_grad for t in folded[pos + 1]))):
             # two levels per launch, the approximation between them kept on chip (mifwt_dwt2_inv_pair); the checks of the
-            # second trip are the reference's own and run before anything is launched
+            # second trip are the reference's own and run before anything is launched.  Separable containers: the crop of the
+            # running approximation to the next detail shape IS the extent the kernel synthesises the approximation tile for
             out_ext2 = level_out_extent((cur.shape[0], *out_ext), pos + 1)
             y = _engine.ENGINE.synthesis_pair(cur, det, folded[pos + 1], rec_lo, rec_hi, out_ext2)
             if y is not None:

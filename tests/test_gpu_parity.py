@@ -762,3 +762,27 @@ def test_idwt_pair_fallbacks_and_views():
         _engine.set_option(_engine.OPT_PAIR_MODE, 0)
     assert torch.equal(got, want)
     check_tree([got], [O.waverec2(O.wavedec2(x.numpy().astype(np.float64), "db3", level=2), "db3")], 2e-6, "idwt pair vs oracle")
+
+
+def test_idwt_pair_serves_separable_containers():
+    """fswaverec2 crops the running approximation to the next level's detail shape (separable_conv_transform.py:94-97);
+    in the two-level kernel that crop is the extent of the approximation tile."""
+    g = torch.Generator().manual_seed(23)
+    for shape in [(2, 257, 131), (3, 200, 301), (1, 515, 515)]:
+        x = torch.randn(*shape, generator=g, dtype=torch.float32).to(dev())
+        for wavelet in ("db2", "db4"):
+            c = ptwt_amd.fswavedec2(x, wavelet, level=3)
+            _engine.level_events = []
+            try:
+                got = ptwt_amd.fswaverec2(c, wavelet)
+                kids = [e[1] for e in _engine.level_events]
+            finally:
+                _engine.level_events = None
+            _engine.set_option(_engine.OPT_PAIR_MODE, 2)
+            try:
+                want = ptwt_amd.fswaverec2(c, wavelet)
+            finally:
+                _engine.set_option(_engine.OPT_PAIR_MODE, 0)
+            assert kids[-1] == _engine.KID_INV_PAIR, (shape, wavelet, kids)
+            assert torch.equal(got, want)
+            assert (got[..., : shape[-2], : shape[-1]] - x).abs().max().item() < 5e-6
