@@ -127,6 +127,19 @@ int mifwt_dwt2_inv_pair_supported(const mifwt_level_desc* d2, const mifwt_level_
 int mifwt_dwt2_inv_pair(const mifwt_level_desc* d2, const mifwt_level_desc* d1, const void* approx2, const void* const* details2,
                         const void* const* details1, void* y, const double* rec_lo, const double* rec_hi, void* stream);
 
+/* The DEEP levels of a 1-D decomposition in one launch — the trailing trips of wavedec's level loop
+ * (src/ptwt/conv_transform.py:133-140).  Below a few thousand samples per row a level is launch latency, not work; here one
+ * workgroup per row parks the row in LDS and runs `nlevels` levels on it.  Rows of contiguous samples (row strides in
+ * elements), f32 / f64, even filt_len <= 32, any boundary mode, n <= mifwt_dwt1_fwd_tail_max_n(dtype), 2 <= nlevels <= 24.
+ *   details  HOST array of nlevels device pointers: detail coefficients of fused level l, [rows, floor((n_l + L - 1) / 2)]
+ *   approx   the last level's approximation
+ * Same sums as nlevels mifwt_dwt_fwd calls (summation order differs: agreement to rounding, not bit for bit).
+ * MIFWT_ERR_UNSUPPORTED outside the envelope, nothing launched. */
+int mifwt_dwt1_fwd_tail_max_n(int dtype);
+int mifwt_dwt1_fwd_tail(int dtype, int filt_len, int mode, int64_t rows, int64_t n, int nlevels, const void* x, int64_t x_row_stride,
+                        void* approx, int64_t approx_row_stride, void* const* details, const int64_t* detail_row_strides,
+                        const double* dec_lo, const double* dec_hi, void* stream);
+
 /* Adjoints (transposes) of the two level maps, for reverse-mode differentiation.  The reference gets them from
  * ATen autograd through F.pad / _pad_symmetric + F.conv{1,2,3}d and torch.stack + F.conv_transpose{1,2,3}d
  * (same call sites as above); here they are explicit entry points that take the SAME descriptor as the
@@ -186,7 +199,8 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  *   9      fully fused 3-D analysis level, LDS bricks (f32, L in {2, 4, 6})
  *   11     fused 2-D analysis level on the matrix cores (banded-Toeplitz MFMA; f16 storage, even L in [18, 32])
  *   12 / 13  two fused 2-D analysis / synthesis levels per launch (mifwt_dwt2_fwd_pair / mifwt_dwt2_inv_pair; never
- *          returned by mifwt_kernel_id, which describes single-level calls) */
+ *          returned by mifwt_kernel_id, which describes single-level calls)
+ *   14     the deep levels of a 1-D analysis in one launch (mifwt_dwt1_fwd_tail; likewise not returned by mifwt_kernel_id) */
 int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 
 /* Library-wide diagnostic switches (process-global, meant for tests and A/B measurements).

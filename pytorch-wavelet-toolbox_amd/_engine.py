@@ -85,6 +85,11 @@ def load_library() -> ctypes.CDLL:
     lib.mifwt_dwt2_inv_pair_supported.argtypes = [desc_p, desc_p]
     lib.mifwt_dwt2_inv_pair.restype = ctypes.c_int
     lib.mifwt_dwt2_inv_pair.argtypes = [desc_p, desc_p, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, dbl_p, dbl_p, vp]
+    lib.mifwt_dwt1_fwd_tail_max_n.restype = ctypes.c_int
+    lib.mifwt_dwt1_fwd_tail_max_n.argtypes = [ctypes.c_int]
+    lib.mifwt_dwt1_fwd_tail.restype = ctypes.c_int
+    lib.mifwt_dwt1_fwd_tail.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, vp,
+                                        ctypes.c_int64, vp, ctypes.c_int64, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int64), dbl_p, dbl_p, vp]
     lib.mifwt_set_option.restype = ctypes.c_int
     lib.mifwt_set_option.argtypes = [ctypes.c_int, ctypes.c_int]
     if lib.mifwt_abi_version() != ABI_VERSION:
@@ -124,6 +129,7 @@ OPT_PAIR_MODE = 8
 OPT_PAIR_ROWS = 9
 KID_PAIR = 12
 KID_INV_PAIR = 13
+KID_TAIL = 14
 
 
 def set_option(key: int, value: int) -> None:
@@ -270,6 +276,48 @@ class HipLevelEngine:
         self._run(p1, 0, x, lambda ws, wsb, stream: lib.mifwt_dwt2_fwd_pair(p1.ref, p2.ref, xp, p1.ptrs, b2, p2.ptrs, lo, hi, stream),
                   kid=KID_PAIR)
         return buf1, buf2
+
+    def analysis_tail(self, x: torch.Tensor, dec_lo: Sequence[float], dec_hi: Sequence[float], mode_id: int, nlevels: int):
+        """The remaining ``nlevels`` levels of a 1-D decomposition in ONE launch (C ABI ``mifwt_dwt1_fwd_tail``): ``x`` [B, N] ->
+        a list of ``nlevels`` buffers [B, 2, M_l] laid out like :meth:`analysis` results, finest first; plane 1 of every buffer
+        holds that level's detail coefficients, plane 0 only of the LAST one its approximation (the others are intermediates
+        that never leave the chip).  Returns None outside the kernel's envelope."""
+        _require_gpu(x)
+        if x.dim() != 2 or x.dtype not in (torch.float32, torch.float64) or x.stride(1) != 1 or nlevels < 2 or nlevels > 24:
+            return None
+        lib = load_library()
+        flen = len(dec_lo)
+        rows, n0 = x.shape
+        if rows == 0 or n0 == 0 or flen > 32 or n0 > lib.mifwt_dwt1_fwd_tail_max_n(_DTYPE_IDS[x.dtype]):
+            return None
+        sizes, n = [], n0
+        for _ in range(nlevels):
+            n = (n + flen - 1) // 2
+            sizes.append(n)
+        bufs = [torch.empty((rows, 2, m), dtype=x.dtype, device=x.device) for m in sizes]
+        esz = x.element_size()
+        det = (ctypes.c_void_p * nlevels)(*[b.data_ptr() + sizes[i] * esz for i, b in enumerate(bufs)])
+        det_rs = (ctypes.c_int64 * nlevels)(*[2 * m for m in sizes])
+        lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
+        p = _Plan()
+        p.ws_bytes, p.kid = 0, KID_TAIL
+        d = LevelDesc()
+        d.ndim = 1
+        d.sig_extent[0] = n0
+        p.desc = d
+        xp, ap = x.data_ptr(), bufs[-1].data_ptr()
+        rc_box = []
+
+        def call(ws, wsb, stream):
+            rc = lib.mifwt_dwt1_fwd_tail(_DTYPE_IDS[x.dtype], flen, mode_id, rows, n0, nlevels, xp, x.stride(0), ap, 2 * sizes[-1],
+                                         det, det_rs, lo, hi, stream)
+            rc_box.append(rc)
+            return 0 if rc == -2 else rc  # "unsupported" is an answer here, not an error
+
+        self._run(p, 0, x, call)
+        if rc_box and rc_box[0] == -2:
+            return None
+        return bufs
 
     def synthesis(self, approx: torch.Tensor, details: List[torch.Tensor], rec_lo: Sequence[float],
                   rec_hi: Sequence[float], out_extent: Sequence[int]) -> torch.Tensor:

@@ -325,6 +325,19 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
                 cur = pair[1][:, 0]
                 done += 2
                 continue
+        if ndim == 1 and level - done >= 2 and not differentiable:
+            # the deep levels of a 1-D pyramid in one launch (mifwt_dwt1_fwd_tail) once a row fits into LDS; the pad checks of
+            # the fused trips are the reference's own and run before anything is launched
+            n = cur.shape[1]
+            for _l in range(level - done):
+                _check_pad([n], flen, "reflect" if mode is None else mode)
+                n = (n + flen - 1) // 2
+            tail = _engine.ENGINE.analysis_tail(cur, dec_lo, dec_hi, mode_id, level - done)
+            if tail is not None:
+                bufs.extend(tail)
+                cur = tail[-1][:, 0]
+                done = level
+                continue
         done += 1
         if differentiable:
             buf = _AnalysisLevel.apply(cur, dec_lo, dec_hi, mode_id, *((tap_t[0], tap_t[1]) if tap_t else (None, None)))

@@ -470,4 +470,17 @@ int mifwt_dwt2_inv_pair(const mifwt_level_desc* d2, const mifwt_level_desc* d1, 
   if (d1->batch == 0) return MIFWT_OK;
   return dwt2_inv_pair(d2, d1, approx2, details2, details1, y, rec_lo, rec_hi, static_cast<hipStream_t>(stream));
 }
+// The deep levels of a 1-D decomposition in one launch (mifwt_dwt1_tail.hip).
+int mifwt_dwt1_fwd_tail_max_n(int dtype) { return dwt1_tail_max_n(dtype); }
+
+int mifwt_dwt1_fwd_tail(int dtype, int filt_len, int mode, int64_t rows, int64_t n, int nlevels, const void* x, int64_t x_row_stride,
+                        void* approx, int64_t approx_row_stride, void* const* details, const int64_t* detail_row_strides,
+                        const double* dec_lo, const double* dec_hi, void* stream) {
+  if (!x || !approx || !details || !detail_row_strides || !dec_lo || !dec_hi) return MIFWT_ERR_BADARG;
+  if (!dwt1_tail_supported(dtype, filt_len, mode, rows, n, nlevels)) return MIFWT_ERR_UNSUPPORTED;
+  for (int l = 0; l < nlevels; ++l)
+    if (!details[l]) return MIFWT_ERR_BADARG;
+  return dwt1_tail(dtype, filt_len, mode, rows, n, nlevels, x, x_row_stride, approx, approx_row_stride, details, detail_row_strides,
+                   dec_lo, dec_hi, static_cast<hipStream_t>(stream));
+}
 }  // extern "C"

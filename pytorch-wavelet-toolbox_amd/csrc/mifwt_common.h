@@ -116,7 +116,7 @@ int stream_call(int dtype, int kind, const StreamCall& c);  // dispatches on dty
 // ---- fused fast paths --------------------------------------------------------------------------------
 // Each returns MIFWT_ERR_UNSUPPORTED when the descriptor is outside its envelope (the dispatcher then
 // falls back to the generic passes) and never touches the workspace.
-enum KernelId { kGeneric = 0, kDwt2FwdStream = 1, kDwt2InvStream = 2, kDwt1FwdRow = 3, kDwt1InvRow = 4, kDwt3FwdStream = 5, kDwt3InvStream = 6, kDwt2FwdTile = 7, kDwt2InvTile = 8, kDwt3FwdTile = 9, kDwt3InvTile = 10, kDwt2FwdMfma = 11, kDwt2FwdPair = 12, kDwt2InvPair = 13 };
+enum KernelId { kGeneric = 0, kDwt2FwdStream = 1, kDwt2InvStream = 2, kDwt1FwdRow = 3, kDwt1InvRow = 4, kDwt3FwdStream = 5, kDwt3InvStream = 6, kDwt2FwdTile = 7, kDwt2InvTile = 8, kDwt3FwdTile = 9, kDwt3InvTile = 10, kDwt2FwdMfma = 11, kDwt2FwdPair = 12, kDwt2InvPair = 13, kDwt1FwdTail = 14 };
 
 bool dwt2_fwd_stream_supported(const mifwt_level_desc* d);
 int dwt2_fwd_stream(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
@@ -147,6 +147,13 @@ int dwt2_fwd_roll(const mifwt_level_desc* d1, const mifwt_level_desc* d2, const 
 bool dwt2_inv_pair_supported(const mifwt_level_desc* d2, const mifwt_level_desc* d1);
 int dwt2_inv_pair(const mifwt_level_desc* d2, const mifwt_level_desc* d1, const void* approx2, const void* const* details2,
                   const void* const* details1, void* y, const double* rec_lo, const double* rec_hi, hipStream_t stream);
+
+// the deep levels of a 1-D decomposition in one launch, one workgroup per row (mifwt_dwt1_tail.hip)
+int dwt1_tail_max_n(int dtype);
+bool dwt1_tail_supported(int dtype, int filt_len, int mode, int64_t rows, int64_t n0, int nlevels);
+int dwt1_tail(int dtype, int filt_len, int mode, int64_t rows, int64_t n0, int nlevels, const void* x, int64_t x_row_stride,
+              void* approx, int64_t approx_row_stride, void* const* details, const int64_t* detail_row_strides, const double* lo,
+              const double* hi, hipStream_t stream);
 
 // which fused 2-D analysis kernel serves this descriptor: kDwt2FwdTile, kDwt2FwdStream, or -1 (neither)
 int dwt2_fwd_choice(const mifwt_level_desc* d);

@@ -1,0 +1,130 @@
+// mifwt_dwt1_tail.hip — the deep levels of a 1-D decomposition in ONE launch (gfx950), kernel id 14.
+//
+// Reference seam: the trailing trips of wavedec's level loop (src/ptwt/conv_transform.py:133-140: _fwt_pad + F.conv1d(stride 2)
+// per level, the approximation fed back).  Once a row is a few thousand samples long a level is a few microseconds of
+// work behind ~5 us of launch latency (the reference's own 1-D speed test, 32 x 10^6 samples at level 10, spends 45 of its
+// 166 us in the last five levels; a 1 x 4096 signal at level 12 is launch latency only).  Here a 256-thread workgroup owns one
+// row: it parks the row in LDS and runs every remaining level on it — detail coefficients go to HBM, the approximation
+// ping-pongs between two LDS buffers and only the last one is stored.  Any boundary mode (the general index map: deep levels
+// are shorter than the filter and fold repeatedly), any even filter length up to 32 taps, f32 / f64 in their own precision.
+//   c_lo/hi[k] = sum_m h_lo/hi[m] x_ext[2k + 1 - m],  k < floor((n + L - 1) / 2)     
+// Traffic is negligible; the point is one launch instead of nlevels.
+#include "mifwt_common.h"
+
+namespace mifwt {
+
+namespace {
+
+constexpr int kTailMaxLevels = 24;
+constexpr int kTailMaxTaps = 32;
+
+struct Dwt1TailArgs {
+  const void* x;
+  void* approx;                  // final approximation [rows, m_last]
+  void* det[kTailMaxLevels];     // per fused level: detail coefficients [rows, m_l]
+  int64_t x_rs, approx_rs, det_rs[kTailMaxLevels];  // row strides (elements)
+  int n0, nlevels, filt_len, mode, cap;             // cap: elements of LDS buffer A (buffer B follows)
+  double lo[kTailMaxTaps], hi[kTailMaxTaps];        // dec_lo / dec_hi, PyWavelets order
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) dwt1_tail_kernel(const Dwt1TailArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tail_lds[];
+  T* A = reinterpret_cast<T*>(tail_lds);
+  T* B = A + a.cap;
+  __shared__ T tlo[kTailMaxTaps], thi[kTailMaxTaps];
+  const int tid = threadIdx.x, L = a.filt_len;
+  const int64_t row = blockIdx.x;
+  if (tid < L) {
+    tlo[tid] = (T)a.lo[tid];
+    thi[tid] = (T)a.hi[tid];
+  }
+  const T* __restrict__ xr = static_cast<const T*>(a.x) + row * a.x_rs;
+  for (int i = tid; i < a.n0; i += 256) A[i] = xr[i];
+  __syncthreads();
+  int n = a.n0;
+  for (int lvl = 0; lvl < a.nlevels; ++lvl) {
+    const int m = (n + L - 1) >> 1;
+    T* __restrict__ dr = static_cast<T*>(a.det[lvl]) + row * a.det_rs[lvl];
+    const bool near = n >= L;  // then every index lies within one period: no division in the map
+    for (int k = tid; k < m; k += 256) {
+      T clo = T(0), chi = T(0);
+      for (int t = 0; t < L; ++t) {
+        const int e = 2 * k + 1 - t;
+        const int s = near ? ext_index_near(e, n, a.mode) : ext_index(e, n, a.mode);
+        const T xv = s < 0 ? T(0) : A[s];
+        clo = __builtin_fma(tlo[t], xv, clo);
+        chi = __builtin_fma(thi[t], xv, chi);
+      }
+      dr[k] = chi;
+      B[k] = clo;
+    }
+    __syncthreads();
+    T* tmp = A;
+    A = B;
+    B = tmp;
+    n = m;
+  }
+  T* __restrict__ ar = static_cast<T*>(a.approx) + row * a.approx_rs;
+  for (int i = tid; i < n; i += 256) ar[i] = A[i];
+}
+
+}  // namespace
+
+// rows of at most this many samples can start the fused tail (both LDS buffers within 96 KB)
+int dwt1_tail_max_n(int dtype) { return dtype == MIFWT_F64 ? 8192 : 16384; }
+
+bool dwt1_tail_supported(int dtype, int filt_len, int mode, int64_t rows, int64_t n0, int nlevels) {
+  if (g_options[MIFWT_OPT_FORCE_GENERIC] || g_options[MIFWT_OPT_PAIR_MODE] == 2) return false;
+  if (dtype != MIFWT_F32 && dtype != MIFWT_F64) return false;
+  if (filt_len < 2 || filt_len > kTailMaxTaps || (filt_len & 1)) return false;
+  if (mode < MIFWT_MODE_ZERO || mode > MIFWT_MODE_SYMMETRIC) return false;
+  if (rows < 1 || rows > (int64_t(1) << 30) || nlevels < 2 || nlevels > kTailMaxLevels) return false;
+  return n0 >= 1 && n0 <= dwt1_tail_max_n(dtype);
+}
+
+int dwt1_tail(int dtype, int filt_len, int mode, int64_t rows, int64_t n0, int nlevels, const void* x, int64_t x_row_stride,
+              void* approx, int64_t approx_row_stride, void* const* details, const int64_t* detail_row_strides, const double* lo,
+              const double* hi, hipStream_t stream) {
+  if (!dwt1_tail_supported(dtype, filt_len, mode, rows, n0, nlevels)) return MIFWT_ERR_UNSUPPORTED;
+  Dwt1TailArgs a;
+  a.x = x;
+  a.approx = approx;
+  a.x_rs = x_row_stride;
+  a.approx_rs = approx_row_stride;
+  for (int l = 0; l < nlevels; ++l) {
+    a.det[l] = details[l];
+    a.det_rs[l] = detail_row_strides[l];
+  }
+  a.n0 = (int)n0;
+  a.nlevels = nlevels;
+  a.filt_len = filt_len;
+  a.mode = mode;
+  for (int t = 0; t < filt_len; ++t) {
+    a.lo[t] = lo[t];
+    a.hi[t] = hi[t];
+  }
+  const int esz = dtype == MIFWT_F64 ? 8 : 4;
+  // buffer A holds the row, buffer B its first approximation; later levels alternate.  A level of fewer than L - 1 samples
+  // GROWS (m = (n + L - 1) / 2 > n), but never beyond L: both buffers hold at least 32 elements
+  a.cap = (int)n0 < 32 ? 32 : (((int)n0 + 3) & ~3);
+  const int m0 = ((int)n0 + filt_len - 1) >> 1;
+  const size_t lds = (size_t)(a.cap + (m0 < 32 ? 32 : ((m0 + 3) & ~3))) * esz;
+  static bool attr_set[2] = {false, false};
+  const int ti = dtype == MIFWT_F64 ? 1 : 0;
+  if (!attr_set[ti]) {
+    const int max_lds = (dwt1_tail_max_n(dtype) + (dwt1_tail_max_n(dtype) + kTailMaxTaps) / 2 + 8) * esz;
+    if (ti)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt1_tail_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    else
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt1_tail_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    attr_set[ti] = true;
+  }
+  if (ti)
+    hipLaunchKernelGGL((dwt1_tail_kernel<double>), dim3((unsigned)rows), dim3(256), lds, stream, a);
+  else
+    hipLaunchKernelGGL((dwt1_tail_kernel<float>), dim3((unsigned)rows), dim3(256), lds, stream, a);
+  return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
+}
+
+}  // namespace mifwt

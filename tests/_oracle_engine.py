@@ -20,6 +20,20 @@ class OracleLevelEngine:
         keys = [format(s, f"0{ndim}b").replace("0", "a").replace("1", "d") for s in range(1 << ndim)]
         return torch.from_numpy(np.stack([bands[k] for k in keys], axis=1))
 
+    def analysis_tail(self, x, dec_lo, dec_hi, mode_id, nlevels):
+        """Stand-in for the fused deep 1-D levels: same return contract as HipLevelEngine.analysis_tail — plane 0 of every
+        buffer but the last is NOT part of it, so it is poisoned here."""
+        if x.dim() != 2 or x.shape[1] > 64 or nlevels < 2:
+            return None
+        bufs, cur = [], x
+        for _ in range(nlevels):
+            buf = self.analysis(cur, dec_lo, dec_hi, mode_id)
+            bufs.append(buf)
+            cur = buf[:, 0].clone()
+        for b in bufs[:-1]:
+            b[:, 0] = float("nan")
+        return bufs
+
     def analysis_pair(self, x, dec_lo, dec_hi, mode_id):
         """Stand-in for the two-levels-per-launch call: same return contract as HipLevelEngine.analysis_pair — plane 0
         of the first buffer (the intermediate approximation) is NOT part of it, so it is poisoned here."""

@@ -786,3 +786,46 @@ def test_idwt_pair_serves_separable_containers():
             assert kids[-1] == _engine.KID_INV_PAIR, (shape, wavelet, kids)
             assert torch.equal(got, want)
             assert (got[..., : shape[-2], : shape[-1]] - x).abs().max().item() < 5e-6
+
+
+# ---- the deep levels of a 1-D decomposition in one launch (mifwt_dwt1_fwd_tail, kernel id 14) --------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_dwt1_tail_fusion_vs_oracle_and_per_level(dtype):
+    """wavedec with the fused deep levels against the fp64 oracle and against the per-level kernels: every boundary mode,
+    filters up to 32 taps, rows longer than the kernel's LDS limit (the first levels then run one by one), levels shorter
+    than the filter (the index map folds repeatedly), batch views with a row stride."""
+    tol = TOL64 if dtype == torch.float64 else TOL32
+    rng = np.random.default_rng(31)
+    cases = [("haar", (1, 4096), None), ("db4", (3, 5000), None), ("db5", (2, 40000), 8), ("sym16", (2, 3000), None), ("db2", (5, 33), None),
+             ("db8", (4, 1000), 6)]
+    for wavelet, shape, level in cases:
+        x = rng.standard_normal(shape)
+        xg = torch.from_numpy(x).to(dtype).to(dev())
+        for mode in MODES:
+            try:
+                want = O.wavedec(x, wavelet, mode=mode, level=level)
+            except RuntimeError:
+                continue
+            _engine.level_events = []
+            try:
+                got = ptwt_amd.wavedec(xg, wavelet, mode=mode, level=level)
+                kids = [e[1] for e in _engine.level_events]
+            finally:
+                _engine.level_events = None
+            if len(want) > 2:
+                assert kids[-1] == _engine.KID_TAIL, (wavelet, shape, mode, kids)
+            check_tree(got, want, tol, f"tail {wavelet} {shape} {mode}")
+            _engine.set_option(_engine.OPT_PAIR_MODE, 2)
+            try:
+                single = ptwt_amd.wavedec(xg, wavelet, mode=mode, level=level)
+            finally:
+                _engine.set_option(_engine.OPT_PAIR_MODE, 0)
+            for a, b in zip(got, single):
+                assert a.shape == b.shape and G.relerr(to_np(a), to_np(b)) < (1e-13 if dtype == torch.float64 else 2e-6)
+    # rows of a wider tensor (row stride != length) and the round trip
+    wide = torch.randn(6, 9000, device=dev(), dtype=dtype)
+    view = wide[::2, 100:8100]
+    c = ptwt_amd.wavedec(view, "db3", level=9)
+    check_tree(c, O.wavedec(view.cpu().double().numpy(), "db3", level=9), tol, "tail strided rows")
+    rec = ptwt_amd.waverec(c, "db3")
+    assert (rec[..., :8000] - view).abs().max().item() < (1e-12 if dtype == torch.float64 else 5e-6)
