@@ -3,7 +3,7 @@
 // Reference seam: the trailing trips of wavedec's level loop (src/ptwt/conv_transform.py:133-140: _fwt_pad + F.conv1d(stride 2)
 // per level, the approximation fed back).  Once a row is a few thousand samples long a level is a few microseconds of
 // work behind ~5 us of launch latency (the reference's own 1-D speed test, 32 x 10^6 samples at level 10, spends 45 of its
-// 166 us in the last five levels; a 1 x 4096 signal at level 12 is launch latency only).  Here a 256-thread workgroup owns one
+// 166 us in the last five levels; a 1 x 4096 signal at level 12 is launch latency only).  Here a 512-thread workgroup owns one
 // row: it parks the row in LDS and runs every remaining level on it — detail coefficients go to HBM, the approximation
 // ping-pongs between two LDS buffers and only the last one is stored.  Any boundary mode (the general index map: deep levels
 // are shorter than the filter and fold repeatedly), any even filter length up to 32 taps, f32 / f64 in their own precision.
@@ -17,6 +17,7 @@ namespace {
 
 constexpr int kTailMaxLevels = 24;
 constexpr int kTailMaxTaps = 32;
+constexpr int kTailThreads = 512;  // a row is one workgroup: more lanes per row, not more rows per CU
 
 struct Dwt1TailArgs {
   const void* x;
@@ -28,7 +29,7 @@ struct Dwt1TailArgs {
 };
 
 template <typename T>
-__global__ void __launch_bounds__(256) dwt1_tail_kernel(const Dwt1TailArgs a) {
+__global__ void __launch_bounds__(kTailThreads) dwt1_tail_kernel(const Dwt1TailArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tail_lds[];
   T* A = reinterpret_cast<T*>(tail_lds);
   T* B = A + a.cap;
@@ -40,18 +41,50 @@ __global__ void __launch_bounds__(256) dwt1_tail_kernel(const Dwt1TailArgs a) {
     thi[tid] = (T)a.hi[tid];
   }
   const T* __restrict__ xr = static_cast<const T*>(a.x) + row * a.x_rs;
-  for (int i = tid; i < a.n0; i += 256) A[i] = xr[i];
+  for (int i = tid; i < a.n0; i += kTailThreads) A[i] = xr[i];
   __syncthreads();
   int n = a.n0;
   for (int lvl = 0; lvl < a.nlevels; ++lvl) {
     const int m = (n + L - 1) >> 1;
     T* __restrict__ dr = static_cast<T*>(a.det[lvl]) + row * a.det_rs[lvl];
     const bool near = n >= L;  // then every index lies within one period: no division in the map
-    for (int k = tid; k < m; k += 256) {
+    // interior outputs k in [k_lo, k_hi): every tap reads inside the row (2k + 1 - (L - 1) >= 0 and 2k + 1 < n) — no boundary
+    // map, and four outputs per thread and step so that their LDS reads are in flight together (one output at a time ran
+    // at LDS latency: 10 us per level on a 15 000-sample row)
+    const int k_lo = min((L - 2) >> 1, m), k_hi = max(min(n >> 1, m), k_lo);
+    for (int k = k_lo + tid; k < k_hi; k += 4 * kTailThreads) {
+      T clo[4], chi[4];
+      const T* xp[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        clo[u] = chi[u] = T(0);
+        const int ku = k + u * kTailThreads;
+        xp[u] = A + 2 * (ku < k_hi ? ku : k) + 1;  // lanes past the end recompute output k (stored once, below)
+      }
+      for (int t = 0; t < L; ++t) {
+        const T wl = tlo[t], wh = thi[t];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const T xv = xp[u][-t];
+          clo[u] = __builtin_fma(wl, xv, clo[u]);
+          chi[u] = __builtin_fma(wh, xv, chi[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ku = k + u * kTailThreads;
+        if (ku < k_hi) {
+          dr[ku] = chi[u];
+          B[ku] = clo[u];
+        }
+      }
+    }
+    // the few outputs at the two ends, through the boundary map
+    for (int idx = tid; idx < k_lo + (m - k_hi); idx += kTailThreads) {
+      const int k = idx < k_lo ? idx : k_hi + (idx - k_lo);
       T clo = T(0), chi = T(0);
       for (int t = 0; t < L; ++t) {
-        const int e = 2 * k + 1 - t;
-        const int s = near ? ext_index_near(e, n, a.mode) : ext_index(e, n, a.mode);
+        const int s = near ? ext_index_near(2 * k + 1 - t, n, a.mode) : ext_index(2 * k + 1 - t, n, a.mode);
         const T xv = s < 0 ? T(0) : A[s];
         clo = __builtin_fma(tlo[t], xv, clo);
         chi = __builtin_fma(thi[t], xv, chi);
@@ -66,7 +99,7 @@ __global__ void __launch_bounds__(256) dwt1_tail_kernel(const Dwt1TailArgs a) {
     n = m;
   }
   T* __restrict__ ar = static_cast<T*>(a.approx) + row * a.approx_rs;
-  for (int i = tid; i < n; i += 256) ar[i] = A[i];
+  for (int i = tid; i < n; i += kTailThreads) ar[i] = A[i];
 }
 
 }  // namespace
@@ -121,9 +154,9 @@ int dwt1_tail(int dtype, int filt_len, int mode, int64_t rows, int64_t n0, int n
     attr_set[ti] = true;
   }
   if (ti)
-    hipLaunchKernelGGL((dwt1_tail_kernel<double>), dim3((unsigned)rows), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((dwt1_tail_kernel<double>), dim3((unsigned)rows), dim3(kTailThreads), lds, stream, a);
   else
-    hipLaunchKernelGGL((dwt1_tail_kernel<float>), dim3((unsigned)rows), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((dwt1_tail_kernel<float>), dim3((unsigned)rows), dim3(kTailThreads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 
