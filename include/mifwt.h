@@ -215,7 +215,9 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 #define MIFWT_OPT_TILE_MODE 5      /* 2-D analysis: 0 = auto (LDS-tile kernel on small planes), 1 = always tile, 2 = never */
 #define MIFWT_OPT_TILE_ROWS 6      /* >0 overrides the tile kernels' output rows per tile */
 #define MIFWT_OPT_MFMA_MODE 7      /* 2-D analysis, f16 storage, 18..32 taps: 0 = matrix-core kernel, 2 = vector tile kernel */
-#define MIFWT_OPT_PAIR_MODE 8      /* two-level analysis launches: 0 = auto (rolling strips for 8 taps, else tiles), 1 = tiles only, 2 = never, 3 = rolling strips wherever they apply */
+#define MIFWT_OPT_PAIR_MODE 8      /* multi-level launches (mifwt_dwt2_fwd_pair, mifwt_dwt2_inv_pair, mifwt_dwt1_fwd_tail): 2 = never (they answer
+                                      UNSUPPORTED / 0); analysis pairs: 0 = auto (rolling strips for 8 taps, else tiles), 1 = tiles only,
+                                      3 = rolling strips wherever they apply */
 #define MIFWT_OPT_PAIR_ROWS 9      /* >0 overrides the pair kernels' level-2 rows per tile (4, 6, 8, 12) / per strip segment (multiple of 8) */
 #define MIFWT_OPT_SYNC_STAGE 10    /* non-zero: tile kernels keep the workgroup barrier between staging and the horizontal pass (A/B) */
 int mifwt_set_option(int key, int value);
