@@ -140,6 +140,17 @@ int mifwt_dwt1_fwd_tail(int dtype, int filt_len, int mode, int64_t rows, int64_t
                         void* approx, int64_t approx_row_stride, void* const* details, const int64_t* detail_row_strides,
                         const double* dec_lo, const double* dec_hi, void* stream);
 
+/* The COARSE levels of a 1-D reconstruction in one launch — the leading trips of waverec's level loop
+ * (src/ptwt/conv_transform.py:184-199: stack + conv_transpose1d(stride 2) + crop per level), mirror of mifwt_dwt1_fwd_tail.
+ *   approx   coarsest approximation [rows, m]       details  HOST array of nlevels device ptrs, coarsest first: [rows, m_l]
+ *   out_len  HOST array: output samples of fused level l = 2 m_l - L + 2 - t, t in {0, 1} (the reference's end-crop,
+ *            src/ptwt/_util.py:231-244); m_{l+1} = out_len[l]
+ *   y        output of the last fused level [rows, out_len[nlevels - 1]]
+ * f32 / f64, even filt_len <= 32, every out_len <= mifwt_dwt1_fwd_tail_max_n(dtype), 2 <= nlevels <= 24. */
+int mifwt_dwt1_inv_tail(int dtype, int filt_len, int64_t rows, int64_t m, int nlevels, const void* approx, int64_t approx_row_stride,
+                        const void* const* details, const int64_t* detail_row_strides, const int32_t* out_len, void* y,
+                        int64_t y_row_stride, const double* rec_lo, const double* rec_hi, void* stream);
+
 /* Adjoints (transposes) of the two level maps, for reverse-mode differentiation.  The reference gets them from
  * ATen autograd through F.pad / _pad_symmetric + F.conv{1,2,3}d and torch.stack + F.conv_transpose{1,2,3}d
  * (same call sites as above); here they are explicit entry points that take the SAME descriptor as the
@@ -200,7 +211,8 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  *   11     fused 2-D analysis level on the matrix cores (banded-Toeplitz MFMA; f16 storage, even L in [18, 32])
  *   12 / 13  two fused 2-D analysis / synthesis levels per launch (mifwt_dwt2_fwd_pair / mifwt_dwt2_inv_pair; never
  *          returned by mifwt_kernel_id, which describes single-level calls)
- *   14     the deep levels of a 1-D analysis in one launch (mifwt_dwt1_fwd_tail; likewise not returned by mifwt_kernel_id) */
+ *   14 / 15  the deep levels of a 1-D analysis / the coarse levels of a 1-D synthesis in one launch (mifwt_dwt1_fwd_tail /
+ *          mifwt_dwt1_inv_tail; likewise not returned by mifwt_kernel_id) */
 int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 
 /* Library-wide diagnostic switches (process-global, meant for tests and A/B measurements).

@@ -90,6 +90,10 @@ def load_library() -> ctypes.CDLL:
     lib.mifwt_dwt1_fwd_tail.restype = ctypes.c_int
     lib.mifwt_dwt1_fwd_tail.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, vp,
                                         ctypes.c_int64, vp, ctypes.c_int64, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int64), dbl_p, dbl_p, vp]
+    lib.mifwt_dwt1_inv_tail.restype = ctypes.c_int
+    lib.mifwt_dwt1_inv_tail.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, vp, ctypes.c_int64,
+                                        ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32), vp,
+                                        ctypes.c_int64, dbl_p, dbl_p, vp]
     lib.mifwt_set_option.restype = ctypes.c_int
     lib.mifwt_set_option.argtypes = [ctypes.c_int, ctypes.c_int]
     if lib.mifwt_abi_version() != ABI_VERSION:
@@ -130,6 +134,7 @@ OPT_PAIR_ROWS = 9
 KID_PAIR = 12
 KID_INV_PAIR = 13
 KID_TAIL = 14
+KID_INV_TAIL = 15
 
 
 def set_option(key: int, value: int) -> None:
@@ -361,6 +366,49 @@ class HipLevelEngine:
         lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
         ap, yp = approx.data_ptr(), y.data_ptr()
         self._run(p, 1, approx, lambda ws, wsb, stream: lib.mifwt_dwt_inv(p.ref, ap, ptrs, yp, lo, hi, ws, wsb, stream))
+        return y
+
+    def synthesis_tail(self, approx: torch.Tensor, details: List[torch.Tensor], rec_lo: Sequence[float], rec_hi: Sequence[float],
+                       out_lens: Sequence[int]):
+        """The first ``len(details)`` (coarsest) levels of a 1-D reconstruction in ONE launch (C ABI ``mifwt_dwt1_inv_tail``):
+        ``approx`` [B, m], ``details[l]`` [B, m_l] coarsest first, ``out_lens[l]`` the (already trimmed) output length of level l
+        -> y [B, out_lens[-1]].  Returns None outside the kernel's envelope."""
+        _require_gpu(approx)
+        nl = len(details)
+        if approx.dim() != 2 or approx.dtype not in (torch.float32, torch.float64) or nl < 2 or nl > 24:
+            return None
+        lib = load_library()
+        flen = len(rec_lo)
+        rows, m0 = approx.shape
+        cap = lib.mifwt_dwt1_fwd_tail_max_n(_DTYPE_IDS[approx.dtype])
+        if rows == 0 or m0 == 0 or flen > 32 or m0 > cap or max(out_lens) > cap or min(out_lens) < 1:
+            return None
+        if approx.stride(1) != 1:
+            approx = approx.contiguous()
+        details = [t if t.stride(1) == 1 else t.contiguous() for t in details]
+        y = torch.empty((rows, int(out_lens[-1])), dtype=approx.dtype, device=approx.device)
+        det = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in details])
+        det_rs = (ctypes.c_int64 * nl)(*[t.stride(0) for t in details])
+        outs = (ctypes.c_int32 * nl)(*[int(v) for v in out_lens])
+        lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
+        p = _Plan()
+        p.ws_bytes, p.kid = 0, KID_INV_TAIL
+        d = LevelDesc()
+        d.ndim = 1
+        d.sig_extent[0] = int(out_lens[-1])
+        p.desc = d
+        ap, yp = approx.data_ptr(), y.data_ptr()
+        rc_box = []
+
+        def call(ws, wsb, stream):
+            rc = lib.mifwt_dwt1_inv_tail(_DTYPE_IDS[approx.dtype], flen, rows, m0, nl, ap, approx.stride(0), det, det_rs, outs, yp,
+                                         y.stride(0), lo, hi, stream)
+            rc_box.append(rc)
+            return 0 if rc == -2 else rc  # "unsupported" is an answer here, not an error
+
+        self._run(p, 1, approx, call)
+        if rc_box and rc_box[0] == -2:
+            return None
         return y
 
     def synthesis_pair(self, approx2: torch.Tensor, details2: List[torch.Tensor], details1: List[torch.Tensor],

@@ -483,4 +483,15 @@ int mifwt_dwt1_fwd_tail(int dtype, int filt_len, int mode, int64_t rows, int64_t
   return dwt1_tail(dtype, filt_len, mode, rows, n, nlevels, x, x_row_stride, approx, approx_row_stride, details, detail_row_strides,
                    dec_lo, dec_hi, static_cast<hipStream_t>(stream));
 }
+// The coarse levels of a 1-D reconstruction in one launch (mifwt_dwt1_tail.hip).
+int mifwt_dwt1_inv_tail(int dtype, int filt_len, int64_t rows, int64_t m, int nlevels, const void* approx, int64_t approx_row_stride,
+                        const void* const* details, const int64_t* detail_row_strides, const int32_t* out_len, void* y,
+                        int64_t y_row_stride, const double* rec_lo, const double* rec_hi, void* stream) {
+  if (!approx || !details || !detail_row_strides || !out_len || !y || !rec_lo || !rec_hi) return MIFWT_ERR_BADARG;
+  if (!idwt1_tail_supported(dtype, filt_len, rows, m, nlevels, out_len)) return MIFWT_ERR_UNSUPPORTED;
+  for (int l = 0; l < nlevels; ++l)
+    if (!details[l]) return MIFWT_ERR_BADARG;
+  return idwt1_tail(dtype, filt_len, rows, m, nlevels, approx, approx_row_stride, details, detail_row_strides, out_len, y, y_row_stride,
+                    rec_lo, rec_hi, static_cast<hipStream_t>(stream));
+}
 }  // extern "C"

@@ -8,7 +8,9 @@
 // ping-pongs between two LDS buffers and only the last one is stored.  Any boundary mode (the general index map: deep levels
 // are shorter than the filter and fold repeatedly), any even filter length up to 32 taps, f32 / f64 in their own precision.
 //   c_lo/hi[k] = sum_m h_lo/hi[m] x_ext[2k + 1 - m],  k < floor((n + L - 1) / 2)     
-// Traffic is negligible; the point is one launch instead of nlevels.
+// Traffic is negligible; the point is one launch instead of nlevels.  The same for the COARSE levels of waverec (kernel id 15,
+// src/ptwt/conv_transform.py:184-199: stack + conv_transpose1d(stride 2) + crop per level): the row grows in LDS until the
+// next level's output would no longer fit.
 #include "mifwt_common.h"
 
 namespace mifwt {
@@ -102,6 +104,58 @@ __global__ void __launch_bounds__(kTailThreads) dwt1_tail_kernel(const Dwt1TailA
   for (int i = tid; i < n; i += kTailThreads) ar[i] = A[i];
 }
 
+struct Idwt1TailArgs {
+  const void* approx;            // coarsest approximation [rows, m0]
+  const void* det[kTailMaxLevels];  // per fused level (coarsest first): detail coefficients [rows, m_l]
+  void* y;                       // output of the last fused level [rows, out_len[nlevels - 1]]
+  int64_t approx_rs, y_rs, det_rs[kTailMaxLevels];
+  int out_len[kTailMaxLevels];   // output samples per level (2 m - L + 2 - trim): the next level's coefficient count
+  int m0, nlevels, filt_len, cap;
+  double lo[kTailMaxTaps], hi[kTailMaxTaps];  // rec_lo / rec_hi, PyWavelets order
+};
+
+// polyphase synthesis, cropped:  y[2p + r] = sum_{i < L/2} g_lo[L-2-2i+r] a[p+i] + g_hi[L-2-2i+r] d[p+i]  (coefficients past the
+// end read as zero), the same formula as the 2-D synthesis kernels apply per axis
+template <typename T>
+__global__ void __launch_bounds__(kTailThreads) idwt1_tail_kernel(const Idwt1TailArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tail_lds[];
+  T* A = reinterpret_cast<T*>(tail_lds);
+  T* B = A + a.cap;
+  __shared__ T tlo[kTailMaxTaps], thi[kTailMaxTaps];
+  const int tid = threadIdx.x, L = a.filt_len, HLn = a.filt_len >> 1;
+  const int64_t row = blockIdx.x;
+  if (tid < L) {
+    tlo[tid] = (T)a.lo[tid];
+    thi[tid] = (T)a.hi[tid];
+  }
+  const T* __restrict__ ar = static_cast<const T*>(a.approx) + row * a.approx_rs;
+  for (int i = tid; i < a.m0; i += kTailThreads) A[i] = ar[i];
+  __syncthreads();
+  int m = a.m0;
+  for (int lvl = 0; lvl < a.nlevels; ++lvl) {
+    const int n = a.out_len[lvl];
+    const T* __restrict__ dr = static_cast<const T*>(a.det[lvl]) + row * a.det_rs[lvl];
+    for (int j = tid; j < n; j += kTailThreads) {
+      const int p = j >> 1, r = j & 1;
+      T acc = T(0);
+      for (int i = 0; i < HLn; ++i) {
+        const int c = p + i;
+        const T av = c < m ? A[c] : T(0), dv = c < m ? dr[c] : T(0);
+        acc = __builtin_fma(tlo[L - 2 - 2 * i + r], av, acc);
+        acc = __builtin_fma(thi[L - 2 - 2 * i + r], dv, acc);
+      }
+      B[j] = acc;
+    }
+    __syncthreads();
+    T* tmp = A;
+    A = B;
+    B = tmp;
+    m = n;
+  }
+  T* __restrict__ yr = static_cast<T*>(a.y) + row * a.y_rs;
+  for (int i = tid; i < m; i += kTailThreads) yr[i] = A[i];
+}
+
 }  // namespace
 
 // rows of at most this many samples can start the fused tail (both LDS buffers within 96 KB)
@@ -157,6 +211,64 @@ int dwt1_tail(int dtype, int filt_len, int mode, int64_t rows, int64_t n0, int n
     hipLaunchKernelGGL((dwt1_tail_kernel<double>), dim3((unsigned)rows), dim3(kTailThreads), lds, stream, a);
   else
     hipLaunchKernelGGL((dwt1_tail_kernel<float>), dim3((unsigned)rows), dim3(kTailThreads), lds, stream, a);
+  return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
+}
+
+bool idwt1_tail_supported(int dtype, int filt_len, int64_t rows, int64_t m0, int nlevels, const int* out_len) {
+  if (g_options[MIFWT_OPT_FORCE_GENERIC] || g_options[MIFWT_OPT_PAIR_MODE] == 2) return false;
+  if (dtype != MIFWT_F32 && dtype != MIFWT_F64) return false;
+  if (filt_len < 2 || filt_len > kTailMaxTaps || (filt_len & 1)) return false;
+  if (rows < 1 || rows > (int64_t(1) << 30) || nlevels < 2 || nlevels > kTailMaxLevels || m0 < 1 || !out_len) return false;
+  int64_t m = m0;
+  for (int l = 0; l < nlevels; ++l) {
+    const int64_t full = 2 * m - filt_len + 2;  // a level's output is this or one less (the reference's end-crop)
+    if (out_len[l] < 1 || (out_len[l] != full && out_len[l] != full - 1)) return false;
+    m = out_len[l];
+    if (m > dwt1_tail_max_n(dtype)) return false;
+  }
+  return m0 <= dwt1_tail_max_n(dtype);
+}
+
+int idwt1_tail(int dtype, int filt_len, int64_t rows, int64_t m0, int nlevels, const void* approx, int64_t approx_row_stride,
+               const void* const* details, const int64_t* detail_row_strides, const int* out_len, void* y, int64_t y_row_stride,
+               const double* lo, const double* hi, hipStream_t stream) {
+  if (!idwt1_tail_supported(dtype, filt_len, rows, m0, nlevels, out_len)) return MIFWT_ERR_UNSUPPORTED;
+  Idwt1TailArgs a;
+  a.approx = approx;
+  a.y = y;
+  a.approx_rs = approx_row_stride;
+  a.y_rs = y_row_stride;
+  int big = (int)m0;
+  for (int l = 0; l < nlevels; ++l) {
+    a.det[l] = details[l];
+    a.det_rs[l] = detail_row_strides[l];
+    a.out_len[l] = out_len[l];
+    big = out_len[l] > big ? out_len[l] : big;
+  }
+  a.m0 = (int)m0;
+  a.nlevels = nlevels;
+  a.filt_len = filt_len;
+  for (int t = 0; t < filt_len; ++t) {
+    a.lo[t] = lo[t];
+    a.hi[t] = hi[t];
+  }
+  const int esz = dtype == MIFWT_F64 ? 8 : 4;
+  a.cap = big < 32 ? 32 : ((big + 3) & ~3);  // both buffers hold the longest row of the walk
+  const size_t lds = (size_t)2 * a.cap * esz;
+  static bool attr_set[2] = {false, false};
+  const int ti = dtype == MIFWT_F64 ? 1 : 0;
+  if (!attr_set[ti]) {
+    const int max_lds = 2 * (dwt1_tail_max_n(dtype) + 8) * esz;
+    if (ti)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&idwt1_tail_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    else
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&idwt1_tail_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    attr_set[ti] = true;
+  }
+  if (ti)
+    hipLaunchKernelGGL((idwt1_tail_kernel<double>), dim3((unsigned)rows), dim3(kTailThreads), lds, stream, a);
+  else
+    hipLaunchKernelGGL((idwt1_tail_kernel<float>), dim3((unsigned)rows), dim3(kTailThreads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 

@@ -44,6 +44,15 @@ class OracleLevelEngine:
         buf1[:, 0] = float("nan")
         return buf1, buf2
 
+    def synthesis_tail(self, approx, details, rec_lo, rec_hi, out_lens):
+        """Stand-in for the fused coarse 1-D synthesis levels (same contract as HipLevelEngine.synthesis_tail)."""
+        if approx.dim() != 2 or max(out_lens) > 64 or len(details) < 2:
+            return None
+        cur = approx
+        for d, n in zip(details, out_lens):
+            cur = self.synthesis(cur, [d], rec_lo, rec_hi, [n])
+        return cur
+
     def synthesis_pair(self, approx2, details2, details1, rec_lo, rec_hi, out_extent):
         """Stand-in for the two-levels-per-launch synthesis call (same contract as HipLevelEngine.synthesis_pair)."""
         if approx2.dim() != 3 or min(out_extent) < 16:

@@ -829,3 +829,32 @@ def test_dwt1_tail_fusion_vs_oracle_and_per_level(dtype):
     check_tree(c, O.wavedec(view.cpu().double().numpy(), "db3", level=9), tol, "tail strided rows")
     rec = ptwt_amd.waverec(c, "db3")
     assert (rec[..., :8000] - view).abs().max().item() < (1e-12 if dtype == torch.float64 else 5e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_idwt1_tail_fusion_vs_oracle_and_per_level(dtype):
+    """waverec with the fused coarse levels (mifwt_dwt1_inv_tail, kernel id 15) against the fp64 oracle and the per-level
+    kernels: odd and even lengths (with and without the reference's end-crop between levels), rows that outgrow the LDS
+    limit mid-way (the remaining levels run one by one), levels shorter than the filter."""
+    tol = 1e-12 if dtype == torch.float64 else 2e-6
+    rng = np.random.default_rng(41)
+    for wavelet, shape, level in [("haar", (1, 4096), None), ("db4", (3, 5001), None), ("db5", (2, 40003), 8), ("sym16", (2, 3000), None),
+                                  ("db2", (5, 33), None), ("db8", (4, 1000), 6)]:
+        x = rng.standard_normal(shape)
+        want_c = O.wavedec(x, wavelet, level=level)
+        want = O.waverec(want_c, wavelet)
+        cg = [torch.from_numpy(c).to(dtype).to(dev()) for c in want_c]
+        _engine.level_events = []
+        try:
+            got = ptwt_amd.waverec(cg, wavelet)
+            kids = [e[1] for e in _engine.level_events]
+        finally:
+            _engine.level_events = None
+        assert kids[0] == _engine.KID_INV_TAIL, (wavelet, shape, kids)
+        assert got.shape == want.shape and G.relerr(to_np(got), want) < tol, (wavelet, shape)
+        _engine.set_option(_engine.OPT_PAIR_MODE, 2)
+        try:
+            single = ptwt_amd.waverec(cg, wavelet)
+        finally:
+            _engine.set_option(_engine.OPT_PAIR_MODE, 0)
+        assert G.relerr(to_np(got), to_np(single)) < (1e-13 if dtype == torch.float64 else 2e-6)
