@@ -238,3 +238,66 @@ def test_cabi_descriptor_validation_and_dispatch():
     d.coef_extent[1] = 8  # inconsistent with (N + L - 1) // 2
     assert lib.mifwt_kernel_id(ctypes.byref(d), 0) == -1
     assert lib.mifwt_dwt_fwd(ctypes.byref(d), None, None, None, None, None, None, 0, None) == -1
+
+
+# ---- multi-level entry points: envelopes and argument checks run on the host ----------------------------------------------
+def _dense_desc(dtype_id, mode, flen, batch, sig, coef):
+    d = _engine.LevelDesc()
+    d.ndim, d.dtype, d.mode, d.filt_len, d.batch = 2, dtype_id, _engine.MODE_IDS[mode], flen, batch
+    for a in range(2):
+        d.sig_extent[a], d.coef_extent[a] = sig[a], coef[a]
+    d.sig_stride[0], d.sig_stride[1], d.sig_stride[2] = sig[0] * sig[1], sig[1], 1
+    for st in (d.approx_stride, d.detail_stride):
+        st[0], st[1], st[2] = 4 * coef[0] * coef[1], coef[1], 1
+    return d
+
+
+def _analysis_pair_descs(dtype_id, mode, flen, batch, shape):
+    c1 = [(n + flen - 1) // 2 for n in shape]
+    c2 = [(n + flen - 1) // 2 for n in c1]
+    return _dense_desc(dtype_id, mode, flen, batch, shape, c1), _dense_desc(dtype_id, mode, flen, batch, c1, c2)
+
+
+def test_cabi_multi_level_envelopes_without_gpu():
+    lib = _engine.load_library()
+    ref = ctypes.byref
+
+    def fwd_ok(dtype_id, mode, flen, shape):
+        d1, d2 = _analysis_pair_descs(dtype_id, mode, flen, 4, shape)
+        return lib.mifwt_dwt2_fwd_pair_supported(ref(d1), ref(d2))
+
+    assert fwd_ok(0, "reflect", 8, (1024, 1024)) == 1 and fwd_ok(0, "symmetric", 2, (256, 300)) == 1
+    assert fwd_ok(0, "periodic", 8, (1024, 1024)) == 0  # level 2 would need the far side of the plane
+    assert fwd_ok(0, "reflect", 16, (1024, 1024)) == 0    # long filters: per level
+    assert fwd_ok(1, "reflect", 8, (1024, 1024)) == 0     # f64: per level (tile kernels)
+    assert fwd_ok(0, "reflect", 8, (1024, 100)) == 0      # level-1 plane narrower than a strip
+    d1, d2 = _analysis_pair_descs(0, "reflect", 8, 4, (1024, 1024))
+    d2.sig_extent[0] += 1  # the second level must start from the first level's approximation
+    assert lib.mifwt_dwt2_fwd_pair_supported(ref(d1), ref(d2)) == 0
+    _engine.set_option(_engine.OPT_PAIR_MODE, 2)
+    try:
+        assert fwd_ok(0, "reflect", 8, (1024, 1024)) == 0
+    finally:
+        _engine.set_option(_engine.OPT_PAIR_MODE, 0)
+    # null pointers are refused before anything is launched
+    d1, d2 = _analysis_pair_descs(0, "reflect", 8, 4, (1024, 1024))
+    assert lib.mifwt_dwt2_fwd_pair(ref(d1), ref(d2), None, None, None, None, None, None, None) == -1
+
+    # synthesis pair: d2 = coarser level (its output = the finer level's coefficient extents), d1 = finer level
+    def inv_descs(flen, out, t=(0, 0)):
+        m1 = [(n + flen - 2 + tt) // 2 for n, tt in zip(out, t)]           # out = 2 m1 - L + 2 - t
+        m2 = [(n + flen - 2) // 2 + (n + flen - 2) % 2 for n in m1]         # m1 = 2 m2 - L + 2 - t'
+        return _dense_desc(0, "zero", flen, 2, m1, m2), _dense_desc(0, "zero", flen, 2, out, m1)
+
+    d2, d1 = inv_descs(8, (1024, 1024))
+    assert lib.mifwt_dwt2_inv_pair_supported(ref(d2), ref(d1)) == 1
+    d2s, d1s = inv_descs(8, (48, 1024))
+    assert lib.mifwt_dwt2_inv_pair_supported(ref(d2s), ref(d1s)) == 0  # fewer than two tiles of output rows
+    d2l, d1l = inv_descs(16, (1024, 1024))
+    assert lib.mifwt_dwt2_inv_pair_supported(ref(d2l), ref(d1l)) == 0
+    assert lib.mifwt_dwt2_inv_pair(ref(d2), ref(d1), None, None, None, None, None, None, None) == -1
+
+    # fused 1-D levels
+    assert lib.mifwt_dwt1_fwd_tail_max_n(0) == 16384 and lib.mifwt_dwt1_fwd_tail_max_n(1) == 8192
+    assert lib.mifwt_dwt1_fwd_tail(0, 8, 2, 4, 4096, 5, None, 4096, None, 0, None, None, None, None, None) == -1
+    assert lib.mifwt_dwt1_inv_tail(0, 8, 4, 100, 3, None, 100, None, None, None, None, 0, None, None, None) == -1
