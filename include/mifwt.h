@@ -116,6 +116,21 @@ int mifwt_dwt2_fwd_pair_supported(const mifwt_level_desc* d1, const mifwt_level_
 int mifwt_dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, const void* x, void* const* details1,
                         void* approx2, void* const* details2, const double* dec_lo, const double* dec_hi, void* stream);
 
+/* UP TO THREE consecutive 2-D analysis levels in one launch — `nlevels` trips of the reference's level loop
+ * (src/ptwt/conv_transform_2.py:142-149); none of the approximations in between reaches HBM (a pyramid returns only the detail
+ * bands of a level that is not the last, conv_transform_2.py:150-156).  descs[l] describes fused level l exactly as a
+ * mifwt_dwt_fwd call would (descs[l]->sig_extent == descs[l-1]->coef_extent; approx_stride of every level but the last and
+ * sig_stride of every level but the first are ignored).
+ *   details  HOST array of nlevels HOST arrays of 3 device ptrs: bands ad, da, dd of fused level l
+ *   approx   band aa of the last fused level
+ * Same sums as nlevels mifwt_dwt_fwd calls (summation order differs: agreement to rounding, not bit for bit).
+ * f32, even L <= 8, modes zero / constant / reflect / symmetric, unit innermost strides, input rows of a multiple of 4 samples
+ * that start on 16-byte boundaries, every fused plane at least 2 L samples per axis (mifwt_dwt2_fwd_pyramid_supported says
+ * 1 / 0); MIFWT_ERR_UNSUPPORTED otherwise, nothing launched.  Kernel id 16. */
+int mifwt_dwt2_fwd_pyramid_supported(int nlevels, const mifwt_level_desc* const* descs);
+int mifwt_dwt2_fwd_pyramid(int nlevels, const mifwt_level_desc* const* descs, const void* x, void* const* const* details, void* approx,
+                           const double* dec_lo, const double* dec_hi, void* stream);
+
 /* TWO consecutive 2-D synthesis levels in one launch — two trips of waverec2's level loop
  * (src/ptwt/conv_transform_2.py:222-249); the approximation between them (the coarser level's cropped output) never
  * reaches HBM.  d2 describes the COARSER level, d1 the finer one, exactly as two mifwt_dwt_inv calls would
@@ -212,7 +227,8 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  *   12 / 13  two fused 2-D analysis / synthesis levels per launch (mifwt_dwt2_fwd_pair / mifwt_dwt2_inv_pair; never
  *          returned by mifwt_kernel_id, which describes single-level calls)
  *   14 / 15  the deep levels of a 1-D analysis / the coarse levels of a 1-D synthesis in one launch (mifwt_dwt1_fwd_tail /
- *          mifwt_dwt1_inv_tail; likewise not returned by mifwt_kernel_id) */
+ *          mifwt_dwt1_inv_tail; likewise not returned by mifwt_kernel_id)
+ *   16     up to three fused 2-D analysis levels per launch (mifwt_dwt2_fwd_pyramid; not returned by mifwt_kernel_id) */
 int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 
 /* Library-wide diagnostic switches (process-global, meant for tests and A/B measurements).
@@ -227,7 +243,7 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 #define MIFWT_OPT_TILE_MODE 5      /* 2-D analysis: 0 = auto (LDS-tile kernel on small planes), 1 = always tile, 2 = never */
 #define MIFWT_OPT_TILE_ROWS 6      /* >0 overrides the tile kernels' output rows per tile */
 #define MIFWT_OPT_MFMA_MODE 7      /* 2-D analysis, f16 storage, 18..32 taps: 0 = matrix-core kernel, 2 = vector tile kernel */
-#define MIFWT_OPT_PAIR_MODE 8      /* multi-level launches (mifwt_dwt2_fwd_pair, mifwt_dwt2_inv_pair, mifwt_dwt1_fwd_tail): 2 = never (they answer
+#define MIFWT_OPT_PAIR_MODE 8      /* multi-level launches (mifwt_dwt2_fwd_pyramid, mifwt_dwt2_fwd_pair, mifwt_dwt2_inv_pair, mifwt_dwt1_fwd_tail): 2 = never (they answer
                                       UNSUPPORTED / 0); analysis pairs: 0 = auto (rolling strips for 8 taps, else tiles), 1 = tiles only,
                                       3 = rolling strips wherever they apply */
 #define MIFWT_OPT_PAIR_ROWS 9      /* >0 overrides the pair kernels' level-2 rows per tile (4, 6, 8, 12) / per strip segment (multiple of 8) */

@@ -81,6 +81,11 @@ def load_library() -> ctypes.CDLL:
     lib.mifwt_dwt2_fwd_pair_supported.argtypes = [desc_p, desc_p]
     lib.mifwt_dwt2_fwd_pair.restype = ctypes.c_int
     lib.mifwt_dwt2_fwd_pair.argtypes = [desc_p, desc_p, vp, ctypes.POINTER(vp), vp, ctypes.POINTER(vp), dbl_p, dbl_p, vp]
+    vpp = ctypes.POINTER(vp)
+    lib.mifwt_dwt2_fwd_pyramid_supported.restype = ctypes.c_int
+    lib.mifwt_dwt2_fwd_pyramid_supported.argtypes = [ctypes.c_int, ctypes.POINTER(desc_p)]
+    lib.mifwt_dwt2_fwd_pyramid.restype = ctypes.c_int
+    lib.mifwt_dwt2_fwd_pyramid.argtypes = [ctypes.c_int, ctypes.POINTER(desc_p), vp, ctypes.POINTER(vpp), vp, dbl_p, dbl_p, vp]
     lib.mifwt_dwt2_inv_pair_supported.restype = ctypes.c_int
     lib.mifwt_dwt2_inv_pair_supported.argtypes = [desc_p, desc_p]
     lib.mifwt_dwt2_inv_pair.restype = ctypes.c_int
@@ -135,6 +140,7 @@ KID_PAIR = 12
 KID_INV_PAIR = 13
 KID_TAIL = 14
 KID_INV_TAIL = 15
+KID_PYRAMID = 16
 
 
 def set_option(key: int, value: int) -> None:
@@ -281,6 +287,53 @@ class HipLevelEngine:
         self._run(p1, 0, x, lambda ws, wsb, stream: lib.mifwt_dwt2_fwd_pair(p1.ref, p2.ref, xp, p1.ptrs, b2, p2.ptrs, lo, hi, stream),
                   kid=KID_PAIR)
         return buf1, buf2
+
+    def analysis_pyramid(self, x: torch.Tensor, dec_lo: Sequence[float], dec_hi: Sequence[float], mode_id: int, nlevels: int):
+        """Up to THREE consecutive 2-D analysis levels in one launch (C ABI ``mifwt_dwt2_fwd_pyramid``): ``x`` [B, H, W] -> a list of
+        buffers laid out like :meth:`analysis` results, finest first; plane 0 (the approximation) is written only in the LAST one —
+        the others are intermediates that never leave the chip.  Fuses as many of the ``nlevels`` requested levels as the library
+        serves for this geometry (possibly fewer); returns None when it serves none."""
+        _require_gpu(x)
+        if x.dim() != 3 or x.dtype != torch.float32:
+            return None
+        flen = len(dec_lo)
+        key = ("pyr", x.shape, x.stride(), mode_id, flen, min(nlevels, 3), ROW_ALIGN)
+        plan = _plans.get(key)
+        if plan is None:
+            if len(_plans) > 4096:
+                _plans.clear()
+            lib = load_library()
+            plans = [self._analysis_plan(x, flen, mode_id)]
+            while len(plans) < min(nlevels, 3) and not plans[-1].empty:
+                pl = plans[-1]
+                lvl = torch.empty(pl.alloc_shape, dtype=x.dtype, device="meta")
+                if pl.view_last is not None:
+                    lvl = lvl[..., : pl.view_last]
+                plans.append(self._analysis_plan(lvl[:, 0], flen, mode_id))
+            n_ok = 0
+            if not any(pl.empty for pl in plans):
+                for n in range(len(plans), 0, -1):
+                    refs = (ctypes.POINTER(LevelDesc) * n)(*[ctypes.pointer(pl.desc) for pl in plans[:n]])
+                    if lib.mifwt_dwt2_fwd_pyramid_supported(n, refs):
+                        n_ok = n
+                        break
+            plan = _plans[key] = (plans[:n_ok], n_ok)
+        plans, n_ok = plan
+        if n_ok == 0:
+            return None
+        bufs = []
+        for pl in plans:
+            b = torch.empty(pl.alloc_shape, dtype=x.dtype, device=x.device)
+            bufs.append(b if pl.view_last is None else b[..., : pl.view_last])
+        # per-call pointer arrays: cached plans are shared between threads
+        rows = [(ctypes.c_void_p * 3)(*[b.data_ptr() + s * pl.plane_bytes for s in (1, 2, 3)]) for b, pl in zip(bufs, plans)]
+        det = (ctypes.POINTER(ctypes.c_void_p) * n_ok)(*[ctypes.cast(r, ctypes.POINTER(ctypes.c_void_p)) for r in rows])
+        refs = (ctypes.POINTER(LevelDesc) * n_ok)(*[ctypes.pointer(pl.desc) for pl in plans])
+        lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
+        lib = _lib
+        xp, ap = x.data_ptr(), bufs[-1].data_ptr()
+        self._run(plans[0], 0, x, lambda ws, wsb, stream: lib.mifwt_dwt2_fwd_pyramid(n_ok, refs, xp, det, ap, lo, hi, stream), kid=KID_PYRAMID)
+        return bufs
 
     def analysis_tail(self, x: torch.Tensor, dec_lo: Sequence[float], dec_hi: Sequence[float], mode_id: int, nlevels: int):
         """The remaining ``nlevels`` levels of a 1-D decomposition in ONE launch (C ABI ``mifwt_dwt1_fwd_tail``): ``x`` [B, N] ->

@@ -314,6 +314,20 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
         mode_id = _mode_id(mode)
         _check_pad(cur.shape[1:], flen, "reflect" if mode is None else mode)
         differentiable = torch.is_grad_enabled() and (cur.requires_grad or tap_t is not None)
+        if ndim == 2 and not differentiable:
+            # up to three levels per launch, the approximations between them kept on chip (mifwt_dwt2_fwd_pyramid); the pad
+            # checks of the fused trips are the reference's own and run before anything is launched
+            want = min(3, level - done)
+            ns = list(cur.shape[1:])
+            for _l in range(want):
+                _check_pad(ns, flen, "reflect" if mode is None else mode)
+                ns = [(n + flen - 1) // 2 for n in ns]
+            pyr = _engine.ENGINE.analysis_pyramid(cur, dec_lo, dec_hi, mode_id, want)
+            if pyr is not None:
+                bufs.extend(pyr)
+                cur = pyr[-1][:, 0]
+                done += len(pyr)
+                continue
         if ndim == 2 and level - done >= 2 and not differentiable:
             # two levels per launch, the approximation between them kept on chip (mifwt_dwt2_fwd_pair); the second
             # level's reflect / periodic pad check is the reference's own (it would raise inside the next trip)

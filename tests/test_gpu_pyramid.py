@@ -1,0 +1,156 @@
+"""GPU parity tests (``-m gpu``) of the multi-level launch ``mifwt_dwt2_fwd_pyramid`` (kernel id 16: up to three 2-D analysis
+levels per launch, solo column strips + loader wave, mifwt_dwt2_fwd_pyr.hip) against the fp64 numpy oracle.
+
+Tolerance: fp32 <= 1e-6 norm-wise per sub-band vs the fp64 oracle.  Every case asserts that the pyramid kernel is
+the one that ran (``_engine.level_events``), so a silent per-level fallback cannot pass.
+"""
+import numpy as np
+import pytest
+import torch
+
+import ptwt_amd
+from oracle import fwt_oracle as O
+from ptwt_amd import _engine
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 1e-6
+MODES = ["reflect", "zero", "constant", "symmetric"]
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def run_traced(fn):
+    """Run ``fn`` with per-level events on; returns (result, [kernel ids of the launches])."""
+    _engine.level_events = []
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+        kids = [e[1] for e in _engine.level_events]
+    finally:
+        _engine.level_events = None
+    return out, kids
+
+
+def check(x, wavelet, mode, level, want_kids=None, seg_rows=0):
+    if seg_rows:
+        _engine.set_option(_engine.OPT_PAIR_ROWS, seg_rows)
+    try:
+        got, kids = run_traced(lambda: ptwt_amd.wavedec2(x.to(dev()), wavelet, mode=mode, level=level))
+    finally:
+        if seg_rows:
+            _engine.set_option(_engine.OPT_PAIR_ROWS, 0)
+    want = O.wavedec2(x.numpy().astype(np.float64), wavelet, mode=mode, level=level)
+    if want_kids is not None:
+        assert kids == want_kids, f"launches {kids}, expected {want_kids}"
+    gf, wf = G.flatten_coeffs(got), G.flatten_coeffs(want)
+    assert [n for n, _ in gf] == [n for n, _ in wf]
+    worst = 0.0
+    for (n, a), (_, b) in zip(gf, wf):
+        assert tuple(a.shape) == tuple(np.shape(b)), n
+        err = G.relerr(a.cpu().numpy(), b)
+        worst = max(worst, err)
+        assert err < TOL32, f"{wavelet} {mode} L{level} {tuple(x.shape)} {n}: rel err {err:.3e}"
+    return worst
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4"])
+def test_pyramid_three_levels_vs_oracle(wavelet, mode):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 200, 328, generator=g, dtype=torch.float32)  # several strips, one workgroup per image
+    check(x, wavelet, mode, 3, want_kids=[_engine.KID_PYRAMID])
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("level", [1, 2])
+def test_pyramid_one_and_two_levels(level, mode):
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 131, 260, generator=g, dtype=torch.float32)  # odd height: the extra pad row of the reference
+    check(x, "db4", mode, level, want_kids=[_engine.KID_PYRAMID])
+
+
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4"])
+def test_pyramid_row_segments(wavelet):
+    """Several row segments per image (prologues, top-aligned mirror rows, last segment takes the rest)."""
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(2, 300, 264, generator=g, dtype=torch.float32)
+    for mode in ("reflect", "symmetric", "zero"):
+        check(x, wavelet, mode, 3, want_kids=[_engine.KID_PYRAMID], seg_rows=8)
+        check(x, wavelet, mode, 2, want_kids=[_engine.KID_PYRAMID], seg_rows=16)
+
+
+def test_pyramid_many_strips_two_groups():
+    """A plane wide enough for more strips than one workgroup has compute waves."""
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(1, 96, 2304, generator=g, dtype=torch.float32)
+    for mode in ("reflect", "constant"):
+        check(x, "db4", mode, 3, want_kids=[_engine.KID_PYRAMID])
+        check(x, "db2", mode, 3, want_kids=[_engine.KID_PYRAMID])
+
+
+def test_pyramid_then_more_levels():
+    """Five levels: three in the pyramid launch, the rest by the per-level / pair kernels."""
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(2, 512, 512, generator=g, dtype=torch.float32)
+    _, kids = run_traced(lambda: ptwt_amd.wavedec2(x.to(dev()), "db4", level=5))
+    assert kids[0] == _engine.KID_PYRAMID and len(kids) >= 2
+    check(x, "db4", "reflect", 5)
+
+
+def test_pyramid_small_and_ragged_planes():
+    g = torch.Generator().manual_seed(16)
+    for shape in [(2, 64, 64), (1, 97, 132), (3, 70, 528), (1, 1000, 36), (2, 129, 1028)]:
+        x = torch.randn(*shape, generator=g, dtype=torch.float32)
+        for wavelet in ("haar", "db4"):
+            for level in (1, 2, 3):
+                check(x, wavelet, "reflect", level)
+                check(x, wavelet, "symmetric", level)
+
+
+def test_pyramid_config2_full_size_all_images():
+    """BASELINE config 2 (64 x 1024^2 db4 level 3): every image of the batch against an on-device fp64 run of the per-level tile
+    kernels (already pinned against the oracle and the goldens), 4 images against the numpy oracle itself."""
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(64, 1024, 1024, generator=g, dtype=torch.float32)
+    xd = x.to(dev())
+    got, kids = run_traced(lambda: ptwt_amd.wavedec2(xd, "db4", level=3))
+    assert kids == [_engine.KID_PYRAMID]
+    ref = ptwt_amd.wavedec2(xd.double(), "db4", level=3)
+    for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(ref)):
+        num = (a.double() - b).flatten(1).norm(dim=1)
+        den = b.flatten(1).norm(dim=1)
+        assert float((num / den).max()) < TOL32, n  # per image
+    for i in (0, 21, 42, 63):
+        want = O.wavedec2(x[i : i + 1].numpy().astype(np.float64), "db4", level=3)
+        for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(want)):
+            assert G.relerr(a[i : i + 1].cpu().numpy(), b) < TOL32, (i, n)
+
+
+def test_pyramid_linearity_and_roundtrip_full_size():
+    g = torch.Generator().manual_seed(18)
+    x = torch.randn(8, 1024, 1024, generator=g, dtype=torch.float32).to(dev())
+    y = torch.randn(8, 1024, 1024, generator=g, dtype=torch.float32).to(dev())
+    cx = ptwt_amd.wavedec2(x, "db4", level=3)
+    cy = ptwt_amd.wavedec2(y, "db4", level=3)
+    cz = ptwt_amd.wavedec2(2.0 * x - 0.5 * y, "db4", level=3)
+    for (n, a), (_, b), (_, c) in zip(G.flatten_coeffs(cx), G.flatten_coeffs(cy), G.flatten_coeffs(cz)):
+        assert float(((2.0 * a - 0.5 * b) - c).norm() / c.norm()) < 2e-6, n
+    rec = ptwt_amd.waverec2(cx, "db4")
+    assert float((rec - x).abs().max()) < 1e-5
+
+
+def test_pyramid_declines_what_it_cannot_serve():
+    lib = _engine.load_library()
+    x = torch.randn(2, 130, 130, device=dev())  # rows of 130 samples are not a multiple of 4
+    assert _engine.ENGINE.analysis_pyramid(x, *ptwt_amd._fwt.host_taps("db4")[:2], _engine.MODE_IDS["reflect"], 3) is None
+    x = torch.randn(2, 128, 128, device=dev())
+    assert _engine.ENGINE.analysis_pyramid(x, *ptwt_amd._fwt.host_taps("db4")[:2], _engine.MODE_IDS["periodic"], 3) is None
+    assert _engine.ENGINE.analysis_pyramid(x.double(), *ptwt_amd._fwt.host_taps("db4")[:2], _engine.MODE_IDS["reflect"], 3) is None
+    # results of unsupported geometries still come from the other kernels
+    got = ptwt_amd.wavedec2(torch.randn(2, 130, 130, device=dev()), "db4", level=2)
+    assert got[0].shape[-1] == 37
+    del lib
