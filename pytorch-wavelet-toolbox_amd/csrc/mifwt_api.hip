@@ -252,6 +252,7 @@ int pick_kernel(const mifwt_level_desc* d, int direction) {
 }  // namespace
 
 namespace mifwt {
+extern unsigned long long* g_pyr_prof;
 int g_options[16] = {0};
 }
 
@@ -264,6 +265,12 @@ int mifwt_set_option(int key, int value) {
 }
 
 int mifwt_abi_version(void) { return MIFWT_ABI_VERSION; }
+
+// diagnostic: device buffer of 2 x uint64 per wave of every workgroup of mifwt_dwt2_fwd_pyramid launches (NULL = off)
+int mifwt_pyr_profile_buffer(void* device_buffer) {
+  g_pyr_prof = static_cast<unsigned long long*>(device_buffer);
+  return MIFWT_OK;
+}
 
 const char* mifwt_strerror(int code) {
   switch (code) {

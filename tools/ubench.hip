@@ -82,6 +82,24 @@ __global__ void __launch_bounds__(256) k_valu(float* out, int iters, f2 tapA, f2
       for (int r = 0; r < 8; ++r)
 #pragma unroll
         for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(x), "v"(x));
+    } else if (MODE == 4) {  // the vertical-pass pattern: 8 accumulators x 8 distinct VGPR tap pairs x 2 samples, all distinct registers
+      f2 t[8], xx[2];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { t[i] = (f2){tapA.x + i, tapA.y - i}; asm volatile("" : "+v"(t[i])); }
+      xx[0] = x; xx[1] = (f2){x.y, x.x};
+      asm volatile("" : "+v"(xx[0]), "+v"(xx[1]));
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc[i]) : "v"(t[(i + r) & 7]), "v"(xx[r & 1]));
+    } else if (MODE == 5) {  // the same with the taps in SGPR pairs
+      f2 xx[2];
+      xx[0] = x; xx[1] = (f2){x.y, x.x};
+      asm volatile("" : "+v"(xx[0]), "+v"(xx[1]));
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc[i]) : "s"((i + r) & 1 ? tapA : tapB), "v"(xx[r & 1]));
     } else if (MODE == 3) {  // v_fmac_f32 with DPP wave_shl:1 source
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -417,14 +435,16 @@ int main(int argc, char** argv) {
     const int iters = 2000;
     for (int wps : {1, 2, 4}) {  // waves per SIMD = blocks of 256 threads per CU
       const int blocks = 256 * wps;
-      const char* names[4] = {"v_fma_f32 (sgpr tap)", "v_pk_fma_f32 sgpr-pair op_sel", "v_pk_fma_f32 vgpr", "v_fmac_f32_dpp wave_shl"};
-      for (int mode = 0; mode < 4; ++mode) {
+      const char* names[6] = {"v_fma_f32 (sgpr tap)", "v_pk_fma_f32 sgpr-pair op_sel", "v_pk_fma_f32 vgpr", "v_fmac_f32_dpp wave_shl", "v_pk_fma_f32 distinct vgpr taps", "v_pk_fma_f32 distinct, sgpr taps"};
+      for (int mode = 0; mode < 6; ++mode) {
         double ms = 0;
         auto go = [&](auto kern) { ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, iters, (f2){1.0f, 0.5f}, (f2){0.25f, 2.0f}); }, 3); };
         if (mode == 0) go(k_valu<0>);
         if (mode == 1) go(k_valu<1>);
         if (mode == 2) go(k_valu<2>);
         if (mode == 3) go(k_valu<3>);
+        if (mode == 4) go(k_valu<4>);
+        if (mode == 5) go(k_valu<5>);
         const double ninstr = 64.0 * iters;                       // per wave
         const double cyc = ms * 1e-3 * prop.clockRate * 1e3;      // at nominal clock
         printf("valu %-32s waves/SIMD=%d  %.4f ms  -> %.2f nominal cycles per wave-instruction per SIMD\n", names[mode], wps, ms, cyc / (ninstr * wps));
