@@ -97,7 +97,7 @@ def cpu_baseline(fn, shape, wavelet, level, mode, dtype):
     from oracle import torch_cpu_port as P
 
     cores = os.cpu_count() or 1
-    sample_b = min(shape[0], 32)
+    sample_b = min(shape[0], 64)  # config 2: the whole 64-image batch
     x = torch.randn(sample_b, *shape[1:], dtype=dtype)
     # oneDNN's conv does not scale to every core of a big host: probe a few thread counts on a small slice
     # and keep the fastest (reported as "cores")
@@ -130,25 +130,25 @@ def cpu_baseline(fn, shape, wavelet, level, mode, dtype):
 
 
 def profiled_traffic(workload, kernel_label=""):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate passes, FETCH_SIZE x2 gfx950 correction; tools/gpu_pmc.sh + tools/summarize_prof.py).
-    PMC counters cannot be collected from inside this process, so the value is the one measured when the
-    profile under profiles/ was taken; None if absent."""
+    """(HBM bytes per launch of the dominant kernel, name of the committed PMC summary it comes from): rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 gfx950 correction (tools/gpu_pmc_pyr.sh +
+    tools/summarize_prof.py).  PMC counters cannot be collected from inside this process, so the value is the one measured
+    when the newest profile of the SAME kernel under profiles/ was taken; (None, None) if there is none."""
     if workload != "wavedec2_db4_L3_64x1024x1024_f32":
-        return None
-    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+        return None, None
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
         if name.endswith("_pmc_level1.json") and not name.startswith("r01a"):
             try:
-                with open(os.path.join(ROOT, "profiles", name)) as f:
+                with open(os.path.join(pdir, name)) as f:
                     prof = json.load(f)
-                # only a profile of the SAME kernel family counts (the committed file names its kernel)
-                fam = "roll" if "roll" in kernel_label else ("pair" if "pair" in kernel_label else "tile")
+                fam = next((k for k in ("pyr", "roll", "pair", "tile") if k in kernel_label), "tile")
                 if fam not in prof.get("kernel", ""):
                     continue
-                return prof.get("hbm_traffic_bytes")
+                return prof.get("hbm_traffic_bytes"), "profiles/" + name
             except Exception:
-                return None
-    return None
+                return None, None
+    return None, None
 
 
 def main():
@@ -245,29 +245,37 @@ def main():
     torch.cuda.synchronize()
     events, _engine.level_events = _engine.level_events, None
 
-    # Dominant-kernel leg: the same K level-1 launches once more, back to back on the launch stream between ONE pair
-    # of HIP events (the per-launch event pairs above add a barrier packet on each side of every kernel: +5-8 % on a
-    # 100 us kernel), so that the figure is comparable with the rocprofv3 kernel-trace average under profiles/.
-    lvl1_b2b_ms = None
+    # Dominant-kernel leg: the first launch of a call (the multi-level kernel where it serves the call), 10 batches of 20
+    # launches back to back on the launch stream, one HIP event pair per batch (an event pair around every launch adds a
+    # barrier packet on each side of the kernel: +5-8 % on a 100 us kernel).  The count does not depend on --steps; the
+    # median batch is the figure, comparable with the rocprofv3 kernel-trace average under profiles/.
+    lvl1_b2b_ms = lvl1_b2b_min = None
+    fused_levels = 1
     first_kid = events[0][1] if events else -1
     if fn_name in ("wavedec2", "fswavedec2", "wavedec3", "wavedec"):
         taps = ptwt_amd._wavelets.host_taps(wavelet)
         mode_id = _engine.MODE_IDS[mode]
-        # the first launch of a call: one level, or levels 1+2 where the two-level kernel serves the call
-        if first_kid == _engine.KID_PAIR:
+        if first_kid == _engine.KID_PYRAMID:
+            fused_levels = len(_engine.ENGINE.analysis_pyramid(bufs[0], taps[0], taps[1], mode_id, level))
+            launch = lambda b: _engine.ENGINE.analysis_pyramid(b, taps[0], taps[1], mode_id, level)  # noqa: E731
+        elif first_kid == _engine.KID_PAIR:
+            fused_levels = 2
             launch = lambda b: _engine.ENGINE.analysis_pair(b, taps[0], taps[1], mode_id)  # noqa: E731
         else:
             launch = lambda b: _engine.ENGINE.analysis(b, taps[0], taps[1], mode_id)  # noqa: E731
-        for i in range(3):
+        for i in range(5):
             launch(bufs[i % len(bufs)])
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for i in range(args.steps):
-            launch(bufs[i % len(bufs)])
-        e1.record()
-        torch.cuda.synchronize()
-        lvl1_b2b_ms = e0.elapsed_time(e1) / args.steps
+        batches = []
+        for _b in range(10):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(20):
+                launch(bufs[i % len(bufs)])
+            e1.record()
+            torch.cuda.synchronize()
+            batches.append(e0.elapsed_time(e1) / 20)
+        lvl1_b2b_ms, lvl1_b2b_min = statistics.median(batches), min(batches)
 
     # Optional, outside the timed region (N > 1): what replicating the coefficients on every rank would cost — one
     # all_gather_into_tensor per level buffer over RCCL / xGMI (ptwt_amd.distributed.gather_coeffs).  Reported, never part
@@ -314,13 +322,20 @@ def main():
         kid1 = next((kid for (tag, kid, ext, s, e) in events if tuple(ext) == tuple(shape[1:])), -1)
         if kid1 == _engine.KID_PAIR:
             lvl1_b = pair_b
+        if kid1 == _engine.KID_PYRAMID:
+            # input + the detail bands of the fused levels + the approximation of the last fused one
+            lvl1_b = algorithmic_bytes(shape[0], shape[1:], flen, fused_levels, esize)[0]
         klabel = {1: "dwt2_fwd_stream_kernel (level 1)", 7: "dwt2_fwd_tile_kernel (level 1)", 0: "generic axis kernels (level 1)",
                   3: "streaming axis kernels (level 1)", 5: "fused 2-D planes + depth pass (level 1)", 9: "dwt3_fwd_tile_kernel (level 1)",
                   11: "dwt2_fwd_mfma_kernel (level 1)",
-                  12: ("dwt2_fwd_roll_kernel" if flen >= 8 else "dwt2_fwd_pair_kernel") + " (levels 1+2 in one launch)"}.get(kid1, f"kernel id {kid1} (level 1)")
+                  12: ("dwt2_fwd_roll_kernel" if flen >= 8 else "dwt2_fwd_pair_kernel") + " (levels 1+2 in one launch)",
+                  16: f"dwt2_fwd_pyr_kernel (levels 1-{fused_levels} in one launch)"}.get(kid1, f"kernel id {kid1} (level 1)")
         per_launch_event_ms = sum(lvl1) / max(1, len(lvl1))
         avg_ms = lvl1_b2b_ms if lvl1_b2b_ms else per_launch_event_ms
         achieved = lvl1_b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic, traffic_src = profiled_traffic(args.workload, klabel)
+        # the dominant kernel is one launch of a step: its steady-state duration cannot exceed the step's (2 % timer slack)
+        consistent = avg_ms <= ms_per_step * 1.02
         result = {
             "metric": "Msamples/s",
             "value": round(samples_per_step / (elapsed / args.steps) / 1e6, 1),
@@ -354,12 +369,15 @@ def main():
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "frac": round(achieved / HBM_PEAK_GBS, 4) if consistent else None,
+                "consistent": consistent,
                 "algorithmic_bytes_per_launch": lvl1_b,
                 "avg_launch_ms": round(avg_ms, 4),
-                "timing": f"one HIP event pair around {args.steps} back-to-back launches of that kernel on the launch stream (same rotating inputs); "
-                          f"with an event pair around every launch inside whole calls: {per_launch_event_ms:.4f} ms",
-                "traffic": profiled_traffic(args.workload, klabel),
+                "min_launch_ms": round(lvl1_b2b_min, 4) if lvl1_b2b_min else None,
+                "timing": "median of 10 batches of 20 back-to-back launches of that kernel on the launch stream, one HIP event pair per batch "
+                          f"(same rotating inputs; independent of --steps); with an event pair around every launch inside whole calls: {per_launch_event_ms:.4f} ms",
+                "traffic": traffic,
+                "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch of this kernel, not measured in this run)") if traffic_src else None,
             },
         }
         if gather_info is not None:

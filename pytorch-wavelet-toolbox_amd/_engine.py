@@ -136,6 +136,8 @@ OPT_TILE_ROWS = 6
 OPT_MFMA_MODE = 7
 OPT_PAIR_MODE = 8
 OPT_PAIR_ROWS = 9
+OPT_DEBUG = 11
+OPT_PYRAMID_MODE = 12
 KID_PAIR = 12
 KID_INV_PAIR = 13
 KID_TAIL = 14

@@ -770,7 +770,7 @@ static bool pyr_plan(int nlev, const mifwt_level_desc* const* d, PyrPlan* p) {
 }
 
 bool dwt2_fwd_pyr_supported(int nlev, const mifwt_level_desc* const* d) {
-  if (nlev < 1 || nlev > 3 || g_options[MIFWT_OPT_PAIR_MODE] == 2) return false;
+  if (nlev < 1 || nlev > 3 || g_options[MIFWT_OPT_PAIR_MODE] == 2 || g_options[MIFWT_OPT_PYRAMID_MODE] == 2) return false;
   const mifwt_level_desc* d0 = d[0];
   const int L = d0->filt_len;
   if (d0->ndim != 2 || d0->dtype != MIFWT_F32 || L < 2 || L > 8 || (L & 1)) return false;
@@ -824,7 +824,7 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
   a.cpw0 = p.cpw0;
   a.cpw = p.cpw;
   a.mode = d[0]->mode;
-  a.dbg = g_options[11];
+  a.dbg = g_options[MIFWT_OPT_DEBUG];
   a.prof = g_pyr_prof;
   for (int m = 0; m < L; ++m) a.tap[m] = (f2){(float)lo[m], (float)hi[m]};
   const int64_t nwg = d[0]->batch * p.nseg * p.ngroups;

@@ -44,6 +44,23 @@ class OracleLevelEngine:
         buf1[:, 0] = float("nan")
         return buf1, buf2
 
+    def analysis_pyramid(self, x, dec_lo, dec_hi, mode_id, nlevels):
+        """Stand-in for the up-to-three-levels-per-launch call: same return contract as HipLevelEngine.analysis_pyramid — plane 0
+        of every buffer but the last is NOT part of it, so it is poisoned here.  Like the kernel it serves rows of a multiple of
+        four samples only, every mode but periodic, filters up to 8 taps, and may fuse fewer levels than asked for."""
+        if x.dim() != 3 or x.dtype != torch.float32 or x.shape[2] % 4 or mode_id == 3 or len(dec_lo) > 8:
+            return None
+        bufs, cur = [], x
+        for _ in range(min(nlevels, 3)):
+            if min(cur.shape[1:]) < 2 * len(dec_lo):
+                break
+            buf = self.analysis(cur, dec_lo, dec_hi, mode_id)
+            bufs.append(buf)
+            cur = buf[:, 0].clone()
+        for b in bufs[:-1]:
+            b[:, 0] = float("nan")
+        return bufs or None
+
     def synthesis_tail(self, approx, details, rec_lo, rec_hi, out_lens):
         """Stand-in for the fused coarse 1-D synthesis levels (same contract as HipLevelEngine.synthesis_tail)."""
         if approx.dim() != 2 or max(out_lens) > 64 or len(details) < 2:

@@ -623,6 +623,18 @@ def test_full_size_config5_slice_properties():
 
 
 # ---- two analysis levels per launch (mifwt_dwt2_fwd_pair, kernel id 12) ----------------------------------------------
+@pytest.fixture(autouse=True)
+def _pair_tests_without_pyramid(request):
+    """The tests of the two-level kernels switch the three-level launch (kernel id 16, tests/test_gpu_pyramid.py) off: it would
+    serve most of their calls first."""
+    if request.node.name.startswith("test_pair_kernel"):
+        _engine.set_option(_engine.OPT_PYRAMID_MODE, 2)
+        yield
+        _engine.set_option(_engine.OPT_PYRAMID_MODE, 0)
+    else:
+        yield
+
+
 def _pair_vs_single(x, wavelet, mode, level, pair_mode=0):
     """wavedec2 with a pair kernel (pair_mode 0: the library's choice, 1: tiles, 3: rolling strips where they apply)
     against the per-level kernels on the same input: bit-identical."""
