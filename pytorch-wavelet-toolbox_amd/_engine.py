@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -160,6 +161,7 @@ class _Plan:
 
 
 _plans: dict = {}
+_tls = threading.local()
 _taps_cache: dict = {}
 
 
@@ -319,18 +321,29 @@ class HipLevelEngine:
                     if lib.mifwt_dwt2_fwd_pyramid_supported(n, refs):
                         n_ok = n
                         break
-            plan = _plans[key] = (plans[:n_ok], n_ok)
-        plans, n_ok = plan
+            keep = plans[:n_ok]
+            refs = (ctypes.POINTER(LevelDesc) * n_ok)(*[ctypes.pointer(pl.desc) for pl in keep]) if n_ok else None
+            plan = _plans[key] = (keep, n_ok, refs)
+        plans, n_ok, refs = plan
         if n_ok == 0:
             return None
         bufs = []
         for pl in plans:
             b = torch.empty(pl.alloc_shape, dtype=x.dtype, device=x.device)
             bufs.append(b if pl.view_last is None else b[..., : pl.view_last])
-        # per-call pointer arrays: cached plans are shared between threads
-        rows = [(ctypes.c_void_p * 3)(*[b.data_ptr() + s * pl.plane_bytes for s in (1, 2, 3)]) for b, pl in zip(bufs, plans)]
-        det = (ctypes.POINTER(ctypes.c_void_p) * n_ok)(*[ctypes.cast(r, ctypes.POINTER(ctypes.c_void_p)) for r in rows])
-        refs = (ctypes.POINTER(LevelDesc) * n_ok)(*[ctypes.pointer(pl.desc) for pl in plans])
+        # the band-pointer arrays are per thread: cached plans are shared between threads, and ctypes drops the GIL in the call
+        slot = _tls.__dict__.setdefault("pyr", {}).get(key)
+        if slot is None:
+            rows = [(ctypes.c_void_p * 3)() for _ in plans]
+            det = (ctypes.POINTER(ctypes.c_void_p) * n_ok)(*[ctypes.cast(r, ctypes.POINTER(ctypes.c_void_p)) for r in rows])
+            slot = _tls.pyr[key] = (rows, det)
+            if len(_tls.pyr) > 256:
+                _tls.pyr.clear()
+                _tls.pyr[key] = slot
+        rows, det = slot
+        for r, b, pl in zip(rows, bufs, plans):
+            base, pb = b.data_ptr(), pl.plane_bytes
+            r[0], r[1], r[2] = base + pb, base + 2 * pb, base + 3 * pb
         lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
         lib = _lib
         xp, ap = x.data_ptr(), bufs[-1].data_ptr()

@@ -19,6 +19,8 @@
 //     queue holds stores only and is never waited on: with both in one queue the in-order counter made every load wait
 //     for the acknowledgement of older stores (150 us for the same traffic).  One s_barrier per 4-row sub-step hands a
 //     landed sub-buffer over;
+//     (Measured and dropped: progress counters in LDS instead of the barriers — waves that spin on a counter steal issue
+//     slots from the waves they wait for: 145-170 us against 111-119 us with barriers on config 2.)
 //   * boundary extension: level-0 pad columns are copied inside LDS after the rows land, ring pad columns after a ring
 //     row is written (edge strips only, one read + one write per step); out-of-plane rows in zero mode are zero rows.
 // Results agree with the per-level kernels to rounding (different summation order), with the fp64 oracle within 1e-6.
@@ -70,7 +72,7 @@ struct PyrArgs {
   int cpw0, cpw;                          // level-NLEV columns of strip 0 / of the other strips
   int mode;
   unsigned long long* prof;  // optional per-wave cycle counts [workgroup][wave][total, in barriers] (mifwt_pyr_profile_buffer)
-  int dbg;  // A/B measurement switches (MIFWT_OPT_DEBUG): 1 = no stores, 2 = no loads, 4 = deep waves idle
+  int dbg;  // A/B measurement switches (MIFWT_OPT_DEBUG): 1 = no stores, 2 = no loads, 4 = deep waves idle, 16 = loader at default priority
   f2 tap[L];  // (dec_lo[m], dec_hi[m])
 };
 
@@ -307,6 +309,9 @@ __global__ void __launch_bounds__(64 * pyr_nwaves(NLEV)) dwt2_fwd_pyr_kernel(con
       }
     };
     constexpr int PER = kPyrSub * NW;  // DMA instructions per sub-step
+    // the loader is the youngest wave on its SIMD and instruction issue goes by priority, then age: without this the older
+    // waves beside it delay the one wave every other wave waits for (measured: 115.6 -> 111.4 us on config 2)
+    if (!(a.dbg & 16)) __builtin_amdgcn_s_setprio(3);
     __syncthreads();  // the other waves have initialised their LDS
 #pragma unroll
     for (int t = 0; t < kPyrNBuf - 1; ++t)
