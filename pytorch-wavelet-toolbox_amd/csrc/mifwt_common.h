@@ -143,8 +143,8 @@ bool dwt2_fwd_roll_supported(const mifwt_level_desc* d1, const mifwt_level_desc*
 int dwt2_fwd_roll(const mifwt_level_desc* d1, const mifwt_level_desc* d2, const void* x, void* const* details1,
                   void* approx2, void* const* details2, const double* dec_lo, const double* dec_hi, hipStream_t stream);
 
-// up to three consecutive 2-D analysis levels in one launch: solo column strips + loader wave, rolling vertical passes
-// (mifwt_dwt2_fwd_pyr.hip): f32, even L <= 8, every mode but periodic, 16-byte aligned input rows; d[l] = level l + 1,
+// up to three consecutive 2-D analysis levels in one launch: cooperative column groups + loader waves, rolling vertical
+// passes (mifwt_dwt2_fwd_pyr.hip): f32, even L <= 8, every mode but periodic, 16-byte aligned input rows; d[l] = level l + 1,
 // details[l] = its three detail planes, approx = the last level's approximation
 bool dwt2_fwd_pyr_supported(int nlev, const mifwt_level_desc* const* d);
 int dwt2_fwd_pyr(int nlev, const mifwt_level_desc* const* d, const void* x, void* const* const* details, void* approx,
