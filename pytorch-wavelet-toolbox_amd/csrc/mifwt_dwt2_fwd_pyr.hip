@@ -24,7 +24,8 @@
 //     same traffic).  One s_barrier per 4-row sub-step hands a landed sub-buffer over.  (Measured and dropped: progress
 //     counters in LDS instead of the barriers — waves that spin on a counter steal issue slots from the waves they wait
 //     for: 145-170 against 111-119 us; three columns per level-1 lane, i.e. 3 + 3 + 3 waves: 112.6 against 108.5 us — a
-//     lone wave runs at 8-9 cycles per instruction whatever shares its SIMD, so fewer, longer waves lose.)
+//     lone wave runs at 8-9 cycles per instruction whatever shares its SIMD, so fewer, longer waves lose; 3 to 6 staging
+//     sub-buffers: alike; pacing the requests with s_sleep instead of issuing a sub-step as one burst: 106-142 against 104 us.)
 //   * stores are never branched around: rows a segment does not own go through a buffer resource of size 0;
 //   * boundary extension: pad columns are filled inside LDS by the waves that read them, right before they do (a row is
 //     complete one barrier after it was written, whoever wrote its columns); out-of-plane rows in zero mode are zero rows.
@@ -82,6 +83,29 @@ __device__ __forceinline__ void pyr_dma_row(const uint32_t (&voff)[3], rsrc_t rs
                  "s_add_u32 m0, m0, 0x800\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %5 offen nt lds\n\t"
                  "s_add_u32 m0, m0, 0x800\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %5 offen nt lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "s"(rsrc), "s"(soff), "s"(lds0) : "memory", "scc");
+  }
+}
+
+// the L + 2 samples under a lane's two columns, from an LDS row whose float index of the first sample is congruent to
+// -(L - 2) modulo 4 (8-byte aligned for L = 4, 8: one 8-byte and then 16-byte reads; 16-byte aligned for L = 2, 6)
+template <int L>
+__device__ __forceinline__ void pyr_load_win2(const unsigned char* row, f2 (&w)[L / 2 + 1]) {
+  constexpr int HP = L / 2;
+  if constexpr (((L - 2) & 3) == 2) {
+    w[0] = *reinterpret_cast<const f2*>(row);
+#pragma unroll
+    for (int j = 0; j < HP / 2; ++j) {
+      const f4 v = *reinterpret_cast<const f4*>(row + 8 + 16 * j);
+      w[1 + 2 * j] = (f2){v.x, v.y};
+      w[2 + 2 * j] = (f2){v.z, v.w};
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < (HP + 1) / 2; ++j) {
+      const f4 v = *reinterpret_cast<const f4*>(row + 16 * j);
+      w[2 * j] = (f2){v.x, v.y};
+      w[2 * j + 1] = (f2){v.z, v.w};
+    }
   }
 }
 
@@ -176,10 +200,13 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
   const int o1 = pA[1] - NC1 * ((pA[1] - cA[1] + NC1 - 1) / NC1);
   const int g0 = max(0, 2 * o1 - HL) & ~3;  // level-0 column at the start of a staged row's body (16-byte aligned)
 
+  // ring-1 rows start sh1 floats later where that gives the level-2 windows (first sample: column 2 cA2 - HL) the alignment
+  // pyr_load_win2 expects, whatever the group's position
+  int sh1 = 0;
+  if constexpr (NLEV >= 2) sh1 = (2 * cA[2] - cA[1]) & 2;  // 2 cA2 - cA1 is 0 or L - 2
   unsigned char* const stage = smem + kPyrCtl;
   unsigned char* const ring1 = stage + a.nbuf * kPyrSub * a.pitch0;
   unsigned char* const ring2 = ring1 + (kPyrRing + 1) * a.pitch1;
-  const int nbuf_mask = a.nbuf - 1;  // nbuf is a power of two
 
   // =====================================================================================================================
   // loader wave
@@ -201,9 +228,11 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
     auto run = [&](auto nch_tag) {
       constexpr int NCH = decltype(nch_tag)::value;
       constexpr int PER = kPyrSub * NCH;
+      int ib = 0;  // staging sub-buffer of the next sub-step to be requested (sub-steps are requested in order)
       auto issue = [&](int t) {
+        const uint32_t buf = (uint32_t)ib * (uint32_t)(kPyrSub * a.pitch0) + (uint32_t)kPyrCtl + kPyrPad * 4u + 1024u * (uint32_t)widx;
+        ib = ib + 1 == a.nbuf ? 0 : ib + 1;
         if (a.dbg & 2) return;
-        const uint32_t buf = (uint32_t)(t & nbuf_mask) * (uint32_t)(kPyrSub * a.pitch0) + (uint32_t)kPyrCtl + kPyrPad * 4u + 1024u * (uint32_t)widx;
 #pragma unroll
         for (int kk = 0; kk < kPyrSub; ++kk) {
           const int e = E0 + kPyrSub * t + kk;
@@ -220,7 +249,9 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
       for (int t = 0; t < nsub; ++t) {
         // sub-step t must have landed; the ones requested after it may still be in flight
         const int later = min(ahead - 1, nsub1 - 1 - t);
-        if (later >= 4) pyr_wait_vm<(4 * PER > 63 ? 63 : 4 * PER)>();
+        if (later >= 6) pyr_wait_vm<(6 * PER > 63 ? 63 : 6 * PER)>();
+        else if (later == 5) pyr_wait_vm<(5 * PER > 63 ? 63 : 5 * PER)>();
+        else if (later == 4) pyr_wait_vm<(4 * PER > 63 ? 63 : 4 * PER)>();
         else if (later == 3) pyr_wait_vm<(3 * PER > 63 ? 63 : 3 * PER)>();
         else if (later == 2) pyr_wait_vm<(2 * PER > 63 ? 63 : 2 * PER)>();
         else if (later == 1) pyr_wait_vm<PER>();
@@ -271,7 +302,7 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
     // ring-1 positions of the lane's columns (columns outside the computed range go to float 0 of the row, which nobody reads)
     uint32_t rw[NC1];
 #pragma unroll
-    for (int k = 0; k < NC1; ++k) rw[k] = (real && c0 + k >= cA[1] && c0 + k < cB[1]) ? 4u * (uint32_t)(kPyrPad + c0 + k - cA[1]) : 0u;
+    for (int k = 0; k < NC1; ++k) rw[k] = (real && c0 + k >= cA[1] && c0 + k < cB[1]) ? 4u * (uint32_t)(kPyrPad + sh1 + c0 + k - cA[1]) : 0u;
     // level-0 pad fill, by the waves whose windows reach the pads: lane -> (row kk of the sub-step, pad column)
     uint32_t f_src = 0, f_dst = 0;
     bool f_on = false;
@@ -296,11 +327,9 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
 
     PyrAcc<L, NC1> acc;
     acc.clear();
-    constexpr int NW2 = NC1 + HP - 1 + 1;  // 8-byte pieces of a window (L - 2 + 2 NC1 samples)
-    auto load_win = [&](const unsigned char* row, f2 (&w)[NW2]) {
-#pragma unroll
-      for (int j = 0; j < NW2; ++j) w[j] = *reinterpret_cast<const f2*>(row + 8 * j);
-    };
+    int bi = 0;  // staging sub-buffer of the next sub-step
+    constexpr int NW2 = HP + 1;  // 8-byte pieces of a window (L + 2 samples; 2 o1 - g0 is a multiple of 4)
+    auto load_win = [&](const unsigned char* row, f2 (&w)[NW2]) { pyr_load_win2<L>(row, w); };
     // horizontal pass of the two rows of a pair, interleaved (2 NC1 independent chains)
     auto h_pair = [&](const f2 (&wa)[NW2], const f2 (&wb)[NW2], f2 (&ha)[NC1], f2 (&hb)[NC1]) {
 #pragma unroll
@@ -329,8 +358,8 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
         constexpr int half = decltype(half_tag)::value;
         pyr_barrier(a.prof, waited);  // the loader has seen this sub-step land
         if (s < nsteps1) {
-          const int t = 2 * s + half;
-          unsigned char* sb = stage + (t & nbuf_mask) * (kPyrSub * a.pitch0);
+          unsigned char* sb = stage + bi * (kPyrSub * a.pitch0);
+          bi = bi + 1 == a.nbuf ? 0 : bi + 1;
           if (f_any) {
             const float v = *reinterpret_cast<const float*>(sb + f_src);
             wave_lds_fence();
@@ -400,7 +429,7 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
       const int G = min(64 * widx + lane, gmax);
       const bool real = 64 * widx + lane <= gmax;
       const int c0 = cA[2] + 2 * G;  // (pA2 - cA2 is even: a lane lies inside or outside the owned range)
-      const uint32_t win = 4u * (uint32_t)(kPyrPad - HL + 2 * c0 - cA[1]);
+      const uint32_t win = 4u * (uint32_t)(kPyrPad + sh1 - HL + 2 * c0 - cA[1]);
       const bool full = real && c0 >= pA[2] && c0 + 1 < pB[2];
       const bool rag1 = real && c0 >= pA[2] && c0 + 1 == pB[2];
       const uint32_t sv2 = full ? 4u * (uint32_t)c0 : kPyrOob, sv1 = rag1 ? 4u * (uint32_t)c0 : kPyrOob;
@@ -419,8 +448,8 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
         const int e = left ? p - HL : a.W[1] + (p - HL);
         if (f_r < 4 && !zero_mode && (left ? wlo < 0 : whi >= a.W[1])) {
           f_on = true;
-          f_src = 4u * (uint32_t)(kPyrPad + fold(e, a.W[1]) - cA[1]);
-          f_dst = 4u * (uint32_t)(kPyrPad + e - cA[1]);
+          f_src = 4u * (uint32_t)(kPyrPad + sh1 + fold(e, a.W[1]) - cA[1]);
+          f_dst = 4u * (uint32_t)(kPyrPad + sh1 + e - cA[1]);
         }
       }
       const bool f_any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(f_on) != 0);
@@ -434,11 +463,8 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
       const int E1 = 2 * rA[2] - HL;
       PyrAcc<L, 2> acc;
       acc.clear();
-      constexpr int NW2 = (L + 2) / 2;
-      auto load_win = [&](const unsigned char* row, f2 (&w)[NW2]) {
-#pragma unroll
-        for (int j = 0; j < NW2; ++j) w[j] = *reinterpret_cast<const f2*>(row + 8 * j);
-      };
+      constexpr int NW2 = HP + 1;
+      auto load_win = [&](const unsigned char* row, f2 (&w)[NW2]) { pyr_load_win2<L>(row, w); };
       auto h_pair = [&](const f2 (&wa)[NW2], const f2 (&wb)[NW2], f2 (&ha)[2], f2 (&hb)[2]) {
 #pragma unroll
         for (int k = 0; k < HP; ++k) {
@@ -659,6 +685,10 @@ static bool pyr_plan(int nlev, const mifwt_level_desc* const* d, PyrPlan* p) {
   if (WN < min_cols || HN < 2 * (HL + 2)) return false;
   p->cpg0 = pyr_group_cols(L, nlev, true);
   p->cpg = pyr_group_cols(L, nlev, false);
+  if (nlev == 1) {  // level-1 lanes hold column pairs that start on even columns
+    p->cpg0 &= ~1;
+    p->cpg &= ~1;
+  }
   if (p->cpg < min_cols) return false;
   if (WN <= p->cpg0) {
     p->ngroups = 1;
@@ -697,8 +727,9 @@ static bool pyr_plan(int nlev, const mifwt_level_desc* const* d, PyrPlan* p) {
   p->pitch1 = nlev >= 2 ? ((kPyrPad + n[1] + HL + 8 + 3) & ~3) * 4 : 0;
   p->pitch2 = nlev >= 3 ? ((kPyrPad + n[2] + HL + 8 + 3) & ~3) * 4 : 0;
   const int rings = (kPyrRing + 1) * (p->pitch1 + p->pitch2);
-  p->nbuf = 8;
-  while (p->nbuf > 2 && (kPyrCtl + p->nbuf * kPyrSub * p->pitch0 + rings > 160 * 1024 || (p->nbuf - 1) * kPyrSub * ((p->nchunks + 1) / 2) > 63)) p->nbuf /= 2;
+  // as many staging sub-buffers as fit (the loaders run nbuf - 1 sub-steps ahead; a wave holds at most 63 requests in flight)
+  p->nbuf = g_options[MIFWT_OPT_PREFETCH_PAIRS] > 1 ? std::min(8, g_options[MIFWT_OPT_PREFETCH_PAIRS]) : 4;  // (3 .. 6 measured alike on config 2)
+  while (p->nbuf > 2 && (kPyrCtl + p->nbuf * kPyrSub * p->pitch0 + rings > 160 * 1024 || (p->nbuf - 1) * kPyrSub * ((p->nchunks + 1) / 2) > 63)) --p->nbuf;
   p->lds = kPyrCtl + p->nbuf * kPyrSub * p->pitch0 + rings;
   if (p->lds > 160 * 1024) return false;
   // one workgroup per CU (the segment count below is chosen for that; two small workgroups on one CU leave others idle)

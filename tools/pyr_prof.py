@@ -16,12 +16,12 @@ ptwt_amd.wavedec2(x, 'db4', level=3)
 torch.cuda.synchronize()
 lib.mifwt_pyr_profile_buffer(None)
 b = buf.view(nwg, nwave, 2).cpu().double()
-roles = ['L1'] * 5 + ['L2'] * 3 + ['L3'] + ['L2'] * 2 + ['L3'] * 4 + ['ld']
+roles = ['L1'] * 5 + ['L2'] * 3 + ['--'] + ['L3'] * 3 + ['--', 'L1', 'ld', 'ld']  # wave -> role (mifwt_dwt2_fwd_pyr.hip pyr_role)
 print('dbg', dbg)
 for seg in range(4):
     sel = b[seg::4]
     tot, wait = sel[..., 0], sel[..., 1]
-    print(f' segment {seg}: ' + '  '.join(f'w{w}{roles[w]}: {tot[:, w].mean()/1e3:.0f}k/{100*wait[:, w].mean()/max(tot[:, w].mean(),1):.0f}%' for w in range(15)))
+    print(f' segment {seg}: ' + '  '.join(f'w{w}{roles[w]}: {tot[:, w].mean()/1e3:.0f}k/{100*wait[:, w].mean()/max(tot[:, w].mean(),1):.0f}%' for w in range(12) if roles[w] != '--'))
 print(' all WGs: L1 total cycles mean %.0f max %.0f ; barrier share L1 %.1f%% deep %.1f%%' % (
     b[:, :5, 0].mean(), b[:, :5, 0].max(), 100 * b[:, :5, 1].sum() / b[:, :5, 0].sum(),
-    100 * b[:, 5:15, 1].sum() / b[:, 5:15, 0].sum()))
+    100 * b[:, [5, 6, 7, 9, 10, 11], 1].sum() / b[:, [5, 6, 7, 9, 10, 11], 0].sum()))

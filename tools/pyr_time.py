@@ -10,6 +10,8 @@ seg = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 dbg = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 if dbg: _engine.set_option(11, dbg)
 pm = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+nb = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+if nb: _engine.set_option(2, nb)
 if pm: _engine.set_option(12, pm)
 if seg: _engine.set_option(_engine.OPT_PAIR_ROWS, seg)
 xs = [torch.randn(*shape, device='cuda') for _ in range(3)]
@@ -29,4 +31,4 @@ for l in range(lev):
     n = [(v + L - 1) // 2 for v in n]; out += 3 * n[0] * n[1]
 out += n[0] * n[1]
 byts = 4 * shape[0] * (shape[1] * shape[2] + out)
-print(f"{wav} L{lev} {shape} seg={seg} dbg={dbg} pyramid_mode={pm}: median {res[3]*1e3:.1f} us  min {res[0]*1e3:.1f} us  -> {byts/res[3]/1e6:.0f} GB/s compulsory = {byts/res[3]/8e9:.3f} of 8 TB/s")
+print(f"{wav} L{lev} {shape} seg={seg} dbg={dbg} pyramid_mode={pm} nbuf={nb}: median {res[3]*1e3:.1f} us  min {res[0]*1e3:.1f} us  -> {byts/res[3]/1e6:.0f} GB/s compulsory = {byts/res[3]/8e9:.3f} of 8 TB/s")
