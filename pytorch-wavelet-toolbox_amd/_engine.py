@@ -157,7 +157,7 @@ class _Plan:
     the filled ``mifwt_level_desc``, the output allocation, scratch size and kernel id.  Cached, so a repeated
     call costs one ``torch.empty`` + one C call per level on the host."""
 
-    __slots__ = ("desc", "ref", "alloc_shape", "view_last", "nb", "plane_bytes", "ws_bytes", "kid", "empty", "ptrs")
+    __slots__ = ("desc", "ref", "alloc_shape", "view_last", "nb", "plane_bytes", "ws_bytes", "kid", "empty")
 
 
 _plans: dict = {}
@@ -173,6 +173,12 @@ def _taps_array(taps: Sequence[float]):
             _taps_cache.clear()
         arr = _taps_cache[key] = (ctypes.c_double * len(key))(*key)
     return arr
+
+
+def _band_ptrs(base: int, plane_bytes: int, n: int):
+    """Device pointers of planes 1 .. n of a level buffer, in a fresh ctypes array: cached plans are shared between threads and
+    ctypes releases the GIL during the C call, so a plan never owns an array that calls write to."""
+    return (ctypes.c_void_p * n)(*[base + s * plane_bytes for s in range(1, n + 1)])
 
 
 def _raw_stream(dev_index: int) -> int:
@@ -215,7 +221,6 @@ class HipLevelEngine:
         p.desc = d
         p.ref = ctypes.byref(d)
         p.plane_bytes = bstride[1] * esz
-        p.ptrs = (ctypes.c_void_p * (nb - 1))()
         p.ws_bytes = 0 if p.empty else lib.mifwt_workspace_bytes(p.ref, 0)
         p.kid = lib.mifwt_kernel_id(p.ref, 0)
         return p
@@ -237,9 +242,7 @@ class HipLevelEngine:
         if p.empty:
             return buf
         base = buf.data_ptr()
-        ptrs = p.ptrs
-        for s in range(1, p.nb):
-            ptrs[s - 1] = base + s * p.plane_bytes
+        ptrs = _band_ptrs(base, p.plane_bytes, p.nb - 1)
         lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
         lib = _lib
         xp = x.data_ptr()
@@ -282,13 +285,11 @@ class HipLevelEngine:
         if p2.view_last is not None:
             buf2 = buf2[..., : p2.view_last]
         b1, b2 = buf1.data_ptr(), buf2.data_ptr()
-        for s in range(1, 4):
-            p1.ptrs[s - 1] = b1 + s * p1.plane_bytes
-            p2.ptrs[s - 1] = b2 + s * p2.plane_bytes
+        ptrs1, ptrs2 = _band_ptrs(b1, p1.plane_bytes, 3), _band_ptrs(b2, p2.plane_bytes, 3)
         lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
         lib = _lib
         xp = x.data_ptr()
-        self._run(p1, 0, x, lambda ws, wsb, stream: lib.mifwt_dwt2_fwd_pair(p1.ref, p2.ref, xp, p1.ptrs, b2, p2.ptrs, lo, hi, stream),
+        self._run(p1, 0, x, lambda ws, wsb, stream: lib.mifwt_dwt2_fwd_pair(p1.ref, p2.ref, xp, ptrs1, b2, ptrs2, lo, hi, stream),
                   kid=KID_PAIR)
         return buf1, buf2
 
@@ -424,13 +425,10 @@ class HipLevelEngine:
                 d.detail_stride[a] = ref_stride[a]
             p.desc = d
             p.ref = ctypes.byref(d)
-            p.ptrs = (ctypes.c_void_p * len(details))()
             p.ws_bytes = lib.mifwt_workspace_bytes(p.ref, 1)
             p.kid = lib.mifwt_kernel_id(p.ref, 1)
             _plans[key] = p
-        ptrs = p.ptrs
-        for i, t in enumerate(details):
-            ptrs[i] = t.data_ptr()
+        ptrs = (ctypes.c_void_p * len(details))(*[t.data_ptr() for t in details])
         lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
         ap, yp = approx.data_ptr(), y.data_ptr()
         self._run(p, 1, approx, lambda ws, wsb, stream: lib.mifwt_dwt_inv(p.ref, ap, ptrs, yp, lo, hi, ws, wsb, stream))
@@ -528,14 +526,13 @@ class HipLevelEngine:
             p.ws_bytes = 0
             p.kid = KID_INV_PAIR
             ok = bool(lib.mifwt_dwt2_inv_pair_supported(ctypes.byref(d2), p.ref))
-            plan = _plans[key] = (p, d2, ctypes.byref(d2), (ctypes.c_void_p * 3)(), (ctypes.c_void_p * 3)(), ok)
-        p, _d2, ref2, ptrs2, ptrs1, ok = plan
+            plan = _plans[key] = (p, d2, ctypes.byref(d2), ok)
+        p, _d2, ref2, ok = plan
         if not ok:
             return None
         y = torch.empty((batch, *out_extent), dtype=approx2.dtype, device=approx2.device)
-        for i in range(3):
-            ptrs2[i] = details2[i].data_ptr()
-            ptrs1[i] = details1[i].data_ptr()
+        ptrs2 = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in details2])  # per call: plans are shared between threads
+        ptrs1 = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in details1])
         lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
         ap, yp = approx2.data_ptr(), y.data_ptr()
         self._run(p, 1, approx2, lambda ws, wsb, stream: lib.mifwt_dwt2_inv_pair(ref2, p.ref, ap, ptrs2, ptrs1, yp, lo, hi, stream))
@@ -572,14 +569,11 @@ class HipLevelEngine:
             p.desc, p.ref = d, ctypes.byref(d)
             p.nb = 1 << ndim
             p.plane_bytes = g_buf.stride(1) * g_buf.element_size()
-            p.ptrs = (ctypes.c_void_p * (p.nb - 1))()
             p.ws_bytes = lib.mifwt_workspace_bytes(p.ref, 2)
             p.kid = lib.mifwt_kernel_id(p.ref, 2)
             _plans[key] = p
         base = g_buf.data_ptr()
-        ptrs = p.ptrs
-        for s in range(1, p.nb):
-            ptrs[s - 1] = base + s * p.plane_bytes
+        ptrs = _band_ptrs(base, p.plane_bytes, p.nb - 1)
         lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
         gp = g_x.data_ptr()
         self._run(p, 2, g_buf, lambda ws, wsb, stream: lib.mifwt_dwt_fwd_adjoint(p.ref, base, ptrs, gp, lo, hi, ws, wsb, stream))
@@ -616,14 +610,11 @@ class HipLevelEngine:
             p.desc, p.ref = d, ctypes.byref(d)
             p.nb = nb
             p.plane_bytes = g_buf.stride(1) * g_buf.element_size()
-            p.ptrs = (ctypes.c_void_p * (nb - 1))()
             p.ws_bytes = lib.mifwt_workspace_bytes(p.ref, 3)
             p.kid = lib.mifwt_kernel_id(p.ref, 3)
             _plans[key] = p
         base = g_buf.data_ptr()
-        ptrs = p.ptrs
-        for s in range(1, nb):
-            ptrs[s - 1] = base + s * p.plane_bytes
+        ptrs = _band_ptrs(base, p.plane_bytes, nb - 1)
         lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
         yp = g_y.data_ptr()
         self._run(p, 3, g_y, lambda ws, wsb, stream: lib.mifwt_dwt_inv_adjoint(p.ref, yp, base, ptrs, lo, hi, ws, wsb, stream))
