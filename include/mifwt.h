@@ -186,7 +186,8 @@ int mifwt_dwt_inv_adjoint(const mifwt_level_desc* desc, const void* g_y, void* g
  * F.conv_transpose1d(groups 2, dilation) + mean).  `rows` independent rows of `n` contiguous samples, row strides in
  * elements, dilation = 2^level_index, periodic extension as an index map.  `scale` multiplies the result: 1 for swt,
  * 0.5 for iswt (the reference's mean over the two reconstructions); with reversed taps and the other scale each
- * call is the adjoint of the other (backward passes).  Even filt_len <= 20, f32 / f64 / f16.
+ * call is the adjoint of the other (backward passes).  Even filt_len <= MIFWT_MAX_FILT (2..20 unrolled, longer
+ * filters through a run-time tap loop), f32 / f64 / f16.
  *   fwd: lo/hi[n] = scale * sum_m dec_lo/hi[m] x[(n + D (L/2 - m)) mod N]
  *   inv: y[n]     = scale * sum_j rec_lo[j] a[(n + D (L/2 - 1 - j)) mod N] + rec_hi[j] d[(same)] */
 int mifwt_swt_fwd(int dtype, int filt_len, int64_t rows, int64_t n, int64_t dilation, const void* x, int64_t x_row_stride,

@@ -10,6 +10,8 @@
 // Bound: HBM (stride 1: N in, 2N out per level).  A lane produces 4 (f32 / f16) or 2 (f64) consecutive samples of one
 // row; every tap is one vector load of that run shifted by a multiple of D — the L-fold re-reads are served by the
 // vector L1 / L2.  Lanes whose window wraps around the row ends take a per-element modulo path.
+// Filter lengths 2..20 are compile-time instantiations (taps in SGPRs, fully unrolled); every other even length up to
+// MIFWT_MAX_FILT (db11+, sym11+, coif4+, dmey) runs the same kernel with L = 0: a run-time tap loop over a 128-entry tap table.
 #include "mifwt_axis_stream.h"
 
 namespace mifwt {
@@ -25,8 +27,9 @@ struct SwtArgs {
   int64_t in0_rs, in1_rs, out0_rs, out1_rs;  // row strides (elements); samples are contiguous
   int rows, n, dilation, nsegs;
   int64_t ntasks;
+  int filt_len;  // read by the run-time-length instantiation (L == 0) only
   A scale;
-  A lo[L], hi[L];
+  A lo[L ? L : MIFWT_MAX_FILT], hi[L ? L : MIFWT_MAX_FILT];
 };
 
 __device__ __forceinline__ int wrap(int i, int n) {
@@ -47,17 +50,19 @@ __global__ void __launch_bounds__(256) swt_kernel(const SwtArgs<typename ElemTra
   const int n0 = (seg * 64 + lane) * E;
   if (n0 >= a.n) return;
   const int D = a.dilation, N = a.n;
+  const int FL = L ? L : a.filt_len;
+  constexpr int kUnroll = L ? L : 1;
   // tap t reads the run starting at n0 + off(t):  analysis off = D (L/2 - t),  synthesis off = D (L/2 - 1 - t)
-  const int off_max = D * (L / 2 - (INVERSE ? 1 : 0));
-  const int off_min = off_max - D * (L - 1);
+  const int off_max = D * (FL / 2 - (INVERSE ? 1 : 0));
+  const int off_min = off_max - D * (FL - 1);
   const bool interior = n0 + off_min >= 0 && n0 + off_max + E <= N;
   const T* __restrict__ p0 = static_cast<const T*>(a.in0) + (int64_t)row * a.in0_rs;
   const T* __restrict__ p1 = INVERSE ? static_cast<const T*>(a.in1) + (int64_t)row * a.in1_rs : nullptr;
   A acc0[E], acc1[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) acc0[e] = acc1[e] = A(0);
-#pragma unroll
-  for (int t = 0; t < L; ++t) {
+#pragma unroll kUnroll
+  for (int t = 0; t < FL; ++t) {
     const int s = n0 + off_max - D * t;
     A v0[E], v1[E];
     if (interior) {
@@ -136,7 +141,8 @@ int swt_launch(const SwtCall& c) {
   a.nsegs = (int)nsegs;
   a.ntasks = nsegs * c.rows;
   a.scale = (A)c.scale;
-  for (int t = 0; t < L; ++t) {
+  a.filt_len = c.filt_len;
+  for (int t = 0; t < c.filt_len; ++t) {
     a.lo[t] = (A)c.lo[t];
     a.hi[t] = (A)c.hi[t];
   }
@@ -163,7 +169,7 @@ int swt_dispatch(const SwtCall& c) {
     case 16: return swt_launch<T, 16>(c);
     case 18: return swt_launch<T, 18>(c);
     case 20: return swt_launch<T, 20>(c);
-    default: return MIFWT_ERR_UNSUPPORTED;
+    default: return swt_launch<T, 0>(c);  // run-time tap loop
   }
 }
 
@@ -171,7 +177,7 @@ int swt_level(int inverse, int dtype, int filt_len, int64_t rows, int64_t n, int
               const void* in1, int64_t in0_rs, int64_t in1_rs, void* out0, void* out1, int64_t out0_rs, int64_t out1_rs,
               const double* lo, const double* hi, double scale, void* stream) {
   if (!in0 || !out0 || !lo || !hi || (inverse && !in1) || (!inverse && !out1)) return MIFWT_ERR_BADARG;
-  if (filt_len < 2 || (filt_len & 1) || rows < 0 || n < 1 || dilation < 1) return MIFWT_ERR_BADARG;
+  if (filt_len < 2 || (filt_len & 1) || filt_len > MIFWT_MAX_FILT || rows < 0 || n < 1 || dilation < 1) return MIFWT_ERR_BADARG;
   if (n > INT32_MAX / 8 || rows > INT32_MAX / 8 || dilation * filt_len > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
   SwtCall c = {inverse, filt_len, rows, n, dilation, in0, in1, out0, out1, in0_rs, in1_rs, out0_rs, out1_rs, lo, hi, scale,
                static_cast<hipStream_t>(stream)};

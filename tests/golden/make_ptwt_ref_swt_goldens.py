@@ -51,6 +51,10 @@ for wavelet in ("haar", "db2", "db4", "sym5", "db8", "bior2.2"):
 case((2, 32, 3), "db3", 2, 90, axis=1)
 case((2, 3, 48), "db2", 4, 91)          # dilation * L > N: the circular pad wraps more than once
 case((40,), "db2", 3, 92)
+# filters longer than the unrolled kernel instantiations (run-time tap loop): 22 .. 102 taps
+for k, (wavelet, shape, level) in enumerate((("db11", (2, 64), 2), ("db12", (2, 128), 3), ("sym13", (1, 96), 2), ("coif4", (3, 64), 3),
+                                             ("dmey", (2, 128), 2), ("db38", (1, 160), 2), ("coif17", (2, 256), 2))):
+    case(shape, wavelet, level, 100 + k)
 
 out = os.path.join(HERE, "ptwt_ref_swt.npz")
 np.savez_compressed(out, index=json.dumps(index), **store)
