@@ -30,6 +30,29 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
+# MIFWT_BENCH_DEVICE=cpu: control-flow dry run without a GPU (tests/test_bench_dryrun.py swaps the level engine for the
+# tests' CPU stand-in and launches this file under torch.distributed.run with the gloo backend): tensors on the host, the
+# synchronisation / event calls become host timers.  Never a measurement; the product engine itself has no CPU path.
+DEVICE_KIND = os.environ.get("MIFWT_BENCH_DEVICE", "cuda")
+
+
+def sync():
+    if DEVICE_KIND == "cuda":
+        torch.cuda.synchronize()
+
+
+class _HostEvent:
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+def new_event():
+    return torch.cuda.Event(enable_timing=True) if DEVICE_KIND == "cuda" else _HostEvent()
+
+
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 
 WORKLOADS = {
@@ -41,6 +64,8 @@ WORKLOADS = {
     "fswavedec2_sym16_L5_32x8192x8192_f16": ("fswavedec2", (32, 8192, 8192), "sym16", 5, "reflect", torch.float16),
     # the reference's own 1-D speed test shape (examples/speed_tests/timeitconv_1d.py:16-36)
     "wavedec_db5_L10_32x1000000_f32": ("wavedec", (32, 1000000), "db5", 10, "periodic", torch.float32),
+    # dry runs of the control flow (MIFWT_BENCH_DEVICE=cpu), not a benchmark shape
+    "dryrun_wavedec2_db4_L2_6x96x96_f32": ("wavedec2", (6, 96, 96), "db4", 2, "reflect", torch.float32),
 }
 
 
@@ -184,8 +209,11 @@ def main():
     # (all ranks on cuda:0, collectives over gloo on host tensors); the real runs use RCCL, one GPU per rank.
     backend = os.environ.get("MIFWT_BENCH_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("MIFWT_BENCH_SAME_DEVICE") == "1" else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    if DEVICE_KIND == "cuda":
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
+    else:
+        dev = torch.device("cpu")
     if distributed:
         import torch.distributed as dist
 
@@ -219,21 +247,21 @@ def main():
         step(spin_steps)
         spin_steps += 1
         if spin_steps % 16 == 0:
-            torch.cuda.synchronize()
+            sync()
     for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize()
+    sync()
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
 
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    torch.cuda.synchronize()
+    sync()
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
 
     # Roofline leg: the same K steps once more with a HIP event pair around every level launch, recorded on
@@ -242,7 +270,7 @@ def main():
     _engine.level_events = []
     for i in range(args.steps):
         step(i)
-    torch.cuda.synchronize()
+    sync()
     events, _engine.level_events = _engine.level_events, None
 
     # Dominant-kernel leg: the first launch of a call (the multi-level kernel where it serves the call), 10 batches of 20
@@ -265,15 +293,15 @@ def main():
             launch = lambda b: _engine.ENGINE.analysis(b, taps[0], taps[1], mode_id)  # noqa: E731
         for i in range(5):
             launch(bufs[i % len(bufs)])
-        torch.cuda.synchronize()
+        sync()
         batches = []
         for _b in range(10):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = new_event(), new_event()
             e0.record()
             for i in range(20):
                 launch(bufs[i % len(bufs)])
             e1.record()
-            torch.cuda.synchronize()
+            sync()
             batches.append(e0.elapsed_time(e1) / 20)
         lvl1_b2b_ms, lvl1_b2b_min = statistics.median(batches), min(batches)
 
@@ -287,13 +315,13 @@ def main():
 
             coeffs = step(0)
             D.gather_coeffs(coeffs)  # warm-up (communicator set-up)
-            torch.cuda.synchronize()
+            sync()
             dist.barrier()
             tg = time.perf_counter()
             reps = 3
             for _ in range(reps):
                 full = D.gather_coeffs(coeffs)
-            torch.cuda.synchronize()
+            sync()
             dist.barrier()
             tg = (time.perf_counter() - tg) / reps
             nbytes = sum(v.numel() * v.element_size() for _, v in _flatten(coeffs))
