@@ -62,6 +62,8 @@ WORKLOADS = {
     "wavedec2_db8_L4_64x4096x4096_f32": ("wavedec2", (64, 4096, 4096), "db8", 4, "reflect", torch.float32),
     # BASELINE configs[4] at a 32-image slice of the 128 (the path is linear in the batch): f16 storage extension
     "fswavedec2_sym16_L5_32x8192x8192_f16": ("fswavedec2", (32, 8192, 8192), "sym16", 5, "reflect", torch.float16),
+    # BASELINE configs[4] at its stated size (17 GB per input buffer)
+    "fswavedec2_sym16_L5_128x8192x8192_f16": ("fswavedec2", (128, 8192, 8192), "sym16", 5, "reflect", torch.float16),
     # the reference's own 1-D speed test shape (examples/speed_tests/timeitconv_1d.py:16-36)
     "wavedec_db5_L10_32x1000000_f32": ("wavedec", (32, 1000000), "db5", 10, "periodic", torch.float32),
     # dry runs of the control flow (MIFWT_BENCH_DEVICE=cpu), not a benchmark shape
@@ -235,7 +237,15 @@ def main():
         ptwt_amd.set_half_storage(True)
     flen = len(ptwt_amd._wavelets.as_wavelet(wavelet))
     torch.manual_seed(1234 + rank)
-    bufs = [torch.randn(*shape, dtype=torch.float32, device=dev).to(dtype) for _ in range(max(1, args.buffers))]
+    def make_input():
+        if prod(shape) < (1 << 31):
+            return torch.randn(*shape, dtype=torch.float32, device=dev).to(dtype)
+        out = torch.empty(*shape, dtype=dtype, device=dev)  # (big batches: no full-size fp32 temporary)
+        for i in range(shape[0]):
+            out[i] = torch.randn(*shape[1:], dtype=torch.float32, device=dev).to(dtype)
+        return out
+
+    bufs = [make_input() for _ in range(max(1, args.buffers))]
 
     def step(i):
         return fn(bufs[i % len(bufs)], wavelet, mode=mode, level=level)

@@ -622,6 +622,44 @@ def test_full_size_config5_slice_properties():
         ptwt_amd.set_half_storage(False)
 
 
+def test_full_size_config5_whole_batch():
+    """BASELINE configs[4] at its stated size on one GPU: 128 x 8192^2 fp16 (17 GB, 8.6e9 samples: element offsets beyond 2^32),
+    sym16, level 5, fswavedec2.  (1) images of the whole-batch call are bit-identical to one-image calls (first, middle, last);
+    (2) EVERY sub-band of every level of the last image within 5e-4 (norm-wise) of the fp64 transform of the same fp16-rounded
+    approximation — on the device in f64 (streaming axis kernels, pinned against the goldens at 1e-12) for all five levels, and
+    against the numpy oracle itself for levels 3-5."""
+    ptwt_amd.set_half_storage(True)
+    try:
+        g = torch.Generator(device=dev()).manual_seed(55)
+        x = torch.empty(128, 8192, 8192, device=dev(), dtype=torch.float16)
+        for i in range(0, 128, 16):
+            x[i : i + 16] = torch.randn(16, 8192, 8192, device=dev(), generator=g).half()
+        c = ptwt_amd.fswavedec2(x, "sym16", level=5)
+        assert tuple(c[0].shape) == (128, 286, 286)
+        assert [tuple(d["dd"].shape) for d in c[1:]] == [(128, n, n) for n in (286, 541, 1051, 2071, 4111)]
+        for i in (0, 77, 127):
+            ci = ptwt_amd.fswavedec2(x[i : i + 1], "sym16", level=5)
+            for (n, a), (_, b) in zip(G.flatten_coeffs(ci), G.flatten_coeffs(c)):
+                assert torch.equal(a[0], b[i]), (i, n)
+        a = x[127:128]
+        for lev in range(1, 6):
+            got = ptwt_amd.fswavedec2(a, "sym16", level=1)
+            ref = ptwt_amd.fswavedec2(a.double(), "sym16", level=1)
+            for (n, u), (_, v) in zip(G.flatten_coeffs(got), G.flatten_coeffs(ref)):
+                err = float((u.double() - v).norm() / v.norm())
+                assert err < 5e-4, (lev, n, err)
+            for k in ("ad", "da", "dd"):  # the level inside the five-level call is this same launch
+                assert torch.equal(got[1][k][0], c[6 - lev][k][127]), (lev, k)
+            if lev >= 3:
+                want = O.fswavedec2(a.double().cpu().numpy(), "sym16", level=1)
+                for (n, u), (_, v) in zip(G.flatten_coeffs(got), G.flatten_coeffs(want)):
+                    assert G.relerr(to_np(u.double()), v) < 5e-4, (lev, n, "oracle")
+            a = got[0]
+        assert torch.equal(a[0], c[0][127])
+    finally:
+        ptwt_amd.set_half_storage(False)
+
+
 # ---- two analysis levels per launch (mifwt_dwt2_fwd_pair, kernel id 12) ----------------------------------------------
 @pytest.fixture(autouse=True)
 def _pair_tests_without_pyramid(request):
