@@ -299,6 +299,9 @@ def main():
         elif first_kid == _engine.KID_PAIR:
             fused_levels = 2
             launch = lambda b: _engine.ENGINE.analysis_pair(b, taps[0], taps[1], mode_id)  # noqa: E731
+        elif first_kid == _engine.KID_LONG:
+            fused_levels = len(_engine.ENGINE.analysis_tail(bufs[0], taps[0], taps[1], mode_id, level))
+            launch = lambda b: _engine.ENGINE.analysis_tail(b, taps[0], taps[1], mode_id, level)  # noqa: E731
         else:
             launch = lambda b: _engine.ENGINE.analysis(b, taps[0], taps[1], mode_id)  # noqa: E731
         for i in range(5):
@@ -360,14 +363,15 @@ def main():
         kid1 = next((kid for (tag, kid, ext, s, e) in events if tuple(ext) == tuple(shape[1:])), -1)
         if kid1 == _engine.KID_PAIR:
             lvl1_b = pair_b
-        if kid1 == _engine.KID_PYRAMID:
+        if kid1 in (_engine.KID_PYRAMID, _engine.KID_LONG):
             # input + the detail bands of the fused levels + the approximation of the last fused one
             lvl1_b = algorithmic_bytes(shape[0], shape[1:], flen, fused_levels, esize)[0]
         klabel = {1: "dwt2_fwd_stream_kernel (level 1)", 7: "dwt2_fwd_tile_kernel (level 1)", 0: "generic axis kernels (level 1)",
                   3: "streaming axis kernels (level 1)", 5: "fused 2-D planes + depth pass (level 1)", 9: "dwt3_fwd_tile_kernel (level 1)",
                   11: "dwt2_fwd_mfma_kernel (level 1)",
                   12: ("dwt2_fwd_roll_kernel" if flen >= 8 else "dwt2_fwd_pair_kernel") + " (levels 1+2 in one launch)",
-                  16: f"dwt2_fwd_pyr_kernel (levels 1-{fused_levels} in one launch)"}.get(kid1, f"kernel id {kid1} (level 1)")
+                  16: f"dwt2_fwd_pyr_kernel (levels 1-{fused_levels} in one launch)",
+                  17: f"dwt1_long_kernel (levels 1-{fused_levels} in one launch)"}.get(kid1, f"kernel id {kid1} (level 1)")
         per_launch_event_ms = sum(lvl1) / max(1, len(lvl1))
         avg_ms = lvl1_b2b_ms if lvl1_b2b_ms else per_launch_event_ms
         achieved = lvl1_b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0

@@ -155,6 +155,20 @@ int mifwt_dwt1_fwd_tail(int dtype, int filt_len, int mode, int64_t rows, int64_t
                         void* approx, int64_t approx_row_stride, void* const* details, const int64_t* detail_row_strides,
                         const double* dec_lo, const double* dec_hi, void* stream);
 
+/* SEVERAL levels of a 1-D decomposition in one launch, a CHUNK of a row per workgroup — the leading trips of wavedec's level
+ * loop (src/ptwt/conv_transform.py:133-140) while a row does not fit into one workgroup, or while there are too few rows
+ * (< 128, of >= 4096 samples) to occupy the chip with one workgroup each: a workgroup owns a chunk of a row plus the
+ * (L - 2)(2^K - 1) halo samples its K levels consume; the approximations between the levels stay in LDS.  Same arguments as
+ * mifwt_dwt1_fwd_tail; f32, even filt_len <= 20, any boundary mode.
+ * mifwt_dwt1_fwd_long_levels answers how many of `want` levels one launch fuses for this geometry (it stops where the halo
+ * would exceed a twelfth of a chunk, and for rows longer than mifwt_dwt1_fwd_tail_max_n where mifwt_dwt1_fwd_tail can take
+ * over; 0 = not served); mifwt_dwt1_fwd_long must be called with exactly that count, MIFWT_ERR_UNSUPPORTED otherwise, nothing
+ * launched.  Agreement with per-level calls to rounding. */
+int mifwt_dwt1_fwd_long_levels(int dtype, int filt_len, int mode, int64_t rows, int64_t n, int want);
+int mifwt_dwt1_fwd_long(int dtype, int filt_len, int mode, int64_t rows, int64_t n, int nlevels, const void* x, int64_t x_row_stride,
+                        void* approx, int64_t approx_row_stride, void* const* details, const int64_t* detail_row_strides,
+                        const double* dec_lo, const double* dec_hi, void* stream);
+
 /* The COARSE levels of a 1-D reconstruction in one launch — the leading trips of waverec's level loop
  * (src/ptwt/conv_transform.py:184-199: stack + conv_transpose1d(stride 2) + crop per level), mirror of mifwt_dwt1_fwd_tail.
  *   approx   coarsest approximation [rows, m]       details  HOST array of nlevels device ptrs, coarsest first: [rows, m_l]
@@ -229,7 +243,8 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  *          returned by mifwt_kernel_id, which describes single-level calls)
  *   14 / 15  the deep levels of a 1-D analysis / the coarse levels of a 1-D synthesis in one launch (mifwt_dwt1_fwd_tail /
  *          mifwt_dwt1_inv_tail; likewise not returned by mifwt_kernel_id)
- *   16     up to three fused 2-D analysis levels per launch (mifwt_dwt2_fwd_pyramid; not returned by mifwt_kernel_id) */
+ *   16     up to three fused 2-D analysis levels per launch (mifwt_dwt2_fwd_pyramid; not returned by mifwt_kernel_id)
+ *   17     several fused 1-D analysis levels of long rows, a chunk per workgroup (mifwt_dwt1_fwd_long; likewise) */
 int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 
 /* Library-wide diagnostic switches (process-global, meant for tests and A/B measurements).

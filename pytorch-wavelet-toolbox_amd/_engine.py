@@ -96,6 +96,10 @@ def load_library() -> ctypes.CDLL:
     lib.mifwt_dwt1_fwd_tail.restype = ctypes.c_int
     lib.mifwt_dwt1_fwd_tail.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, vp,
                                         ctypes.c_int64, vp, ctypes.c_int64, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int64), dbl_p, dbl_p, vp]
+    lib.mifwt_dwt1_fwd_long.restype = ctypes.c_int
+    lib.mifwt_dwt1_fwd_long.argtypes = lib.mifwt_dwt1_fwd_tail.argtypes
+    lib.mifwt_dwt1_fwd_long_levels.restype = ctypes.c_int
+    lib.mifwt_dwt1_fwd_long_levels.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]
     lib.mifwt_dwt1_inv_tail.restype = ctypes.c_int
     lib.mifwt_dwt1_inv_tail.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, vp, ctypes.c_int64,
                                         ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32), vp,
@@ -144,6 +148,7 @@ KID_INV_PAIR = 13
 KID_TAIL = 14
 KID_INV_TAIL = 15
 KID_PYRAMID = 16
+KID_LONG = 17
 
 
 def set_option(key: int, value: int) -> None:
@@ -352,8 +357,9 @@ class HipLevelEngine:
         return bufs
 
     def analysis_tail(self, x: torch.Tensor, dec_lo: Sequence[float], dec_hi: Sequence[float], mode_id: int, nlevels: int):
-        """The remaining ``nlevels`` levels of a 1-D decomposition in ONE launch (C ABI ``mifwt_dwt1_fwd_tail``): ``x`` [B, N] ->
-        a list of ``nlevels`` buffers [B, 2, M_l] laid out like :meth:`analysis` results, finest first; plane 1 of every buffer
+        """The next levels of a 1-D decomposition in ONE launch — all ``nlevels`` remaining ones once a row fits into a workgroup (C
+        ABI ``mifwt_dwt1_fwd_tail``), as many as the chunked long-row kernel fuses before that (``mifwt_dwt1_fwd_long``): ``x`` [B, N]
+        -> a list of up to ``nlevels`` buffers [B, 2, M_l] laid out like :meth:`analysis` results, finest first; plane 1 of every buffer
         holds that level's detail coefficients, plane 0 only of the LAST one its approximation (the others are intermediates
         that never leave the chip).  Returns None outside the kernel's envelope."""
         _require_gpu(x)
@@ -362,7 +368,15 @@ class HipLevelEngine:
         lib = load_library()
         flen = len(dec_lo)
         rows, n0 = x.shape
-        if rows == 0 or n0 == 0 or flen > 32 or n0 > lib.mifwt_dwt1_fwd_tail_max_n(_DTYPE_IDS[x.dtype]):
+        if rows == 0 or n0 == 0 or flen > 32:
+            return None
+        # rows too long for one workgroup, or too few rows to occupy the chip with one workgroup each: the chunked kernel fuses
+        # as many levels as its halo rule allows (C ABI mifwt_dwt1_fwd_long), the caller comes back for the rest
+        k_long = lib.mifwt_dwt1_fwd_long_levels(_DTYPE_IDS[x.dtype], flen, mode_id, rows, n0, nlevels) if x.dtype == torch.float32 else 0
+        long_rows = k_long >= 2
+        if long_rows:
+            nlevels = k_long
+        elif n0 > lib.mifwt_dwt1_fwd_tail_max_n(_DTYPE_IDS[x.dtype]):
             return None
         sizes, n = [], n0
         for _ in range(nlevels):
@@ -374,7 +388,7 @@ class HipLevelEngine:
         det_rs = (ctypes.c_int64 * nlevels)(*[2 * m for m in sizes])
         lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
         p = _Plan()
-        p.ws_bytes, p.kid = 0, KID_TAIL
+        p.ws_bytes, p.kid = 0, (KID_LONG if long_rows else KID_TAIL)
         d = LevelDesc()
         d.ndim = 1
         d.sig_extent[0] = n0
@@ -383,8 +397,8 @@ class HipLevelEngine:
         rc_box = []
 
         def call(ws, wsb, stream):
-            rc = lib.mifwt_dwt1_fwd_tail(_DTYPE_IDS[x.dtype], flen, mode_id, rows, n0, nlevels, xp, x.stride(0), ap, 2 * sizes[-1],
-                                         det, det_rs, lo, hi, stream)
+            entry = lib.mifwt_dwt1_fwd_long if long_rows else lib.mifwt_dwt1_fwd_tail
+            rc = entry(_DTYPE_IDS[x.dtype], flen, mode_id, rows, n0, nlevels, xp, x.stride(0), ap, 2 * sizes[-1], det, det_rs, lo, hi, stream)
             rc_box.append(rc)
             return 0 if rc == -2 else rc  # "unsupported" is an answer here, not an error
 

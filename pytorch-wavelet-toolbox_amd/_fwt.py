@@ -340,8 +340,9 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
                 done += 2
                 continue
         if ndim == 1 and level - done >= 2 and not differentiable:
-            # the deep levels of a 1-D pyramid in one launch (mifwt_dwt1_fwd_tail) once a row fits into LDS; the pad checks of
-            # the fused trips are the reference's own and run before anything is launched
+            # the deep levels of a 1-D pyramid in one launch (mifwt_dwt1_fwd_tail) once a row fits into LDS, several levels of
+            # longer rows per launch before that (mifwt_dwt1_fwd_long); the pad checks of the fused trips are the reference's
+            # own and run before anything is launched
             n = cur.shape[1]
             for _l in range(level - done):
                 _check_pad([n], flen, "reflect" if mode is None else mode)
@@ -350,7 +351,7 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
             if tail is not None:
                 bufs.extend(tail)
                 cur = tail[-1][:, 0]
-                done = level
+                done += len(tail)
                 continue
         done += 1
         if differentiable:

@@ -516,6 +516,21 @@ int mifwt_dwt1_fwd_tail(int dtype, int filt_len, int mode, int64_t rows, int64_t
   return dwt1_tail(dtype, filt_len, mode, rows, n, nlevels, x, x_row_stride, approx, approx_row_stride, details, detail_row_strides,
                    dec_lo, dec_hi, static_cast<hipStream_t>(stream));
 }
+// Several levels of a 1-D decomposition of long rows in one launch (mifwt_dwt1_long.hip).
+int mifwt_dwt1_fwd_long_levels(int dtype, int filt_len, int mode, int64_t rows, int64_t n, int want) {
+  return dwt1_long_levels(dtype, filt_len, mode, rows, n, want);
+}
+
+int mifwt_dwt1_fwd_long(int dtype, int filt_len, int mode, int64_t rows, int64_t n, int nlevels, const void* x, int64_t x_row_stride,
+                        void* approx, int64_t approx_row_stride, void* const* details, const int64_t* detail_row_strides,
+                        const double* dec_lo, const double* dec_hi, void* stream) {
+  if (!x || !approx || !details || !detail_row_strides || !dec_lo || !dec_hi) return MIFWT_ERR_BADARG;
+  if (nlevels < 1 || dwt1_long_levels(dtype, filt_len, mode, rows, n, nlevels) != nlevels) return MIFWT_ERR_UNSUPPORTED;
+  for (int l = 0; l < nlevels; ++l)
+    if (!details[l]) return MIFWT_ERR_BADARG;
+  return dwt1_long(dtype, filt_len, mode, rows, n, nlevels, x, x_row_stride, approx, approx_row_stride, details, detail_row_strides,
+                   dec_lo, dec_hi, static_cast<hipStream_t>(stream));
+}
 // The coarse levels of a 1-D reconstruction in one launch (mifwt_dwt1_tail.hip).
 int mifwt_dwt1_inv_tail(int dtype, int filt_len, int64_t rows, int64_t m, int nlevels, const void* approx, int64_t approx_row_stride,
                         const void* const* details, const int64_t* detail_row_strides, const int32_t* out_len, void* y,

@@ -1,0 +1,105 @@
+"""GPU parity tests (``-m gpu``) of ``mifwt_dwt1_fwd_long`` (kernel id 17: several 1-D analysis levels of long rows per launch,
+a chunk per workgroup, mifwt_dwt1_long.hip) against the fp64 numpy oracle and the per-level kernels.
+
+Tolerance: fp32 <= 1e-6 norm-wise per sub-band vs the fp64 oracle.  Every case asserts that the chunked kernel
+ran (``_engine.level_events``), so a silent per-level fallback cannot pass.
+"""
+import numpy as np
+import pytest
+import torch
+
+import ptwt_amd
+from oracle import fwt_oracle as O
+from ptwt_amd import _engine
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 1e-6
+MODES = ["reflect", "zero", "constant", "symmetric", "periodic"]
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def traced(fn):
+    _engine.level_events = []
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+        kids = [e[1] for e in _engine.level_events]
+    finally:
+        _engine.level_events = None
+    return out, kids
+
+
+def check(x, wavelet, mode, level, first_kid=_engine.KID_LONG):
+    got, kids = traced(lambda: ptwt_amd.wavedec(x.to(dev()), wavelet, mode=mode, level=level))
+    want = O.wavedec(x.numpy().astype(np.float64), wavelet, mode=mode, level=level)
+    if first_kid is not None:
+        assert kids[0] == first_kid, (wavelet, mode, tuple(x.shape), kids)
+    assert len(got) == len(want)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert tuple(a.shape) == tuple(b.shape), (i, a.shape, b.shape)
+        err = G.relerr(a.cpu().numpy(), b)
+        assert err < TOL32, f"{wavelet} {mode} L{level} {tuple(x.shape)} coefficient {i}: rel err {err:.3e}"
+    return kids
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db5", "db8", "sym10"])
+def test_long_rows_vs_oracle(wavelet, mode):
+    """Several interior chunks per row, odd and even lengths at every level, both end pieces; the tail kernel finishes."""
+    g = torch.Generator().manual_seed(7)
+    for shape, level in (((3, 100003), 8), ((2, 65536), 6), ((1, 40001), 5)):
+        x = torch.randn(*shape, generator=g, dtype=torch.float32)
+        kids = check(x, wavelet, mode, level)
+        assert len(kids) <= 3, kids  # chunked launch (+ a second one for short filters' deep halos) + tail
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_long_rows_two_levels_and_strided_rows(mode):
+    """Rows just beyond twice the one-workgroup limit (two fused levels, few chunks) and rows of a wider tensor whose starts
+    are not 16-byte aligned (scalar loads)."""
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 33001, generator=g, dtype=torch.float32)
+    check(x, "db3", mode, 4)
+    wide = torch.randn(4, 70001, generator=g, dtype=torch.float32)
+    view = wide[::2, 3:66002]
+    xd = wide.to(dev())[::2, 3:66002]
+    got, kids = traced(lambda: ptwt_amd.wavedec(xd, "db4", mode=mode, level=7))
+    assert kids[0] == _engine.KID_LONG, kids
+    want = O.wavedec(view.numpy().astype(np.float64), "db4", mode=mode, level=7)
+    for a, b in zip(got, want):
+        assert G.relerr(a.cpu().numpy(), b) < TOL32
+
+
+def test_long_rows_match_per_level_kernels_and_round_trip():
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(4, 250000, generator=g, dtype=torch.float32).to(dev())
+    for wavelet in ("db5", "sym4"):
+        got, kids = traced(lambda: ptwt_amd.wavedec(x, wavelet, mode="periodic", level=10))
+        assert kids[0] == _engine.KID_LONG and len(kids) <= 3, kids  # long rows, the same kernel on the shorter rows, (tail)
+        _engine.set_option(_engine.OPT_PAIR_MODE, 2)
+        try:
+            single = ptwt_amd.wavedec(x, wavelet, mode="periodic", level=10)
+        finally:
+            _engine.set_option(_engine.OPT_PAIR_MODE, 0)
+        for a, b in zip(got, single):
+            assert a.shape == b.shape and float((a - b).norm() / b.norm()) < 2e-6
+        rec = ptwt_amd.waverec(ptwt_amd.wavedec(x, wavelet, level=10), wavelet)
+        assert float((rec[..., : x.shape[-1]] - x).abs().max()) < 2e-5
+
+
+def test_reference_speed_test_shape():
+    """The reference's own 1-D speed test (examples/speed_tests/timeitconv_1d.py:10-12): 32 x 10^6 fp32, db5, level 10,
+    periodic — two launches; three rows against the oracle."""
+    g = torch.Generator(device=dev()).manual_seed(10)
+    x = torch.randn(32, 1000000, device=dev(), generator=g)
+    got, kids = traced(lambda: ptwt_amd.wavedec(x, "db5", mode="periodic", level=10))
+    assert kids == [_engine.KID_LONG, _engine.KID_LONG], kids  # 6 levels of the 10^6-sample rows, 4 of the 15 633-sample rows
+    rows = [0, 13, 31]
+    want = O.wavedec(x[rows].cpu().numpy().astype(np.float64), "db5", mode="periodic", level=10)
+    for a, b in zip(got, want):
+        assert G.relerr(a[rows].cpu().numpy(), b) < TOL32

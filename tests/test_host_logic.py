@@ -301,3 +301,35 @@ def test_cabi_multi_level_envelopes_without_gpu():
     assert lib.mifwt_dwt1_fwd_tail_max_n(0) == 16384 and lib.mifwt_dwt1_fwd_tail_max_n(1) == 8192
     assert lib.mifwt_dwt1_fwd_tail(0, 8, 2, 4, 4096, 5, None, 4096, None, 0, None, None, None, None, None) == -1
     assert lib.mifwt_dwt1_inv_tail(0, 8, 4, 100, 3, None, 100, None, None, None, None, 0, None, None, None) == -1
+
+
+def test_dwt1_long_plan_and_argument_checks():
+    """mifwt_dwt1_fwd_long_levels is host arithmetic (how many levels the chunked 1-D launch fuses); mifwt_dwt1_fwd_long rejects
+    bad arguments and level counts it would not fuse before touching the device."""
+    import ctypes
+
+    from ptwt_amd import _engine
+
+    lib = _engine.load_library()
+    lv = lib.mifwt_dwt1_fwd_long_levels
+    F32, F64, PER, REFL = 0, 1, 3, 2
+    assert lv(F32, 10, PER, 32, 1000000, 10) == 6     # the reference's speed test: down to 15 633 samples, the tail's range
+    assert lv(F32, 10, PER, 32, 15633, 4) == 4        # few rows of medium length: chunked too (about one workgroup per CU)
+    assert lv(F32, 10, PER, 32, 15633, 2) == 2
+    assert lv(F32, 10, PER, 500, 15633, 4) == 0       # enough rows for one workgroup each: mifwt_dwt1_fwd_tail
+    assert lv(F32, 10, PER, 4, 3000, 4) == 0          # short rows
+    assert lv(F64, 10, PER, 32, 1000000, 10) == 0     # f32 only
+    assert lv(F32, 22, PER, 32, 1000000, 10) == 0     # even filt_len <= 20
+    assert lv(F32, 10, REFL, 32, 1000000, 1) == 0     # a single level is the per-level kernels' job
+    assert lv(F32, 2, REFL, 1, 32000000, 12) == 8     # haar: no halo, the level cap
+    assert lv(F32, 20, REFL, 8, 1000000, 10) == 5     # long filters: the halo rule stops earlier
+    null = ctypes.c_void_p(0)
+    taps = (ctypes.c_double * 10)(*([0.1] * 10))
+    det = (ctypes.c_void_p * 6)(*([1] * 6))
+    rs = (ctypes.c_int64 * 6)(*([0] * 6))
+    one = ctypes.c_void_p(16)
+    assert lib.mifwt_dwt1_fwd_long(F32, 10, PER, 32, 1000000, 6, null, 0, one, 0, det, rs, taps, taps, null) == -1    # BADARG
+    det8 = (ctypes.c_void_p * 8)(*([1] * 8))
+    rs8 = (ctypes.c_int64 * 8)(*([0] * 8))
+    assert lib.mifwt_dwt1_fwd_long(F32, 10, PER, 32, 1000000, 7, one, 1000000, one, 0, det8, rs8, taps, taps, null) == -2  # more than one launch fuses
+    assert lib.mifwt_dwt1_fwd_long(F64, 10, PER, 32, 1000000, 6, one, 1000000, one, 0, det, rs, taps, taps, null) == -2
