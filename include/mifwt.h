@@ -126,7 +126,8 @@ int mifwt_dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, 
  * Same sums as nlevels mifwt_dwt_fwd calls (summation order differs: agreement to rounding, not bit for bit).
  * f32, even L <= 8, modes zero / constant / reflect / symmetric, unit innermost strides, input rows of a multiple of 4 samples
  * that start on 16-byte boundaries, every fused plane at least 2 L samples per axis (mifwt_dwt2_fwd_pyramid_supported says
- * 1 / 0); MIFWT_ERR_UNSUPPORTED otherwise, nothing launched.  Kernel id 16. */
+ * 1 / 0); the three detail planes of a level within 1 GiB of one another (one buffer resource serves them; they are planes
+ * of one level buffer in practice); MIFWT_ERR_UNSUPPORTED otherwise, nothing launched.  Kernel id 16. */
 int mifwt_dwt2_fwd_pyramid_supported(int nlevels, const mifwt_level_desc* const* descs);
 int mifwt_dwt2_fwd_pyramid(int nlevels, const mifwt_level_desc* const* descs, const void* x, void* const* const* details, void* approx,
                            const double* dec_lo, const double* dec_hi, void* stream);

@@ -49,7 +49,9 @@ constexpr int kPyrMaxChunks = 5;  // 1 KiB requests per staged row (three for th
 template <int L, int NLEV>
 struct PyrArgs {
   const float* x;
-  float* det[NLEV][3];  // [level - 1][band ad, da, dd]
+  float* det[NLEV];         // [level - 1]: the lowest of the level's three detail planes
+  uint32_t doff[NLEV][3];   // byte offsets of the bands ad, da, dd from it (one buffer resource serves the three)
+  uint32_t dspan[NLEV];     // the largest of them
   float* approx;        // band aa of level NLEV
   int64_t xs_b, ds_b[NLEV], as_b;
   int xs_h, ds_h[NLEV], as_h;
@@ -134,7 +136,7 @@ __device__ __forceinline__ void pyr_role(int wave, int nl1, int nchunks, int& ro
   }
 }
 
-template <int L, int NLEV>
+template <int L, int NLEV, bool PROF>
 __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrArgs<L, NLEV> a) {
   constexpr int HL = L - 2, HP = L / 2;
   constexpr int NC1 = 2;          // columns per level-1 lane (three were measured: 112.6 against 108.5 us on config 2)
@@ -265,9 +267,9 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
   }
 
   unsigned long long waited = 0;
-  const unsigned long long t_start = a.prof ? __builtin_readcyclecounter() : 0;
+  const unsigned long long t_start = PROF ? __builtin_readcyclecounter() : 0;
   auto prof_out = [&]() {
-    if (a.prof && lane == 0) {
+    if (PROF && lane == 0) {
       unsigned long long* o = a.prof + ((size_t)blockIdx.x * kPyrWaves + wave) * 2;
       o[0] = __builtin_readcyclecounter() - t_start;
       o[1] = waited;
@@ -318,12 +320,13 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
       }
     }
     const bool f_any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(f_on) != 0);
-    const uint32_t dbytes = (a.dbg & 1) ? 0u : ((uint32_t)(a.H[1] - 1) * (uint32_t)a.ds_h[0] + (uint32_t)a.W[1]) * 4u;
+    // one buffer resource for the three detail planes of the image (band = scalar offset), one for the approximation; a row
+    // the segment does not own is stored at a per-lane offset beyond every resource (dropped) — the resources never change
+    const uint32_t dbytes = (a.dbg & 1) ? 0u : a.dspan[0] + ((uint32_t)(a.H[1] - 1) * (uint32_t)a.ds_h[0] + (uint32_t)a.W[1]) * 4u;
     const uint32_t abytes = (a.dbg & 1) ? 0u : ((uint32_t)(a.H[NLEV] - 1) * (uint32_t)a.as_h + (uint32_t)a.W[NLEV]) * 4u;
-    const float* const dp0 = a.det[0][0] + (int64_t)img * a.ds_b[0];
-    const float* const dp1 = a.det[0][1] + (int64_t)img * a.ds_b[0];
-    const float* const dp2 = a.det[0][2] + (int64_t)img * a.ds_b[0];
-    const float* const app = a.approx + (int64_t)img * a.as_b;
+    const rsrc_t rd = pyr_rsrc(a.det[0] + (int64_t)img * a.ds_b[0], dbytes);
+    const rsrc_t ra = pyr_rsrc(a.approx + (int64_t)img * a.as_b, NLEV == 1 ? abytes : 0u);
+    const uint32_t o0 = a.doff[0][0], o1 = a.doff[0][1], o2 = a.doff[0][2];
 
     PyrAcc<L, NC1> acc;
     acc.clear();
@@ -356,7 +359,7 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
       constexpr int SM = decltype(sm_tag)::value;
       pyr_static_for<2>([&](auto half_tag) {
         constexpr int half = decltype(half_tag)::value;
-        pyr_barrier(a.prof, waited);  // the loader has seen this sub-step land
+        pyr_barrier<PROF>(waited);  // the loader has seen this sub-step land
         if (s < nsteps1) {
           unsigned char* sb = stage + bi * (kPyrSub * a.pitch0);
           bi = bi + 1 == a.nbuf ? 0 : bi + 1;
@@ -386,22 +389,21 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
               for (int k = 0; k < NC1; ++k) *reinterpret_cast<float*>(rr + rw[k]) = lo[k].x;
             }
             const bool own = i >= oA[1] && i < oB[1];
-            const uint32_t nb = own ? dbytes : 0u;
-            const rsrc_t r0 = pyr_rsrc(dp0, nb), r1 = pyr_rsrc(dp1, nb), r2 = pyr_rsrc(dp2, nb);
+            const uint32_t v2 = own ? sv2 : kPyrOob;
             const uint32_t so = own ? (uint32_t)i * (uint32_t)a.ds_h[0] * 4u : 0u;
-            __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].x, hi[1].x}, r0, sv2, so, 0);
-            __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].y, lo[1].y}, r1, sv2, so, 0);
-            __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].y, hi[1].y}, r2, sv2, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].x, hi[1].x}, rd, v2, so + o0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].y, lo[1].y}, rd, v2, so + o1, 0);
+            __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].y, hi[1].y}, rd, v2, so + o2, 0);
             if (rag) {
-              pyr_store1(hi[0].x, r0, sv1, so);
-              pyr_store1(lo[0].y, r1, sv1, so);
-              pyr_store1(hi[0].y, r2, sv1, so);
+              const uint32_t v1 = own ? sv1 : kPyrOob;
+              pyr_store1(hi[0].x, rd, v1, so + o0);
+              pyr_store1(lo[0].y, rd, v1, so + o1);
+              pyr_store1(hi[0].y, rd, v1, so + o2);
             }
             if constexpr (NLEV == 1) {
-              const rsrc_t ra = pyr_rsrc(app, own ? abytes : 0u);
               const uint32_t sa = own ? (uint32_t)i * (uint32_t)a.as_h * 4u : 0u;
-              __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].x, lo[1].x}, ra, sv2, sa, 0);
-              if (rag) pyr_store1(lo[0].x, ra, sv1, sa);
+              __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].x, lo[1].x}, ra, v2, sa, 0);
+              if (rag) pyr_store1(lo[0].x, ra, own ? sv1 : kPyrOob, sa);
             }
           });
         }
@@ -453,12 +455,11 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
         }
       }
       const bool f_any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(f_on) != 0);
-      const uint32_t dbytes = (a.dbg & 1) ? 0u : ((uint32_t)(a.H[2] - 1) * (uint32_t)a.ds_h[1] + (uint32_t)a.W[2]) * 4u;
+      const uint32_t dbytes = (a.dbg & 1) ? 0u : a.dspan[1] + ((uint32_t)(a.H[2] - 1) * (uint32_t)a.ds_h[1] + (uint32_t)a.W[2]) * 4u;
       const uint32_t abytes = (a.dbg & 1) ? 0u : ((uint32_t)(a.H[NLEV] - 1) * (uint32_t)a.as_h + (uint32_t)a.W[NLEV]) * 4u;
-      const float* const dp0 = a.det[1][0] + (int64_t)img * a.ds_b[1];
-      const float* const dp1 = a.det[1][1] + (int64_t)img * a.ds_b[1];
-      const float* const dp2 = a.det[1][2] + (int64_t)img * a.ds_b[1];
-      const float* const app = a.approx + (int64_t)img * a.as_b;
+      const rsrc_t rd = pyr_rsrc(a.det[1] + (int64_t)img * a.ds_b[1], dbytes);
+      const rsrc_t ra = pyr_rsrc(a.approx + (int64_t)img * a.as_b, NLEV == 2 ? abytes : 0u);
+      const uint32_t o0 = a.doff[1][0], o1 = a.doff[1][1], o2 = a.doff[1][2];
       const int ro1 = HP - 1 - rA[1];
       const int E1 = 2 * rA[2] - HL;
       PyrAcc<L, 2> acc;
@@ -488,8 +489,8 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
       int ph = 0;  // pair index modulo L/2 of the next block
 #pragma unroll 1
       for (int s = 0; s < nsteps; ++s) {
-        pyr_barrier(a.prof, waited);
-        pyr_barrier(a.prof, waited);  // level 1's first two rows of this step (and everything before) are in ring 1
+        pyr_barrier<PROF>(waited);
+        pyr_barrier<PROF>(waited);  // level 1's first two rows of this step (and everything before) are in ring 1
         if (s >= D2 && 2 * (s - D2) < npair2 && !(a.dbg & 4)) {
           uint32_t so_r[4];  // ring-1 byte offsets of the step's four rows
 #pragma unroll
@@ -527,22 +528,21 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
                 *reinterpret_cast<float*>(rr + rw[1]) = lo[1].x;
               }
               const bool own = i >= oA[2] && i < oB[2];
-              const uint32_t nb = own ? dbytes : 0u;
-              const rsrc_t r0 = pyr_rsrc(dp0, nb), r1 = pyr_rsrc(dp1, nb), r2 = pyr_rsrc(dp2, nb);
+              const uint32_t v2 = own ? sv2 : kPyrOob;
               const uint32_t so = own ? (uint32_t)i * (uint32_t)a.ds_h[1] * 4u : 0u;
-              __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].x, hi[1].x}, r0, sv2, so, 0);
-              __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].y, lo[1].y}, r1, sv2, so, 0);
-              __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].y, hi[1].y}, r2, sv2, so, 0);
+              __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].x, hi[1].x}, rd, v2, so + o0, 0);
+              __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].y, lo[1].y}, rd, v2, so + o1, 0);
+              __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].y, hi[1].y}, rd, v2, so + o2, 0);
               if (rag) {
-                pyr_store1(hi[0].x, r0, sv1, so);
-                pyr_store1(lo[0].y, r1, sv1, so);
-                pyr_store1(hi[0].y, r2, sv1, so);
+                const uint32_t v1 = own ? sv1 : kPyrOob;
+                pyr_store1(hi[0].x, rd, v1, so + o0);
+                pyr_store1(lo[0].y, rd, v1, so + o1);
+                pyr_store1(hi[0].y, rd, v1, so + o2);
               }
               if constexpr (NLEV == 2) {
-                const rsrc_t ra = pyr_rsrc(app, own ? abytes : 0u);
                 const uint32_t sa = own ? (uint32_t)i * (uint32_t)a.as_h * 4u : 0u;
-                __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].x, lo[1].x}, ra, sv2, sa, 0);
-                if (rag) pyr_store1(lo[0].x, ra, sv1, sa);
+                __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].x, lo[1].x}, ra, v2, sa, 0);
+                if (rag) pyr_store1(lo[0].x, ra, own ? sv1 : kPyrOob, sa);
               }
             });
           });
@@ -578,12 +578,11 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
       }
     }
     const bool f_any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(f_on) != 0);
-    const uint32_t dbytes = (a.dbg & 1) ? 0u : ((uint32_t)(a.H[3] - 1) * (uint32_t)a.ds_h[2] + (uint32_t)a.W[3]) * 4u;
+    const uint32_t dbytes = (a.dbg & 1) ? 0u : a.dspan[2] + ((uint32_t)(a.H[3] - 1) * (uint32_t)a.ds_h[2] + (uint32_t)a.W[3]) * 4u;
     const uint32_t abytes = (a.dbg & 1) ? 0u : ((uint32_t)(a.H[3] - 1) * (uint32_t)a.as_h + (uint32_t)a.W[3]) * 4u;
-    const float* const dp0 = a.det[2][0] + (int64_t)img * a.ds_b[2];
-    const float* const dp1 = a.det[2][1] + (int64_t)img * a.ds_b[2];
-    const float* const dp2 = a.det[2][2] + (int64_t)img * a.ds_b[2];
-    const float* const app = a.approx + (int64_t)img * a.as_b;
+    const rsrc_t rd = pyr_rsrc(a.det[2] + (int64_t)img * a.ds_b[2], dbytes);
+    const rsrc_t ra = pyr_rsrc(a.approx + (int64_t)img * a.as_b, abytes);
+    const uint32_t o0 = a.doff[2][0], o1 = a.doff[2][1], o2 = a.doff[2][2];
     const int ro2 = HP - 1 - rA[2];
     const int E2 = 2 * rA[3] - HL;
     PyrAcc<L, 1> acc;
@@ -609,7 +608,7 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
     int ph = 0;
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
-      pyr_barrier(a.prof, waited);
+      pyr_barrier<PROF>(waited);
       if (s >= D3 && s - D3 < npair3 && !(a.dbg & 4)) {
         uint32_t so_r[2];
 #pragma unroll
@@ -637,16 +636,16 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
           const int i = rA[3] + (s - D3) - (HP - 1);
           const f2 lo = acc.lo[PyrAcc<L, 1>::done(R)][0], hi = acc.hi[PyrAcc<L, 1>::done(R)][0];
           const bool own = i >= oA[3] && i < oB[3];
-          const uint32_t nb = own ? dbytes : 0u;
+          const uint32_t v = own ? sv : kPyrOob;
           const uint32_t so = own ? (uint32_t)i * (uint32_t)a.ds_h[2] * 4u : 0u;
-          pyr_store1(hi.x, pyr_rsrc(dp0, nb), sv, so);
-          pyr_store1(lo.y, pyr_rsrc(dp1, nb), sv, so);
-          pyr_store1(hi.y, pyr_rsrc(dp2, nb), sv, so);
-          pyr_store1(lo.x, pyr_rsrc(app, own ? abytes : 0u), sv, own ? (uint32_t)i * (uint32_t)a.as_h * 4u : 0u);
+          pyr_store1(hi.x, rd, v, so + o0);
+          pyr_store1(lo.y, rd, v, so + o1);
+          pyr_store1(hi.y, rd, v, so + o2);
+          pyr_store1(lo.x, ra, v, own ? (uint32_t)i * (uint32_t)a.as_h * 4u : 0u);
         });
         ph = ph + 1 == HP ? 0 : ph + 1;
       }
-      pyr_barrier(a.prof, waited);
+      pyr_barrier<PROF>(waited);
     }
     prof_out();
   }
@@ -790,7 +789,18 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
   a.H[0] = (int)d[0]->sig_extent[0];
   a.W[0] = (int)d[0]->sig_extent[1];
   for (int l = 0; l < NLEV; ++l) {
-    for (int b = 0; b < 3; ++b) a.det[l][b] = static_cast<float*>(details[l][b]);
+    uintptr_t lo_p = reinterpret_cast<uintptr_t>(details[l][0]);
+    for (int b = 1; b < 3; ++b) lo_p = std::min(lo_p, reinterpret_cast<uintptr_t>(details[l][b]));
+    a.det[l] = reinterpret_cast<float*>(lo_p);
+    a.dspan[l] = 0;
+    for (int b = 0; b < 3; ++b) {
+      const uintptr_t off = reinterpret_cast<uintptr_t>(details[l][b]) - lo_p;
+      // one resource spans a level's three planes of an image: they must lie within 1 GiB of one another (they are the
+      // planes of one level buffer in every caller of this library)
+      if (off >= (uintptr_t(1) << 30) || (off & 3)) return MIFWT_ERR_UNSUPPORTED;
+      a.doff[l][b] = (uint32_t)off;
+      a.dspan[l] = std::max(a.dspan[l], (uint32_t)off);
+    }
     a.ds_b[l] = d[l]->detail_stride[0];
     a.ds_h[l] = (int)d[l]->detail_stride[1];
     a.H[l + 1] = (int)d[l]->coef_extent[0];
@@ -818,14 +828,22 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
   for (int m = 0; m < L; ++m) a.tap[m] = (f2){(float)lo[m], (float)hi[m]};
   const int64_t nwg = d[0]->batch * p.nseg * p.ngroups;
   if (nwg > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
+  // (the per-wave cycle profile of tools/pyr_prof.py exists for the three-level 8-tap kernel only)
+  constexpr bool kCanProf = L == 8 && NLEV == 3;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
+      return MIFWT_ERR_LAUNCH;
+    if (kCanProf && hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, kCanProf>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return MIFWT_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV>), dim3((unsigned)nwg), dim3(64 * kPyrWaves), p.lds, stream, a);
+  if (kCanProf && a.prof)
+    hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, kCanProf>), dim3((unsigned)nwg), dim3(64 * kPyrWaves), p.lds, stream, a);
+  else
+    hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, false>), dim3((unsigned)nwg), dim3(64 * kPyrWaves), p.lds, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 

@@ -33,8 +33,9 @@ __device__ __forceinline__ void pyr_store1(float v, rsrc_t rsrc, uint32_t voff, 
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rsrc, voff, soff, 0);
 }
 // workgroup barrier; with profiling on, the cycles spent in it are added to `waited`
-__device__ __forceinline__ void pyr_barrier(const unsigned long long* prof, unsigned long long& waited) {
-  if (prof) {
+template <bool PROF>
+__device__ __forceinline__ void pyr_barrier(unsigned long long& waited) {
+  if constexpr (PROF) {
     const unsigned long long t0 = __builtin_readcyclecounter();
     __syncthreads();
     waited += __builtin_readcyclecounter() - t0;
@@ -49,7 +50,7 @@ __device__ __forceinline__ void pyr_wait_vm() {
 
 // packed FMAs acc (+)= (tap.x, tap.y) * pair.x / pair.y with the tap pair in an SGPR pair: with the three-operand pattern of the
 // passes (accumulator, tap, sample all distinct) 4.7 cycles per wave-instruction at two waves per SIMD against 5.5 for taps held
-// in VGPR pairs (tools/ubench.hip "distinct" rows, profiles/r02_ubench.txt)
+// in VGPR pairs (tools/ubench.hip "distinct" rows, profiles/r02_ubench_valu_copy.txt)
 __device__ __forceinline__ void vfma_lo(f2& acc, const f2 tap, const f2 pair) {
   asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(tap), "v"(pair));
 }
