@@ -115,16 +115,32 @@ class _AnalysisLevel(torch.autograd.Function):
         return _engine.ENGINE.analysis(x, dec_lo, dec_hi, mode_id)
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, g_buf):
         sig_shape, dec_lo, dec_hi, mode_id = ctx.meta
         (x,) = ctx.saved_tensors
-        g_x = _engine.ENGINE.analysis_adjoint(g_buf, sig_shape, dec_lo, dec_hi, mode_id) if ctx.needs_input_grad[0] else None
+        # the adjoint is itself a differentiable level op (its derivative is this level again): gradients of any order w.r.t.
+        # the data, as the reference has them from plain F.pad + conv.  (The tap gradients below are first order only.)
+        g_x = _AnalysisAdjointLevel.apply(g_buf, sig_shape, dec_lo, dec_hi, mode_id) if ctx.needs_input_grad[0] else None
         g_lo = g_hi = None
         if x is not None and (ctx.needs_input_grad[4] or ctx.needs_input_grad[5]):
-            g_lo, g_hi = _analysis_tap_grads(x, g_buf, dec_lo, dec_hi, mode_id)
+            g_lo, g_hi = _analysis_tap_grads(x, g_buf.detach(), dec_lo, dec_hi, mode_id)
             g_lo, g_hi = _like(g_lo, ctx.taps[0]), _like(g_hi, ctx.taps[1])
         return g_x, None, None, None, g_lo, g_hi
+
+
+class _AnalysisAdjointLevel(torch.autograd.Function):
+    """The transpose of one analysis level, ``g_buf`` [B, 2^n, M..] -> ``g_x`` [B, N..] (C ABI ``mifwt_dwt_fwd_adjoint``) — linear, so
+    its own backward is the analysis level."""
+
+    @staticmethod
+    def forward(ctx, g_buf, sig_shape, dec_lo, dec_hi, mode_id):
+        ctx.meta = (dec_lo, dec_hi, mode_id)
+        return _engine.ENGINE.analysis_adjoint(g_buf, sig_shape, dec_lo, dec_hi, mode_id)
+
+    @staticmethod
+    def backward(ctx, gg_x):
+        dec_lo, dec_hi, mode_id = ctx.meta
+        return _AnalysisLevel.apply(gg_x, dec_lo, dec_hi, mode_id, None, None), None, None, None, None
 
 
 class _SynthesisLevel(torch.autograd.Function):
@@ -144,19 +160,34 @@ class _SynthesisLevel(torch.autograd.Function):
         return _engine.ENGINE.synthesis(approx, list(details), rec_lo, rec_hi, out_ext)
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, g_y):
         coef_shape, rec_lo, rec_hi, ndet = ctx.meta
         g_bands = (None,) * (ndet + 1)
         if any(ctx.needs_input_grad[5:]):
-            g = _engine.ENGINE.synthesis_adjoint(g_y, coef_shape, rec_lo, rec_hi)
+            g = _SynthesisAdjointLevel.apply(g_y, coef_shape, rec_lo, rec_hi)  # differentiable in turn: any order w.r.t. the data
             g_bands = tuple(g[:, s] for s in range(ndet + 1))
         g_lo = g_hi = None
         saved = ctx.saved_tensors
         if saved and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
-            g_lo, g_hi = _synthesis_tap_grads(g_y, saved[0], saved[1:], rec_lo, rec_hi)
+            g_lo, g_hi = _synthesis_tap_grads(g_y.detach(), saved[0], saved[1:], rec_lo, rec_hi)
             g_lo, g_hi = _like(g_lo, ctx.taps[0]), _like(g_hi, ctx.taps[1])
         return (None, None, None, g_lo, g_hi) + g_bands
+
+
+class _SynthesisAdjointLevel(torch.autograd.Function):
+    """The transpose of one synthesis level, ``g_y`` [B, out..] -> [B, 2^n, M..] (C ABI ``mifwt_dwt_inv_adjoint``); its own backward is
+    the synthesis level."""
+
+    @staticmethod
+    def forward(ctx, g_y, coef_shape, rec_lo, rec_hi):
+        ctx.meta = (tuple(g_y.shape[1:]), rec_lo, rec_hi)
+        return _engine.ENGINE.synthesis_adjoint(g_y, coef_shape, rec_lo, rec_hi)
+
+    @staticmethod
+    def backward(ctx, gg):
+        out_ext, rec_lo, rec_hi = ctx.meta
+        bands = [gg[:, s] for s in range(gg.shape[1])]
+        return _SynthesisLevel.apply(rec_lo, rec_hi, out_ext, None, None, bands[0], *bands[1:]), None, None, None
 
 
 _warned_tap_grad = False

@@ -11,6 +11,7 @@ from __future__ import annotations
 import json
 import math
 import os
+import weakref
 from functools import lru_cache
 from typing import List, Sequence, Tuple
 
@@ -63,9 +64,27 @@ def as_wavelet(wavelet):
     return _named(wavelet) if isinstance(wavelet, str) else wavelet
 
 
+_tensor_taps: dict = {}  # id(tensor) -> (weakref, version, data_ptr, floats)
+
+
 def _to_floats(seq) -> Tuple[float, ...]:
-    if hasattr(seq, "detach"):  # torch tensor (possibly a learnable parameter on the GPU)
-        seq = seq.detach().reshape(-1).cpu().tolist()
+    """Host copy of a tap sequence.  The kernels take the taps by value in their launch arguments, so a tensor-valued filter
+    (a learnable parameter on the GPU) costs one small device-to-host copy — once per VALUE: the copy is cached until the
+    tensor is modified in place (optimizer step) or re-pointed, so the many level launches and transform calls between two
+    updates of a learnable wavelet do not synchronise with the device again."""
+    if hasattr(seq, "detach"):
+        ent = _tensor_taps.get(id(seq))
+        ver = getattr(seq, "_version", None)
+        if ent is not None and ent[0]() is seq and ent[1] == ver and ent[2] == seq.data_ptr():
+            return ent[3]
+        vals = tuple(float(v) for v in seq.detach().reshape(-1).cpu().tolist())
+        if len(_tensor_taps) > 256:
+            _tensor_taps.clear()
+        try:
+            _tensor_taps[id(seq)] = (weakref.ref(seq), ver, seq.data_ptr(), vals)
+        except TypeError:
+            pass
+        return vals
     return tuple(float(v) for v in seq)
 
 

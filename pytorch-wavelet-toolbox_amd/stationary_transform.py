@@ -79,30 +79,32 @@ def _level_inv(a: torch.Tensor, d: torch.Tensor, lo: Sequence[float], hi: Sequen
 
 
 class _SwtLevel(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, lo, hi, dilation):
-        ctx.meta = (lo, hi, dilation)
-        return _level_fwd(x, lo, hi, dilation, 1.0)
+    """One stationary analysis level (free output scale).  With reversed taps the synthesis kernel is its transpose and vice
+    versa, so each Function's backward is the other Function: gradients of any order, as the reference has them from
+    _circular_pad + conv1d."""
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
+    def forward(ctx, x, lo, hi, dilation, scale=1.0):
+        ctx.meta = (lo, hi, dilation, scale)
+        return _level_fwd(x, lo, hi, dilation, scale)
+
+    @staticmethod
     def backward(ctx, g_buf):
-        lo, hi, dilation = ctx.meta
-        return _level_inv(g_buf[:, 0], g_buf[:, 1], lo[::-1], hi[::-1], dilation, 1.0), None, None, None
+        lo, hi, dilation, scale = ctx.meta
+        return _IswtLevel.apply(g_buf[:, 0], g_buf[:, 1], lo[::-1], hi[::-1], dilation, scale), None, None, None, None
 
 
 class _IswtLevel(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, d, lo, hi, dilation):
-        ctx.meta = (lo, hi, dilation)
-        return _level_inv(a, d, lo, hi, dilation, 0.5)
+    def forward(ctx, a, d, lo, hi, dilation, scale=0.5):
+        ctx.meta = (lo, hi, dilation, scale)
+        return _level_inv(a, d, lo, hi, dilation, scale)
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, g_y):
-        lo, hi, dilation = ctx.meta
-        g = _level_fwd(g_y, lo[::-1], hi[::-1], dilation, 0.5)
-        return g[:, 0], g[:, 1], None, None, None
+        lo, hi, dilation, scale = ctx.meta
+        g = _SwtLevel.apply(g_y, lo[::-1], hi[::-1], dilation, scale)
+        return g[:, 0], g[:, 1], None, None, None, None
 
 
 def swt_max_level(input_len: int) -> int:

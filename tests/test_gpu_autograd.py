@@ -179,3 +179,80 @@ def test_learnable_wavelet_module_trains():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0 for p in w.parameters())
     opt.step()
     assert all(not torch.equal(b, p.detach()) for b, p in zip(before, w.parameters()))
+
+
+@pytest.mark.parametrize("fn,rec,shape,mode", [("wavedec", "waverec", (3, 200), "reflect"), ("wavedec2", "waverec2", (2, 40, 52), "symmetric"),
+                                                ("wavedec3", "waverec3", (1, 20, 18, 22), "zero"), ("fswavedec2", "fswaverec2", (2, 36, 40), "periodic")])
+def test_second_order_gradients(fn, rec, shape, mode):
+    """Gradients of gradients w.r.t. the data (gradient penalties, Hessian-vector products): the reference has them because it
+    is plain F.pad + conv / conv_transpose; here every adjoint is a differentiable level op in turn.  The transform is linear
+    (c = A x), so for f(x) = sum w_i c_i^2 / 2 the Hessian-vector product is H v = A^T diag(w) A v = the FIRST-order gradient of
+    f at v: both sides come from the same kernels, only the route through autograd differs."""
+    torch.manual_seed(3)
+    x = torch.randn(*shape, device=dev(), dtype=torch.float64, requires_grad=True)
+    v = torch.randn(*shape, device=dev(), dtype=torch.float64)
+
+    def f(t):
+        cs = flat(getattr(ptwt_amd, fn)(t, "db3", level=2, mode=mode))
+        return sum((weight(c, i) * c.square()).sum() for i, c in enumerate(cs)) / 2
+
+    (g,) = torch.autograd.grad(f(x), x, create_graph=True)
+    (hv,) = torch.autograd.grad((g * v).sum(), x)
+    vv = v.clone().requires_grad_(True)
+    (want,) = torch.autograd.grad(f(vv), vv)
+    assert G.relerr(hv.cpu().numpy(), want.cpu().numpy()) < 1e-11
+    # and through the synthesis side: y = R c, d/dc of <grad_c(sum y^2 / 2), u> = R^T R u
+    cs = [c.detach().clone().requires_grad_(True) for c in flat(getattr(ptwt_amd, fn)(x.detach(), "db3", level=2, mode=mode))]
+    coeffs = rebuild(getattr(ptwt_amd, fn)(x.detach(), "db3", level=2, mode=mode), cs)
+    y = getattr(ptwt_amd, rec)(coeffs, "db3")
+    gs = torch.autograd.grad(y.square().sum() / 2, cs, create_graph=True)
+    us = [torch.randn_like(c) for c in cs]
+    hu = torch.autograd.grad(sum((a * b).sum() for a, b in zip(gs, us)), cs)
+    cu = [u.clone().requires_grad_(True) for u in us]
+    yu = getattr(ptwt_amd, rec)(rebuild(coeffs, cu), "db3")
+    want = torch.autograd.grad(yu.square().sum() / 2, cu)
+    for a, b in zip(hu, want):
+        assert G.relerr(a.cpu().numpy(), b.cpu().numpy()) < 1e-11
+
+
+def test_second_order_gradients_swt():
+    torch.manual_seed(4)
+    x = torch.randn(3, 96, device=dev(), dtype=torch.float64, requires_grad=True)
+    v = torch.randn(3, 96, device=dev(), dtype=torch.float64)
+
+    def f(t):
+        return sum((weight(c, i) * c.square()).sum() for i, c in enumerate(ptwt_amd.swt(t, "db2", 3))) / 2
+
+    (g,) = torch.autograd.grad(f(x), x, create_graph=True)
+    (hv,) = torch.autograd.grad((g * v).sum(), x)
+    vv = v.clone().requires_grad_(True)
+    (want,) = torch.autograd.grad(f(vv), vv)
+    assert G.relerr(hv.cpu().numpy(), want.cpu().numpy()) < 1e-11
+    cs = [c.detach().clone().requires_grad_(True) for c in ptwt_amd.swt(x.detach(), "db2", 3)]
+    gs = torch.autograd.grad(ptwt_amd.iswt(cs, "db2").square().sum() / 2, cs, create_graph=True)
+    us = [torch.randn_like(c) for c in cs]
+    hu = torch.autograd.grad(sum((a * b).sum() for a, b in zip(gs, us)), cs)
+    cu = [u.clone().requires_grad_(True) for u in us]
+    want = torch.autograd.grad(ptwt_amd.iswt(cu, "db2").square().sum() / 2, cu)
+    for a, b in zip(hu, want):
+        assert G.relerr(a.cpu().numpy(), b.cpu().numpy()) < 1e-11
+
+
+def test_tensor_taps_are_read_back_once_per_value():
+    """Tap tensors on the GPU are copied to the host once per value (the kernels take taps by value): repeated calls between two
+    updates of a learnable wavelet reuse the copy, an in-place update invalidates it."""
+    from ptwt_amd import _wavelets
+
+    t = torch.tensor([0.5, 0.5], device=dev())
+    a = _wavelets._to_floats(t)
+    assert _wavelets._to_floats(t) is a
+    with torch.no_grad():
+        t.mul_(2.0)
+    b = _wavelets._to_floats(t)
+    assert b == (1.0, 1.0) and b is not a
+    bank = tuple(torch.tensor(v, device=dev(), dtype=torch.float64) for v in ptwt_amd._wavelets.host_taps("db2"))
+    x = torch.randn(2, 64, device=dev(), dtype=torch.float64)
+    c1 = ptwt_amd.wavedec(x, bank, level=2)
+    c2 = ptwt_amd.wavedec(x, "db2", level=2)
+    for u, w in zip(c1, c2):
+        assert torch.equal(u, w)
