@@ -230,7 +230,7 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
 
 /* Which kernel family a call would dispatch to (tests use it to assert the fast path is the one that ran);
  * negative = error code.
- *   0  generic per-axis passes (any strides, any L <= 128)
+ *   0  generic per-axis passes (any strides, any L <= 128; f32 / f64 / f16 storage — the fallback of every call no fused kernel takes)
  *   1 / 2  fused single-launch 2-D analysis / synthesis level, streaming wave strips (f32, even L <= 16)
  *   7 / 8  fused single-launch 2-D analysis / synthesis level, LDS tiles (f32 / f16, even L <= 20, 24, 32; f64, even L <= 16); the
  *          default 2-D kernels — the streaming analysis kernel is kept for 16-tap filters on planes >= ~1500^2

@@ -224,7 +224,7 @@ size_t route_ws(const mifwt_level_desc* d, int direction, int kid) {
     case kDwt3InvStream: return plane3_ws_bytes(d, direction);
     case kDwt1FwdRow:
     case kDwt1InvRow: return rows_ws_bytes(d, direction);
-    default: return d->dtype == MIFWT_F16 ? 0 : generic_ws(d, direction);
+    default: return generic_ws(d, direction);
   }
 }
 
@@ -311,7 +311,7 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction) {
 // taps), so they ride on the fast kernels; other boundary modes fold their halo back in the generic adjoint passes.
 size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction) {
   if (direction == 2) {
-    if (validate(desc, 0) != MIFWT_OK || desc->dtype == MIFWT_F16) return 0;
+    if (validate(desc, 0) != MIFWT_OK) return 0;
     if (desc->mode == MIFWT_MODE_ZERO) return route_ws(desc, 1, pick_kernel(desc, 1));
     return generic_ws(desc, 1);
   }
@@ -335,7 +335,6 @@ static int run_fwd(const mifwt_level_desc* desc, const void* x, void* approx, vo
   if (desc->batch == 0) return MIFWT_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int kid = pick_kernel(desc, 0);
-  if (kid == kGeneric && desc->dtype == MIFWT_F16) return MIFWT_ERR_UNSUPPORTED;
   const size_t need = route_ws(desc, 0, kid);
   if (need > 0 && (!workspace || workspace_bytes < need)) return MIFWT_ERR_WORKSPACE;
   switch (kid) {
@@ -361,7 +360,6 @@ static int run_inv(const mifwt_level_desc* desc, const void* approx, const void*
   if (desc->batch == 0) return MIFWT_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int kid = pick_kernel(desc, 1);
-  if (kid == kGeneric && desc->dtype == MIFWT_F16) return MIFWT_ERR_UNSUPPORTED;
   const size_t need = route_ws(desc, 1, kid);
   if (need > 0 && (!workspace || workspace_bytes < need)) return MIFWT_ERR_WORKSPACE;
   switch (kid) {
@@ -406,7 +404,6 @@ int mifwt_dwt_fwd_adjoint(const mifwt_level_desc* desc, const void* g_approx, co
   for (int s = 1; s < (1 << desc->ndim); ++s)
     if (!g_details[s - 1]) return MIFWT_ERR_BADARG;
   if (desc->batch == 0) return MIFWT_OK;
-  if (desc->dtype == MIFWT_F16) return MIFWT_ERR_UNSUPPORTED;
   const size_t need = generic_ws(desc, 1);
   if (need > 0 && (!workspace || workspace_bytes < need)) return MIFWT_ERR_WORKSPACE;
   return generic_inv(desc, g_approx, g_details, g_x, dec_lo, dec_hi, workspace, static_cast<hipStream_t>(stream), true);

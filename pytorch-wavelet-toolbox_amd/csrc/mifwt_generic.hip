@@ -1,7 +1,8 @@
 // mifwt_generic.hip — generic per-axis analysis / synthesis kernels for gfx950.
 //
 // The catch-all behind the fused fast paths: one transformed axis per launch, any filter length up to
-// 128 taps, any boundary mode, arbitrary element strides, f32 or f64.  A thread owns one output
+// 128 taps, any boundary mode, arbitrary element strides, f32 / f64 in their own precision and f16 STORAGE with f32 arithmetic (the
+// intermediate passes of an N-D level are then rounded to f16 like every other f16 path of the library).  A thread owns one output
 // coefficient position and produces the low- and high-pass value together (analysis), or one output
 // sample (synthesis, polyphase gather: only the L/2 non-zero products of the transposed convolution are
 // formed and only the cropped interior is computed).  Up to four independent (input -> lo, hi) jobs of
@@ -35,8 +36,8 @@ struct AxisJobs {
   AxisJob job[4];
 };
 
-template <typename T>
-__global__ void __launch_bounds__(256) axis_fwd_kernel(AxisJobs jobs, AxisGeom g, Taps<T> taps) {
+template <typename T, typename A>
+__global__ void __launch_bounds__(256) axis_fwd_kernel(AxisJobs jobs, AxisGeom g, Taps<A> taps) {
   const AxisJob& jb = jobs.job[blockIdx.y];
   const T* __restrict__ in = static_cast<const T*>(jb.in0);
   T* __restrict__ lo = static_cast<T*>(jb.out0);
@@ -59,20 +60,20 @@ __global__ void __launch_bounds__(256) axis_fwd_kernel(AxisJobs jobs, AxisGeom g
       hbase += c[d] * jb.out1_stride[d];
     }
     const int k = (int)c[g.taxis];
-    T acc_lo = 0, acc_hi = 0;
+    A acc_lo = 0, acc_hi = 0;
     for (int m = 0; m < g.filt_len; ++m) {
       const int src = ext_index(2 * k + 1 - m, g.n_src, g.mode);
-      const T v = src >= 0 ? in[ibase + (int64_t)src * stride_t] : T(0);
+      const A v = src >= 0 ? (A)in[ibase + (int64_t)src * stride_t] : A(0);
       acc_lo = fma(taps.lo[m], v, acc_lo);
       acc_hi = fma(taps.hi[m], v, acc_hi);
     }
-    lo[lbase] = acc_lo;
-    hi[hbase] = acc_hi;
+    lo[lbase] = (T)acc_lo;
+    hi[hbase] = (T)acc_hi;
   }
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) axis_inv_kernel(AxisJobs jobs, AxisGeom g, Taps<T> taps) {
+template <typename T, typename A>
+__global__ void __launch_bounds__(256) axis_inv_kernel(AxisJobs jobs, AxisGeom g, Taps<A> taps) {
   const AxisJob& jb = jobs.job[blockIdx.y];
   const T* __restrict__ a = static_cast<const T*>(jb.in0);
   const T* __restrict__ dd = static_cast<const T*>(jb.in1);
@@ -103,13 +104,13 @@ __global__ void __launch_bounds__(256) axis_inv_kernel(AxisJobs jobs, AxisGeom g
     if (k_lo < 0) k_lo = 0;
     int k_hi = q >> 1;
     if (k_hi > g.n_src - 1) k_hi = g.n_src - 1;
-    T acc = 0;
+    A acc = 0;
     for (int k = k_lo; k <= k_hi; ++k) {
       const int t = q - 2 * k;
-      acc = fma(taps.lo[t], a[abase + (int64_t)k * sa], acc);
-      acc = fma(taps.hi[t], dd[dbase + (int64_t)k * sd], acc);
+      acc = fma(taps.lo[t], (A)a[abase + (int64_t)k * sa], acc);
+      acc = fma(taps.hi[t], (A)dd[dbase + (int64_t)k * sd], acc);
     }
-    y[ybase] = acc;
+    y[ybase] = (T)acc;
   }
 }
 
@@ -118,8 +119,8 @@ __global__ void __launch_bounds__(256) axis_inv_kernel(AxisJobs jobs, AxisGeom g
 //     u[e] = sum_k g_lo[k] h_lo[2k + 1 - e] + g_hi[k] h_hi[2k + 1 - e],
 // the gradient folds the halo back through the boundary index map:  g_x[i] = sum_{e : ext_index(e) = i} u[e].
 // (The reference gets this from ATen autograd through F.pad / _pad_symmetric + F.conv*d.)
-template <typename T>
-__global__ void __launch_bounds__(256) axis_adj_kernel(AxisJobs jobs, AxisGeom g, Taps<T> taps) {
+template <typename T, typename A>
+__global__ void __launch_bounds__(256) axis_adj_kernel(AxisJobs jobs, AxisGeom g, Taps<A> taps) {
   const AxisJob& jb = jobs.job[blockIdx.y];
   const T* __restrict__ a = static_cast<const T*>(jb.in0);
   const T* __restrict__ dd = static_cast<const T*>(jb.in1);
@@ -147,31 +148,31 @@ __global__ void __launch_bounds__(256) axis_adj_kernel(AxisJobs jobs, AxisGeom g
       ybase += c[d] * jb.out0_stride[d];
     }
     const int i = (int)c[g.taxis];
-    auto u = [&](int e) -> T {  // 2k + 1 - e in [0, L)  <=>  k in [ceil((e - 1) / 2), floor((e + L - 2) / 2)]
+    auto u = [&](int e) -> A {  // 2k + 1 - e in [0, L)  <=>  k in [ceil((e - 1) / 2), floor((e + L - 2) / 2)]
       int k_lo = e >> 1;        // ceil((e - 1) / 2) = floor(e / 2) for every integer e
       if (k_lo < 0) k_lo = 0;
       int k_hi = (e + L - 2) >> 1;
       if (k_hi > M - 1) k_hi = M - 1;
-      T acc = 0;
+      A acc = 0;
       for (int k = k_lo; k <= k_hi; ++k) {
         const int m = 2 * k + 1 - e;
-        acc = fma(taps.lo[m], a[abase + (int64_t)k * sa], acc);
-        acc = fma(taps.hi[m], dd[dbase + (int64_t)k * sd], acc);
+        acc = fma(taps.lo[m], (A)a[abase + (int64_t)k * sa], acc);
+        acc = fma(taps.hi[m], (A)dd[dbase + (int64_t)k * sd], acc);
       }
       return acc;
     };
-    T acc = u(i);
+    A acc = u(i);
     if (g.mode != MIFWT_MODE_ZERO && (i < border || i >= N - border)) {
       for (int e = -pl; e < 0; ++e)
         if (ext_index(e, N, g.mode) == i) acc += u(e);
       for (int e = N; e < N + pr; ++e)
         if (ext_index(e, N, g.mode) == i) acc += u(e);
     }
-    y[ybase] = acc;
+    y[ybase] = (T)acc;
   }
 }
 
-template <typename T>
+template <typename T, typename A = T>
 static int launch_axis(int kind, const AxisJob* jobs, int njobs, const int64_t out_ext[4], int taxis,
                        int64_t n_src, int mode, int filt_len, const double* lo, const double* hi,
                        hipStream_t stream, int64_t n_sig = 0) {  // kind: 0 analysis, 1 synthesis, 2 analysis adjoint
@@ -190,20 +191,20 @@ static int launch_axis(int kind, const AxisJob* jobs, int njobs, const int64_t o
   g.n_sig = (int)n_sig;
   g.mode = mode;
   g.filt_len = filt_len;
-  Taps<T> taps;
+  Taps<A> taps;
   for (int m = 0; m < kMaxFilt; ++m) {
-    taps.lo[m] = m < filt_len ? (T)lo[m] : T(0);
-    taps.hi[m] = m < filt_len ? (T)hi[m] : T(0);
+    taps.lo[m] = m < filt_len ? (A)lo[m] : A(0);
+    taps.hi[m] = m < filt_len ? (A)hi[m] : A(0);
   }
   const int64_t want = (g.total + 255) / 256;
   const unsigned gx = (unsigned)(want < 8192 ? want : 8192);  // grid-stride beyond 256 CUs x 32 blocks
   dim3 grid(gx, (unsigned)njobs), block(256);
   if (kind == 2)
-    hipLaunchKernelGGL(axis_adj_kernel<T>, grid, block, 0, stream, js, g, taps);
+    hipLaunchKernelGGL((axis_adj_kernel<T, A>), grid, block, 0, stream, js, g, taps);
   else if (kind == 1)
-    hipLaunchKernelGGL(axis_inv_kernel<T>, grid, block, 0, stream, js, g, taps);
+    hipLaunchKernelGGL((axis_inv_kernel<T, A>), grid, block, 0, stream, js, g, taps);
   else
-    hipLaunchKernelGGL(axis_fwd_kernel<T>, grid, block, 0, stream, js, g, taps);
+    hipLaunchKernelGGL((axis_fwd_kernel<T, A>), grid, block, 0, stream, js, g, taps);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 
@@ -211,6 +212,7 @@ int launch_axis_fwd(int dtype, const AxisJob* jobs, int njobs, const int64_t out
                     int mode, int filt_len, const double* lo, const double* hi, hipStream_t stream) {
   if (dtype == MIFWT_F32) return launch_axis<float>(0, jobs, njobs, out_ext, taxis, n_in, mode, filt_len, lo, hi, stream);
   if (dtype == MIFWT_F64) return launch_axis<double>(0, jobs, njobs, out_ext, taxis, n_in, mode, filt_len, lo, hi, stream);
+  if (dtype == MIFWT_F16) return launch_axis<_Float16, float>(0, jobs, njobs, out_ext, taxis, n_in, mode, filt_len, lo, hi, stream);
   return MIFWT_ERR_UNSUPPORTED;
 }
 
@@ -218,6 +220,7 @@ int launch_axis_inv(int dtype, const AxisJob* jobs, int njobs, const int64_t out
                     int filt_len, const double* lo, const double* hi, hipStream_t stream) {
   if (dtype == MIFWT_F32) return launch_axis<float>(1, jobs, njobs, out_ext, taxis, m_in, 0, filt_len, lo, hi, stream);
   if (dtype == MIFWT_F64) return launch_axis<double>(1, jobs, njobs, out_ext, taxis, m_in, 0, filt_len, lo, hi, stream);
+  if (dtype == MIFWT_F16) return launch_axis<_Float16, float>(1, jobs, njobs, out_ext, taxis, m_in, 0, filt_len, lo, hi, stream);
   return MIFWT_ERR_UNSUPPORTED;
 }
 
@@ -225,6 +228,7 @@ int launch_axis_adj(int dtype, const AxisJob* jobs, int njobs, const int64_t out
                     int64_t n_sig, int mode, int filt_len, const double* lo, const double* hi, hipStream_t stream) {
   if (dtype == MIFWT_F32) return launch_axis<float>(2, jobs, njobs, out_ext, taxis, m_in, mode, filt_len, lo, hi, stream, n_sig);
   if (dtype == MIFWT_F64) return launch_axis<double>(2, jobs, njobs, out_ext, taxis, m_in, mode, filt_len, lo, hi, stream, n_sig);
+  if (dtype == MIFWT_F16) return launch_axis<_Float16, float>(2, jobs, njobs, out_ext, taxis, m_in, mode, filt_len, lo, hi, stream, n_sig);
   return MIFWT_ERR_UNSUPPORTED;
 }
 

@@ -908,3 +908,32 @@ def test_idwt1_tail_fusion_vs_oracle_and_per_level(dtype):
         finally:
             _engine.set_option(_engine.OPT_PAIR_MODE, 0)
         assert G.relerr(to_np(got), to_np(single)) < (1e-13 if dtype == torch.float64 else 2e-6)
+
+
+def test_f16_storage_outside_the_fused_envelopes():
+    """f16 storage on geometries no fused kernel takes (planes shorter than the filter, filter lengths the streaming kernels are
+    not instantiated for, 3-D) and its backward with a non-zero boundary mode: the generic per-axis passes serve them (f16
+    storage, f32 arithmetic) instead of MIFWT_ERR_UNSUPPORTED.  Oracle: fp64 transform of the f16-quantised input, 2e-3 per level
+    (the passes of an N-D level round to f16 in between, like every f16 path)."""
+    ptwt_amd.set_half_storage(True)
+    try:
+        torch.manual_seed(21)
+        for fn, ofn, shape, wavelet, mode, level in [("wavedec2", O.wavedec2, (2, 5, 40), "db4", "symmetric", 1),
+                                                     ("wavedec2", O.wavedec2, (2, 70, 66), "db11", "reflect", 2),
+                                                     ("wavedec3", O.wavedec3, (1, 20, 24, 18), "db2", "constant", 2),
+                                                     ("wavedec", O.wavedec, (3, 300), "coif5", "periodic", 2)]:
+            x = torch.randn(*shape, device=dev()).half()
+            got = getattr(ptwt_amd, fn)(x, wavelet, mode=mode, level=level)
+            want = ofn(x.double().cpu().numpy(), wavelet, mode=mode, level=level)
+            for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(want)):
+                assert a.dtype == torch.float16 and G.relerr(to_np(a.double()), b) < 2e-3 * level, (fn, wavelet, n)
+        # backward through a reflect-mode level in f16 storage: adjoint identity <A x, w> = <x, A^T w> in f16 tolerance
+        x = torch.randn(2, 48, 52, device=dev()).half().requires_grad_(True)
+        c = ptwt_amd.wavedec2(x, "db3", mode="reflect", level=1)
+        ws = [torch.randn_like(t) for _, t in G.flatten_coeffs(c)]
+        lhs = sum((t.float() * w.float()).sum() for (_, t), w in zip(G.flatten_coeffs(c), ws))
+        (gx,) = torch.autograd.grad(sum((t * w).sum() for (_, t), w in zip(G.flatten_coeffs(c), ws)), x)
+        rhs = (x.detach().float() * gx.float()).sum()
+        assert abs(float(lhs.detach() - rhs)) < 5e-3 * float(lhs.detach().abs() + rhs.abs() + 1.0)
+    finally:
+        ptwt_amd.set_half_storage(False)
