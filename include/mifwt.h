@@ -223,6 +223,13 @@ int mifwt_swt_inv(int dtype, int filt_len, int64_t rows, int64_t n, int64_t dila
 int mifwt_tap_correlate(int dtype, int64_t rows, int64_t m_len, int64_t n_len, const void* a, int64_t a_row_stride,
                         const void* b, int64_t b_row_stride, int filt_len, int c0, int sgn, int mode, double* out,
                         void* stream);
+/* The same reduction for the STATIONARY levels (mifwt_swt_fwd / mifwt_swt_inv: stride 1, dilation D, periodic with any number of
+ * wraps):     out[t] += sum_{row < rows} sum_{k < n} a[row, k] * b[row, (k + c0 + tstep * t) mod n],     t in [0, filt_len)
+ *   swt level,  dL/d dec[m]:  a = upstream gradient of the band, b = level input,        c0 = D L/2,       tstep = -D
+ *   iswt level, dL/d rec[j]:  a = upstream gradient of y,        b = the band (a or d),  c0 = D (L/2 - 1), tstep = -D  (times the
+ *   level's scale, which the host applies).  f32 / f64. */
+int mifwt_tap_correlate_dilated(int dtype, int64_t rows, int64_t n, const void* a, int64_t a_row_stride, const void* b,
+                                int64_t b_row_stride, int filt_len, int64_t c0, int64_t tstep, double* out, void* stream);
 
 /* Scratch bytes one call needs (0 on the fused paths).  direction: 0 = analysis, 1 = synthesis,
  * 2 = mifwt_dwt_fwd_adjoint, 3 = mifwt_dwt_inv_adjoint (same numbering for mifwt_kernel_id). */

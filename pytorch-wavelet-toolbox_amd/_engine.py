@@ -78,6 +78,9 @@ def load_library() -> ctypes.CDLL:
     lib.mifwt_tap_correlate.restype = ctypes.c_int
     lib.mifwt_tap_correlate.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, vp,
                                         ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
+    lib.mifwt_tap_correlate_dilated.restype = ctypes.c_int
+    lib.mifwt_tap_correlate_dilated.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64,
+                                                ctypes.c_int, ctypes.c_int64, ctypes.c_int64, vp, vp]
     lib.mifwt_dwt2_fwd_pair_supported.restype = ctypes.c_int
     lib.mifwt_dwt2_fwd_pair_supported.argtypes = [desc_p, desc_p]
     lib.mifwt_dwt2_fwd_pair.restype = ctypes.c_int
@@ -649,6 +652,22 @@ class HipLevelEngine:
             rc = lib.mifwt_tap_correlate(_DTYPE_IDS[a.dtype], a.shape[0], a.shape[1], b.shape[1], a.data_ptr(), a.stride(0),
                                          b.data_ptr(), b.stride(0), filt_len, c0, sgn, mode_id, out.data_ptr(),
                                          _raw_stream(a.device.index if a.device.index is not None else torch.cuda.current_device()))
+        _check(rc)
+
+    def tap_correlate_dilated(self, a: torch.Tensor, b: torch.Tensor, filt_len: int, c0: int, tstep: int, out: torch.Tensor) -> None:
+        """``out[t] += sum_{row, k} a[row, k] * b[row, (k + c0 + tstep t) mod N]`` (C ABI ``mifwt_tap_correlate_dilated``): the tap
+        gradients of the stationary levels; ``a``, ``b`` [rows, N] (contiguous samples), ``out`` float64 [filt_len]."""
+        _require_gpu(a)
+        lib = load_library()
+        if a.stride(-1) != 1:
+            a = a.contiguous()
+        if b.stride(-1) != 1:
+            b = b.contiguous()
+        assert a.dim() == 2 and a.shape == b.shape and out.dtype == torch.float64
+        with torch.cuda.device(a.device):
+            rc = lib.mifwt_tap_correlate_dilated(_DTYPE_IDS[a.dtype], a.shape[0], a.shape[1], a.data_ptr(), a.stride(0), b.data_ptr(),
+                                                 b.stride(0), filt_len, c0, tstep, out.data_ptr(),
+                                                 _raw_stream(a.device.index if a.device.index is not None else torch.cuda.current_device()))
         _check(rc)
 
     @staticmethod

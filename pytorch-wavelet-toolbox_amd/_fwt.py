@@ -190,21 +190,6 @@ class _SynthesisAdjointLevel(torch.autograd.Function):
         return _SynthesisLevel.apply(rec_lo, rec_hi, out_ext, None, None, bands[0], *bands[1:]), None, None, None
 
 
-_warned_tap_grad = False
-
-
-def _warn_tap_grad(wavelet) -> None:
-    """For the transforms whose taps are constants to autograd (swt / iswt, packet trees): say so once."""
-    global _warned_tap_grad
-    if _warned_tap_grad or _tap_tensors(wavelet) is None:
-        return
-    import warnings
-
-    _warned_tap_grad = True
-    warnings.warn("ptwt_amd: this transform treats the filter taps as constants; gradients w.r.t. learnable wavelet taps are "
-                  "propagated by wavedec/waverec{,2,3} and fswavedec/fswaverec{2,3} only.", stacklevel=3)
-
-
 def _tap_tensors(wavelet):
     """(dec_lo, dec_hi, rec_lo, rec_hi) as the caller's TENSORS when the filter bank is learnable (any of them requires
     grad and grad mode is on), else None.  src/ptwt/_util.py:115-132 keeps such taps in the graph with torch.as_tensor."""

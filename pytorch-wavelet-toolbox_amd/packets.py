@@ -122,8 +122,9 @@ class _PacketTree(collections.UserDict):
         dec_lo, dec_hi, _, _ = host_taps(self.wavelet)
         mode_id = _fwt._mode_id(self.mode)
         _fwt._check_pad(flat.shape[1:], len(dec_lo), "reflect" if self.mode is None else self.mode)
-        if flat.requires_grad and torch.is_grad_enabled():
-            out = _fwt._AnalysisLevel.apply(flat, dec_lo, dec_hi, mode_id, None, None)
+        tap_t = _fwt._tap_tensors(self.wavelet)  # learnable filter bank: the taps stay in the graph (src/ptwt/_util.py:115-132)
+        if torch.is_grad_enabled() and (flat.requires_grad or tap_t is not None):
+            out = _fwt._AnalysisLevel.apply(flat, dec_lo, dec_hi, mode_id, *((tap_t[0], tap_t[1]) if tap_t else (None, None)))
         else:
             out = _engine.ENGINE.analysis(flat, dec_lo, dec_hi, mode_id)  # [B * nb^level, nb, M..]
         nxt = out.reshape(src.shape[0], *([nb] * (level + 1)), *out.shape[2:])
@@ -176,6 +177,7 @@ class _PacketTree(collections.UserDict):
             root = self[""]  # raises the reference's ValueError for an uninitialised tree
             self.maxlevel = dwt_max_level(min(self._layout.fold(root).shape[1:]), filter_length(self.wavelet))
         _, _, rec_lo, rec_hi = host_taps(self.wavelet)
+        tap_t = _fwt._tap_tensors(self.wavelet)
         flen = len(rec_lo)
         nb = len(self._bands)
         nd = self._ndim
@@ -196,8 +198,8 @@ class _PacketTree(collections.UserDict):
                         assert out_ext[a] == target[a] + 1, "padding error, please open an issue on github"
                         out_ext[a] = target[a]
             approx, details = flat[:, 0], [flat[:, s] for s in range(1, nb)]
-            if torch.is_grad_enabled() and flat.requires_grad:
-                rec = _fwt._SynthesisLevel.apply(rec_lo, rec_hi, tuple(out_ext), None, None, approx, *details)
+            if torch.is_grad_enabled() and (flat.requires_grad or tap_t is not None):
+                rec = _fwt._SynthesisLevel.apply(rec_lo, rec_hi, tuple(out_ext), *((tap_t[2], tap_t[3]) if tap_t else (None, None)), approx, *details)
             else:
                 rec = _engine.ENGINE.synthesis(approx, details, rec_lo, rec_hi, out_ext)
             buf = rec.reshape(children.shape[0], *([nb] * level), *rec.shape[1:])

@@ -79,32 +79,69 @@ def _level_inv(a: torch.Tensor, d: torch.Tensor, lo: Sequence[float], hi: Sequen
 
 
 class _SwtLevel(torch.autograd.Function):
-    """One stationary analysis level (free output scale).  With reversed taps the synthesis kernel is its transpose and vice
-    versa, so each Function's backward is the other Function: gradients of any order, as the reference has them from
-    _circular_pad + conv1d."""
+    """One stationary analysis level (free output scale), differentiable w.r.t. its input and (optionally) the dec taps.  With
+    reversed taps the synthesis kernel is its transpose and vice versa, so each Function's backward is the other Function:
+    gradients of any order w.r.t. the data, as the reference has them from _circular_pad + conv1d; the tap gradients (first
+    order) are the dilated correlation ``mifwt_tap_correlate_dilated``.  ``lo_t`` / ``hi_t``: the tap TENSORS or None (they only tie
+    the op into the graph; the kernels take the host copies)."""
 
     @staticmethod
-    def forward(ctx, x, lo, hi, dilation, scale=1.0):
+    def forward(ctx, x, lo, hi, dilation, scale=1.0, lo_t=None, hi_t=None):
         ctx.meta = (lo, hi, dilation, scale)
+        ctx.taps = (lo_t, hi_t)
+        need_taps = any(t is not None and t.requires_grad for t in (lo_t, hi_t))
+        ctx.save_for_backward(x if need_taps else None)
         return _level_fwd(x, lo, hi, dilation, scale)
 
     @staticmethod
     def backward(ctx, g_buf):
         lo, hi, dilation, scale = ctx.meta
-        return _IswtLevel.apply(g_buf[:, 0], g_buf[:, 1], lo[::-1], hi[::-1], dilation, scale), None, None, None, None
+        (x,) = ctx.saved_tensors
+        g_x = _IswtLevel.apply(g_buf[:, 0], g_buf[:, 1], lo[::-1], hi[::-1], dilation, scale) if ctx.needs_input_grad[0] else None
+        g_lo = g_hi = None
+        if x is not None and (ctx.needs_input_grad[5] or ctx.needs_input_grad[6]):
+            # lo[n] = s sum_m h[m] x[(n + D (L/2 - m)) mod N]  =>  dL/dh[m] = s sum_n g_lo[n] x[(n + D L/2 - D m) mod N]
+            L = len(lo)
+            g_lo = torch.zeros(L, dtype=torch.float64, device=x.device)
+            g_hi = torch.zeros_like(g_lo)
+            gb = g_buf.detach()
+            _engine.ENGINE.tap_correlate_dilated(gb[:, 0], x, L, dilation * (L // 2), -dilation, g_lo)
+            _engine.ENGINE.tap_correlate_dilated(gb[:, 1], x, L, dilation * (L // 2), -dilation, g_hi)
+            g_lo, g_hi = _fwt._like(g_lo * scale, ctx.taps[0]), _fwt._like(g_hi * scale, ctx.taps[1])
+        return g_x, None, None, None, None, g_lo, g_hi
 
 
 class _IswtLevel(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, d, lo, hi, dilation, scale=0.5):
+    def forward(ctx, a, d, lo, hi, dilation, scale=0.5, lo_t=None, hi_t=None):
         ctx.meta = (lo, hi, dilation, scale)
+        ctx.taps = (lo_t, hi_t)
+        need_taps = any(t is not None and t.requires_grad for t in (lo_t, hi_t))
+        if need_taps:
+            ctx.save_for_backward(a, d)
+        else:
+            ctx.save_for_backward()
         return _level_inv(a, d, lo, hi, dilation, scale)
 
     @staticmethod
     def backward(ctx, g_y):
         lo, hi, dilation, scale = ctx.meta
-        g = _SwtLevel.apply(g_y, lo[::-1], hi[::-1], dilation, scale)
-        return g[:, 0], g[:, 1], None, None, None, None
+        g_a = g_d = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            g = _SwtLevel.apply(g_y, lo[::-1], hi[::-1], dilation, scale)
+            g_a, g_d = g[:, 0], g[:, 1]
+        g_lo = g_hi = None
+        saved = ctx.saved_tensors
+        if saved and (ctx.needs_input_grad[6] or ctx.needs_input_grad[7]):
+            # y[n] = s sum_j g_lo[j] a[(n + D (L/2 - 1 - j)) mod N] + g_hi[j] d[...]  =>  dL/dg_lo[j] = s sum_n g_y[n] a[(n + D (L/2 - 1) - D j) mod N]
+            L = len(lo)
+            g_lo = torch.zeros(L, dtype=torch.float64, device=g_y.device)
+            g_hi = torch.zeros_like(g_lo)
+            gy = g_y.detach()
+            _engine.ENGINE.tap_correlate_dilated(gy, saved[0], L, dilation * (L // 2 - 1), -dilation, g_lo)
+            _engine.ENGINE.tap_correlate_dilated(gy, saved[1], L, dilation * (L // 2 - 1), -dilation, g_hi)
+            g_lo, g_hi = _fwt._like(g_lo * scale, ctx.taps[0]), _fwt._like(g_hi * scale, ctx.taps[1])
+        return g_a, g_d, None, None, None, None, g_lo, g_hi
 
 
 def swt_max_level(input_len: int) -> int:
@@ -124,14 +161,14 @@ def swt(data: torch.Tensor, wavelet: Union[Wavelet, str], level: Optional[int] =
     layout = _fwt._Layout(data, 1, axes)
     x = layout.fold(data)
     dec_lo, dec_hi, _, _ = host_taps(wavelet)
-    _fwt._warn_tap_grad(wavelet)
+    tap_t = _fwt._tap_tensors(wavelet)  # learnable filter bank: the taps stay in the graph (src/ptwt/_util.py:115-132)
     if level is None:
         level = swt_max_level(x.shape[-1])
     out: List[torch.Tensor] = []
     cur = x
     for lvl in range(level):
-        if cur.requires_grad and torch.is_grad_enabled():
-            buf = _SwtLevel.apply(cur, dec_lo, dec_hi, 2 ** lvl)
+        if torch.is_grad_enabled() and (cur.requires_grad or tap_t is not None):
+            buf = _SwtLevel.apply(cur, dec_lo, dec_hi, 2 ** lvl, 1.0, *((tap_t[0], tap_t[1]) if tap_t else (None, None)))
         else:
             buf = _level_fwd(cur, dec_lo, dec_hi, 2 ** lvl, 1.0)
         out.append(layout.unfold(buf[:, 1]))
@@ -153,15 +190,15 @@ def iswt(coeffs: Sequence[torch.Tensor], wavelet: Union[Wavelet, str], *, axis: 
             raise ValueError(f"Unexpected input type {type(t)}")
     _fwt._check_same_device_dtype(coeffs)
     _, _, rec_lo, rec_hi = host_taps(wavelet)
-    _fwt._warn_tap_grad(wavelet)
+    tap_t = _fwt._tap_tensors(wavelet)
     cur = layout.fold(coeffs[0])
     details = [layout.fold(t) for t in coeffs[1:]]
     for pos, det in enumerate(details):
         dilation = 2 ** (len(details) - pos - 1)
         if det.shape != cur.shape:
             raise RuntimeError("stack expects each tensor to be equal size")  # torch.stack in the reference (:146)
-        if torch.is_grad_enabled() and (cur.requires_grad or det.requires_grad):
-            cur = _IswtLevel.apply(cur, det, rec_lo, rec_hi, dilation)
+        if torch.is_grad_enabled() and (cur.requires_grad or det.requires_grad or tap_t is not None):
+            cur = _IswtLevel.apply(cur, det, rec_lo, rec_hi, dilation, 0.5, *((tap_t[2], tap_t[3]) if tap_t else (None, None)))
         else:
             cur = _level_inv(cur, det, rec_lo, rec_hi, dilation, 0.5)
     return layout.unfold(cur)

@@ -74,6 +74,41 @@ case("fswavedec3", "fswaverec3", (1, 12, 11, 13), "db2", 77, mode="reflect", lev
 case("wavedec2", "waverec2", (2, 40, 44), "bior2.2", 78, mode="symmetric", level=2)
 case("wavedec", "waverec", (3, 5, 64), "sym4", 79, mode="reflect", level=3, axis=-1)
 
+# stationary transform: same loss construction (a list of tensors in, one tensor out)
+for k, (shape, wavelet, level) in enumerate((((2, 64), "db2", 3), ((3, 48), "haar", 2), ((1, 96), "sym4", None))):
+    case("swt", "iswt", shape, wavelet, 90 + k, level=level)
+
+
+def packet_case(dim, shape, wavelet, mode, maxlevel, seed, **kw):
+    """Packet trees: loss_a over the leaves of maxlevel (natural order), loss_s over reconstruct()'s root."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(*shape, generator=g, dtype=torch.float64)
+    taps = [torch.tensor(list(t), dtype=torch.float64, requires_grad=True) for t in pywt.Wavelet(wavelet).filter_bank]
+    wt = WaveletTensorTuple(*taps)
+    cls = ptwt.WaveletPacket if dim == 1 else ptwt.WaveletPacket2D
+    wp = cls(x, wt, mode=mode, maxlevel=maxlevel, **kw)
+    keys = wp.get_level(maxlevel, "natural")
+    loss = sum((weight(wp[k], i) * wp[k]).sum() for i, k in enumerate(keys))
+    g_dec = torch.autograd.grad(loss, taps[:2], retain_graph=True)
+    wp.reconstruct()
+    y = wp[""]
+    g_all = torch.autograd.grad((weight(y, 7) * y).sum(), taps, allow_unused=True)
+    key = "t%03d" % len(index)
+    store[key + "_x"] = x.numpy()
+    store[key + "_gdec_lo"], store[key + "_gdec_hi"] = g_dec[0].numpy(), g_dec[1].numpy()
+    for name, t in zip(("dec_lo", "dec_hi", "rec_lo", "rec_hi"), g_all):
+        store["%s_gall_%s" % (key, name)] = t.numpy()
+    kwj = {k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()}
+    index.append(dict(key=key, fn="packet%d" % dim, rec="reconstruct", shape=list(shape), wavelet=wavelet,
+                      kw=dict(mode=mode, maxlevel=maxlevel, **kwj), keys=keys))
+
+
+packet_case(1, (2, 67), "db3", "reflect", 3, 95)
+packet_case(1, (3, 64), "haar", "periodic", 3, 96)
+packet_case(2, (2, 35, 38), "db2", "symmetric", 2, 97)
+packet_case(2, (1, 32, 32), "haar", "zero", 2, 98)
+packet_case(2, (2, 35, 38), "db2", "constant", 2, 99, separable=True)
+
 out = os.path.join(HERE, "ptwt_ref_tapgrads.npz")
 np.savez_compressed(out, index=json.dumps(index), **store)
 print("wrote", out, len(index), "cases", os.path.getsize(out) // 1024, "KiB")

@@ -119,7 +119,7 @@ def test_no_grad_and_detached_paths_unchanged():
 def test_tap_gradients_vs_reference_autograd():
     """Gradients w.r.t. learnable filter taps (the four taps as leaf tensors, 4-tuple wavelet form) against the
     reference's own autograd (tests/golden/ptwt_ref_tapgrads.npz): analysis w.r.t. dec taps, analysis + synthesis w.r.t.
-    all four; fp64, 1e-10 norm-wise."""
+    all four — the ten level transforms, swt / iswt and the packet trees; fp64, 1e-10 norm-wise."""
     import json
     import os
 
@@ -136,6 +136,20 @@ def test_tap_gradients_vs_reference_autograd():
         taps = [torch.tensor(banks[name][f], dtype=torch.float64, device=dev(), requires_grad=True)
                 for f in ("dec_lo", "dec_hi", "rec_lo", "rec_hi")]
         wt = WaveletTensorTuple(*taps)
+        if case["fn"].startswith("packet"):  # packet trees: leaves of maxlevel, then reconstruct()'s root
+            cls = ptwt_amd.WaveletPacket if case["fn"] == "packet1" else ptwt_amd.WaveletPacket2D
+            wp = cls(x, wt, **kw)
+            assert wp.get_level(kw["maxlevel"], "natural") == case["keys"]
+            loss = sum((weight(wp[key], i) * wp[key]).sum() for i, key in enumerate(case["keys"]))
+            g_dec = torch.autograd.grad(loss, taps[:2], retain_graph=True)
+            assert G.relerr(g_dec[0].cpu().numpy(), z[k + "_gdec_lo"]) < 1e-10, (case, "dec_lo")
+            assert G.relerr(g_dec[1].cpu().numpy(), z[k + "_gdec_hi"]) < 1e-10, (case, "dec_hi")
+            wp.reconstruct()
+            y = wp[""]
+            g_all = torch.autograd.grad((weight(y, 7) * y).sum(), taps)
+            for nme, g in zip(("dec_lo", "dec_hi", "rec_lo", "rec_hi"), g_all):
+                assert G.relerr(g.cpu().numpy(), z["%s_gall_%s" % (k, nme)]) < 1e-10, (case, nme)
+            continue
         coeffs = getattr(ptwt_amd, case["fn"])(x, wt, **kw)
         fl = flat(coeffs)
         loss = sum((weight(t, i) * t).sum() for i, t in enumerate(fl))
