@@ -125,7 +125,8 @@ int mifwt_dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, 
  *   approx   band aa of the last fused level
  * Same sums as nlevels mifwt_dwt_fwd calls (summation order differs: agreement to rounding, not bit for bit).
  * f32, even L <= 8, modes zero / constant / reflect / symmetric, unit innermost strides, input rows of a multiple of 4 samples
- * that start on 16-byte boundaries, every fused plane at least 2 L samples per axis (mifwt_dwt2_fwd_pyramid_supported says
+ * that start on 16-byte boundaries, every fused plane at least 2 L samples per axis; in auto mode (MIFWT_OPT_PYRAMID_MODE 0) only
+ * for planes of 512 .. 1280 columns, where a workgroup streams whole rows (mifwt_dwt2_fwd_pyramid_supported says
  * 1 / 0); the three detail planes of a level within 1 GiB of one another (one buffer resource serves them; they are planes
  * of one level buffer in practice); MIFWT_ERR_UNSUPPORTED otherwise, nothing launched.  Kernel id 16. */
 int mifwt_dwt2_fwd_pyramid_supported(int nlevels, const mifwt_level_desc* const* descs);
@@ -271,7 +272,7 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
                                       UNSUPPORTED / 0); analysis pairs: 0 = auto (rolling strips for 8 taps, else tiles), 1 = tiles only,
                                       3 = rolling strips wherever they apply */
 #define MIFWT_OPT_PAIR_ROWS 9      /* >0 overrides the pair kernels' level-2 rows per tile (4, 6, 8, 12) / per strip segment (multiple of 8) */
-#define MIFWT_OPT_PYRAMID_MODE 12 /* mifwt_dwt2_fwd_pyramid: 0 = auto, 2 = never (it answers UNSUPPORTED / 0; the two-level and per-level kernels then serve the call) */
+#define MIFWT_OPT_PYRAMID_MODE 12 /* mifwt_dwt2_fwd_pyramid: 0 = auto (planes of 512 .. 1280 columns), 1 = wherever the kernel can run, 2 = never (it answers UNSUPPORTED / 0; the two-level and per-level kernels then serve the call) */
 #define MIFWT_OPT_DEBUG 11        /* A/B measurement switches of the multi-level kernel (results are then wrong): 1 = no stores, 2 = no loads, 4 = no deep levels, 16 = loader wave at default priority */
 #define MIFWT_OPT_SYNC_STAGE 10    /* non-zero: tile kernels keep the workgroup barrier between staging and the horizontal pass (A/B) */
 int mifwt_set_option(int key, int value);

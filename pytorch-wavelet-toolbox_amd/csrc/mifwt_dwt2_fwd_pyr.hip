@@ -692,7 +692,15 @@ static bool pyr_plan(int nlev, const mifwt_level_desc* const* d, PyrPlan* p) {
   if (WN <= p->cpg0) {
     p->ngroups = 1;
   } else {
+    // as few groups as the lane grids allow, of EQUAL width (groups of the maximum width plus a narrow last one left a
+    // quarter of the workgroups with a third of the work: 4096-column planes ran 28 % slower per byte than 1024-column ones)
     p->ngroups = 1 + (WN - p->cpg0 + p->cpg - 1) / p->cpg;
+    int base = (WN + p->ngroups - 1) / p->ngroups;
+    if (nlev == 1) base = (base + 1) & ~1;
+    if (base < p->cpg) {
+      p->cpg0 = base;
+      p->cpg = base;
+    }
     const int last = WN - p->cpg0 - (p->ngroups - 2) * p->cpg;
     if (last < min_cols) p->cpg0 -= min_cols - last;
   }
@@ -773,7 +781,14 @@ bool dwt2_fwd_pyr_supported(int nlev, const mifwt_level_desc* const* d) {
   const mifwt_level_desc* dn = d[nlev - 1];
   if (dn->approx_stride[2] != 1 || dn->coef_extent[0] * dn->approx_stride[1] >= lim) return false;
   PyrPlan p;
-  return pyr_plan(nlev, d, &p);
+  if (!pyr_plan(nlev, d, &p)) return false;
+  // Where it pays (tools/pyr_matrix.py, tools/pyr_big.py; MIFWT_OPT_PYRAMID_MODE 1 overrides): planes of 512 .. 1280 columns.
+  // A workgroup then reads whole rows, one after the other — contiguous megabytes.  Wider planes are cut into column groups
+  // whose workgroups read 4 KB pieces 16 KB apart: 64 x 4096^2 ran at 0.44 of the HBM peak against 0.65 for the per-level
+  // tile kernel (2-D tiles keep DRAM pages open), independent of segment length and row pitch; narrower planes leave most
+  // lanes of the level-2 / 3 waves idle (256^2: 74 against 50 us).
+  if (g_options[MIFWT_OPT_PYRAMID_MODE] != 1 && (p.ngroups > 1 || d0->sig_extent[1] < 512)) return false;
+  return true;
 }
 
 
