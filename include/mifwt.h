@@ -182,6 +182,21 @@ int mifwt_dwt1_inv_tail(int dtype, int filt_len, int64_t rows, int64_t m, int nl
                         const void* const* details, const int64_t* detail_row_strides, const int32_t* out_len, void* y,
                         int64_t y_row_stride, const double* rec_lo, const double* rec_hi, void* stream);
 
+/* The FINEST levels of a 1-D reconstruction in one launch, a chunk of the output row per workgroup — the trailing trips of
+ * waverec's level loop (src/ptwt/conv_transform.py:184-199) once a level's output no longer fits into one workgroup's LDS
+ * (mirror of mifwt_dwt1_fwd_long; the coarse levels before it are mifwt_dwt1_inv_tail's).
+ *   m        HOST array of nlevels + 1 ints: m[s] = coefficients per row entering fused step s (coarsest first) — the length
+ *            of approx for s = 0, of details[s] for every s — and m[s + 1] = 2 m[s] - L + 2 - t its output length (t in {0, 1}:
+ *            the reference's end-crop, src/ptwt/_util.py:231-244); m[nlevels] = samples per row of y
+ *   approx   [rows, m[0]]     details  HOST array of nlevels device ptrs, coarsest first: [rows, m[s]]     y  [rows, m[nlevels]]
+ * f32, even filt_len <= 20, 2 <= nlevels <= 8 with (L/2) 2^nlevels below a twelfth of an 8 K-sample chunk, output rows longer
+ * than mifwt_dwt1_fwd_tail_max_n (mifwt_dwt1_inv_long_supported says 1 / 0); MIFWT_ERR_UNSUPPORTED otherwise, nothing
+ * launched.  Agreement with per-level calls to rounding.  Kernel id 18. */
+int mifwt_dwt1_inv_long_supported(int dtype, int filt_len, int64_t rows, int nlevels, const int32_t* m);
+int mifwt_dwt1_inv_long(int dtype, int filt_len, int64_t rows, int nlevels, const int32_t* m, const void* approx, int64_t approx_row_stride,
+                        const void* const* details, const int64_t* detail_row_strides, void* y, int64_t y_row_stride,
+                        const double* rec_lo, const double* rec_hi, void* stream);
+
 /* Adjoints (transposes) of the two level maps, for reverse-mode differentiation.  The reference gets them from
  * ATen autograd through F.pad / _pad_symmetric + F.conv{1,2,3}d and torch.stack + F.conv_transpose{1,2,3}d
  * (same call sites as above); here they are explicit entry points that take the SAME descriptor as the
@@ -253,7 +268,8 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  *   14 / 15  the deep levels of a 1-D analysis / the coarse levels of a 1-D synthesis in one launch (mifwt_dwt1_fwd_tail /
  *          mifwt_dwt1_inv_tail; likewise not returned by mifwt_kernel_id)
  *   16     up to three fused 2-D analysis levels per launch (mifwt_dwt2_fwd_pyramid; not returned by mifwt_kernel_id)
- *   17     several fused 1-D analysis levels of long rows, a chunk per workgroup (mifwt_dwt1_fwd_long; likewise) */
+ *   17 / 18  several fused 1-D analysis / synthesis levels of long rows, a chunk per workgroup (mifwt_dwt1_fwd_long /
+ *          mifwt_dwt1_inv_long; likewise) */
 int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 
 /* Library-wide diagnostic switches (process-global, meant for tests and A/B measurements).

@@ -103,6 +103,11 @@ def load_library() -> ctypes.CDLL:
     lib.mifwt_dwt1_fwd_long.argtypes = lib.mifwt_dwt1_fwd_tail.argtypes
     lib.mifwt_dwt1_fwd_long_levels.restype = ctypes.c_int
     lib.mifwt_dwt1_fwd_long_levels.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int]
+    lib.mifwt_dwt1_inv_long_supported.restype = ctypes.c_int
+    lib.mifwt_dwt1_inv_long_supported.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int32)]
+    lib.mifwt_dwt1_inv_long.restype = ctypes.c_int
+    lib.mifwt_dwt1_inv_long.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), vp, ctypes.c_int64,
+                                        ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int64), vp, ctypes.c_int64, dbl_p, dbl_p, vp]
     lib.mifwt_dwt1_inv_tail.restype = ctypes.c_int
     lib.mifwt_dwt1_inv_tail.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, vp, ctypes.c_int64,
                                         ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32), vp,
@@ -152,6 +157,7 @@ KID_TAIL = 14
 KID_INV_TAIL = 15
 KID_PYRAMID = 16
 KID_LONG = 17
+KID_INV_LONG = 18
 
 
 def set_option(key: int, value: int) -> None:
@@ -493,6 +499,49 @@ class HipLevelEngine:
         if rc_box and rc_box[0] == -2:
             return None
         return y
+
+    def synthesis_long(self, approx: torch.Tensor, details: List[torch.Tensor], rec_lo: Sequence[float], rec_hi: Sequence[float],
+                       out_lens: Sequence[int]):
+        """The FINEST levels of a 1-D reconstruction in one launch, a chunk of the output row per workgroup (C ABI
+        ``mifwt_dwt1_inv_long``): same arguments as :meth:`synthesis_tail`.  Fuses as many of the given levels as the kernel's halo
+        rule allows, counted from the finest: returns ``(y, n_fused)`` with ``y`` the output of the last given level when all of
+        them were fused — or ``(None, k)`` telling the caller to run the first ``len(details) - k`` levels some other way first and
+        come back; ``(None, 0)`` outside the kernel's envelope."""
+        _require_gpu(approx)
+        nl = len(details)
+        if approx.dim() != 2 or approx.dtype != torch.float32 or nl < 2:
+            return None, 0
+        lib = load_library()
+        flen = len(rec_lo)
+        rows = approx.shape[0]
+        lens = [int(approx.shape[1])] + [int(v) for v in out_lens]
+        k = min(nl, 8)
+        while k >= 2:
+            m = (ctypes.c_int32 * (k + 1))(*lens[nl - k:])
+            if lib.mifwt_dwt1_inv_long_supported(0, flen, rows, k, m):
+                break
+            k -= 1
+        if k < 2:
+            return None, 0
+        if k < nl:
+            return None, k
+        if approx.stride(1) != 1:
+            approx = approx.contiguous()
+        details = [t if t.stride(1) == 1 else t.contiguous() for t in details]
+        y = torch.empty((rows, lens[-1]), dtype=approx.dtype, device=approx.device)
+        det = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in details])
+        det_rs = (ctypes.c_int64 * nl)(*[t.stride(0) for t in details])
+        lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
+        p = _Plan()
+        p.ws_bytes, p.kid = 0, KID_INV_LONG
+        d = LevelDesc()
+        d.ndim = 1
+        d.sig_extent[0] = lens[-1]
+        p.desc = d
+        ap, yp = approx.data_ptr(), y.data_ptr()
+        self._run(p, 1, approx, lambda ws, wsb, stream: lib.mifwt_dwt1_inv_long(0, flen, rows, nl, m, ap, approx.stride(0), det, det_rs, yp,
+                                                                              y.stride(0), lo, hi, stream))
+        return y, nl
 
     def synthesis_pair(self, approx2: torch.Tensor, details2: List[torch.Tensor], details1: List[torch.Tensor],
                        rec_lo: Sequence[float], rec_hi: Sequence[float], out_extent: Sequence[int]):

@@ -454,14 +454,38 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
             except (ValueError, RuntimeError, AssertionError):
                 outs = []  # the per-level loop below raises the reference's error at the level it belongs to
             cap = 16384 if cur.dtype == torch.float32 else 8192
-            nfuse = 0
-            while nfuse < len(outs) and outs[nfuse] <= cap:
-                nfuse += 1
-            if nfuse >= 2:
-                y = _engine.ENGINE.synthesis_tail(cur, [lvl[0] for lvl in folded[:nfuse]], rec_lo, rec_hi, outs[:nfuse])
-                if y is not None:
-                    cur = y
-                    pos = nfuse
+            dets = [lvl[0] for lvl in folded]
+            eng = _engine.ENGINE
+
+            def fuse(cur, a, b):
+                """Levels a .. b-1 with as few launches as possible: the finest ones in the chunked launch (mifwt_dwt1_inv_long:
+                as many as its halo rule allows), what is coarser first — chunked as well while there are too few rows for one
+                workgroup each, else in the one-workgroup-per-row launch (mifwt_dwt1_inv_tail) while the outputs fit into LDS."""
+                if b - a >= 2:
+                    y, k = eng.synthesis_long(cur, dets[a:b], rec_lo, rec_hi, outs[a:b])
+                    if y is not None:
+                        return y
+                    if 2 <= k < b - a:
+                        cur = fuse(cur, a, b - k)
+                        a = b - k
+                        y, _k = eng.synthesis_long(cur, dets[a:b], rec_lo, rec_hi, outs[a:b])
+                        if y is not None:
+                            return y
+                    nf = 0
+                    while a + nf < b and outs[a + nf] <= cap:
+                        nf += 1
+                    if nf >= 2:
+                        y = eng.synthesis_tail(cur, dets[a:a + nf], rec_lo, rec_hi, outs[a:a + nf])
+                        if y is not None:
+                            cur, a = y, a + nf
+                while a < b:
+                    cur = eng.synthesis(cur, folded[a], rec_lo, rec_hi, [outs[a]])
+                    a += 1
+                return cur
+
+            if len(outs) == len(folded):
+                cur = fuse(cur, 0, len(folded))
+                pos = len(folded)
     while pos < len(folded):
         det = folded[pos]
         if separable:

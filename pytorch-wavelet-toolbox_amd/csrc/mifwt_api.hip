@@ -528,6 +528,21 @@ int mifwt_dwt1_fwd_long(int dtype, int filt_len, int mode, int64_t rows, int64_t
   return dwt1_long(dtype, filt_len, mode, rows, n, nlevels, x, x_row_stride, approx, approx_row_stride, details, detail_row_strides,
                    dec_lo, dec_hi, static_cast<hipStream_t>(stream));
 }
+// The finest levels of a 1-D reconstruction in one launch, a chunk of the output per workgroup (mifwt_dwt1_long.hip).
+int mifwt_dwt1_inv_long_supported(int dtype, int filt_len, int64_t rows, int nlevels, const int32_t* m) {
+  return idwt1_long_supported(dtype, filt_len, rows, nlevels, m);
+}
+
+int mifwt_dwt1_inv_long(int dtype, int filt_len, int64_t rows, int nlevels, const int32_t* m, const void* approx, int64_t approx_row_stride,
+                        const void* const* details, const int64_t* detail_row_strides, void* y, int64_t y_row_stride,
+                        const double* rec_lo, const double* rec_hi, void* stream) {
+  if (!m || !approx || !details || !detail_row_strides || !y || !rec_lo || !rec_hi) return MIFWT_ERR_BADARG;
+  if (!idwt1_long_supported(dtype, filt_len, rows, nlevels, m)) return MIFWT_ERR_UNSUPPORTED;
+  for (int l = 0; l < nlevels; ++l)
+    if (!details[l]) return MIFWT_ERR_BADARG;
+  return idwt1_long(dtype, filt_len, rows, nlevels, m, approx, approx_row_stride, details, detail_row_strides, y, y_row_stride, rec_lo,
+                    rec_hi, static_cast<hipStream_t>(stream));
+}
 // The coarse levels of a 1-D reconstruction in one launch (mifwt_dwt1_tail.hip).
 int mifwt_dwt1_inv_tail(int dtype, int filt_len, int64_t rows, int64_t m, int nlevels, const void* approx, int64_t approx_row_stride,
                         const void* const* details, const int64_t* detail_row_strides, const int32_t* out_len, void* y,

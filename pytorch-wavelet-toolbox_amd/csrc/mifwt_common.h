@@ -117,7 +117,7 @@ int stream_call(int dtype, int kind, const StreamCall& c);  // dispatches on dty
 // Each returns MIFWT_ERR_UNSUPPORTED when the descriptor is outside its envelope (the dispatcher then
 // falls back to the generic passes) and never touches the workspace.
 enum KernelId { kGeneric = 0, kDwt2FwdStream = 1, kDwt2InvStream = 2, kDwt1FwdRow = 3, kDwt1InvRow = 4, kDwt3FwdStream = 5, kDwt3InvStream = 6, kDwt2FwdTile = 7, kDwt2InvTile = 8, kDwt3FwdTile = 9, kDwt3InvTile = 10, kDwt2FwdMfma = 11, kDwt2FwdPair = 12, kDwt2InvPair = 13, kDwt1FwdTail = 14, kDwt1InvTail = 15, kDwt2FwdPyr = 16,
-  kDwt1FwdLong = 17 };
+  kDwt1FwdLong = 17, kDwt1InvLong = 18 };
 
 bool dwt2_fwd_stream_supported(const mifwt_level_desc* d);
 int dwt2_fwd_stream(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
@@ -169,6 +169,12 @@ int dwt1_long(int dtype, int filt_len, int mode, int64_t rows, int64_t n0, int n
               void* approx, int64_t approx_row_stride, void* const* details, const int64_t* detail_row_strides, const double* lo,
               const double* hi, hipStream_t stream);
 // ... and the coarse levels of a 1-D reconstruction (same file); out_len[l] = output samples of fused level l
+// the finest levels of a 1-D reconstruction in one launch, a chunk of the output row per workgroup (mifwt_dwt1_long.hip);
+// m[s] = coefficients per row entering fused step s (coarsest first), m[nlevels] = output length
+int idwt1_long_supported(int dtype, int filt_len, int64_t rows, int nlevels, const int* m);
+int idwt1_long(int dtype, int filt_len, int64_t rows, int nlevels, const int* m, const void* approx, int64_t approx_row_stride,
+               const void* const* details, const int64_t* detail_row_strides, void* y, int64_t y_row_stride, const double* lo,
+               const double* hi, hipStream_t stream);
 bool idwt1_tail_supported(int dtype, int filt_len, int64_t rows, int64_t m0, int nlevels, const int* out_len);
 int idwt1_tail(int dtype, int filt_len, int64_t rows, int64_t m0, int nlevels, const void* approx, int64_t approx_row_stride,
                const void* const* details, const int64_t* detail_row_strides, const int* out_len, void* y, int64_t y_row_stride,

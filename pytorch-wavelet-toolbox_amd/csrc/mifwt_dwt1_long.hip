@@ -413,6 +413,199 @@ int launch_long(const LongPlan& p, int mode, int64_t rows, const void* x, int64_
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 
+
+// =============================================================================================================================
+// SYNTHESIS: the finest K levels of a 1-D reconstruction in one launch, a chunk of the output row per workgroup (kernel id 18).
+// Reference seam: the trailing trips of waverec's level loop (src/ptwt/conv_transform.py:184-199: stack + conv_transpose1d(stride 2)
+// + crop per level).  Polyphase form, cropped (the formula of mifwt_dwt1_inv_tail and of the 2-D synthesis kernels per axis):
+//     y[2p + r] = sum_{i < L/2} g_lo[L-2-2i+r] a[p+i] + g_hi[L-2-2i+r] d[p+i]        (coefficients past the end read as zero)
+// A workgroup owns output samples [x0, x1); step s (coarsest first) consumes coefficients [x0 >> (K-s), ...) — L/2 - 1 more per
+// level at the right end.  The approximation of the coarsest fused level is parked in LDS, every step reads its detail band
+// straight from global memory (buffer loads: out of range = 0), the running approximation ping-pongs between two LDS
+// buffers, the last step stores 16 bytes per lane.  No boundary map on this side: every workgroup runs the same body.
+template <int L>
+struct Idwt1LongArgs {
+  const float* approx;               // [rows, m[0]]: the approximation entering the first fused step
+  const float* det[kLongMaxLevels];  // det[s]: detail coefficients of step s (coarsest first) [rows, m[s]]
+  float* y;                          // [rows, m[K]]
+  int64_t approx_rs, y_rs, det_rs[kLongMaxLevels];
+  int m[kLongMaxLevels + 1];         // m[s] = coefficients per row entering step s; m[s + 1] = its (cropped) output length
+  int nlevels, rows, chunk, nchunks, cap;  // chunk = output samples per workgroup (a multiple of 4); cap = floats of LDS buffer A
+  int vec;                           // output rows start on 16-byte boundaries
+  f2 ga[L / 2], gd[L / 2];           // (g[L-2-2i], g[L-1-2i]) of rec_lo / rec_hi
+};
+
+template <int L, int T>
+__global__ void __launch_bounds__(T) idwt1_long_kernel(const Idwt1LongArgs<L> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char long_lds[];
+  __shared__ int rlo[kLongMaxLevels + 1], rhi[kLongMaxLevels + 1];
+  float* bufA = reinterpret_cast<float*>(long_lds);
+  float* bufB = bufA + a.cap + kLongPad;
+  constexpr int HLn = L / 2;
+  constexpr int U = L <= 10 ? 2 : 1;        // position pairs per lane and trip
+  constexpr int NA = HLn / 2 + 1;           // 8-byte pieces of a lane's window: HLn + 1 coefficients (two positions)
+  const int tid = threadIdx.x, K = a.nlevels;
+  const int row = blockIdx.x / a.nchunks;
+  const int c = blockIdx.x - row * a.nchunks;
+  const int x0 = c * a.chunk, x1 = min(a.m[K], x0 + a.chunk);
+  if (tid == 0) {
+    // coefficient range of every step: [lo >> 1, ((hi - 1) >> 1) + L/2) of the range below it, clipped to the row
+    int lo = x0, hi = x1;
+    rlo[K] = lo;
+    rhi[K] = hi;
+    for (int s = K - 1; s >= 0; --s) {
+      hi = min(a.m[s], ((hi - 1) >> 1) + HLn);
+      lo >>= 1;
+      rlo[s] = lo;
+      rhi[s] = hi;
+    }
+  }
+  __syncthreads();
+  {  // park the approximation of the first step (+ zeros behind it: what windows read past the range)
+    const int lo = rlo[0], hi = rhi[0];
+    const float* __restrict__ ar = a.approx + (int64_t)row * a.approx_rs;
+    for (int i = tid; i < hi - lo + HLn + 3; i += T) bufA[i] = lo + i < hi ? ar[lo + i] : 0.f;
+  }
+  __syncthreads();
+  f2 ga[HLn], gd[HLn];
+#pragma unroll
+  for (int i = 0; i < HLn; ++i) {
+    ga[i] = a.ga[i];
+    gd[i] = a.gd[i];
+  }
+  float* src = bufA;
+  float* dst = bufB;
+  float* __restrict__ yr = a.y + (int64_t)row * a.y_rs;
+  for (int s = 0; s < K; ++s) {
+    const int ilo = rlo[s], olo = rlo[s + 1], ohi = rhi[s + 1];
+    const bool last = s == K - 1;
+    const rsrc_t dres = pyr_rsrc(a.det[s] + (int64_t)row * a.det_rs[s], (uint32_t)a.m[s] * 4u);
+    // a lane takes two adjacent positions p, p + 1 (four outputs 2p .. 2p + 3); positions start at ilo = olo >> 1.  Outputs
+    // [ohi, ohi + L/2 + 3) are written as zeros: the next step's windows read them
+    const int pend = ((last ? ohi : ohi + HLn + 3) + 1) >> 1;
+    for (int pt0 = ilo; pt0 < pend; pt0 += 2 * T * U) {
+      f2 aw[U][NA];
+      float dw[U][2 * NA];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (pt0 + 2 * T * u < pend) {  // (same for every lane)
+          const int p = pt0 + 2 * (tid + T * u);
+          const float* w = src + ((p < pend ? p : ilo) - ilo);  // (8-byte aligned: positions advance in pairs from ilo)
+#pragma unroll
+          for (int k = 0; k < NA; ++k) aw[u][k] = *reinterpret_cast<const f2*>(w + 2 * k);
+#pragma unroll
+          for (int k = 0; k < HLn + 1; ++k) dw[u][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dres, 4u * (uint32_t)(p + k), 0, 0));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (pt0 + 2 * T * u < pend) {
+          const int p = pt0 + 2 * (tid + T * u);
+          float af[2 * NA];
+#pragma unroll
+          for (int k = 0; k < NA; ++k) {
+            af[2 * k] = aw[u][k].x;
+            af[2 * k + 1] = aw[u][k].y;
+          }
+          f2 y0 = {0.f, 0.f}, y1 = {0.f, 0.f};  // (even, odd) output of position p / p + 1
+#pragma unroll
+          for (int i = 0; i < HLn; ++i) {
+            y0 += ga[i] * af[i] + gd[i] * dw[u][i];
+            y1 += ga[i] * af[i + 1] + gd[i] * dw[u][i + 1];
+          }
+          const int j = 2 * p;
+          if (last) {
+            if (j + 4 <= ohi && a.vec) {
+              *reinterpret_cast<f4*>(yr + j) = (f4){y0.x, y0.y, y1.x, y1.y};
+            } else {
+              if (j < ohi) yr[j] = y0.x;
+              if (j + 1 < ohi) yr[j + 1] = y0.y;
+              if (j + 2 < ohi) yr[j + 2] = y1.x;
+              if (j + 3 < ohi) yr[j + 3] = y1.y;
+            }
+          } else {
+            float* o = dst + (j - olo);
+            if (j >= olo) o[0] = j < ohi ? y0.x : 0.f;
+            o[1] = j + 1 < ohi ? y0.y : 0.f;
+            o[2] = j + 2 < ohi ? y1.x : 0.f;
+            o[3] = j + 3 < ohi ? y1.y : 0.f;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    float* tmp = src;
+    src = dst;
+    dst = tmp;
+  }
+}
+
+struct InvLongPlan {
+  int nlevels, chunk, nchunks, cap;
+};
+
+// how many of the FINEST levels one launch fuses: all `nlevels` given ones if the halo rule allows (the halo of K levels is
+// about (L/2 - 1) 2^K output samples: below a twelfth of a chunk), else fewer — the caller runs the coarser ones first
+bool inv_long_plan(int dtype, int L, int64_t rows, int nlevels, const int* m, InvLongPlan* p) {
+  if (g_options[MIFWT_OPT_FORCE_GENERIC] || g_options[MIFWT_OPT_PAIR_MODE] == 2) return false;
+  if (dtype != MIFWT_F32 || L < 2 || L > 20 || (L & 1) || nlevels < 2 || nlevels > kLongMaxLevels || !m) return false;
+  if (rows < 1 || rows > (int64_t(1) << 24)) return false;
+  for (int s = 0; s < nlevels; ++s) {
+    const int64_t full = 2 * (int64_t)m[s] - L + 2;
+    if (m[s] < 1 || (m[s + 1] != full && m[s + 1] != full - 1) || m[s + 1] < 1) return false;
+  }
+  const int n = m[nlevels];
+  if (n > (1 << 30)) return false;
+  // output rows one workgroup could hold (mifwt_dwt1_inv_tail) are still cut into chunks while there are too few of them to
+  // occupy the chip: smaller chunks, about one workgroup per CU
+  const bool big = n > dwt1_tail_max_n(dtype);
+  if (!big && (rows >= 128 || n < 4096)) return false;
+  int cap = kLongCapA;
+  if (!big) {
+    cap = 1024;
+    while (cap < kLongCapA && (int64_t)cap * 256 < rows * n) cap *= 2;
+  }
+  const int halo = (L / 2) * (1 << nlevels);
+  if (halo > cap / 12) return false;
+  p->nlevels = nlevels;
+  p->cap = cap / 2 + 64;              // buffer A holds the inputs of the LAST step at most: half a chunk of outputs + halo
+  p->chunk = (cap - 2 * halo - 64) & ~3;
+  if (p->chunk < 4 * L) return false;
+  p->nchunks = (n + p->chunk - 1) / p->chunk;
+  if (!big && p->nchunks < 2) return false;  // one workgroup per row: mifwt_dwt1_inv_tail does that
+  if (rows * (int64_t)p->nchunks > (int64_t(1) << 30)) return false;
+  return true;
+}
+
+template <int L>
+int launch_inv_long(const InvLongPlan& p, int64_t rows, const int* m, const void* approx, int64_t approx_rs, const void* const* details,
+                    const int64_t* det_rs, void* y, int64_t y_rs, const double* lo, const double* hi, hipStream_t stream) {
+  Idwt1LongArgs<L> a;
+  a.approx = static_cast<const float*>(approx);
+  a.y = static_cast<float*>(y);
+  a.approx_rs = approx_rs;
+  a.y_rs = y_rs;
+  for (int s = 0; s < p.nlevels; ++s) {
+    a.det[s] = static_cast<const float*>(details[s]);
+    a.det_rs[s] = det_rs[s];
+  }
+  for (int s = 0; s <= p.nlevels; ++s) a.m[s] = m[s];
+  a.nlevels = p.nlevels;
+  a.rows = (int)rows;
+  a.chunk = p.chunk;
+  a.nchunks = p.nchunks;
+  a.cap = p.cap;
+  a.vec = ((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (y_rs & 3) == 0) ? 1 : 0;
+  for (int i = 0; i < L / 2; ++i) {
+    a.ga[i] = (f2){(float)lo[L - 2 - 2 * i], (float)lo[L - 1 - 2 * i]};
+    a.gd[i] = (f2){(float)hi[L - 2 - 2 * i], (float)hi[L - 1 - 2 * i]};
+  }
+  const size_t lds = (size_t)2 * (p.cap + kLongPad) * sizeof(float);  // either buffer may hold the inputs of the last step
+  const unsigned grid = (unsigned)(rows * p.nchunks);
+  hipLaunchKernelGGL((idwt1_long_kernel<L, kLongThreads>), dim3(grid), dim3(kLongThreads), lds, stream, a);
+  return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
+}
+
 }  // namespace
 
 int dwt1_long_levels(int dtype, int filt_len, int mode, int64_t rows, int64_t n0, int want) {
@@ -442,6 +635,35 @@ int dwt1_long(int dtype, int filt_len, int mode, int64_t rows, int64_t n0, int n
     default: return MIFWT_ERR_UNSUPPORTED;
   }
 #undef MIFWT_LONG_CASE
+}
+
+int idwt1_long_supported(int dtype, int filt_len, int64_t rows, int nlevels, const int* m) {
+  InvLongPlan p;
+  return inv_long_plan(dtype, filt_len, rows, nlevels, m, &p) ? 1 : 0;
+}
+
+int idwt1_long(int dtype, int filt_len, int64_t rows, int nlevels, const int* m, const void* approx, int64_t approx_row_stride,
+               const void* const* details, const int64_t* detail_row_strides, void* y, int64_t y_row_stride, const double* lo,
+               const double* hi, hipStream_t stream) {
+  InvLongPlan p;
+  if (!inv_long_plan(dtype, filt_len, rows, nlevels, m, &p)) return MIFWT_ERR_UNSUPPORTED;
+#define MIFWT_INV_LONG_CASE(LL) \
+  case LL:                      \
+    return launch_inv_long<LL>(p, rows, m, approx, approx_row_stride, details, detail_row_strides, y, y_row_stride, lo, hi, stream);
+  switch (filt_len) {
+    MIFWT_INV_LONG_CASE(2)
+    MIFWT_INV_LONG_CASE(4)
+    MIFWT_INV_LONG_CASE(6)
+    MIFWT_INV_LONG_CASE(8)
+    MIFWT_INV_LONG_CASE(10)
+    MIFWT_INV_LONG_CASE(12)
+    MIFWT_INV_LONG_CASE(14)
+    MIFWT_INV_LONG_CASE(16)
+    MIFWT_INV_LONG_CASE(18)
+    MIFWT_INV_LONG_CASE(20)
+    default: return MIFWT_ERR_UNSUPPORTED;
+  }
+#undef MIFWT_INV_LONG_CASE
 }
 
 }  // namespace mifwt

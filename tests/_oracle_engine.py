@@ -70,6 +70,18 @@ class OracleLevelEngine:
             cur = self.synthesis(cur, [d], rec_lo, rec_hi, [n])
         return cur
 
+    def synthesis_long(self, approx, details, rec_lo, rec_hi, out_lens):
+        """Stand-in for the chunked fine 1-D synthesis levels (same contract as HipLevelEngine.synthesis_long): rows of more than 48
+        output samples count as "long" here; at most three levels per call, so the come-back-later answer is exercised too."""
+        if approx.dim() != 2 or len(details) < 2 or out_lens[-1] <= 48:
+            return None, 0
+        if len(details) > 3:
+            return None, 3
+        cur = approx
+        for d, n in zip(details, out_lens):
+            cur = self.synthesis(cur, [d], rec_lo, rec_hi, [n])
+        return cur, len(details)
+
     def synthesis_pair(self, approx2, details2, details1, rec_lo, rec_hi, out_extent):
         """Stand-in for the two-levels-per-launch synthesis call (same contract as HipLevelEngine.synthesis_pair)."""
         if approx2.dim() != 3 or min(out_extent) < 16:

@@ -103,3 +103,40 @@ def test_reference_speed_test_shape():
     want = O.wavedec(x[rows].cpu().numpy().astype(np.float64), "db5", mode="periodic", level=10)
     for a, b in zip(got, want):
         assert G.relerr(a[rows].cpu().numpy(), b) < TOL32
+
+
+# ---- the finest synthesis levels in one launch (mifwt_dwt1_inv_long, kernel id 18) ---------------------------------------------
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db5", "db8", "sym10"])
+def test_long_rows_synthesis_vs_oracle(wavelet):
+    """waverec of long rows: coarse levels in the one-workgroup-per-row launch, the fine ones in the chunked launch — against the
+    fp64 oracle on the same coefficients (odd and even lengths at every level: with and without the reference's end-crop), and
+    against the per-level kernels."""
+    rng = np.random.default_rng(17)
+    for shape, level in (((3, 100003), 8), ((2, 65536), 6), ((1, 40001), 5), ((2, 1000000), 10)):
+        x = rng.standard_normal(shape)
+        want_c = O.wavedec(x, wavelet, level=level)
+        want = O.waverec(want_c, wavelet)
+        cg = [torch.from_numpy(c).float().to(dev()) for c in want_c]
+        got, kids = traced(lambda: ptwt_amd.waverec(cg, wavelet))
+        assert kids[-1] == _engine.KID_INV_LONG, (wavelet, shape, kids)
+        assert got.shape == want.shape and G.relerr(got.cpu().numpy(), want) < 2e-6, (wavelet, shape)
+        _engine.set_option(_engine.OPT_PAIR_MODE, 2)
+        try:
+            single = ptwt_amd.waverec(cg, wavelet)
+        finally:
+            _engine.set_option(_engine.OPT_PAIR_MODE, 0)
+        assert float((got - single).norm() / single.norm()) < 2e-6
+
+
+def test_long_rows_synthesis_round_trip_and_strided_coefficients():
+    g = torch.Generator(device=dev()).manual_seed(19)
+    x = torch.randn(32, 1000000, device=dev(), generator=g)
+    c = ptwt_amd.wavedec(x, "db5", mode="periodic", level=10)
+    rec, kids = traced(lambda: ptwt_amd.waverec(c, "db5"))
+    assert kids[-1] == _engine.KID_INV_LONG and len(kids) <= 3, kids
+    assert rec.shape[-1] >= x.shape[-1] and float((rec[:, : x.shape[-1]] - x).abs().max()) < 2e-5
+    # coefficient rows of wider tensors (row strides that are not the lengths, odd element offsets)
+    wide = [torch.randn(t.shape[0], t.shape[1] + 5, device=dev()) for t in c]
+    views = [w[:, 3: 3 + t.shape[1]].copy_(t) for w, t in zip(wide, c)]
+    rec2 = ptwt_amd.waverec(views, "db5")
+    assert torch.equal(rec2, rec)

@@ -900,7 +900,10 @@ def test_idwt1_tail_fusion_vs_oracle_and_per_level(dtype):
             kids = [e[1] for e in _engine.level_events]
         finally:
             _engine.level_events = None
-        assert kids[0] == _engine.KID_INV_TAIL, (wavelet, shape, kids)
+        if dtype == torch.float64 or shape[-1] < 4096:
+            assert kids[0] == _engine.KID_INV_TAIL, (wavelet, shape, kids)
+        else:  # f32: few long rows are cut into chunks instead (mifwt_dwt1_inv_long, tests/test_gpu_long1d.py)
+            assert _engine.KID_INV_LONG in kids or _engine.KID_INV_TAIL in kids, (wavelet, shape, kids)
         assert got.shape == want.shape and G.relerr(to_np(got), want) < tol, (wavelet, shape)
         _engine.set_option(_engine.OPT_PAIR_MODE, 2)
         try:
