@@ -432,6 +432,7 @@ struct Idwt1LongArgs {
   int m[kLongMaxLevels + 1];         // m[s] = coefficients per row entering step s; m[s + 1] = its (cropped) output length
   int nlevels, rows, chunk, nchunks, cap;  // chunk = output samples per workgroup (a multiple of 4); cap = floats of LDS buffer A
   int vec;                           // output rows start on 16-byte boundaries
+  int dvec[kLongMaxLevels];          // detail rows of step s start on 8-byte boundaries: 8-byte loads where the walk starts on an even position
   f2 ga[L / 2], gd[L / 2];           // (g[L-2-2i], g[L-1-2i]) of rec_lo / rec_hi
 };
 
@@ -439,6 +440,8 @@ template <int L, int T>
 __global__ void __launch_bounds__(T) idwt1_long_kernel(const Idwt1LongArgs<L> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char long_lds[];
   __shared__ int rlo[kLongMaxLevels + 1], rhi[kLongMaxLevels + 1];
+  // buffer A (a.cap floats) holds the inputs of the LAST step (half a chunk of outputs + halo), buffer B half of that: the step
+  // before; the walk starts in whichever buffer makes the parities come out that way
   float* bufA = reinterpret_cast<float*>(long_lds);
   float* bufB = bufA + a.cap + kLongPad;
   constexpr int HLn = L / 2;
@@ -464,7 +467,8 @@ __global__ void __launch_bounds__(T) idwt1_long_kernel(const Idwt1LongArgs<L> a)
   {  // park the approximation of the first step (+ zeros behind it: what windows read past the range)
     const int lo = rlo[0], hi = rhi[0];
     const float* __restrict__ ar = a.approx + (int64_t)row * a.approx_rs;
-    for (int i = tid; i < hi - lo + HLn + 3; i += T) bufA[i] = lo + i < hi ? ar[lo + i] : 0.f;
+    float* first = (a.nlevels & 1) ? bufA : bufB;  // step s reads A when nlevels - 1 - s is even
+    for (int i = tid; i < hi - lo + HLn + 3; i += T) first[i] = lo + i < hi ? ar[lo + i] : 0.f;
   }
   __syncthreads();
   f2 ga[HLn], gd[HLn];
@@ -473,8 +477,8 @@ __global__ void __launch_bounds__(T) idwt1_long_kernel(const Idwt1LongArgs<L> a)
     ga[i] = a.ga[i];
     gd[i] = a.gd[i];
   }
-  float* src = bufA;
-  float* dst = bufB;
+  float* src = (a.nlevels & 1) ? bufA : bufB;
+  float* dst = (a.nlevels & 1) ? bufB : bufA;
   float* __restrict__ yr = a.y + (int64_t)row * a.y_rs;
   for (int s = 0; s < K; ++s) {
     const int ilo = rlo[s], olo = rlo[s + 1], ohi = rhi[s + 1];
@@ -483,56 +487,78 @@ __global__ void __launch_bounds__(T) idwt1_long_kernel(const Idwt1LongArgs<L> a)
     // a lane takes two adjacent positions p, p + 1 (four outputs 2p .. 2p + 3); positions start at ilo = olo >> 1.  Outputs
     // [ohi, ohi + L/2 + 3) are written as zeros: the next step's windows read them
     const int pend = ((last ? ohi : ohi + HLn + 3) + 1) >> 1;
-    for (int pt0 = ilo; pt0 < pend; pt0 += 2 * T * U) {
-      f2 aw[U][NA];
-      float dw[U][2 * NA];
+    // 8-byte detail loads where the rows are aligned and the walk starts on an even position (always so in the last step: x0 is
+    // a multiple of 4), else 4-byte loads
+    auto walk = [&](auto dv_tag) {
+      constexpr bool DV = decltype(dv_tag)::value;
+      for (int pt0 = ilo; pt0 < pend; pt0 += 2 * T * U) {
+        f2 aw[U][NA], dw[U][NA];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (pt0 + 2 * T * u < pend) {  // (same for every lane)
-          const int p = pt0 + 2 * (tid + T * u);
-          const float* w = src + ((p < pend ? p : ilo) - ilo);  // (8-byte aligned: positions advance in pairs from ilo)
+        for (int u = 0; u < U; ++u) {
+          if (pt0 + 2 * T * u < pend) {  // (same for every lane)
+            const int p = pt0 + 2 * (tid + T * u);
+            const float* w = src + ((p < pend ? p : ilo) - ilo);  // (8-byte aligned: positions advance in pairs from ilo)
 #pragma unroll
-          for (int k = 0; k < NA; ++k) aw[u][k] = *reinterpret_cast<const f2*>(w + 2 * k);
+            for (int k = 0; k < NA; ++k) aw[u][k] = *reinterpret_cast<const f2*>(w + 2 * k);
 #pragma unroll
-          for (int k = 0; k < HLn + 1; ++k) dw[u][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dres, 4u * (uint32_t)(p + k), 0, 0));
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (pt0 + 2 * T * u < pend) {
-          const int p = pt0 + 2 * (tid + T * u);
-          float af[2 * NA];
-#pragma unroll
-          for (int k = 0; k < NA; ++k) {
-            af[2 * k] = aw[u][k].x;
-            af[2 * k + 1] = aw[u][k].y;
-          }
-          f2 y0 = {0.f, 0.f}, y1 = {0.f, 0.f};  // (even, odd) output of position p / p + 1
-#pragma unroll
-          for (int i = 0; i < HLn; ++i) {
-            y0 += ga[i] * af[i] + gd[i] * dw[u][i];
-            y1 += ga[i] * af[i + 1] + gd[i] * dw[u][i + 1];
-          }
-          const int j = 2 * p;
-          if (last) {
-            if (j + 4 <= ohi && a.vec) {
-              *reinterpret_cast<f4*>(yr + j) = (f4){y0.x, y0.y, y1.x, y1.y};
-            } else {
-              if (j < ohi) yr[j] = y0.x;
-              if (j + 1 < ohi) yr[j + 1] = y0.y;
-              if (j + 2 < ohi) yr[j + 2] = y1.x;
-              if (j + 3 < ohi) yr[j + 3] = y1.y;
+            for (int k = 0; k < NA; ++k) {
+              if constexpr (DV) {
+                dw[u][k] = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(dres, 4u * (uint32_t)(p + 2 * k), 0, 0));
+              } else {
+                dw[u][k].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dres, 4u * (uint32_t)(p + 2 * k), 0, 0));
+                dw[u][k].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dres, 4u * (uint32_t)(p + 2 * k + 1), 0, 0));
+              }
             }
-          } else {
-            float* o = dst + (j - olo);
-            if (j >= olo) o[0] = j < ohi ? y0.x : 0.f;
-            o[1] = j + 1 < ohi ? y0.y : 0.f;
-            o[2] = j + 2 < ohi ? y1.x : 0.f;
-            o[3] = j + 3 < ohi ? y1.y : 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (pt0 + 2 * T * u < pend) {
+            const int p = pt0 + 2 * (tid + T * u);
+            // (even, odd) output of position p (y0) and p + 1 (y1): tap pair in an SGPR pair, packed FMAs; coefficient p + i is
+            // the .x / .y half of window piece i / 2
+            f2 y0 = vmul_lo(ga[0], aw[u][0]), y1 = vmul_hi(ga[0], aw[u][0]);
+            vfma_lo(y0, gd[0], dw[u][0]);
+            vfma_hi(y1, gd[0], dw[u][0]);
+#pragma unroll
+            for (int i = 1; i < HLn; ++i) {
+              if (i & 1) {
+                vfma_hi(y0, ga[i], aw[u][i / 2]);
+                vfma_hi(y0, gd[i], dw[u][i / 2]);
+                vfma_lo(y1, ga[i], aw[u][(i + 1) / 2]);
+                vfma_lo(y1, gd[i], dw[u][(i + 1) / 2]);
+              } else {
+                vfma_lo(y0, ga[i], aw[u][i / 2]);
+                vfma_lo(y0, gd[i], dw[u][i / 2]);
+                vfma_hi(y1, ga[i], aw[u][i / 2]);
+                vfma_hi(y1, gd[i], dw[u][i / 2]);
+              }
+            }
+            const int j = 2 * p;
+            if (last) {
+              if (j + 4 <= ohi && a.vec) {
+                *reinterpret_cast<f4*>(yr + j) = (f4){y0.x, y0.y, y1.x, y1.y};
+              } else {
+                if (j < ohi) yr[j] = y0.x;
+                if (j + 1 < ohi) yr[j + 1] = y0.y;
+                if (j + 2 < ohi) yr[j + 2] = y1.x;
+                if (j + 3 < ohi) yr[j + 3] = y1.y;
+              }
+            } else if (p < pend) {  // (lanes past the end of the walk must not write: the other buffer follows this one)
+              float* o = dst + (j - olo);
+              if (j >= olo) o[0] = j < ohi ? y0.x : 0.f;
+              o[1] = j + 1 < ohi ? y0.y : 0.f;
+              o[2] = j + 2 < ohi ? y1.x : 0.f;
+              o[3] = j + 3 < ohi ? y1.y : 0.f;
+            }
           }
         }
       }
-    }
+    };
+    if (a.dvec[s] && !(ilo & 1))
+      walk(std::true_type{});
+    else
+      walk(std::false_type{});
     __syncthreads();
     float* tmp = src;
     src = dst;
@@ -596,11 +622,12 @@ int launch_inv_long(const InvLongPlan& p, int64_t rows, const int* m, const void
   a.nchunks = p.nchunks;
   a.cap = p.cap;
   a.vec = ((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (y_rs & 3) == 0) ? 1 : 0;
+  for (int s = 0; s < p.nlevels; ++s) a.dvec[s] = ((reinterpret_cast<uintptr_t>(details[s]) & 7) == 0 && (det_rs[s] & 1) == 0) ? 1 : 0;
   for (int i = 0; i < L / 2; ++i) {
     a.ga[i] = (f2){(float)lo[L - 2 - 2 * i], (float)lo[L - 1 - 2 * i]};
     a.gd[i] = (f2){(float)hi[L - 2 - 2 * i], (float)hi[L - 1 - 2 * i]};
   }
-  const size_t lds = (size_t)2 * (p.cap + kLongPad) * sizeof(float);  // either buffer may hold the inputs of the last step
+  const size_t lds = (size_t)(p.cap + kLongPad + p.cap / 2 + 64 + kLongPad) * sizeof(float);
   const unsigned grid = (unsigned)(rows * p.nchunks);
   hipLaunchKernelGGL((idwt1_long_kernel<L, kLongThreads>), dim3(grid), dim3(kLongThreads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
