@@ -333,3 +333,39 @@ def test_dwt1_long_plan_and_argument_checks():
     rs8 = (ctypes.c_int64 * 8)(*([0] * 8))
     assert lib.mifwt_dwt1_fwd_long(F32, 10, PER, 32, 1000000, 7, one, 1000000, one, 0, det8, rs8, taps, taps, null) == -2  # more than one launch fuses
     assert lib.mifwt_dwt1_fwd_long(F64, 10, PER, 32, 1000000, 6, one, 1000000, one, 0, det, rs, taps, taps, null) == -2
+
+
+def test_dwt1_inv_long_plan_and_argument_checks():
+    """mifwt_dwt1_inv_long_supported is host arithmetic (which level counts the chunked 1-D synthesis launch fuses); the call rejects
+    bad arguments before touching the device."""
+    import ctypes
+
+    from ptwt_amd import _engine
+
+    lib = _engine.load_library()
+    sup = lib.mifwt_dwt1_inv_long_supported
+
+    def lens(n, flen, level):
+        out = [n]
+        for _ in range(level):
+            out.append((out[-1] + flen - 1) // 2)
+        return out[::-1]  # coarsest first; m[s + 1] = 2 m[s] - L + 2 - t
+
+    m = lens(1000000, 10, 10)
+    arr = lambda v: (ctypes.c_int32 * len(v))(*v)  # noqa: E731
+    assert sup(0, 10, 32, 7, arr(m[3:])) == 1            # the finest seven levels of the speed-test shape
+    assert sup(0, 10, 32, 8, arr(m[2:])) == 0            # eight: the halo would exceed a twelfth of a chunk
+    assert sup(0, 10, 32, 3, arr(m[:4])) == 1            # 985 -> 7821 samples, 32 rows: chunked too (too few rows for one workgroup each)
+    assert sup(0, 10, 500, 3, arr(m[:4])) == 0           # enough rows: mifwt_dwt1_inv_tail
+    assert sup(1, 10, 32, 7, arr(m[3:])) == 0            # f32 only
+    assert sup(0, 10, 32, 1, arr(m[9:])) == 0            # a single level is the per-level kernels' job
+    bad = list(m[3:])
+    bad[3] += 2
+    assert sup(0, 10, 32, 7, arr(bad)) == 0              # lengths that are not a synthesis chain
+    null = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(16)
+    taps = (ctypes.c_double * 10)(*([0.1] * 10))
+    det = (ctypes.c_void_p * 7)(*([16] * 7))
+    rs = (ctypes.c_int64 * 7)(*([0] * 7))
+    assert lib.mifwt_dwt1_inv_long(0, 10, 32, 7, arr(m[3:]), null, 0, det, rs, one, 0, taps, taps, null) == -1
+    assert lib.mifwt_dwt1_inv_long(0, 10, 32, 8, arr(m[2:]), one, 0, det, rs, one, 0, taps, taps, null) == -2
