@@ -110,7 +110,7 @@ struct Idwt1TailArgs {
   void* y;                       // output of the last fused level [rows, out_len[nlevels - 1]]
   int64_t approx_rs, y_rs, det_rs[kTailMaxLevels];
   int out_len[kTailMaxLevels];   // output samples per level (2 m - L + 2 - trim): the next level's coefficient count
-  int m0, nlevels, filt_len, cap;
+  int m0, nlevels, filt_len, cap, cap_small;  // cap / cap_small: elements of the BIG / SMALL (and detail) LDS buffers
   double lo[kTailMaxTaps], hi[kTailMaxTaps];  // rec_lo / rec_hi, PyWavelets order
 };
 
@@ -118,9 +118,14 @@ struct Idwt1TailArgs {
 // end read as zero), the same formula as the 2-D synthesis kernels apply per axis
 template <typename T>
 __global__ void __launch_bounds__(kTailThreads) idwt1_tail_kernel(const Idwt1TailArgs a) {
+  // LDS: a BIG buffer (the last level's output at most), a SMALL one (its input) and the detail row of the level at hand.  The
+  // walk alternates between BIG and SMALL and starts so that the last level reads SMALL; the last level stores straight to
+  // global memory.  (Reading the detail coefficients from global memory inside the tap loop — one dependent load per tap —
+  // made the four coarse levels of 32 rows of 15 633 samples a 93 us launch.)
   extern __shared__ __attribute__((aligned(16))) unsigned char tail_lds[];
-  T* A = reinterpret_cast<T*>(tail_lds);
-  T* B = A + a.cap;
+  T* big = reinterpret_cast<T*>(tail_lds);
+  T* small = big + a.cap;
+  T* D = small + a.cap_small;
   __shared__ T tlo[kTailMaxTaps], thi[kTailMaxTaps];
   const int tid = threadIdx.x, L = a.filt_len, HLn = a.filt_len >> 1;
   const int64_t row = blockIdx.x;
@@ -128,23 +133,37 @@ __global__ void __launch_bounds__(kTailThreads) idwt1_tail_kernel(const Idwt1Tai
     tlo[tid] = (T)a.lo[tid];
     thi[tid] = (T)a.hi[tid];
   }
+  T* A = (a.nlevels & 1) ? small : big;  // level l reads SMALL when nlevels - 1 - l is even
+  T* B = (a.nlevels & 1) ? big : small;
   const T* __restrict__ ar = static_cast<const T*>(a.approx) + row * a.approx_rs;
-  for (int i = tid; i < a.m0; i += kTailThreads) A[i] = ar[i];
-  __syncthreads();
+  for (int i = tid; i < a.m0 + HLn; i += kTailThreads) A[i] = i < a.m0 ? ar[i] : T(0);  // (zeros behind the row: what the windows read past it)
+  T* __restrict__ yr = static_cast<T*>(a.y) + row * a.y_rs;
   int m = a.m0;
   for (int lvl = 0; lvl < a.nlevels; ++lvl) {
     const int n = a.out_len[lvl];
+    const bool last = lvl == a.nlevels - 1;
     const T* __restrict__ dr = static_cast<const T*>(a.det[lvl]) + row * a.det_rs[lvl];
-    for (int j = tid; j < n; j += kTailThreads) {
-      const int p = j >> 1, r = j & 1;
-      T acc = T(0);
-      for (int i = 0; i < HLn; ++i) {
-        const int c = p + i;
-        const T av = c < m ? A[c] : T(0), dv = c < m ? dr[c] : T(0);
-        acc = __builtin_fma(tlo[L - 2 - 2 * i + r], av, acc);
-        acc = __builtin_fma(thi[L - 2 - 2 * i + r], dv, acc);
+    for (int i = tid; i < m + HLn; i += kTailThreads) D[i] = i < m ? dr[i] : T(0);
+    __syncthreads();  // (also: A complete)
+    // a thread owns a position p: the outputs 2p and 2p + 1 share their L/2 coefficient pairs
+    for (int p = tid; 2 * p < n + (last ? 0 : HLn); p += kTailThreads) {
+      T acc0 = T(0), acc1 = T(0);
+      if (2 * p < n) {
+        for (int i = 0; i < HLn; ++i) {
+          const T av = A[p + i], dv = D[p + i];
+          acc0 = __builtin_fma(tlo[L - 2 - 2 * i], av, acc0);
+          acc0 = __builtin_fma(thi[L - 2 - 2 * i], dv, acc0);
+          acc1 = __builtin_fma(tlo[L - 1 - 2 * i], av, acc1);
+          acc1 = __builtin_fma(thi[L - 1 - 2 * i], dv, acc1);
+        }
       }
-      B[j] = acc;
+      if (last) {
+        yr[2 * p] = acc0;
+        if (2 * p + 1 < n) yr[2 * p + 1] = acc1;
+      } else {  // (+ zeros behind the row for the next level's windows)
+        B[2 * p] = acc0;
+        B[2 * p + 1] = 2 * p + 1 < n ? acc1 : T(0);
+      }
     }
     __syncthreads();
     T* tmp = A;
@@ -152,8 +171,6 @@ __global__ void __launch_bounds__(kTailThreads) idwt1_tail_kernel(const Idwt1Tai
     B = tmp;
     m = n;
   }
-  T* __restrict__ yr = static_cast<T*>(a.y) + row * a.y_rs;
-  for (int i = tid; i < m; i += kTailThreads) yr[i] = A[i];
 }
 
 }  // namespace
@@ -253,12 +270,27 @@ int idwt1_tail(int dtype, int filt_len, int64_t rows, int64_t m0, int nlevels, c
     a.hi[t] = hi[t];
   }
   const int esz = dtype == MIFWT_F64 ? 8 : 4;
-  a.cap = big < 32 ? 32 : ((big + 3) & ~3);  // both buffers hold the longest row of the walk
-  const size_t lds = (size_t)2 * a.cap * esz;
+  // BIG holds the outputs of the levels nlevels - 1, nlevels - 3, ... (and the input of level 0 if nlevels is even), SMALL the
+  // others; every row is followed by L/2 zeros
+  int need_big = 32, need_small = 32;
+  {
+    int len = (int)m0;  // row parked for level l
+    for (int l = 0; l <= nlevels; ++l) {
+      const bool in_small = ((nlevels - 1 - l) & 1) == 0;  // level l reads SMALL when nlevels - 1 - l is even (l = nlevels: the output, never parked)
+      if (l < nlevels) {
+        int& need = in_small ? need_small : need_big;
+        need = std::max(need, len + filt_len / 2 + 4);
+        len = out_len[l];
+      }
+    }
+  }
+  a.cap = (need_big + 3) & ~3;
+  a.cap_small = (need_small + 3) & ~3;
+  const size_t lds = (size_t)(a.cap + 2 * a.cap_small) * esz;
   static bool attr_set[2] = {false, false};
   const int ti = dtype == MIFWT_F64 ? 1 : 0;
   if (!attr_set[ti]) {
-    const int max_lds = 2 * (dwt1_tail_max_n(dtype) + 8) * esz;
+    const int max_lds = 2 * (dwt1_tail_max_n(dtype) + 64) * esz;
     if (ti)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&idwt1_tail_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     else
