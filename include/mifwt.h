@@ -197,6 +197,12 @@ int mifwt_dwt1_inv_long(int dtype, int filt_len, int64_t rows, int nlevels, cons
                         const void* const* details, const int64_t* detail_row_strides, void* y, int64_t y_row_stride,
                         const double* rec_lo, const double* rec_hi, void* stream);
 
+/* Diagnostic: the launch geometry mifwt_dwt1_fwd_long (inverse = 0: mode, n, nlevels = the `want` argument; m ignored) or
+ * mifwt_dwt1_inv_long (inverse = 1: nlevels, m; mode, n ignored) would use: out6 = {levels, chunk, nchunks, end_l, end_r, cap}
+ * (chunk: level-K outputs per interior workgroup / output samples per workgroup; end_l, end_r: level-K outputs of the two end
+ * pieces, analysis only; cap: floats of LDS buffer A).  Returns 1, or 0 when the geometry is not served. */
+int mifwt_dwt1_long_plan(int inverse, int dtype, int filt_len, int mode, int64_t rows, int64_t n, int nlevels, const int32_t* m, int32_t* out6);
+
 /* Adjoints (transposes) of the two level maps, for reverse-mode differentiation.  The reference gets them from
  * ATen autograd through F.pad / _pad_symmetric + F.conv{1,2,3}d and torch.stack + F.conv_transpose{1,2,3}d
  * (same call sites as above); here they are explicit entry points that take the SAME descriptor as the

@@ -543,6 +543,11 @@ int mifwt_dwt1_inv_long(int dtype, int filt_len, int64_t rows, int nlevels, cons
   return idwt1_long(dtype, filt_len, rows, nlevels, m, approx, approx_row_stride, details, detail_row_strides, y, y_row_stride, rec_lo,
                     rec_hi, static_cast<hipStream_t>(stream));
 }
+// Launch geometry of the chunked 1-D kernels (diagnostic: the host-side model tests check coverage and LDS capacities with it).
+int mifwt_dwt1_long_plan(int inverse, int dtype, int filt_len, int mode, int64_t rows, int64_t n, int nlevels, const int32_t* m, int32_t* out6) {
+  if (!out6) return 0;
+  return inverse ? idwt1_long_plan_query(dtype, filt_len, rows, nlevels, m, out6) : dwt1_long_plan_query(dtype, filt_len, mode, rows, n, nlevels, out6);
+}
 // The coarse levels of a 1-D reconstruction in one launch (mifwt_dwt1_tail.hip).
 int mifwt_dwt1_inv_tail(int dtype, int filt_len, int64_t rows, int64_t m, int nlevels, const void* approx, int64_t approx_row_stride,
                         const void* const* details, const int64_t* detail_row_strides, const int32_t* out_len, void* y,

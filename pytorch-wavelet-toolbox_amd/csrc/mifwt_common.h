@@ -172,6 +172,8 @@ int dwt1_long(int dtype, int filt_len, int mode, int64_t rows, int64_t n0, int n
 // the finest levels of a 1-D reconstruction in one launch, a chunk of the output row per workgroup (mifwt_dwt1_long.hip);
 // m[s] = coefficients per row entering fused step s (coarsest first), m[nlevels] = output length
 int idwt1_long_supported(int dtype, int filt_len, int64_t rows, int nlevels, const int* m);
+int dwt1_long_plan_query(int dtype, int filt_len, int mode, int64_t rows, int64_t n0, int want, int* out);
+int idwt1_long_plan_query(int dtype, int filt_len, int64_t rows, int nlevels, const int* m, int* out);
 int idwt1_long(int dtype, int filt_len, int64_t rows, int nlevels, const int* m, const void* approx, int64_t approx_row_stride,
                const void* const* details, const int64_t* detail_row_strides, void* y, int64_t y_row_stride, const double* lo,
                const double* hi, hipStream_t stream);

@@ -664,6 +664,22 @@ int dwt1_long(int dtype, int filt_len, int mode, int64_t rows, int64_t n0, int n
 #undef MIFWT_LONG_CASE
 }
 
+// the launch geometry of both directions, for the host-side model tests (tests/test_long1d_model.py): out[0..5] =
+// {levels, chunk, nchunks, end_l, end_r, cap} (analysis) / {levels, chunk, nchunks, 0, 0, cap} (synthesis)
+int dwt1_long_plan_query(int dtype, int filt_len, int mode, int64_t rows, int64_t n0, int want, int* out) {
+  LongPlan p;
+  if (!out || !long_plan(dtype, filt_len, mode, rows, n0, want, &p)) return 0;
+  out[0] = p.nlevels; out[1] = p.chunk; out[2] = p.nchunks; out[3] = p.end_l; out[4] = p.end_r; out[5] = p.cap;
+  return 1;
+}
+
+int idwt1_long_plan_query(int dtype, int filt_len, int64_t rows, int nlevels, const int* m, int* out) {
+  InvLongPlan p;
+  if (!out || !inv_long_plan(dtype, filt_len, rows, nlevels, m, &p)) return 0;
+  out[0] = p.nlevels; out[1] = p.chunk; out[2] = p.nchunks; out[3] = 0; out[4] = 0; out[5] = p.cap;
+  return 1;
+}
+
 int idwt1_long_supported(int dtype, int filt_len, int64_t rows, int nlevels, const int* m) {
   InvLongPlan p;
   return inv_long_plan(dtype, filt_len, rows, nlevels, m, &p) ? 1 : 0;
