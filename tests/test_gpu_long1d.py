@@ -140,3 +140,43 @@ def test_long_rows_synthesis_round_trip_and_strided_coefficients():
     views = [w[:, 3: 3 + t.shape[1]].copy_(t) for w, t in zip(wide, c)]
     rec2 = ptwt_amd.waverec(views, "db5")
     assert torch.equal(rec2, rec)
+
+
+def test_long_rows_randomised_against_per_level_kernels():
+    """Random lengths around the planner's thresholds, filters, modes, row counts and level counts: the chunked launches (both
+    directions, long rows and few medium rows) against the per-level kernels on the same data (those are pinned against the
+    oracle and the goldens); 2e-6 norm-wise per coefficient vector."""
+    rng = np.random.default_rng(2024)
+    wavelets = ["haar", "db2", "db3", "db4", "db5", "db7", "sym8", "db10", "coif1", "bior2.2"]
+    lengths = [4096, 4097, 5003, 8191, 16384, 16385, 16391, 20000, 32768, 32771, 50001, 65537, 131073, 262145, 300007]
+    ran_fwd = ran_inv = 0
+    for trial in range(48):
+        wavelet = wavelets[rng.integers(len(wavelets))]
+        n = lengths[rng.integers(len(lengths))] + int(rng.integers(0, 3))
+        rows = int(rng.choice([1, 2, 3, 7, 33, 130]))
+        if rows * n > 6_000_000:
+            rows = max(1, 6_000_000 // n)
+        mode = MODES[rng.integers(len(MODES))]
+        flen = len(ptwt_amd._wavelets.host_taps(wavelet)[0])
+        maxlev = int(np.floor(np.log2(n / (flen - 1)))) if n >= flen - 1 else 0
+        level = int(rng.integers(2, max(3, min(maxlev, 12) + 1)))
+        x = torch.randn(rows, n, device=dev())
+        try:
+            got, kids = traced(lambda: ptwt_amd.wavedec(x, wavelet, mode=mode, level=level))
+        except RuntimeError:  # torch's refusal of reflect / circular pads longer than the row, reproduced by the host layer
+            continue
+        _engine.set_option(_engine.OPT_PAIR_MODE, 2)
+        try:
+            want = ptwt_amd.wavedec(x, wavelet, mode=mode, level=level)
+            rec_want = ptwt_amd.waverec(want, wavelet)
+        finally:
+            _engine.set_option(_engine.OPT_PAIR_MODE, 0)
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert a.shape == b.shape, (trial, wavelet, n, rows, mode, level, i)
+            err = float((a - b).norm() / b.norm().clamp_min(1e-30))
+            assert err < 2e-6, (trial, wavelet, n, rows, mode, level, i, err, kids)
+        rec, rkids = traced(lambda: ptwt_amd.waverec(want, wavelet))
+        assert rec.shape == rec_want.shape and float((rec - rec_want).norm() / rec_want.norm()) < 2e-6, (trial, wavelet, n, rows, level, rkids)
+        ran_fwd += _engine.KID_LONG in kids
+        ran_inv += _engine.KID_INV_LONG in rkids
+    assert ran_fwd >= 20 and ran_inv >= 20, (ran_fwd, ran_inv)
