@@ -170,3 +170,43 @@ def test_pyramid_declines_what_it_cannot_serve():
     got = ptwt_amd.wavedec2(torch.randn(2, 130, 130, device=dev()), "db4", level=2)
     assert got[0].shape[-1] == 37
     del lib
+
+
+def test_pyramid_randomised_against_per_level_kernels():
+    """Random plane shapes (one to four column groups, odd heights, widths that are multiples of 4), batches, filters, modes, level
+    counts and row-segment overrides through the multi-level launch against the per-level kernels on the same data (those are
+    pinned against the oracle and the goldens); 2e-6 norm-wise per sub-band."""
+    rng = np.random.default_rng(77)
+    ran = 0
+    for trial in range(40):
+        wavelet = ["haar", "db2", "db3", "db4"][rng.integers(4)]
+        mode = MODES[rng.integers(len(MODES))]
+        h = int(rng.integers(40, 400))
+        w = 4 * int(rng.integers(10, 1100))
+        b = int(rng.integers(1, 5))
+        if b * h * w > 3_000_000:
+            b, h = 1, min(h, 3_000_000 // w)
+        level = int(rng.integers(1, 4))
+        seg = int(rng.choice([0, 0, 8, 16]))
+        x = torch.randn(b, h, w, device=dev())
+        if seg:
+            _engine.set_option(_engine.OPT_PAIR_ROWS, seg)
+        try:
+            got, kids = run_traced(lambda: ptwt_amd.wavedec2(x, wavelet, mode=mode, level=level))
+        except RuntimeError:
+            continue
+        finally:
+            _engine.set_option(_engine.OPT_PAIR_ROWS, 0)
+        _engine.set_option(_engine.OPT_PYRAMID_MODE, 2)
+        _engine.set_option(_engine.OPT_PAIR_MODE, 2)
+        try:
+            want = ptwt_amd.wavedec2(x, wavelet, mode=mode, level=level)
+        finally:
+            _engine.set_option(_engine.OPT_PAIR_MODE, 0)
+            _engine.set_option(_engine.OPT_PYRAMID_MODE, 1)
+        for (n, u), (_, v) in zip(G.flatten_coeffs(got), G.flatten_coeffs(want)):
+            assert u.shape == v.shape
+            err = float((u - v).norm() / v.norm().clamp_min(1e-30))
+            assert err < 2e-6, (trial, wavelet, mode, (b, h, w), level, seg, n, err, kids)
+        ran += _engine.KID_PYRAMID in kids
+    assert ran >= 20, ran
