@@ -175,6 +175,14 @@ class _Plan:
 
 
 _plans: dict = {}
+
+
+def _trim_plans() -> None:
+    """Keep the plan cache bounded without dropping everything at once: past 4096 entries the oldest quarter goes (dicts keep
+    insertion order), so a caller that cycles through many geometries keeps its recent ones."""
+    if len(_plans) > 4096:
+        for k in list(_plans)[:1024]:
+            _plans.pop(k, None)
 _tls = threading.local()
 _taps_cache: dict = {}
 
@@ -247,8 +255,7 @@ class HipLevelEngine:
         key = (x.shape, x.stride(), x.dtype, mode_id, flen, ROW_ALIGN)
         p = _plans.get(key)
         if p is None:
-            if len(_plans) > 4096:
-                _plans.clear()
+            _trim_plans()
             p = _plans[key] = self._analysis_plan(x, flen, mode_id)
         buf = torch.empty(p.alloc_shape, dtype=x.dtype, device=x.device)
         if p.view_last is not None:
@@ -275,8 +282,7 @@ class HipLevelEngine:
         key = ("pair", x.shape, x.stride(), x.dtype, mode_id, flen, ROW_ALIGN)
         plan = _plans.get(key)
         if plan is None:
-            if len(_plans) > 4096:
-                _plans.clear()
+            _trim_plans()
             lib = load_library()
             p1 = self._analysis_plan(x, flen, mode_id)
             ok = False
@@ -319,8 +325,7 @@ class HipLevelEngine:
         key = ("pyr", x.shape, x.stride(), mode_id, flen, min(nlevels, 3), ROW_ALIGN)
         plan = _plans.get(key)
         if plan is None:
-            if len(_plans) > 4096:
-                _plans.clear()
+            _trim_plans()
             lib = load_library()
             plans = [self._analysis_plan(x, flen, mode_id)]
             while len(plans) < min(nlevels, 3) and not plans[-1].empty:
@@ -434,8 +439,7 @@ class HipLevelEngine:
         key = ("inv", approx.shape, approx.stride(), ref_stride, approx.dtype, flen, tuple(out_extent))
         p = _plans.get(key)
         if p is None:
-            if len(_plans) > 4096:
-                _plans.clear()
+            _trim_plans()
             p = _Plan()
             d = LevelDesc()
             d.ndim, d.dtype, d.mode, d.filt_len, d.batch = ndim, _DTYPE_IDS[approx.dtype], 0, flen, batch
@@ -567,8 +571,7 @@ class HipLevelEngine:
         key = ("invpair", approx2.shape, approx2.stride(), st2, m1, st1, flen, tuple(out_extent))
         plan = _plans.get(key)
         if plan is None:
-            if len(_plans) > 4096:
-                _plans.clear()
+            _trim_plans()
             d2, d1 = LevelDesc(), LevelDesc()
             for d in (d1, d2):
                 d.ndim, d.dtype, d.mode, d.filt_len, d.batch = 2, _DTYPE_IDS[approx2.dtype], 0, flen, batch

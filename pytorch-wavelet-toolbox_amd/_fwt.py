@@ -312,8 +312,7 @@ def _check_pad(extents: Sequence[int], flen: int, mode: str) -> None:
 
 
 # ------------------------------------------------------------------------------------------ analysis
-def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: AxisHint, ndim: int,
-             fs_level_rule: bool = False):
+def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: AxisHint, ndim: int):
     """Multi-level analysis.  Returns ``(layout, approx [B,*M], [buffer [B,2^n,*M] per level, coarsest first])``."""
     axes = _ensure_axes(axes, ndim)
     layout = _Layout(data, ndim, axes)

@@ -397,7 +397,15 @@ def test_half_storage_extension():
         x1 = torch.randn(3, 1001).to(torch.float16)
         c = ptwt_amd.wavedec(x1.to(dev()), "db4", level=2)
         y = ptwt_amd.waverec(c, "db4")
-        assert G.relerr(to_np(y[..., :1001].double()), x1.double().numpy()) < 2e-3
+        assert G.relerr(to_np(y[..., :1001].double()), x1.double().numpy()) < 2e-3  # four roundings to f16 on the way
+        # ... and step by step at 5e-4: each synthesis level against the oracle fed the same f16 coefficients
+        cur = c[0]
+        for d in c[1:]:
+            cur = cur[..., : d.shape[-1]]
+            nxt = ptwt_amd.waverec([cur, d], "db4")
+            ref = O.waverec([to_np(cur.double()), to_np(d.double())], "db4")
+            assert G.relerr(to_np(nxt.double()), ref) < 5e-4
+            cur = nxt
     finally:
         ptwt_amd.set_half_storage(False)
 
@@ -462,13 +470,23 @@ def test_mfma_dwt2_long_filters_half(wavelet):
                         vec = ptwt_amd.wavedec2(xq.to(dev()), wavelet, mode=mode, level=level)
                     finally:
                         _engine.set_option(7, 0)
-                # one f16 rounding of the intermediate + one of the output per level: 5e-4 for a single level; every further
-                # level starts from an f16-rounded approximation (the oracle's is exact), so the bound grows with the depth
-                tol = 5e-4 if level == 1 else 1e-3
-                for (n, a), (_, b), (_, c) in zip(G.flatten_coeffs(got), G.flatten_coeffs(want), G.flatten_coeffs(vec)):
-                    assert a.dtype == torch.float16
-                    assert G.relerr(to_np(a.double()), b) < tol, (wavelet, mode, shape, n)
-                    assert G.relerr(to_np(a.double()), to_np(c.double())) < tol + 1e-4, (wavelet, mode, shape, n)
+                # one f16 rounding of the intermediate + one of the output per level: 5e-4 PER LEVEL, each level against the oracle
+                # fed the same f16-rounded approximation the kernel was fed (the levels inside the multi-level call are these
+                # same launches: bit-identical)
+                cur = xq.to(dev())
+                for lev in range(1, level + 1):
+                    one = ptwt_amd.wavedec2(cur, wavelet, mode=mode, level=1)
+                    ref = O.wavedec2(cur.double().cpu().numpy(), wavelet, mode=mode, level=1)
+                    for (n, a), (_, b) in zip(G.flatten_coeffs(one), G.flatten_coeffs(ref)):
+                        assert a.dtype == torch.float16
+                        assert G.relerr(to_np(a.double()), b) < 5e-4, (wavelet, mode, shape, lev, n)
+                    for a, b in zip(one[1], got[level + 1 - lev]):
+                        assert torch.equal(a, b), (wavelet, mode, shape, lev)
+                    cur = one[0]
+                assert torch.equal(cur, got[0])
+                del want
+                for (n, a), (_, c) in zip(G.flatten_coeffs(got), G.flatten_coeffs(vec)):
+                    assert G.relerr(to_np(a.double()), to_np(c.double())) < (5e-4 if level == 1 else 1e-3) + 1e-4, (wavelet, mode, shape, n)
     finally:
         _engine.set_option(7, 0)
         ptwt_amd.set_half_storage(False)
@@ -746,6 +764,37 @@ def test_pair_kernel_vs_oracle_and_fallbacks():
     kids = _pair_vs_single(view, "db3", "reflect", 2)
     assert kids == [_engine.KID_PAIR]
     check_tree(ptwt_amd.wavedec2(view, "db3", level=2), O.wavedec2(view.cpu().numpy().astype(np.float64), "db3", mode="reflect", level=2), TOL32)
+
+
+@pytest.mark.parametrize("mode", ["reflect", "zero", "constant", "symmetric"])
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4"])
+def test_pair_kernels_vs_oracle_at_odd_extents(wavelet, mode):
+    """The two-levels-per-launch kernels against the fp64 ORACLE (not only against the per-level kernels): analysis pair (tiles and
+    rolling strips) and synthesis pair, odd extents at both levels."""
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(2, 211, 307, generator=g, dtype=torch.float32)
+    want = O.wavedec2(x.numpy().astype(np.float64), wavelet, mode=mode, level=2)
+    for pair_mode in (1, 3):
+        _engine.set_option(_engine.OPT_PAIR_MODE, pair_mode)
+        _engine.level_events = []
+        try:
+            got = ptwt_amd.wavedec2(x.to(dev()), wavelet, mode=mode, level=2)
+            kids = [e[1] for e in _engine.level_events]
+        finally:
+            _engine.level_events = None
+            _engine.set_option(_engine.OPT_PAIR_MODE, 0)
+        assert kids == [_engine.KID_PAIR], kids
+        check_tree(got, want, TOL32, f"pair {wavelet} {mode} mode {pair_mode}")
+    coeffs = [torch.from_numpy(want[0]).float().to(dev())] + [tuple(torch.from_numpy(np.asarray(t)).float().to(dev()) for t in d) for d in want[1:]]
+    _engine.level_events = []
+    try:
+        rec = ptwt_amd.waverec2(coeffs, wavelet)
+        kids = [e[1] for e in _engine.level_events]
+    finally:
+        _engine.level_events = None
+    assert kids == [_engine.KID_INV_PAIR], kids
+    ref = O.waverec2(want, wavelet)
+    assert rec.shape == ref.shape and G.relerr(to_np(rec), ref) < 2e-6
 
 
 def test_pair_kernel_full_size_config2_round_trip():
