@@ -158,8 +158,9 @@ int mifwt_dwt1_fwd_tail(int dtype, int filt_len, int mode, int64_t rows, int64_t
                         const double* dec_lo, const double* dec_hi, void* stream);
 
 /* SEVERAL levels of a 1-D decomposition in one launch, a CHUNK of a row per workgroup — the leading trips of wavedec's level
- * loop (src/ptwt/conv_transform.py:133-140) while a row does not fit into one workgroup, or while there are too few rows
- * (< 128, of >= 4096 samples) to occupy the chip with one workgroup each: a workgroup owns a chunk of a row plus the
+ * loop (src/ptwt/conv_transform.py:133-140) for rows of at least 4096 samples (longer than one workgroup's LDS or not: the
+ * one-workgroup-per-row launch is a latency chain; few rows get smaller chunks, about one workgroup per CU; the two end pieces may
+ * be the whole row): a workgroup owns a chunk of a row plus the
  * (L - 2)(2^K - 1) halo samples its K levels consume; the approximations between the levels stay in LDS.  Same arguments as
  * mifwt_dwt1_fwd_tail; f32, even filt_len <= 20, any boundary mode.
  * mifwt_dwt1_fwd_long_levels answers how many of `want` levels one launch fuses for this geometry (it stops where the halo
@@ -189,8 +190,8 @@ int mifwt_dwt1_inv_tail(int dtype, int filt_len, int64_t rows, int64_t m, int nl
  *            of approx for s = 0, of details[s] for every s — and m[s + 1] = 2 m[s] - L + 2 - t its output length (t in {0, 1}:
  *            the reference's end-crop, src/ptwt/_util.py:231-244); m[nlevels] = samples per row of y
  *   approx   [rows, m[0]]     details  HOST array of nlevels device ptrs, coarsest first: [rows, m[s]]     y  [rows, m[nlevels]]
- * f32, even filt_len <= 20, 2 <= nlevels <= 8 with (L/2) 2^nlevels below a twelfth of an 8 K-sample chunk, output rows longer
- * than mifwt_dwt1_fwd_tail_max_n (mifwt_dwt1_inv_long_supported says 1 / 0); MIFWT_ERR_UNSUPPORTED otherwise, nothing
+ * f32, even filt_len <= 20, 2 <= nlevels <= 8 with (L/2) 2^nlevels below a twelfth of a chunk (8 K samples; smaller for few
+ * short rows), output rows of at least 1024 samples (mifwt_dwt1_inv_long_supported says 1 / 0); MIFWT_ERR_UNSUPPORTED otherwise, nothing
  * launched.  Agreement with per-level calls to rounding.  Kernel id 18. */
 int mifwt_dwt1_inv_long_supported(int dtype, int filt_len, int64_t rows, int nlevels, const int32_t* m);
 int mifwt_dwt1_inv_long(int dtype, int filt_len, int64_t rows, int nlevels, const int32_t* m, const void* approx, int64_t approx_row_stride,

@@ -329,10 +329,12 @@ bool long_plan(int dtype, int L, int mode, int64_t rows, int64_t n0, int want, L
   if (dtype != MIFWT_F32 || L < 2 || L > 20 || (L & 1) || want < 1) return false;
   if (mode < 0 || mode > MIFWT_MODE_SYMMETRIC) return false;
   if (rows < 1 || rows > (int64_t(1) << 24) || n0 > (int64_t(1) << 30)) return false;
-  // rows one workgroup could hold (mifwt_dwt1_fwd_tail) are still cut into chunks while there are too few of them to occupy
-  // the chip: smaller chunks, about one workgroup per CU
+  // rows one workgroup could hold (mifwt_dwt1_fwd_tail) are still served here when they are at least 4096 samples long: with
+  // few rows to occupy the chip (smaller chunks, about one workgroup per CU), and with many rows because the one-workgroup-per-
+  // row launch runs its levels as one latency chain on 512 lanes (1024 rows of 16 384 samples, 8 levels: 149 us there, 65 here;
+  // 4096 rows of 4096 samples — the two end pieces ARE the row — 120 against 84 us)
   const bool big = n0 > dwt1_tail_max_n(dtype);
-  if (!big && (rows >= 128 || n0 < 4096)) return false;
+  if (!big && n0 < 4096) return false;
   int cap = kLongCapA;
   if (!big) {
     cap = 1024;
@@ -364,7 +366,6 @@ bool long_plan(int dtype, int L, int mode, int64_t rows, int64_t n0, int want, L
   int e = chunk / 2 - (halo >> (K + 1)) - 2;
   if (e < L + 1) return false;
   if (2 * e >= nK) {
-    if (!big) return false;  // one workgroup per row: mifwt_dwt1_fwd_tail does that with all levels
     p->end_l = nK / 2;
     p->end_r = nK - p->end_l;
     p->nchunks = 0;
@@ -582,10 +583,11 @@ bool inv_long_plan(int dtype, int L, int64_t rows, int nlevels, const int* m, In
   }
   const int n = m[nlevels];
   if (n > (1 << 30)) return false;
-  // output rows one workgroup could hold (mifwt_dwt1_inv_tail) are still cut into chunks while there are too few of them to
-  // occupy the chip: smaller chunks, about one workgroup per CU
+  // output rows one workgroup could hold (mifwt_dwt1_inv_tail) are still served here when they are at least 1024 samples long
+  // (few rows: smaller chunks, about one workgroup per CU; many rows: 1024 x 16 384 142 -> 48 us, 4096 x 4096 86 -> 44 us,
+  // 16 384 x 1024 111 -> 74 us against the one-workgroup-per-row launch)
   const bool big = n > dwt1_tail_max_n(dtype);
-  if (!big && (rows >= 128 || n < 4096)) return false;
+  if (!big && n < 1024) return false;
   int cap = kLongCapA;
   if (!big) {
     cap = 1024;
@@ -598,7 +600,6 @@ bool inv_long_plan(int dtype, int L, int64_t rows, int nlevels, const int* m, In
   p->chunk = (cap - 2 * halo - 64) & ~3;
   if (p->chunk < 4 * L) return false;
   p->nchunks = (n + p->chunk - 1) / p->chunk;
-  if (!big && p->nchunks < 2) return false;  // one workgroup per row: mifwt_dwt1_inv_tail does that
   if (rows * (int64_t)p->nchunks > (int64_t(1) << 30)) return false;
   return true;
 }

@@ -180,3 +180,31 @@ def test_long_rows_randomised_against_per_level_kernels():
         ran_fwd += _engine.KID_LONG in kids
         ran_inv += _engine.KID_INV_LONG in rkids
     assert ran_fwd >= 20 and ran_inv >= 20, (ran_fwd, ran_inv)
+
+
+@pytest.mark.parametrize("mode", ["reflect", "periodic", "zero"])
+def test_many_medium_rows_through_the_chunked_launches(mode):
+    """Many rows of 1 K .. 16 K samples (the chunked launches serve them too: the two end pieces may be the whole row): against
+    the per-level kernels and, on a few rows, the oracle."""
+    g = torch.Generator(device=dev()).manual_seed(31)
+    for shape, wavelet, level in [((600, 4099), "db4", 6), ((300, 16384), "db5", 8), ((2000, 1031), "db2", 5), ((500, 8192), "haar", 10),
+                                  ((257, 12001), "sym8", 7)]:
+        x = torch.randn(*shape, device=dev(), generator=g)
+        got, kids = traced(lambda: ptwt_amd.wavedec(x, wavelet, mode=mode, level=level))
+        _engine.set_option(_engine.OPT_PAIR_MODE, 2)
+        try:
+            want = ptwt_amd.wavedec(x, wavelet, mode=mode, level=level)
+            rec_want = ptwt_amd.waverec(want, wavelet)
+        finally:
+            _engine.set_option(_engine.OPT_PAIR_MODE, 0)
+        if shape[1] >= 4096:
+            assert kids[0] == _engine.KID_LONG, (shape, kids)
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert a.shape == b.shape and float((a - b).norm() / b.norm()) < 2e-6, (shape, wavelet, mode, i, kids)
+        rows = [0, shape[0] // 2, shape[0] - 1]
+        ref = O.wavedec(x[rows].cpu().numpy().astype(np.float64), wavelet, mode=mode, level=level)
+        for a, b in zip(got, ref):
+            assert G.relerr(a[rows].cpu().numpy(), b) < TOL32
+        rec, rkids = traced(lambda: ptwt_amd.waverec(want, wavelet))
+        assert _engine.KID_INV_LONG in rkids, (shape, rkids)
+        assert rec.shape == rec_want.shape and float((rec - rec_want).norm() / rec_want.norm()) < 2e-6, (shape, wavelet, rkids)

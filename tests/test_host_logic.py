@@ -316,7 +316,8 @@ def test_dwt1_long_plan_and_argument_checks():
     assert lv(F32, 10, PER, 32, 1000000, 10) == 6     # the reference's speed test: down to 15 633 samples, the tail's range
     assert lv(F32, 10, PER, 32, 15633, 4) == 4        # few rows of medium length: chunked too (about one workgroup per CU)
     assert lv(F32, 10, PER, 32, 15633, 2) == 2
-    assert lv(F32, 10, PER, 500, 15633, 4) == 0       # enough rows for one workgroup each: mifwt_dwt1_fwd_tail
+    assert lv(F32, 10, PER, 500, 15633, 4) == 4       # many rows as well (the one-workgroup-per-row launch is a latency chain)
+    assert lv(F32, 8, REFL, 4096, 4096, 6) == 6       # the two end pieces are the whole row
     assert lv(F32, 10, PER, 4, 3000, 4) == 0          # short rows
     assert lv(F64, 10, PER, 32, 1000000, 10) == 0     # f32 only
     assert lv(F32, 22, PER, 32, 1000000, 10) == 0     # even filt_len <= 20
@@ -356,7 +357,9 @@ def test_dwt1_inv_long_plan_and_argument_checks():
     assert sup(0, 10, 32, 7, arr(m[3:])) == 1            # the finest seven levels of the speed-test shape
     assert sup(0, 10, 32, 8, arr(m[2:])) == 0            # eight: the halo would exceed a twelfth of a chunk
     assert sup(0, 10, 32, 3, arr(m[:4])) == 1            # 985 -> 7821 samples, 32 rows: chunked too (too few rows for one workgroup each)
-    assert sup(0, 10, 500, 3, arr(m[:4])) == 0           # enough rows: mifwt_dwt1_inv_tail
+    assert sup(0, 10, 500, 3, arr(m[:4])) == 1           # many rows as well
+    assert sup(0, 10, 500, 2, arr(m[:3])) == 1           # 1962-sample outputs: still served (>= 1024)
+    assert sup(0, 10, 500, 2, arr([250, 492, 976])) == 0  # shorter: mifwt_dwt1_inv_tail
     assert sup(1, 10, 32, 7, arr(m[3:])) == 0            # f32 only
     assert sup(0, 10, 32, 1, arr(m[9:])) == 0            # a single level is the per-level kernels' job
     bad = list(m[3:])

@@ -64,7 +64,8 @@ def ranges(A, B, last, K, HL, n, ends):
 
 @pytest.mark.parametrize("wavelet,mode,n0,rows,want", [("db5", "periodic", 1000000, 32, 10), ("db4", "reflect", 100003, 3, 8), ("haar", "zero", 65536, 2, 6),
                                                         ("sym10", "symmetric", 40001, 1, 5), ("db2", "constant", 33001, 2, 4), ("db5", "periodic", 15633, 32, 4),
-                                                        ("db3", "reflect", 5000, 3, 9)])
+                                                        ("db3", "reflect", 5000, 3, 9), ("db4", "reflect", 4096, 4096, 6), ("db4", "symmetric", 16384, 1024, 8),
+                                                        ("db2", "periodic", 6001, 700, 7)])
 def test_analysis_chunks_cover_every_level_once_and_fit(wavelet, mode, n0, rows, want):
     lo, hi = host_taps(wavelet)[:2]
     L, HL = len(lo), len(lo) - 2
@@ -103,7 +104,8 @@ def test_analysis_chunks_cover_every_level_once_and_fit(wavelet, mode, n0, rows,
         assert (owned[l] == 1).all(), (l, np.flatnonzero(owned[l] != 1)[:8])
 
 
-@pytest.mark.parametrize("wavelet,n0,rows,level", [("db5", 1000000, 32, 10), ("db4", 100003, 3, 8), ("haar", 65536, 2, 6), ("sym10", 40001, 1, 5), ("db5", 7821, 32, 3)])
+@pytest.mark.parametrize("wavelet,n0,rows,level", [("db5", 1000000, 32, 10), ("db4", 100003, 3, 8), ("haar", 65536, 2, 6), ("sym10", 40001, 1, 5), ("db5", 7821, 32, 3), ("db4", 4096, 4096, 6), ("db2", 1024, 16384, 5),
+                                                   ("db4", 16384, 1024, 8)])
 def test_synthesis_chunks_cover_the_output_once_and_fit(wavelet, n0, rows, level):
     L = len(host_taps(wavelet)[0])
     HLn = L // 2
