@@ -164,8 +164,7 @@ int mifwt_dwt1_fwd_tail(int dtype, int filt_len, int mode, int64_t rows, int64_t
  * (L - 2)(2^K - 1) halo samples its K levels consume; the approximations between the levels stay in LDS.  Same arguments as
  * mifwt_dwt1_fwd_tail; f32, even filt_len <= 20, any boundary mode.
  * mifwt_dwt1_fwd_long_levels answers how many of `want` levels one launch fuses for this geometry (it stops where the halo
- * would exceed a twelfth of a chunk, and for rows longer than mifwt_dwt1_fwd_tail_max_n where mifwt_dwt1_fwd_tail can take
- * over; 0 = not served); mifwt_dwt1_fwd_long must be called with exactly that count, MIFWT_ERR_UNSUPPORTED otherwise, nothing
+ * would exceed a twelfth of a chunk; 0 = not served); mifwt_dwt1_fwd_long must be called with exactly that count, MIFWT_ERR_UNSUPPORTED otherwise, nothing
  * launched.  Agreement with per-level calls to rounding. */
 int mifwt_dwt1_fwd_long_levels(int dtype, int filt_len, int mode, int64_t rows, int64_t n, int want);
 int mifwt_dwt1_fwd_long(int dtype, int filt_len, int mode, int64_t rows, int64_t n, int nlevels, const void* x, int64_t x_row_stride,

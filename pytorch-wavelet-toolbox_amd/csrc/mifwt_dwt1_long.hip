@@ -323,7 +323,7 @@ struct LongPlan {
 };
 
 // how many levels one launch fuses for rows of n0 samples when `want` are asked for: as many as keep the halo below a
-// twelfth of a chunk, for long rows stopping where mifwt_dwt1_fwd_tail can take over; 0 = not this kernel's case
+// twelfth of a chunk (at most 8); 0 = not this kernel's case
 bool long_plan(int dtype, int L, int mode, int64_t rows, int64_t n0, int want, LongPlan* p) {
   if (g_options[MIFWT_OPT_FORCE_GENERIC] || g_options[MIFWT_OPT_PAIR_MODE] == 2) return false;
   if (dtype != MIFWT_F32 || L < 2 || L > 20 || (L & 1) || want < 1) return false;
@@ -352,7 +352,6 @@ bool long_plan(int dtype, int L, int mode, int64_t rows, int64_t n0, int want, L
     n = (n + L - 1) / 2;
     ++K;
     p->n[K] = (int)n;
-    if (big && n <= dwt1_tail_max_n(dtype)) break;
   }
   if (K < 2) return false;  // (the interior walk's alignment argument needs two levels; one level is the per-level kernels' job)
   const int halo = (L - 2) * ((1 << K) - 1);
