@@ -19,7 +19,9 @@ namespace {
 
 constexpr int kTailMaxLevels = 24;
 constexpr int kTailMaxTaps = 32;
-constexpr int kTailThreads = 512;  // a row is one workgroup: more lanes per row, not more rows per CU
+constexpr int kTailThreads = 512;  // at most; a row is one workgroup, short rows get fewer lanes (more workgroups per CU: 16 384 rows
+                                   // of 1024 samples ran one latency chain per CU slot with 512 mostly idle lanes each)
+static int tail_threads(int64_t n) { return n <= 2048 ? 128 : (n <= 6144 ? 256 : kTailThreads); }
 
 struct Dwt1TailArgs {
   const void* x;
@@ -36,14 +38,14 @@ __global__ void __launch_bounds__(kTailThreads) dwt1_tail_kernel(const Dwt1TailA
   T* A = reinterpret_cast<T*>(tail_lds);
   T* B = A + a.cap;
   __shared__ T tlo[kTailMaxTaps], thi[kTailMaxTaps];
-  const int tid = threadIdx.x, L = a.filt_len;
+  const int tid = threadIdx.x, nt = blockDim.x, L = a.filt_len;
   const int64_t row = blockIdx.x;
   if (tid < L) {
     tlo[tid] = (T)a.lo[tid];
     thi[tid] = (T)a.hi[tid];
   }
   const T* __restrict__ xr = static_cast<const T*>(a.x) + row * a.x_rs;
-  for (int i = tid; i < a.n0; i += kTailThreads) A[i] = xr[i];
+  for (int i = tid; i < a.n0; i += nt) A[i] = xr[i];
   __syncthreads();
   int n = a.n0;
   for (int lvl = 0; lvl < a.nlevels; ++lvl) {
@@ -54,13 +56,13 @@ __global__ void __launch_bounds__(kTailThreads) dwt1_tail_kernel(const Dwt1TailA
     // map, and four outputs per thread and step so that their LDS reads are in flight together (one output at a time ran
     // at LDS latency: 10 us per level on a 15 000-sample row)
     const int k_lo = min((L - 2) >> 1, m), k_hi = max(min(n >> 1, m), k_lo);
-    for (int k = k_lo + tid; k < k_hi; k += 4 * kTailThreads) {
+    for (int k = k_lo + tid; k < k_hi; k += 4 * nt) {
       T clo[4], chi[4];
       const T* xp[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         clo[u] = chi[u] = T(0);
-        const int ku = k + u * kTailThreads;
+        const int ku = k + u * nt;
         xp[u] = A + 2 * (ku < k_hi ? ku : k) + 1;  // lanes past the end recompute output k (stored once, below)
       }
       for (int t = 0; t < L; ++t) {
@@ -74,7 +76,7 @@ __global__ void __launch_bounds__(kTailThreads) dwt1_tail_kernel(const Dwt1TailA
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int ku = k + u * kTailThreads;
+        const int ku = k + u * nt;
         if (ku < k_hi) {
           dr[ku] = chi[u];
           B[ku] = clo[u];
@@ -82,7 +84,7 @@ __global__ void __launch_bounds__(kTailThreads) dwt1_tail_kernel(const Dwt1TailA
       }
     }
     // the few outputs at the two ends, through the boundary map
-    for (int idx = tid; idx < k_lo + (m - k_hi); idx += kTailThreads) {
+    for (int idx = tid; idx < k_lo + (m - k_hi); idx += nt) {
       const int k = idx < k_lo ? idx : k_hi + (idx - k_lo);
       T clo = T(0), chi = T(0);
       for (int t = 0; t < L; ++t) {
@@ -101,7 +103,7 @@ __global__ void __launch_bounds__(kTailThreads) dwt1_tail_kernel(const Dwt1TailA
     n = m;
   }
   T* __restrict__ ar = static_cast<T*>(a.approx) + row * a.approx_rs;
-  for (int i = tid; i < n; i += kTailThreads) ar[i] = A[i];
+  for (int i = tid; i < n; i += nt) ar[i] = A[i];
 }
 
 struct Idwt1TailArgs {
@@ -127,7 +129,7 @@ __global__ void __launch_bounds__(kTailThreads) idwt1_tail_kernel(const Idwt1Tai
   T* small = big + a.cap;
   T* D = small + a.cap_small;
   __shared__ T tlo[kTailMaxTaps], thi[kTailMaxTaps];
-  const int tid = threadIdx.x, L = a.filt_len, HLn = a.filt_len >> 1;
+  const int tid = threadIdx.x, nt = blockDim.x, L = a.filt_len, HLn = a.filt_len >> 1;
   const int64_t row = blockIdx.x;
   if (tid < L) {
     tlo[tid] = (T)a.lo[tid];
@@ -136,17 +138,17 @@ __global__ void __launch_bounds__(kTailThreads) idwt1_tail_kernel(const Idwt1Tai
   T* A = (a.nlevels & 1) ? small : big;  // level l reads SMALL when nlevels - 1 - l is even
   T* B = (a.nlevels & 1) ? big : small;
   const T* __restrict__ ar = static_cast<const T*>(a.approx) + row * a.approx_rs;
-  for (int i = tid; i < a.m0 + HLn; i += kTailThreads) A[i] = i < a.m0 ? ar[i] : T(0);  // (zeros behind the row: what the windows read past it)
+  for (int i = tid; i < a.m0 + HLn; i += nt) A[i] = i < a.m0 ? ar[i] : T(0);  // (zeros behind the row: what the windows read past it)
   T* __restrict__ yr = static_cast<T*>(a.y) + row * a.y_rs;
   int m = a.m0;
   for (int lvl = 0; lvl < a.nlevels; ++lvl) {
     const int n = a.out_len[lvl];
     const bool last = lvl == a.nlevels - 1;
     const T* __restrict__ dr = static_cast<const T*>(a.det[lvl]) + row * a.det_rs[lvl];
-    for (int i = tid; i < m + HLn; i += kTailThreads) D[i] = i < m ? dr[i] : T(0);
+    for (int i = tid; i < m + HLn; i += nt) D[i] = i < m ? dr[i] : T(0);
     __syncthreads();  // (also: A complete)
     // a thread owns a position p: the outputs 2p and 2p + 1 share their L/2 coefficient pairs
-    for (int p = tid; 2 * p < n + (last ? 0 : HLn); p += kTailThreads) {
+    for (int p = tid; 2 * p < n + (last ? 0 : HLn); p += nt) {
       T acc0 = T(0), acc1 = T(0);
       if (2 * p < n) {
         for (int i = 0; i < HLn; ++i) {
@@ -225,9 +227,9 @@ int dwt1_tail(int dtype, int filt_len, int mode, int64_t rows, int64_t n0, int n
     attr_set[ti] = true;
   }
   if (ti)
-    hipLaunchKernelGGL((dwt1_tail_kernel<double>), dim3((unsigned)rows), dim3(kTailThreads), lds, stream, a);
+    hipLaunchKernelGGL((dwt1_tail_kernel<double>), dim3((unsigned)rows), dim3(tail_threads(n0)), lds, stream, a);
   else
-    hipLaunchKernelGGL((dwt1_tail_kernel<float>), dim3((unsigned)rows), dim3(kTailThreads), lds, stream, a);
+    hipLaunchKernelGGL((dwt1_tail_kernel<float>), dim3((unsigned)rows), dim3(tail_threads(n0)), lds, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 
@@ -298,9 +300,9 @@ int idwt1_tail(int dtype, int filt_len, int64_t rows, int64_t m0, int nlevels, c
     attr_set[ti] = true;
   }
   if (ti)
-    hipLaunchKernelGGL((idwt1_tail_kernel<double>), dim3((unsigned)rows), dim3(kTailThreads), lds, stream, a);
+    hipLaunchKernelGGL((idwt1_tail_kernel<double>), dim3((unsigned)rows), dim3(tail_threads(out_len[nlevels - 1])), lds, stream, a);
   else
-    hipLaunchKernelGGL((idwt1_tail_kernel<float>), dim3((unsigned)rows), dim3(kTailThreads), lds, stream, a);
+    hipLaunchKernelGGL((idwt1_tail_kernel<float>), dim3((unsigned)rows), dim3(tail_threads(out_len[nlevels - 1])), lds, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 
