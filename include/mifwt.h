@@ -189,8 +189,8 @@ int mifwt_dwt1_inv_tail(int dtype, int filt_len, int64_t rows, int64_t m, int nl
  *            of approx for s = 0, of details[s] for every s — and m[s + 1] = 2 m[s] - L + 2 - t its output length (t in {0, 1}:
  *            the reference's end-crop, src/ptwt/_util.py:231-244); m[nlevels] = samples per row of y
  *   approx   [rows, m[0]]     details  HOST array of nlevels device ptrs, coarsest first: [rows, m[s]]     y  [rows, m[nlevels]]
- * f32, even filt_len <= 20, 2 <= nlevels <= 8 with (L/2) 2^nlevels below a twelfth of a chunk (8 K samples; smaller for few
- * short rows), output rows of at least 1024 samples (mifwt_dwt1_inv_long_supported says 1 / 0); MIFWT_ERR_UNSUPPORTED otherwise, nothing
+ * f32 / f64, even filt_len <= 20, 2 <= nlevels <= 8 with (L/2) 2^nlevels below a twelfth of a chunk (8 K f32 / 4 K f64 samples;
+ * smaller for few short rows), output rows of at least 1024 samples (mifwt_dwt1_inv_long_supported says 1 / 0); MIFWT_ERR_UNSUPPORTED otherwise, nothing
  * launched.  Agreement with per-level calls to rounding.  Kernel id 18. */
 int mifwt_dwt1_inv_long_supported(int dtype, int filt_len, int64_t rows, int nlevels, const int32_t* m);
 int mifwt_dwt1_inv_long(int dtype, int filt_len, int64_t rows, int nlevels, const int32_t* m, const void* approx, int64_t approx_row_stride,

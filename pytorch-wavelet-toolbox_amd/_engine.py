@@ -513,7 +513,7 @@ class HipLevelEngine:
         come back; ``(None, 0)`` outside the kernel's envelope."""
         _require_gpu(approx)
         nl = len(details)
-        if approx.dim() != 2 or approx.dtype != torch.float32 or nl < 2:
+        if approx.dim() != 2 or approx.dtype not in (torch.float32, torch.float64) or nl < 2:
             return None, 0
         lib = load_library()
         flen = len(rec_lo)
@@ -522,7 +522,7 @@ class HipLevelEngine:
         k = min(nl, 8)
         while k >= 2:
             m = (ctypes.c_int32 * (k + 1))(*lens[nl - k:])
-            if lib.mifwt_dwt1_inv_long_supported(0, flen, rows, k, m):
+            if lib.mifwt_dwt1_inv_long_supported(_DTYPE_IDS[approx.dtype], flen, rows, k, m):
                 break
             k -= 1
         if k < 2:
@@ -543,7 +543,7 @@ class HipLevelEngine:
         d.sig_extent[0] = lens[-1]
         p.desc = d
         ap, yp = approx.data_ptr(), y.data_ptr()
-        self._run(p, 1, approx, lambda ws, wsb, stream: lib.mifwt_dwt1_inv_long(0, flen, rows, nl, m, ap, approx.stride(0), det, det_rs, yp,
+        self._run(p, 1, approx, lambda ws, wsb, stream: lib.mifwt_dwt1_inv_long(_DTYPE_IDS[approx.dtype], flen, rows, nl, m, ap, approx.stride(0), det, det_rs, yp,
                                                                               y.stride(0), lo, hi, stream))
         return y, nl
 

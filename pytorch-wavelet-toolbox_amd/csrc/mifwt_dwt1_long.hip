@@ -566,6 +566,116 @@ __global__ void __launch_bounds__(T) idwt1_long_kernel(const Idwt1LongArgs<L> a)
   }
 }
 
+// ---- the same launch for f64 data (the reference's second dtype): plain double FMAs, 16-byte LDS reads, 8-byte detail loads ----
+template <int L>
+struct Idwt1LongArgsD {
+  const double* approx;
+  const double* det[kLongMaxLevels];
+  double* y;
+  int64_t approx_rs, y_rs, det_rs[kLongMaxLevels];
+  int m[kLongMaxLevels + 1];
+  int nlevels, rows, chunk, nchunks, cap;  // cap = doubles of LDS buffer A
+  int vec;                                 // output rows start on 16-byte boundaries
+  double glo[L], ghi[L];                   // rec_lo / rec_hi, PyWavelets order
+};
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+template <int L, int T>
+__global__ void __launch_bounds__(T) idwt1_long_kernel_f64(const Idwt1LongArgsD<L> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char long_lds[];
+  __shared__ int rlo[kLongMaxLevels + 1], rhi[kLongMaxLevels + 1];
+  double* bufA = reinterpret_cast<double*>(long_lds);
+  double* bufB = bufA + a.cap + kLongPad;
+  constexpr int HLn = L / 2;
+  constexpr int NA = HLn / 2 + 1;  // 16-byte pieces of a lane's window: HLn + 1 coefficients (two positions)
+  const int tid = threadIdx.x, K = a.nlevels;
+  const int row = blockIdx.x / a.nchunks;
+  const int c = blockIdx.x - row * a.nchunks;
+  const int x0 = c * a.chunk, x1 = min(a.m[K], x0 + a.chunk);
+  if (tid == 0) {
+    int lo = x0, hi = x1;
+    rlo[K] = lo;
+    rhi[K] = hi;
+    for (int s = K - 1; s >= 0; --s) {
+      hi = min(a.m[s], ((hi - 1) >> 1) + HLn);
+      lo >>= 1;
+      rlo[s] = lo;
+      rhi[s] = hi;
+    }
+  }
+  __syncthreads();
+  {
+    const int lo = rlo[0], hi = rhi[0];
+    const double* __restrict__ ar = a.approx + (int64_t)row * a.approx_rs;
+    double* first = (a.nlevels & 1) ? bufA : bufB;
+    for (int i = tid; i < hi - lo + HLn + 3; i += T) first[i] = lo + i < hi ? ar[lo + i] : 0.0;
+  }
+  __syncthreads();
+  double glo[L], ghi[L];
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    glo[i] = a.glo[i];
+    ghi[i] = a.ghi[i];
+  }
+  double* src = (a.nlevels & 1) ? bufA : bufB;
+  double* dst = (a.nlevels & 1) ? bufB : bufA;
+  double* __restrict__ yr = a.y + (int64_t)row * a.y_rs;
+  for (int s = 0; s < K; ++s) {
+    const int ilo = rlo[s], olo = rlo[s + 1], ohi = rhi[s + 1];
+    const bool last = s == K - 1;
+    const rsrc_t dres = pyr_rsrc(a.det[s] + (int64_t)row * a.det_rs[s], (uint32_t)a.m[s] * 8u);
+    const int pend = ((last ? ohi : ohi + HLn + 3) + 1) >> 1;
+    for (int pt0 = ilo; pt0 < pend; pt0 += 2 * T) {
+      const int p = pt0 + 2 * tid;
+      const double* w = src + ((p < pend ? p : ilo) - ilo);  // (16-byte aligned: positions advance in pairs from ilo)
+      double af[2 * NA], df[HLn + 1];
+#pragma unroll
+      for (int k = 0; k < NA; ++k) {
+        const d2 v = *reinterpret_cast<const d2*>(w + 2 * k);
+        af[2 * k] = v.x;
+        af[2 * k + 1] = v.y;
+      }
+#pragma unroll
+      for (int k = 0; k < HLn + 1; ++k) df[k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(dres, 8u * (uint32_t)(p + k), 0, 0));
+      double y0e = 0.0, y0o = 0.0, y1e = 0.0, y1o = 0.0;  // outputs 2p, 2p + 1, 2p + 2, 2p + 3: the per-level kernels' summation order
+#pragma unroll
+      for (int i = 0; i < HLn; ++i) {
+        y0e = __builtin_fma(glo[L - 2 - 2 * i], af[i], y0e);
+        y0e = __builtin_fma(ghi[L - 2 - 2 * i], df[i], y0e);
+        y0o = __builtin_fma(glo[L - 1 - 2 * i], af[i], y0o);
+        y0o = __builtin_fma(ghi[L - 1 - 2 * i], df[i], y0o);
+        y1e = __builtin_fma(glo[L - 2 - 2 * i], af[i + 1], y1e);
+        y1e = __builtin_fma(ghi[L - 2 - 2 * i], df[i + 1], y1e);
+        y1o = __builtin_fma(glo[L - 1 - 2 * i], af[i + 1], y1o);
+        y1o = __builtin_fma(ghi[L - 1 - 2 * i], df[i + 1], y1o);
+      }
+      const int j = 2 * p;
+      if (last) {
+        if (j + 4 <= ohi && a.vec) {
+          *reinterpret_cast<d2*>(yr + j) = (d2){y0e, y0o};
+          *reinterpret_cast<d2*>(yr + j + 2) = (d2){y1e, y1o};
+        } else {
+          if (j < ohi) yr[j] = y0e;
+          if (j + 1 < ohi) yr[j + 1] = y0o;
+          if (j + 2 < ohi) yr[j + 2] = y1e;
+          if (j + 3 < ohi) yr[j + 3] = y1o;
+        }
+      } else if (p < pend) {
+        double* o = dst + (j - olo);
+        if (j >= olo) o[0] = j < ohi ? y0e : 0.0;
+        o[1] = j + 1 < ohi ? y0o : 0.0;
+        o[2] = j + 2 < ohi ? y1e : 0.0;
+        o[3] = j + 3 < ohi ? y1o : 0.0;
+      }
+    }
+    __syncthreads();
+    double* tmp = src;
+    src = dst;
+    dst = tmp;
+  }
+}
+
 struct InvLongPlan {
   int nlevels, chunk, nchunks, cap;
 };
@@ -574,7 +684,7 @@ struct InvLongPlan {
 // about (L/2 - 1) 2^K output samples: below a twelfth of a chunk), else fewer — the caller runs the coarser ones first
 bool inv_long_plan(int dtype, int L, int64_t rows, int nlevels, const int* m, InvLongPlan* p) {
   if (g_options[MIFWT_OPT_FORCE_GENERIC] || g_options[MIFWT_OPT_PAIR_MODE] == 2) return false;
-  if (dtype != MIFWT_F32 || L < 2 || L > 20 || (L & 1) || nlevels < 2 || nlevels > kLongMaxLevels || !m) return false;
+  if ((dtype != MIFWT_F32 && dtype != MIFWT_F64) || L < 2 || L > 20 || (L & 1) || nlevels < 2 || nlevels > kLongMaxLevels || !m) return false;
   if (rows < 1 || rows > (int64_t(1) << 24)) return false;
   for (int s = 0; s < nlevels; ++s) {
     const int64_t full = 2 * (int64_t)m[s] - L + 2;
@@ -587,10 +697,11 @@ bool inv_long_plan(int dtype, int L, int64_t rows, int nlevels, const int* m, In
   // 16 384 x 1024 111 -> 74 us against the one-workgroup-per-row launch)
   const bool big = n > dwt1_tail_max_n(dtype);
   if (!big && n < 1024) return false;
-  int cap = kLongCapA;
+  const int cap_max = dtype == MIFWT_F64 ? kLongCapA / 2 : kLongCapA;  // elements: the same LDS bytes for either type
+  int cap = cap_max;
   if (!big) {
     cap = 1024;
-    while (cap < kLongCapA && (int64_t)cap * 256 < rows * n) cap *= 2;
+    while (cap < cap_max && (int64_t)cap * 256 < rows * n) cap *= 2;
   }
   const int halo = (L / 2) * (1 << nlevels);
   if (halo > cap / 12) return false;
@@ -630,6 +741,40 @@ int launch_inv_long(const InvLongPlan& p, int64_t rows, const int* m, const void
   const size_t lds = (size_t)(p.cap + kLongPad + p.cap / 2 + 64 + kLongPad) * sizeof(float);
   const unsigned grid = (unsigned)(rows * p.nchunks);
   hipLaunchKernelGGL((idwt1_long_kernel<L, kLongThreads>), dim3(grid), dim3(kLongThreads), lds, stream, a);
+  return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
+}
+
+template <int L>
+int launch_inv_long_f64(const InvLongPlan& p, int64_t rows, const int* m, const void* approx, int64_t approx_rs, const void* const* details,
+                        const int64_t* det_rs, void* y, int64_t y_rs, const double* lo, const double* hi, hipStream_t stream) {
+  Idwt1LongArgsD<L> a;
+  a.approx = static_cast<const double*>(approx);
+  a.y = static_cast<double*>(y);
+  a.approx_rs = approx_rs;
+  a.y_rs = y_rs;
+  for (int s = 0; s < p.nlevels; ++s) {
+    a.det[s] = static_cast<const double*>(details[s]);
+    a.det_rs[s] = det_rs[s];
+  }
+  for (int s = 0; s <= p.nlevels; ++s) a.m[s] = m[s];
+  a.nlevels = p.nlevels;
+  a.rows = (int)rows;
+  a.chunk = p.chunk;
+  a.nchunks = p.nchunks;
+  a.cap = p.cap;
+  a.vec = ((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (y_rs & 1) == 0) ? 1 : 0;
+  for (int i = 0; i < L; ++i) {
+    a.glo[i] = lo[i];
+    a.ghi[i] = hi[i];
+  }
+  const size_t lds = (size_t)(p.cap + kLongPad + p.cap / 2 + 64 + kLongPad) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&idwt1_long_kernel_f64<L, kLongThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    attr_set = true;
+  }
+  const unsigned grid = (unsigned)(rows * p.nchunks);
+  hipLaunchKernelGGL((idwt1_long_kernel_f64<L, kLongThreads>), dim3(grid), dim3(kLongThreads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 
@@ -690,9 +835,11 @@ int idwt1_long(int dtype, int filt_len, int64_t rows, int nlevels, const int* m,
                const double* hi, hipStream_t stream) {
   InvLongPlan p;
   if (!inv_long_plan(dtype, filt_len, rows, nlevels, m, &p)) return MIFWT_ERR_UNSUPPORTED;
-#define MIFWT_INV_LONG_CASE(LL) \
-  case LL:                      \
-    return launch_inv_long<LL>(p, rows, m, approx, approx_row_stride, details, detail_row_strides, y, y_row_stride, lo, hi, stream);
+#define MIFWT_INV_LONG_CASE(LL)                                                                                                          \
+  case LL:                                                                                                                               \
+    return dtype == MIFWT_F64                                                                                                            \
+               ? launch_inv_long_f64<LL>(p, rows, m, approx, approx_row_stride, details, detail_row_strides, y, y_row_stride, lo, hi, stream) \
+               : launch_inv_long<LL>(p, rows, m, approx, approx_row_stride, details, detail_row_strides, y, y_row_stride, lo, hi, stream);
   switch (filt_len) {
     MIFWT_INV_LONG_CASE(2)
     MIFWT_INV_LONG_CASE(4)

@@ -208,3 +208,24 @@ def test_many_medium_rows_through_the_chunked_launches(mode):
         rec, rkids = traced(lambda: ptwt_amd.waverec(want, wavelet))
         assert _engine.KID_INV_LONG in rkids, (shape, rkids)
         assert rec.shape == rec_want.shape and float((rec - rec_want).norm() / rec_want.norm()) < 2e-6, (shape, wavelet, rkids)
+
+
+@pytest.mark.parametrize("wavelet", ["haar", "db3", "db5", "sym10"])
+def test_long_rows_synthesis_f64(wavelet):
+    """The chunked synthesis launch on f64 data (the reference's second dtype): against the fp64 oracle at 1e-12 and bit for bit
+    against the per-level kernels (same summation order)."""
+    rng = np.random.default_rng(23)
+    for shape, level in (((3, 100003), 8), ((2, 65536), 6), ((40, 9001), 5), ((300, 4099), 4)):
+        x = rng.standard_normal(shape)
+        want_c = O.wavedec(x, wavelet, level=level)
+        want = O.waverec(want_c, wavelet)
+        cg = [torch.from_numpy(c).to(dev()) for c in want_c]
+        got, kids = traced(lambda: ptwt_amd.waverec(cg, wavelet))
+        assert kids[-1] == _engine.KID_INV_LONG, (wavelet, shape, kids)
+        assert got.dtype == torch.float64 and got.shape == want.shape and G.relerr(got.cpu().numpy(), want) < 1e-12, (wavelet, shape)
+        _engine.set_option(_engine.OPT_PAIR_MODE, 2)
+        try:
+            single = ptwt_amd.waverec(cg, wavelet)
+        finally:
+            _engine.set_option(_engine.OPT_PAIR_MODE, 0)
+        assert float((got - single).abs().max()) < 1e-13 * float(single.abs().max())

@@ -360,7 +360,8 @@ def test_dwt1_inv_long_plan_and_argument_checks():
     assert sup(0, 10, 500, 3, arr(m[:4])) == 1           # many rows as well
     assert sup(0, 10, 500, 2, arr(m[:3])) == 1           # 1962-sample outputs: still served (>= 1024)
     assert sup(0, 10, 500, 2, arr([250, 492, 976])) == 0  # shorter: mifwt_dwt1_inv_tail
-    assert sup(1, 10, 32, 7, arr(m[3:])) == 0            # f32 only
+    assert sup(1, 10, 32, 7, arr(m[3:])) == 0            # f64: half the elements per chunk, the halo rule allows six levels
+    assert sup(1, 10, 32, 6, arr(m[4:])) == 1
     assert sup(0, 10, 32, 1, arr(m[9:])) == 0            # a single level is the per-level kernels' job
     bad = list(m[3:])
     bad[3] += 2
