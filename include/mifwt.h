@@ -116,19 +116,23 @@ int mifwt_dwt2_fwd_pair_supported(const mifwt_level_desc* d1, const mifwt_level_
 int mifwt_dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, const void* x, void* const* details1,
                         void* approx2, void* const* details2, const double* dec_lo, const double* dec_hi, void* stream);
 
-/* UP TO THREE consecutive 2-D analysis levels in one launch — `nlevels` trips of the reference's level loop
+/* SEVERAL consecutive 2-D analysis levels in one launch — `nlevels` trips of the reference's level loop
  * (src/ptwt/conv_transform_2.py:142-149); none of the approximations in between reaches HBM (a pyramid returns only the detail
  * bands of a level that is not the last, conv_transform_2.py:150-156).  descs[l] describes fused level l exactly as a
  * mifwt_dwt_fwd call would (descs[l]->sig_extent == descs[l-1]->coef_extent; approx_stride of every level but the last and
  * sig_stride of every level but the first are ignored).
  *   details  HOST array of nlevels HOST arrays of 3 device ptrs: bands ad, da, dd of fused level l
  *   approx   band aa of the last fused level
- * Same sums as nlevels mifwt_dwt_fwd calls (summation order differs: agreement to rounding, not bit for bit).
- * f32, even L <= 8, modes zero / constant / reflect / symmetric, unit innermost strides, input rows of a multiple of 4 samples
- * that start on 16-byte boundaries, every fused plane at least 2 L samples per axis; in auto mode (MIFWT_OPT_PYRAMID_MODE 0) only
- * for planes of 512 .. 1280 columns, where a workgroup streams whole rows (mifwt_dwt2_fwd_pyramid_supported says
- * 1 / 0); the three detail planes of a level within 1 GiB of one another (one buffer resource serves them; they are planes
- * of one level buffer in practice); MIFWT_ERR_UNSUPPORTED otherwise, nothing launched.  Kernel id 16. */
+ * Same sums as nlevels mifwt_dwt_fwd calls (summation order differs: agreement to rounding, not bit for bit).  Two kernels:
+ *   (1) kernel id 16, up to THREE levels, rows streamed through registers and LDS rings: f32, even L <= 8, modes zero / constant /
+ *       reflect / symmetric, unit innermost strides, input rows of a multiple of 4 samples that start on 16-byte boundaries, every
+ *       fused plane at least 2 L samples per axis; in auto mode (MIFWT_OPT_PYRAMID_MODE 0) only for planes of 512 .. 1280 columns,
+ *       where a workgroup streams whole rows; the three detail planes of a level within 1 GiB of one another;
+ *   (2) kernel id 20, up to EIGHT levels — the whole pyramid — of planes small enough to live in LDS (the plane and its
+ *       horizontally filtered image, both with their boundary extension, <= 160 KB: 128 x 128 up to 12 taps), a workgroup per
+ *       image at a time: f32, even L <= 20, every boundary mode, unit innermost strides; in auto mode not for planes that fill a
+ *       CU's LDS alone when the batch is smaller than 512 images (MIFWT_OPT_PYRAMID_MODE 3 lifts that).
+ * mifwt_dwt2_fwd_pyramid_supported says which one serves the call (0 none, 1, 2); MIFWT_ERR_UNSUPPORTED otherwise, nothing launched. */
 int mifwt_dwt2_fwd_pyramid_supported(int nlevels, const mifwt_level_desc* const* descs);
 int mifwt_dwt2_fwd_pyramid(int nlevels, const mifwt_level_desc* const* descs, const void* x, void* const* const* details, void* approx,
                            const double* dec_lo, const double* dec_hi, void* stream);
@@ -275,7 +279,8 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  *          mifwt_dwt1_inv_tail; likewise not returned by mifwt_kernel_id)
  *   16     up to three fused 2-D analysis levels per launch (mifwt_dwt2_fwd_pyramid; not returned by mifwt_kernel_id)
  *   17 / 18  several fused 1-D analysis / synthesis levels of long rows, a chunk per workgroup (mifwt_dwt1_fwd_long /
- *          mifwt_dwt1_inv_long; likewise) */
+ *          mifwt_dwt1_inv_long; likewise)
+ *   20     every level of a 2-D analysis of a small plane in one launch (mifwt_dwt2_fwd_pyramid's second kernel; likewise) */
 int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 
 /* Library-wide diagnostic switches (process-global, meant for tests and A/B measurements).
@@ -294,8 +299,8 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
                                       UNSUPPORTED / 0); analysis pairs: 0 = auto (rolling strips for 8 taps, else tiles), 1 = tiles only,
                                       3 = rolling strips wherever they apply */
 #define MIFWT_OPT_PAIR_ROWS 9      /* >0 overrides the pair kernels' level-2 rows per tile (4, 6, 8, 12) / per strip segment (multiple of 8) */
-#define MIFWT_OPT_PYRAMID_MODE 12 /* mifwt_dwt2_fwd_pyramid: 0 = auto (planes of 512 .. 1280 columns), 1 = wherever the kernel can run, 2 = never (it answers UNSUPPORTED / 0; the two-level and per-level kernels then serve the call) */
-#define MIFWT_OPT_DEBUG 11        /* A/B measurement switches of the multi-level kernel (results are then wrong): 1 = no stores, 2 = no loads, 4 = no deep levels, 16 = loader wave at default priority */
+#define MIFWT_OPT_PYRAMID_MODE 12 /* mifwt_dwt2_fwd_pyramid: 0 = auto (each of its two kernels where it is the fastest route), 1 = the streaming kernel wherever it can run, 3 = the small-plane kernel wherever it can run, 2 = never (it answers UNSUPPORTED / 0; the two-level and per-level kernels then serve the call) */
+#define MIFWT_OPT_DEBUG 11        /* A/B measurement switches of the multi-level kernels (results are then wrong): 1 = no stores, 2 = no loads, 4 = no deep levels, 16 = loader wave at default priority (streaming kernel); 64 / 128 = no horizontal / vertical pass (small-plane kernel) */
 #define MIFWT_OPT_SYNC_STAGE 10    /* non-zero: tile kernels keep the workgroup barrier between staging and the horizontal pass (A/B) */
 int mifwt_set_option(int key, int value);
 

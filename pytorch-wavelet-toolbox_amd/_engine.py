@@ -158,6 +158,8 @@ KID_INV_TAIL = 15
 KID_PYRAMID = 16
 KID_LONG = 17
 KID_INV_LONG = 18
+KID_SMALL = 20
+MAX_PYRAMID_LEVELS = 8  # mifwt_dwt2_fwd_pyramid: three for the streaming kernel, eight for the small-plane kernel
 
 
 def set_option(key: int, value: int) -> None:
@@ -314,7 +316,8 @@ class HipLevelEngine:
         return buf1, buf2
 
     def analysis_pyramid(self, x: torch.Tensor, dec_lo: Sequence[float], dec_hi: Sequence[float], mode_id: int, nlevels: int):
-        """Up to THREE consecutive 2-D analysis levels in one launch (C ABI ``mifwt_dwt2_fwd_pyramid``): ``x`` [B, H, W] -> a list of
+        """Several consecutive 2-D analysis levels in one launch (C ABI ``mifwt_dwt2_fwd_pyramid``: up to three through the streaming
+        kernel, up to eight — the whole pyramid — for planes that fit into LDS): ``x`` [B, H, W] -> a list of
         buffers laid out like :meth:`analysis` results, finest first; plane 0 (the approximation) is written only in the LAST one —
         the others are intermediates that never leave the chip.  Fuses as many of the ``nlevels`` requested levels as the library
         serves for this geometry (possibly fewer); returns None when it serves none."""
@@ -322,29 +325,30 @@ class HipLevelEngine:
         if x.dim() != 3 or x.dtype != torch.float32:
             return None
         flen = len(dec_lo)
-        key = ("pyr", x.shape, x.stride(), mode_id, flen, min(nlevels, 3), ROW_ALIGN)
+        key = ("pyr", x.shape, x.stride(), mode_id, flen, min(nlevels, MAX_PYRAMID_LEVELS), ROW_ALIGN)
         plan = _plans.get(key)
         if plan is None:
             _trim_plans()
             lib = load_library()
             plans = [self._analysis_plan(x, flen, mode_id)]
-            while len(plans) < min(nlevels, 3) and not plans[-1].empty:
+            while len(plans) < min(nlevels, MAX_PYRAMID_LEVELS) and not plans[-1].empty:
                 pl = plans[-1]
                 lvl = torch.empty(pl.alloc_shape, dtype=x.dtype, device="meta")
                 if pl.view_last is not None:
                     lvl = lvl[..., : pl.view_last]
                 plans.append(self._analysis_plan(lvl[:, 0], flen, mode_id))
-            n_ok = 0
+            n_ok, route = 0, 0
             if not any(pl.empty for pl in plans):
                 for n in range(len(plans), 0, -1):
                     refs = (ctypes.POINTER(LevelDesc) * n)(*[ctypes.pointer(pl.desc) for pl in plans[:n]])
-                    if lib.mifwt_dwt2_fwd_pyramid_supported(n, refs):
+                    route = lib.mifwt_dwt2_fwd_pyramid_supported(n, refs)
+                    if route:
                         n_ok = n
                         break
             keep = plans[:n_ok]
             refs = (ctypes.POINTER(LevelDesc) * n_ok)(*[ctypes.pointer(pl.desc) for pl in keep]) if n_ok else None
-            plan = _plans[key] = (keep, n_ok, refs)
-        plans, n_ok, refs = plan
+            plan = _plans[key] = (keep, n_ok, refs, KID_SMALL if route == 2 else KID_PYRAMID)
+        plans, n_ok, refs, kid = plan
         if n_ok == 0:
             return None
         bufs = []
@@ -367,7 +371,7 @@ class HipLevelEngine:
         lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
         lib = _lib
         xp, ap = x.data_ptr(), bufs[-1].data_ptr()
-        self._run(plans[0], 0, x, lambda ws, wsb, stream: lib.mifwt_dwt2_fwd_pyramid(n_ok, refs, xp, det, ap, lo, hi, stream), kid=KID_PYRAMID)
+        self._run(plans[0], 0, x, lambda ws, wsb, stream: lib.mifwt_dwt2_fwd_pyramid(n_ok, refs, xp, det, ap, lo, hi, stream), kid=kid)
         return bufs
 
     def analysis_tail(self, x: torch.Tensor, dec_lo: Sequence[float], dec_hi: Sequence[float], mode_id: int, nlevels: int):

@@ -330,9 +330,10 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
         _check_pad(cur.shape[1:], flen, "reflect" if mode is None else mode)
         differentiable = torch.is_grad_enabled() and (cur.requires_grad or tap_t is not None)
         if ndim == 2 and not differentiable:
-            # up to three levels per launch, the approximations between them kept on chip (mifwt_dwt2_fwd_pyramid); the pad
+            # several levels per launch (three of a big plane, the whole pyramid of a small one), the approximations between them kept
+            # on chip (mifwt_dwt2_fwd_pyramid); the pad
             # checks of the fused trips are the reference's own and run before anything is launched
-            want = min(3, level - done)
+            want = min(_engine.MAX_PYRAMID_LEVELS, level - done)
             ns = list(cur.shape[1:])
             for _l in range(want):
                 _check_pad(ns, flen, "reflect" if mode is None else mode)

@@ -455,16 +455,26 @@ int mifwt_dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, 
   return dwt2_fwd_pair(d1, d2, x, details1, approx2, details2, dec_lo, dec_hi, st);
 }
 // Up to three consecutive 2-D analysis levels in one launch (mifwt_dwt2_fwd_pyr.hip).
+// which kernel serves a multi-level 2-D analysis call: 0 none, 1 the streaming three-level kernel (mifwt_dwt2_fwd_pyr.hip), 2 the
+// whole-pyramid kernel for small planes (mifwt_dwt2_fwd_small.hip).  Auto mode prefers the small-plane kernel; with
+// MIFWT_OPT_PYRAMID_MODE 1 ("the streaming kernel wherever it can run") the streaming kernel goes first.
+static int pyramid_route(int nlevels, const mifwt_level_desc* const* descs) {
+  const bool pyr = nlevels <= 3 && dwt2_fwd_pyr_supported(nlevels, descs);
+  if (pyr && g_options[MIFWT_OPT_PYRAMID_MODE] == 1) return 1;
+  if (dwt2_fwd_small_supported(nlevels, descs)) return 2;
+  return pyr ? 1 : 0;
+}
+
 int mifwt_dwt2_fwd_pyramid_supported(int nlevels, const mifwt_level_desc* const* descs) {
-  if (!descs || nlevels < 1 || nlevels > 3) return 0;
+  if (!descs || nlevels < 1 || nlevels > 8) return 0;
   for (int l = 0; l < nlevels; ++l)
     if (!descs[l] || validate(descs[l], 0) != MIFWT_OK) return 0;
-  return dwt2_fwd_pyr_supported(nlevels, descs) ? 1 : 0;
+  return pyramid_route(nlevels, descs);
 }
 
 int mifwt_dwt2_fwd_pyramid(int nlevels, const mifwt_level_desc* const* descs, const void* x, void* const* const* details, void* approx,
                            const double* dec_lo, const double* dec_hi, void* stream) {
-  if (!descs || nlevels < 1 || nlevels > 3) return MIFWT_ERR_BADARG;
+  if (!descs || nlevels < 1 || nlevels > 8) return MIFWT_ERR_BADARG;
   for (int l = 0; l < nlevels; ++l) {
     if (!descs[l]) return MIFWT_ERR_BADARG;
     const int rc = validate(descs[l], 0);
@@ -476,8 +486,10 @@ int mifwt_dwt2_fwd_pyramid(int nlevels, const mifwt_level_desc* const* descs, co
     for (int s = 0; s < 3; ++s)
       if (!details[l][s]) return MIFWT_ERR_BADARG;
   }
-  if (!dwt2_fwd_pyr_supported(nlevels, descs)) return MIFWT_ERR_UNSUPPORTED;
+  const int route = pyramid_route(nlevels, descs);
+  if (route == 0) return MIFWT_ERR_UNSUPPORTED;
   if (descs[0]->batch == 0) return MIFWT_OK;
+  if (route == 2) return dwt2_fwd_small(nlevels, descs, x, details, approx, dec_lo, dec_hi, static_cast<hipStream_t>(stream));
   return dwt2_fwd_pyr(nlevels, descs, x, details, approx, dec_lo, dec_hi, static_cast<hipStream_t>(stream));
 }
 // Two consecutive 2-D synthesis levels in one launch (mifwt_idwt2_pair.hip); d2 describes the coarser level, whose

@@ -45,14 +45,18 @@ class OracleLevelEngine:
         return buf1, buf2
 
     def analysis_pyramid(self, x, dec_lo, dec_hi, mode_id, nlevels):
-        """Stand-in for the up-to-three-levels-per-launch call: same return contract as HipLevelEngine.analysis_pyramid — plane 0
-        of every buffer but the last is NOT part of it, so it is poisoned here.  Like the kernel it serves rows of a multiple of
-        four samples only, every mode but periodic, filters up to 8 taps, and may fuse fewer levels than asked for."""
-        if x.dim() != 3 or x.dtype != torch.float32 or x.shape[2] % 4 or mode_id == 3 or len(dec_lo) > 8:
+        """Stand-in for the several-levels-per-launch call: same return contract as HipLevelEngine.analysis_pyramid — plane 0
+        of every buffer but the last is NOT part of it, so it is poisoned here.  Like the library it has two routes: planes of at most
+        48 x 48 samples get up to eight levels in any mode (the small-plane kernel); bigger ones up to three, rows of a multiple of
+        four samples only, every mode but periodic, filters up to 8 taps (the streaming kernel), and may fuse fewer levels than asked."""
+        if x.dim() != 3 or x.dtype != torch.float32:
+            return None
+        small = x.shape[1] * x.shape[2] <= 48 * 48 and len(dec_lo) <= 20
+        if not small and (x.shape[2] % 4 or mode_id == 3 or len(dec_lo) > 8):
             return None
         bufs, cur = [], x
-        for _ in range(min(nlevels, 3)):
-            if min(cur.shape[1:]) < 2 * len(dec_lo):
+        for _ in range(min(nlevels, 8 if small else 3)):
+            if not small and min(cur.shape[1:]) < 2 * len(dec_lo):
                 break
             buf = self.analysis(cur, dec_lo, dec_hi, mode_id)
             bufs.append(buf)

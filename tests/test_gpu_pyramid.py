@@ -161,14 +161,15 @@ def test_pyramid_declines_what_it_cannot_serve():
         got = _engine.ENGINE.analysis_pyramid(torch.randn(*shape, device=dev()), *taps, _engine.MODE_IDS["reflect"], 3)
         assert (got is not None) == served, shape
     _engine.set_option(_engine.OPT_PYRAMID_MODE, 1)
-    x = torch.randn(2, 130, 130, device=dev())  # rows of 130 samples are not a multiple of 4
+    x = torch.randn(2, 650, 650, device=dev())  # rows of 650 samples are not a multiple of 4 (and too big for the small-plane kernel)
     assert _engine.ENGINE.analysis_pyramid(x, *ptwt_amd._fwt.host_taps("db4")[:2], _engine.MODE_IDS["reflect"], 3) is None
-    x = torch.randn(2, 128, 128, device=dev())
+    x = torch.randn(2, 640, 640, device=dev())  # (a plane too big for the small-plane kernel, which does serve periodic)
     assert _engine.ENGINE.analysis_pyramid(x, *ptwt_amd._fwt.host_taps("db4")[:2], _engine.MODE_IDS["periodic"], 3) is None
+    x = torch.randn(2, 128, 128, device=dev())
     assert _engine.ENGINE.analysis_pyramid(x.double(), *ptwt_amd._fwt.host_taps("db4")[:2], _engine.MODE_IDS["reflect"], 3) is None
     # results of unsupported geometries still come from the other kernels
-    got = ptwt_amd.wavedec2(torch.randn(2, 130, 130, device=dev()), "db4", level=2)
-    assert got[0].shape[-1] == 37
+    got = ptwt_amd.wavedec2(torch.randn(2, 650, 650, device=dev()), "db4", level=2)
+    assert got[0].shape[-1] == 167
     del lib
 
 
@@ -210,3 +211,67 @@ def test_pyramid_randomised_against_per_level_kernels():
             assert err < 2e-6, (trial, wavelet, mode, (b, h, w), level, seg, n, err, kids)
         ran += _engine.KID_PYRAMID in kids
     assert ran >= 20, ran
+
+
+# ---- the whole pyramid of a small plane in one launch (mifwt_dwt2_fwd_pyramid's second kernel, kernel id 20) ----------------------
+ALL_MODES = MODES + ["periodic"]
+
+
+@pytest.mark.parametrize("mode", ALL_MODES)
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db4", "sym6", "db10"])
+def test_small_planes_whole_pyramid_vs_oracle(wavelet, mode):
+    """Image patches and small planes: every level in ONE launch, a workgroup per image; all five modes, filters up to 20 taps,
+    odd extents, levels deeper than the filter is long (the boundary map folds repeatedly)."""
+    _engine.set_option(_engine.OPT_PYRAMID_MODE, 3)  # (wherever it can run: auto leaves few big planes to the per-level kernels)
+    g = torch.Generator().manual_seed(41)
+    for shape, level in (((5, 64, 64), 3), ((7, 32, 32), None), ((3, 28, 28), 2), ((2, 128, 128), 4), ((4, 37, 53), 3), ((2, 97, 120), None), ((1, 16, 130), 2)):
+        x = torch.randn(*shape, generator=g, dtype=torch.float32)
+        try:
+            want = O.wavedec2(x.numpy().astype(np.float64), wavelet, mode=mode, level=level)
+        except (RuntimeError, ValueError):
+            continue
+        got, kids = run_traced(lambda: ptwt_amd.wavedec2(x.to(dev()), wavelet, mode=mode, level=level))
+        if len(want) == 1:  # (level None: the plane is shorter than the filter, nothing to do)
+            continue
+        if (shape, wavelet) != ((2, 128, 128), "db10"):  # (its two padded LDS images take 182 KB: served level by level)
+            assert kids == [_engine.KID_SMALL], (wavelet, mode, shape, kids)
+        gf, wf = G.flatten_coeffs(got), G.flatten_coeffs(want)
+        assert [n for n, _ in gf] == [n for n, _ in wf]
+        for (n, a), (_, b) in zip(gf, wf):
+            assert tuple(a.shape) == tuple(np.shape(b)), n
+            assert G.relerr(a.cpu().numpy(), b) < TOL32, (wavelet, mode, shape, level, n)
+
+
+def test_small_planes_views_big_batches_and_deep_levels_of_big_planes():
+    _engine.set_option(_engine.OPT_PYRAMID_MODE, 3)
+    g = torch.Generator(device=dev()).manual_seed(42)
+    # a crop of a wider tensor (row / image strides that are not the extents), channels folded into the batch
+    wide = torch.randn(6, 3, 80, 100, device=dev(), generator=g)
+    view = wide[:, :, 5:69, 10:74]
+    got, kids = run_traced(lambda: ptwt_amd.wavedec2(view, "db3", level=3))
+    assert kids == [_engine.KID_SMALL], kids
+    want = O.wavedec2(view.cpu().numpy().astype(np.float64), "db3", level=3)
+    for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(want)):
+        assert G.relerr(a.cpu().numpy(), b) < TOL32, n
+    # 20 000 patches: agreement with the per-level kernels on every image
+    x = torch.randn(20000, 32, 32, device=dev(), generator=g)
+    got, kids = run_traced(lambda: ptwt_amd.wavedec2(x, "db2", level=3))
+    assert kids == [_engine.KID_SMALL]
+    _engine.set_option(_engine.OPT_PYRAMID_MODE, 2)
+    _engine.set_option(_engine.OPT_PAIR_MODE, 2)
+    try:
+        ref = ptwt_amd.wavedec2(x, "db2", level=3)
+    finally:
+        _engine.set_option(_engine.OPT_PAIR_MODE, 0)
+        _engine.set_option(_engine.OPT_PYRAMID_MODE, 3)
+    for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(ref)):
+        assert float(((a - b).flatten(1).norm(dim=1) / b.flatten(1).norm(dim=1).clamp_min(1e-30)).max()) < 2e-6, n
+    # the deep levels of a bigger pyramid: three levels streamed, the rest in the small-plane launch
+    x = torch.randn(4, 1024, 1024, device=dev(), generator=g)
+    got, kids = run_traced(lambda: ptwt_amd.wavedec2(x, "db4", level=6))
+    assert kids == [_engine.KID_PYRAMID, _engine.KID_SMALL], kids
+    want = O.wavedec2(x[:1].cpu().numpy().astype(np.float64), "db4", level=6)
+    for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(want)):
+        assert G.relerr(a[:1].cpu().numpy(), b) < TOL32, n
+    rec = ptwt_amd.waverec2(got, "db4")
+    assert float((rec - x).abs().max()) < 2e-5

@@ -303,6 +303,46 @@ def test_cabi_multi_level_envelopes_without_gpu():
     assert lib.mifwt_dwt1_inv_tail(0, 8, 4, 100, 3, None, 100, None, None, None, None, 0, None, None, None) == -1
 
 
+def test_cabi_pyramid_routes_without_gpu():
+    """mifwt_dwt2_fwd_pyramid_supported is host arithmetic: which of the two multi-level 2-D analysis kernels serves a call
+    (0 none, 1 the streaming three-level kernel, 2 the small-plane whole-pyramid kernel)."""
+    lib = _engine.load_library()
+
+    def route(mode, flen, batch, shape, nlev, dtype_id=0):
+        descs, cur = [], list(shape)
+        for _ in range(nlev):
+            nxt = [(n + flen - 1) // 2 for n in cur]
+            descs.append(_dense_desc(dtype_id, mode, flen, batch, cur, nxt))
+            cur = nxt
+        refs = (ctypes.POINTER(type(descs[0])) * nlev)(*[ctypes.pointer(d) for d in descs])
+        return lib.mifwt_dwt2_fwd_pyramid_supported(nlev, refs)
+
+    assert route("reflect", 8, 64, (1024, 1024), 3) == 1
+    assert route("reflect", 8, 64, (1024, 1024), 4) == 0            # the streaming kernel fuses three levels
+    assert route("periodic", 8, 64, (1024, 1024), 3) == 0
+    assert route("reflect", 8, 64, (4096, 4096), 3) == 0            # column groups: per level in auto mode
+    assert route("reflect", 4, 4096, (64, 64), 3) == 2
+    assert route("periodic", 4, 4096, (64, 64), 5) == 2             # every mode, deeper than three levels
+    assert route("zero", 20, 100, (61, 47), 8) == 2                 # odd extents, 20 taps, eight levels
+    assert route("reflect", 4, 4096, (64, 64), 9) == 0
+    assert route("reflect", 4, 4096, (64, 64), 3, dtype_id=1) == 0  # f64: per level
+    assert route("reflect", 22, 100, (61, 47), 2) == 0
+    assert route("reflect", 8, 1024, (128, 128), 3) == 2            # fills a CU's LDS alone: only for big batches
+    assert route("reflect", 8, 256, (128, 128), 3) == 0
+    assert route("reflect", 20, 1024, (128, 128), 3) == 0           # 182 KB of LDS images
+    assert route("reflect", 8, 64, (256, 256), 3) == 0
+    _engine.set_option(_engine.OPT_PYRAMID_MODE, 3)
+    try:
+        assert route("reflect", 8, 256, (128, 128), 3) == 2
+    finally:
+        _engine.set_option(_engine.OPT_PYRAMID_MODE, 2)
+    try:
+        assert route("reflect", 4, 4096, (64, 64), 3) == 0 and route("reflect", 8, 64, (1024, 1024), 3) == 0
+    finally:
+        _engine.set_option(_engine.OPT_PYRAMID_MODE, 0)
+    assert lib.mifwt_dwt2_fwd_pyramid(9, None, None, None, None, None, None, None) == -1
+
+
 def test_dwt1_long_plan_and_argument_checks():
     """mifwt_dwt1_fwd_long_levels is host arithmetic (how many levels the chunked 1-D launch fuses); mifwt_dwt1_fwd_long rejects
     bad arguments and level counts it would not fuse before touching the device."""
