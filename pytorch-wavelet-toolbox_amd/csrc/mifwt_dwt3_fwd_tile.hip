@@ -16,6 +16,8 @@
 // ((2T + L - 2) / 2T per axis) is re-read through L2.  Envelope: f32, L in {2, 4, 6}; longer filters use the composed
 // route (the brick would no longer allow two workgroups per CU).
 // Algorithmic traffic: 4*B*D*H*W read + 8*4*B*Do*Ho*Wo written.
+#include <type_traits>
+
 #include "mifwt_stream.h"
 
 namespace mifwt {
@@ -23,6 +25,7 @@ namespace mifwt {
 namespace {
 
 constexpr int kTC3 = 64;
+constexpr int kExtra3 = 2;  // leftover columns the last column tile of the slice-per-wave kernel can take along
 
 template <int L>
 struct Dwt3TileArgs {
@@ -35,6 +38,7 @@ struct Dwt3TileArgs {
   int segd;                     // unused
   FastDiv div_c, div_r, div_d;  // slice-per-wave kernel: by tiles_c, tiles_r, tiles_d
   int k_limit;  // the brick kernels store columns < k_limit; dwt3_fwd_tail_kernel the few beyond (see launch3)
+  int extra;    // slice-per-wave kernel: the last column tile also makes columns k_limit .. k_limit + extra - 1 (<= kExtra3)
   int mode;
   f2 tap[L];  // (dec_lo[m], dec_hi[m])
 };
@@ -242,12 +246,13 @@ __global__ void __launch_bounds__(256, 2) dwt3_fwd_tile_kernel(const Dwt3TileArg
 template <int L, int TD>
 __global__ void __launch_bounds__(256, 2) dwt3_fwd_slice_kernel(const Dwt3TileArgs<L> a) {
   constexpr int TR = 4, HL = L - 2;
-  constexpr int ID = 2 * TD + HL, IR = 2 * TR + HL, IC = 2 * kTC3 + HL;
+  constexpr int ID = 2 * TD + HL, IR = 2 * TR + HL, IC = 2 * (kTC3 + kExtra3) + HL;
   constexpr int XP = (IC + 1) & ~1;  // row pitch (floats)
-  constexpr int SP = IR * XP;        // slice pitch (floats); >= TR * 256 (the slice's (H, W) image)
+  constexpr int SP = IR * XP;        // slice pitch (floats); >= the slice's (H, W) image, TR x (64 + kExtra3) columns x 4
   constexpr int NQ = (IC + 63) / 64;
   constexpr int SPW = (ID + 3) / 4;  // slices per wave
-  static_assert(SP >= TR * 4 * kTC3, "the (H, W) image of a slice must fit into the slice it replaces");
+  constexpr int XIMG = TR * 4 * kTC3;  // where the (H, W) image of the extra columns starts: [TR][kExtra3] x (aa, da, ad, dd)
+  static_assert(SP >= TR * 4 * (kTC3 + kExtra3), "the (H, W) image of a slice must fit into the slice it replaces");
   static_assert((TD * TR) % 4 == 0, "output (slice, row) pairs are dealt to four waves");
   extern __shared__ __attribute__((aligned(16))) float ring[];  // [ID][IR][XP]
 
@@ -267,7 +272,12 @@ __global__ void __launch_bounds__(256, 2) dwt3_fwd_slice_kernel(const Dwt3TileAr
   fold.set(a.mode);
   const uint32_t row_bytes = (uint32_t)a.xs_h * 4u, slice_bytes = (uint32_t)a.xs_d * 4u;
   // column and row maps are the same for every slice of the walk: once per workgroup
-  const int nc_need = 2 * (min(k0 + kTC3, a.k_limit) - k0) + HL;
+  // The last column tile takes the one or two leftover columns of a plane just over a multiple of 64 columns along (129 = 2 * 64 + 1
+  // for 256^3 with db2): their input samples are two more columns of its brick, and a handful of lanes filter them beside
+  // the 64 lane-columns.  (A separate kernel for them read every row tail as its own 64-byte transaction and scattered single floats:
+  // 56 us for 1 / 129 of level 1 of config 3, a fifth of the level.)
+  const int ex = (int)utc == a.tiles_c - 1 ? a.extra : 0;
+  const int nc_need = 2 * (min(k0 + kTC3, a.k_limit) - k0 + ex) + HL;
   const int nr_need = 2 * (min(j0 + TR, a.Ho) - j0) + HL;
   const int c_first = 2 * k0 - HL, r_first = 2 * j0 - HL;
   uint32_t coff[NQ];
@@ -335,7 +345,37 @@ __global__ void __launch_bounds__(256, 2) dwt3_fwd_slice_kernel(const Dwt3TileAr
         pkfma_hi(rowv[i], a.tap[L - 2 - 2 * p], xx);
       }
     }
+    // extra columns: lane = (output row j, extra column e) filters its own L rows along W, then along H
+    f4 ximg = {0.f, 0.f, 0.f, 0.f};
+    const int xj = min(lane >> 1, TR - 1), xe = lane & 1;
+    if (ex) {
+      f2 lo2, hi2;
+#pragma unroll
+      for (int m = 0; m < L; ++m) {
+        const f2* row = reinterpret_cast<const f2*>(&sl[(2 * xj + (L - 1) - m) * XP + 2 * (kTC3 + xe)]);
+        f2 hv;
+#pragma unroll
+        for (int p = 0; p < L / 2; ++p) {
+          const f2 xx = row[p];
+          if (p == 0) {
+            hv = pkmul_lo(a.tap[L - 1], xx);
+          } else {
+            pkfma_lo(hv, a.tap[L - 1 - 2 * p], xx);
+          }
+          pkfma_hi(hv, a.tap[L - 2 - 2 * p], xx);
+        }
+        if (m == 0) {
+          lo2 = pkmul_lo(a.tap[0], hv);
+          hi2 = pkmul_hi(a.tap[0], hv);
+        } else {
+          pkfma_lo(lo2, a.tap[m], hv);
+          pkfma_hi(hi2, a.tap[m], hv);
+        }
+      }
+      ximg = (f4){lo2.x, lo2.y, hi2.x, hi2.y};
+    }
     wave_lds_fence();  // every raw row has been read before the image overwrites the slot
+    if (ex && lane < 2 * TR && xe < ex) *reinterpret_cast<f4*>(&sl[XIMG + (xj * kExtra3 + xe) * 4]) = ximg;
 #pragma unroll
     for (int j = 0; j < TR; ++j) {
       f2 lo2, hi2;
@@ -373,39 +413,47 @@ __global__ void __launch_bounds__(256, 2) dwt3_fwd_slice_kernel(const Dwt3TileAr
   }
   __syncthreads();
 
-  // D pass + stores: (output slice, row) pairs dealt to the waves, lane = output column
+  // D pass + stores: (output slice, row) pairs dealt to the waves, lane = output column (second call: lane = extra column)
+  auto dpass = [&](auto xtag) {
+    constexpr bool kX = decltype(xtag)::value;
+    const int kk = kX ? a.k_limit + (lane & 1) : k;
+    const bool on = kX ? lane < ex : k < a.k_limit;
 #pragma unroll
-  for (int i = 0; i < (TD * TR) / 4; ++i) {
-    const int pr = wave * ((TD * TR) / 4) + i, dz = pr / TR, j = pr - dz * TR;
-    f2 acc[4];  // acc[c] = (depth-low, depth-high) of component c
+    for (int i = 0; i < (TD * TR) / 4; ++i) {
+      const int pr = wave * ((TD * TR) / 4) + i, dz = pr / TR, j = pr - dz * TR;
+      const int ioff = kX ? XIMG + (j * kExtra3 + (lane & 1)) * 4 : (j * kTC3 + lane) * 4;
+      f2 acc[4];  // acc[c] = (depth-low, depth-high) of component c
 #pragma unroll
-    for (int m = 0; m < L; ++m) {
-      const f4 hv = *reinterpret_cast<const f4*>(&ring[(2 * dz + (L - 1) - m) * SP + (j * kTC3 + lane) * 4]);
-      const f2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
-      if (m == 0) {
-        acc[0] = pkmul_lo(a.tap[0], h01);
-        acc[1] = pkmul_hi(a.tap[0], h01);
-        acc[2] = pkmul_lo(a.tap[0], h23);
-        acc[3] = pkmul_hi(a.tap[0], h23);
-      } else {
-        pkfma_lo(acc[0], a.tap[m], h01);
-        pkfma_hi(acc[1], a.tap[m], h01);
-        pkfma_lo(acc[2], a.tap[m], h23);
-        pkfma_hi(acc[3], a.tap[m], h23);
+      for (int m = 0; m < L; ++m) {
+        const f4 hv = *reinterpret_cast<const f4*>(&ring[(2 * dz + (L - 1) - m) * SP + ioff]);
+        const f2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
+        if (m == 0) {
+          acc[0] = pkmul_lo(a.tap[0], h01);
+          acc[1] = pkmul_hi(a.tap[0], h01);
+          acc[2] = pkmul_lo(a.tap[0], h23);
+          acc[3] = pkmul_hi(a.tap[0], h23);
+        } else {
+          pkfma_lo(acc[0], a.tap[m], h01);
+          pkfma_hi(acc[1], a.tap[m], h01);
+          pkfma_lo(acc[2], a.tap[m], h23);
+          pkfma_hi(acc[3], a.tap[m], h23);
+        }
+      }
+      const int zo = z0 + dz, y = j0 + j;
+      if (zo < zb && y < a.Ho && on) {
+        const int off_a = zo * (int)a.os_d[0] + y * (int)a.os_h[0] + kk;  // approximation strides
+        const int off_d = zo * (int)a.os_d[1] + y * (int)a.os_h[1] + kk;  // detail strides (bands 1..7)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int hw = 2 * (c & 1) + (c >> 1);  // component c = (H bit = c & 1, W bit = c >> 1) -> band = 4 depth + 2 H + W
+          obase[hw][hw == 0 ? off_a : off_d] = acc[c].x;
+          obase[4 + hw][off_d] = acc[c].y;
+        }
       }
     }
-    const int zo = z0 + dz, y = j0 + j;
-    if (zo < zb && y < a.Ho && k < a.k_limit) {
-      const int off_a = zo * (int)a.os_d[0] + y * (int)a.os_h[0] + k;  // approximation strides
-      const int off_d = zo * (int)a.os_d[1] + y * (int)a.os_h[1] + k;  // detail strides (bands 1..7)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int hw = 2 * (c & 1) + (c >> 1);  // component c = (H bit = c & 1, W bit = c >> 1) -> band = 4 depth + 2 H + W
-        obase[hw][hw == 0 ? off_a : off_d] = acc[c].x;
-        obase[4 + hw][off_d] = acc[c].y;
-      }
-    }
-  }
+  };
+  dpass(std::false_type{});
+  if (ex) dpass(std::true_type{});
 }
 
 // The last few columns of a plane whose width is just over a multiple of 64 (129 = 2 * 64 + 1 for 256^3 with db2)
@@ -516,7 +564,7 @@ int launch3(const mifwt_level_desc* d, const void* x, void* approx, void* const*
   // TD < 0 selects the slice-per-wave kernel with bricks of -TD output slices
   constexpr bool kRoll = TD < 0;
   constexpr int TDA = TD < 0 ? -TD : TD;
-  constexpr int ID = 2 * TDA + L - 2, IR = 2 * TR + L - 2, XP = (2 * kTC3 + L - 2 + 1) & ~1;
+  constexpr int ID = 2 * TDA + L - 2, IR = 2 * TR + L - 2, XP = (2 * (kTC3 + (kRoll ? kExtra3 : 0)) + L - 2 + 1) & ~1;
   constexpr size_t lds_bytes = (size_t)ID * IR * XP * sizeof(float);
   Dwt3TileArgs<L> a;
   a.x = static_cast<const float*>(x);
@@ -541,8 +589,11 @@ int launch3(const mifwt_level_desc* d, const void* x, void* approx, void* const*
   // columns: whole bricks of 64; a remainder of at most 8 columns behind at least one full brick goes to the direct
   // kernel (a brick column for it would run with <= 8 of 64 lanes)
   const int rem = a.Wo % kTC3;
-  const bool split = a.Wo > kTC3 && rem > 0 && rem <= 8;
-  a.k_limit = split ? a.Wo - rem : a.Wo;
+  const bool behind = a.Wo > kTC3 && rem > 0 && rem <= 8;   // a few columns behind at least one full brick
+  const bool along = behind && kRoll && rem <= kExtra3;     // the last column tile of the slice-per-wave kernel takes them along
+  const bool split = behind && !along;                      // ... or they go to the tail kernel
+  a.extra = along ? rem : 0;
+  a.k_limit = behind ? a.Wo - rem : a.Wo;
   a.tiles_c = (a.k_limit + kTC3 - 1) / kTC3;
   a.tiles_r = (a.Ho + TR - 1) / TR;
   a.segd = 0;

@@ -524,7 +524,8 @@ def test_fused_dwt3_tile_vs_oracle_and_composed(wavelet):
     every axis, tiny volumes) and against the composed route (fused 2-D planes + depth pass, tile mode 2)."""
     rng = np.random.default_rng(len(wavelet) + 5)
     flen = len(O.filter_bank(wavelet)[0])
-    for shape in [(2, 21, 37, 141), (1, 2 * flen + 1, 2 * flen, 2 * flen + 3), (3, 9, 70, 66)]:
+    # (.., 130) / (.., 128): one or two coefficient columns behind a full brick column — the last column tile takes them along
+    for shape in [(2, 21, 37, 141), (1, 2 * flen + 1, 2 * flen, 2 * flen + 3), (3, 9, 70, 66), (2, 12, 21, 130), (1, 11, 20, 128)]:
         assert _engine.kernel_id(3, torch.float32, "reflect", flen, shape[0], shape[1:]) == 9
         x = rng.standard_normal(shape)
         xg = torch.from_numpy(x).float().to(dev())
