@@ -130,12 +130,28 @@ int mifwt_dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, 
  *       where a workgroup streams whole rows; the three detail planes of a level within 1 GiB of one another;
  *   (2) kernel id 20, up to EIGHT levels — the whole pyramid — of planes small enough to live in LDS (the plane and its
  *       horizontally filtered image, both with their boundary extension, <= 160 KB: 128 x 128 up to 12 taps), a workgroup per
- *       image at a time: f32, even L <= 20, every boundary mode, unit innermost strides; in auto mode not for planes that fill a
- *       CU's LDS alone when the batch is smaller than 512 images (MIFWT_OPT_PYRAMID_MODE 3 lifts that).
+ *       image at a time: f32, even L <= 20, every boundary mode, unit innermost strides; in auto mode planes that keep a
+ *       CU's LDS to themselves only from 112 KB of LDS images and 512 images upwards (MIFWT_OPT_PYRAMID_MODE 3 lifts that).
  * mifwt_dwt2_fwd_pyramid_supported says which one serves the call (0 none, 1, 2); MIFWT_ERR_UNSUPPORTED otherwise, nothing launched. */
 int mifwt_dwt2_fwd_pyramid_supported(int nlevels, const mifwt_level_desc* const* descs);
 int mifwt_dwt2_fwd_pyramid(int nlevels, const mifwt_level_desc* const* descs, const void* x, void* const* const* details, void* approx,
                            const double* dec_lo, const double* dec_hi, void* stream);
+
+/* EVERY level of a 2-D reconstruction of a small plane in one launch (kernel id 21) — all trips of waverec2's level loop
+ * (src/ptwt/conv_transform_2.py:222-249) for planes small enough to live in LDS; the running approximation never reaches HBM.
+ * descs[0] describes the COARSEST level, descs[nlevels-1] the finest, each exactly as a mifwt_dwt_inv call would: coef_extent = the
+ * level's coefficient extents, detail_stride its bands' strides; approx_stride counts for descs[0] only (the coarsest approximation),
+ * sig_extent / sig_stride for the last one only (y).  The output of level l is cropped to descs[l+1]->coef_extent (which must not
+ * exceed 2 M - L + 2 per axis): the reference's trims (conv_transform_2.py:240-247) and the separable containers' crop
+ * (separable_conv_transform.py:94-97) are both that.
+ *   approx   the coarsest approximation        details  HOST array of nlevels HOST arrays of 3 device ptrs: bands ad, da, dd
+ * Same sums as nlevels mifwt_dwt_inv calls (summation order differs: agreement to rounding).  f32, even L <= 20, dense coefficient
+ * planes (row stride = width), the finest level's coefficients and its vertically synthesised image <= 160 KB (128 x 128 outputs for 8
+ * taps); in auto mode planes that keep a CU's LDS to themselves only from 128 KB of LDS images and 512 images upwards
+ * (MIFWT_OPT_PYRAMID_MODE 3 lifts that, 2 switches the kernel off).  _supported says 1 / 0; MIFWT_ERR_UNSUPPORTED otherwise, nothing launched. */
+int mifwt_dwt2_inv_pyramid_supported(int nlevels, const mifwt_level_desc* const* descs);
+int mifwt_dwt2_inv_pyramid(int nlevels, const mifwt_level_desc* const* descs, const void* approx, const void* const* const* details, void* y,
+                           const double* rec_lo, const double* rec_hi, void* stream);
 
 /* TWO consecutive 2-D synthesis levels in one launch — two trips of waverec2's level loop
  * (src/ptwt/conv_transform_2.py:222-249); the approximation between them (the coarser level's cropped output) never
@@ -280,7 +296,8 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  *   16     up to three fused 2-D analysis levels per launch (mifwt_dwt2_fwd_pyramid; not returned by mifwt_kernel_id)
  *   17 / 18  several fused 1-D analysis / synthesis levels of long rows, a chunk per workgroup (mifwt_dwt1_fwd_long /
  *          mifwt_dwt1_inv_long; likewise)
- *   20     every level of a 2-D analysis of a small plane in one launch (mifwt_dwt2_fwd_pyramid's second kernel; likewise) */
+ *   20 / 21  every level of a 2-D analysis / synthesis of a small plane in one launch (mifwt_dwt2_fwd_pyramid's second kernel /
+ *          mifwt_dwt2_inv_pyramid; likewise) */
 int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 
 /* Library-wide diagnostic switches (process-global, meant for tests and A/B measurements).

@@ -88,6 +88,10 @@ def load_library() -> ctypes.CDLL:
     vpp = ctypes.POINTER(vp)
     lib.mifwt_dwt2_fwd_pyramid_supported.restype = ctypes.c_int
     lib.mifwt_dwt2_fwd_pyramid_supported.argtypes = [ctypes.c_int, ctypes.POINTER(desc_p)]
+    lib.mifwt_dwt2_inv_pyramid_supported.restype = ctypes.c_int
+    lib.mifwt_dwt2_inv_pyramid_supported.argtypes = [ctypes.c_int, ctypes.POINTER(desc_p)]
+    lib.mifwt_dwt2_inv_pyramid.restype = ctypes.c_int
+    lib.mifwt_dwt2_inv_pyramid.argtypes = [ctypes.c_int, ctypes.POINTER(desc_p), vp, ctypes.POINTER(vpp), vp, dbl_p, dbl_p, vp]
     lib.mifwt_dwt2_fwd_pyramid.restype = ctypes.c_int
     lib.mifwt_dwt2_fwd_pyramid.argtypes = [ctypes.c_int, ctypes.POINTER(desc_p), vp, ctypes.POINTER(vpp), vp, dbl_p, dbl_p, vp]
     lib.mifwt_dwt2_inv_pair_supported.restype = ctypes.c_int
@@ -159,6 +163,7 @@ KID_PYRAMID = 16
 KID_LONG = 17
 KID_INV_LONG = 18
 KID_SMALL = 20
+KID_INV_SMALL = 21
 MAX_PYRAMID_LEVELS = 8  # mifwt_dwt2_fwd_pyramid: three for the streaming kernel, eight for the small-plane kernel
 
 
@@ -609,6 +614,68 @@ class HipLevelEngine:
         lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
         ap, yp = approx2.data_ptr(), y.data_ptr()
         self._run(p, 1, approx2, lambda ws, wsb, stream: lib.mifwt_dwt2_inv_pair(ref2, p.ref, ap, ptrs2, ptrs1, yp, lo, hi, stream))
+        return y
+
+    def synthesis_pyramid(self, approx: torch.Tensor, levels: List[List[torch.Tensor]], rec_lo: Sequence[float],
+                          rec_hi: Sequence[float], out_extent: Sequence[int]):
+        """EVERY level of a 2-D reconstruction of a small plane in one launch (C ABI ``mifwt_dwt2_inv_pyramid``): the coarsest
+        approximation [B, Mh, Mw], ``levels`` = per level (coarsest first) its bands ad, da, dd [B, Mh_l, Mw_l]; the running
+        approximation is cropped to the next level's band extents, the finest level's output to ``out_extent``.
+        Returns y [B, *out_extent], or None when the library does not serve this geometry (the caller then goes level by level)."""
+        _require_gpu(approx)
+        n = len(levels)
+        if approx.dim() != 3 or approx.dtype != torch.float32 or n < 1 or n > MAX_PYRAMID_LEVELS:
+            return None
+        flen = len(rec_lo)
+        batch = approx.shape[0]
+        key = ("invpyr", approx.shape, approx.stride(), tuple((tuple(lv[0].shape[1:]), lv[0].stride(0)) for lv in levels), flen, tuple(out_extent))
+        plan = _plans.get(key)
+        if plan is None:
+            _trim_plans()
+            lib = load_library()
+            descs = []
+            for i, lv in enumerate(levels):
+                d = LevelDesc()
+                d.ndim, d.dtype, d.mode, d.filt_len, d.batch = 2, _DTYPE_IDS[approx.dtype], 0, flen, batch
+                m = lv[0].shape[1:]
+                out = levels[i + 1][0].shape[1:] if i + 1 < n else out_extent
+                for a in range(2):
+                    d.coef_extent[a] = int(m[a])
+                    d.sig_extent[a] = int(out[a])
+                dense = [int(m[0]) * int(m[1]), int(m[1]), 1]
+                ydense = [int(out[0]) * int(out[1]), int(out[1]), 1]
+                for a in range(3):
+                    d.sig_stride[a] = ydense[a]
+                    d.approx_stride[a] = approx.stride(a) if i == 0 else dense[a]
+                    d.detail_stride[a] = dense[a]
+                d.detail_stride[0] = lv[0].stride(0)
+                descs.append(d)
+            refs = (ctypes.POINTER(LevelDesc) * n)(*[ctypes.pointer(d) for d in descs])
+            ok = tuple(approx.shape[1:]) == tuple(levels[0][0].shape[1:]) and bool(lib.mifwt_dwt2_inv_pyramid_supported(n, refs))
+            p = _Plan()
+            p.desc = descs[-1]
+            p.ref = ctypes.byref(descs[-1])
+            p.ws_bytes = 0
+            p.kid = KID_INV_SMALL
+            plan = _plans[key] = (p, descs, refs, ok)
+        p, _descs, refs, ok = plan
+        if not ok:
+            return None
+        # dense band planes (views into a level buffer are: [B, 4, Mh, Mw] -> batch stride 4 planes); anything else is copied
+        dets = []
+        for lv in levels:
+            m = lv[0].shape[1:]
+            want = (lv[0].stride(0), int(m[1]), 1)
+            dets.append([t if t.stride() == want else None for t in lv])
+        if any(t is None for lv in dets for t in lv) or (approx.stride(1), approx.stride(2)) != (int(approx.shape[2]), 1):
+            return None
+        y = torch.empty((batch, *out_extent), dtype=approx.dtype, device=approx.device)
+        rows = [(ctypes.c_void_p * 3)(*[t.data_ptr() for t in lv]) for lv in dets]  # per call: plans are shared between threads
+        det = (ctypes.POINTER(ctypes.c_void_p) * n)(*[ctypes.cast(r, ctypes.POINTER(ctypes.c_void_p)) for r in rows])
+        lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
+        lib = _lib
+        ap, yp = approx.data_ptr(), y.data_ptr()
+        self._run(p, 1, approx, lambda ws, wsb, stream: lib.mifwt_dwt2_inv_pyramid(n, refs, ap, det, yp, lo, hi, stream))
         return y
 
     # ---- adjoints (reverse-mode differentiation; C ABI mifwt_dwt_fwd_adjoint / mifwt_dwt_inv_adjoint) -------------

@@ -492,6 +492,32 @@ int mifwt_dwt2_fwd_pyramid(int nlevels, const mifwt_level_desc* const* descs, co
   if (route == 2) return dwt2_fwd_small(nlevels, descs, x, details, approx, dec_lo, dec_hi, static_cast<hipStream_t>(stream));
   return dwt2_fwd_pyr(nlevels, descs, x, details, approx, dec_lo, dec_hi, static_cast<hipStream_t>(stream));
 }
+// Every level of a 2-D reconstruction of a small plane in one launch (mifwt_dwt2_inv_small.hip); descs[0] = the coarsest level.
+int mifwt_dwt2_inv_pyramid_supported(int nlevels, const mifwt_level_desc* const* descs) {
+  if (!descs || nlevels < 1 || nlevels > 8) return 0;
+  for (int l = 0; l < nlevels; ++l)
+    if (!descs[l] || validate(descs[l], 1) != MIFWT_OK) return 0;
+  return dwt2_inv_small_supported(nlevels, descs) ? 1 : 0;
+}
+
+int mifwt_dwt2_inv_pyramid(int nlevels, const mifwt_level_desc* const* descs, const void* approx, const void* const* const* details, void* y,
+                           const double* rec_lo, const double* rec_hi, void* stream) {
+  if (!descs || nlevels < 1 || nlevels > 8) return MIFWT_ERR_BADARG;
+  for (int l = 0; l < nlevels; ++l) {
+    if (!descs[l]) return MIFWT_ERR_BADARG;
+    const int rc = validate(descs[l], 1);
+    if (rc != MIFWT_OK) return rc;
+  }
+  if (!approx || !details || !y || !rec_lo || !rec_hi) return MIFWT_ERR_BADARG;
+  for (int l = 0; l < nlevels; ++l) {
+    if (!details[l]) return MIFWT_ERR_BADARG;
+    for (int s = 0; s < 3; ++s)
+      if (!details[l][s]) return MIFWT_ERR_BADARG;
+  }
+  if (!dwt2_inv_small_supported(nlevels, descs)) return MIFWT_ERR_UNSUPPORTED;
+  if (descs[0]->batch == 0) return MIFWT_OK;
+  return dwt2_inv_small(nlevels, descs, approx, details, y, rec_lo, rec_hi, static_cast<hipStream_t>(stream));
+}
 // Two consecutive 2-D synthesis levels in one launch (mifwt_idwt2_pair.hip); d2 describes the coarser level, whose
 // (cropped) output is the approximation of d1 and is never materialised.
 int mifwt_dwt2_inv_pair_supported(const mifwt_level_desc* d2, const mifwt_level_desc* d1) {

@@ -117,7 +117,7 @@ int stream_call(int dtype, int kind, const StreamCall& c);  // dispatches on dty
 // Each returns MIFWT_ERR_UNSUPPORTED when the descriptor is outside its envelope (the dispatcher then
 // falls back to the generic passes) and never touches the workspace.
 enum KernelId { kGeneric = 0, kDwt2FwdStream = 1, kDwt2InvStream = 2, kDwt1FwdRow = 3, kDwt1InvRow = 4, kDwt3FwdStream = 5, kDwt3InvStream = 6, kDwt2FwdTile = 7, kDwt2InvTile = 8, kDwt3FwdTile = 9, kDwt3InvTile = 10, kDwt2FwdMfma = 11, kDwt2FwdPair = 12, kDwt2InvPair = 13, kDwt1FwdTail = 14, kDwt1InvTail = 15, kDwt2FwdPyr = 16,
-  kDwt1FwdLong = 17, kDwt1InvLong = 18, kDwt2FwdSmall = 20 };
+  kDwt1FwdLong = 17, kDwt1InvLong = 18, kDwt2FwdSmall = 20, kDwt2InvSmall = 21 };
 
 bool dwt2_fwd_stream_supported(const mifwt_level_desc* d);
 int dwt2_fwd_stream(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
@@ -150,6 +150,10 @@ int dwt2_fwd_roll(const mifwt_level_desc* d1, const mifwt_level_desc* d2, const 
 bool dwt2_fwd_small_supported(int nlevels, const mifwt_level_desc* const* d);
 int dwt2_fwd_small(int nlevels, const mifwt_level_desc* const* d, const void* x, void* const* const* details, void* approx, const double* lo,
                    const double* hi, hipStream_t stream);
+// every level of a 2-D reconstruction of a small plane in one launch (mifwt_dwt2_inv_small.hip); d[0] = the coarsest level
+bool dwt2_inv_small_supported(int nlevels, const mifwt_level_desc* const* d);
+int dwt2_inv_small(int nlevels, const mifwt_level_desc* const* d, const void* approx, const void* const* const* details, void* y,
+                   const double* lo, const double* hi, hipStream_t stream);
 // details[l] = its three detail planes, approx = the last level's approximation
 bool dwt2_fwd_pyr_supported(int nlev, const mifwt_level_desc* const* d);
 int dwt2_fwd_pyr(int nlev, const mifwt_level_desc* const* d, const void* x, void* const* const* details, void* approx,

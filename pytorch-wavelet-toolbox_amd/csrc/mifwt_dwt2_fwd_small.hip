@@ -306,12 +306,14 @@ bool small_plan(int nlev, const mifwt_level_desc* const* d, SmallPlan* p) {
   if ((cap_a + cap_b) * 4 > kSmallLdsBytes) return false;
   p->cap_a = (int)cap_a;
   p->lds = (int)((cap_a + cap_b) * 4);
-  // One resident workgroup per 80 KB of LDS it takes: big planes get the lanes of the workgroups they displace.
-  p->threads = p->lds > 80 * 1024 ? 1024 : p->lds > 40 * 1024 ? 512 : 256;
-  const int per_cu = std::max(1, std::min(160 * 1024 / p->lds, 2048 / p->threads));
-  // A plane that fills a CU's LDS alone runs its phases back to back; that pays only when the CU gets several images and the next
-  // one's load overlaps (256 x 131^2, one image per CU: 20 us against 17 us for a launch per level).
-  if (per_cu == 1 && d0->batch < 2 * 256 && g_options[MIFWT_OPT_PYRAMID_MODE] != 3) return false;
+  // resident workgroups per CU by LDS (4 KB of slack: two workgroups of 80.8 KB did NOT share a CU), threads by what they displace
+  const int slots = 160 * 1024 / (p->lds + 4096);
+  p->threads = slots < 2 ? 1024 : slots < 4 ? 512 : 256;
+  const int per_cu = std::max(1, std::min(slots, 2048 / p->threads));
+  // A plane that keeps a CU's LDS to itself runs its phases back to back; that pays only when the CU gets several images (the next
+  // one's load overlaps: 256 x 131^2, one image per CU, 20 us against 17 us for a launch per level) and the plane is big enough for
+  // the per-image fixed costs (2048 x 96^2: 82-97 us against 59-75; 1024 x 112^2 even; 120^2 and up ahead: tools/small_time.py probe).
+  if (per_cu == 1 && (d0->batch < 2 * 256 || p->lds < 112 * 1024) && g_options[MIFWT_OPT_PYRAMID_MODE] != 3) return false;
   p->grid = (int)std::min<int64_t>(d0->batch, int64_t(256) * per_cu);
   return true;
 }

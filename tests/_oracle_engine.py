@@ -65,6 +65,23 @@ class OracleLevelEngine:
             b[:, 0] = float("nan")
         return bufs or None
 
+    def synthesis_pyramid(self, approx, levels, rec_lo, rec_hi, out_extent):
+        """Stand-in for the whole-reconstruction-in-one-launch call (same contract as HipLevelEngine.synthesis_pyramid): planes of at
+        most 48 x 48 output samples, the running approximation cropped to the next level's band extents."""
+        if approx.dim() != 3 or approx.dtype != torch.float32 or out_extent[0] * out_extent[1] > 48 * 48:
+            return None
+        if tuple(approx.shape) != tuple(levels[0][0].shape):
+            return None
+        flen = len(rec_lo)
+        cur = approx
+        for i, det in enumerate(levels):
+            nxt = levels[i + 1][0].shape[1:] if i + 1 < len(levels) else out_extent
+            full = [2 * m - flen + 2 for m in cur.shape[1:]]
+            if any(n > f or n < 1 for n, f in zip(nxt, full)):
+                return None
+            cur = self.synthesis(cur, det, rec_lo, rec_hi, full)[:, : nxt[0], : nxt[1]]
+        return cur.contiguous()
+
     def synthesis_tail(self, approx, details, rec_lo, rec_hi, out_lens):
         """Stand-in for the fused coarse 1-D synthesis levels (same contract as HipLevelEngine.synthesis_tail)."""
         if approx.dim() != 2 or max(out_lens) > 64 or len(details) < 2:

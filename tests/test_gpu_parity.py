@@ -841,7 +841,7 @@ def test_idwt_pair_kernel_bit_identical_to_per_level(wavelet):
 def test_idwt_pair_fallbacks_and_views():
     g = torch.Generator().manual_seed(22)
     x = torch.randn(2, 300, 260, generator=g, dtype=torch.float32)
-    # f64, long filters and small planes are served level by level
+    # f64 and long filters are served level by level, small planes by the whole-reconstruction launch
     for xx, wavelet in [(x.double(), "db2"), (x, "db8"), (x[..., :60, :60], "db2")]:
         c = ptwt_amd.wavedec2(xx.to(dev()), wavelet, level=2)
         _engine.level_events = []
@@ -850,7 +850,8 @@ def test_idwt_pair_fallbacks_and_views():
             kids = [e[1] for e in _engine.level_events]
         finally:
             _engine.level_events = None
-        assert _engine.KID_INV_PAIR not in kids and len(kids) == 2, (wavelet, kids)
+        assert _engine.KID_INV_PAIR not in kids and (len(kids) == 2 or kids == [_engine.KID_INV_SMALL]), (wavelet, kids)
+        assert (kids == [_engine.KID_INV_SMALL]) == (xx.shape[-1] == 60), (wavelet, kids)
     # coefficients that are views with foreign strides (channels-last style batch) still reconstruct exactly as per level
     c = ptwt_amd.wavedec2(x.to(dev()), "db3", level=2)
     cv = [c[0].transpose(0, 1).contiguous().transpose(0, 1)] + [type(d)(*(t.clone() for t in d)) for d in c[1:]]

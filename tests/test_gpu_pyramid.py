@@ -275,3 +275,83 @@ def test_small_planes_views_big_batches_and_deep_levels_of_big_planes():
         assert G.relerr(a[:1].cpu().numpy(), b) < TOL32, n
     rec = ptwt_amd.waverec2(got, "db4")
     assert float((rec - x).abs().max()) < 2e-5
+
+
+# ---- the whole reconstruction of a small plane in one launch (mifwt_dwt2_inv_pyramid, kernel id 21) -------------------------------
+def _to_dev32(coeffs):
+    """Oracle coefficients (fp64 numpy) -> the same container of f32 device tensors, plus their f32 values back as fp64 numpy."""
+    def conv(t):
+        return torch.from_numpy(np.ascontiguousarray(t)).float().to(dev())
+    out, back = [conv(coeffs[0])], []
+    for c in coeffs[1:]:
+        if isinstance(c, dict):
+            out.append({k: conv(v) for k, v in c.items()})
+        else:
+            out.append(type(c)(*[conv(v) for v in c]) if hasattr(c, "_fields") else tuple(conv(v) for v in c))
+    back.append(out[0].cpu().numpy().astype(np.float64))
+    for c in out[1:]:
+        if isinstance(c, dict):
+            back.append({k: v.cpu().numpy().astype(np.float64) for k, v in c.items()})
+        else:
+            back.append(tuple(v.cpu().numpy().astype(np.float64) for v in c))
+    return tuple(out), tuple(back)
+
+
+@pytest.mark.parametrize("mode", ALL_MODES)
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db4", "sym6", "db10"])
+def test_small_planes_whole_reconstruction_vs_oracle(wavelet, mode):
+    """waverec2 of image patches and small planes: every level in ONE launch; coefficients of every boundary mode (odd extents: the
+    running approximation is trimmed between the levels), filters up to 20 taps."""
+    _engine.set_option(_engine.OPT_PYRAMID_MODE, 3)
+    rng = np.random.default_rng(43)
+    for shape, level in (((5, 64, 64), 3), ((7, 32, 32), None), ((3, 28, 28), 2), ((2, 128, 128), 4), ((4, 37, 53), 3), ((2, 97, 120), None), ((1, 16, 130), 2),
+                         ((3, 50, 50), 1)):
+        x = rng.standard_normal(shape)
+        try:
+            coeffs = O.wavedec2(x, wavelet, mode=mode, level=level)
+        except (RuntimeError, ValueError):
+            continue
+        if len(coeffs) == 1:
+            continue
+        cdev, c32 = _to_dev32(coeffs)
+        want = O.waverec2(c32, wavelet)
+        got, kids = run_traced(lambda: ptwt_amd.waverec2(cdev, wavelet))
+        if (shape, wavelet) not in (((2, 128, 128), "db10"), ((2, 128, 128), "sym6"), ((2, 97, 120), "db10")):  # (more than 160 KB of LDS: level by level)
+            assert kids == [_engine.KID_INV_SMALL], (wavelet, mode, shape, kids)
+        assert tuple(got.shape) == tuple(want.shape)
+        assert G.relerr(got.cpu().numpy(), want) < TOL32, (wavelet, mode, shape, level)
+
+
+def test_small_planes_reconstruction_separable_big_batches_and_round_trip():
+    _engine.set_option(_engine.OPT_PYRAMID_MODE, 3)
+    rng = np.random.default_rng(44)
+    # separable containers: the running approximation is CROPPED to the next level's detail shape
+    x = rng.standard_normal((3, 45, 61))
+    coeffs = O.fswavedec2(x, "db3", mode="symmetric", level=3)
+    cdev, c32 = _to_dev32(coeffs)
+    got, kids = run_traced(lambda: ptwt_amd.fswaverec2(cdev, "db3"))
+    assert kids == [_engine.KID_INV_SMALL], kids
+    want = O.fswaverec2(c32, "db3")
+    assert tuple(got.shape) == tuple(want.shape) and G.relerr(got.cpu().numpy(), want) < TOL32
+    # 20 000 patches: round trip, and agreement with the per-level kernels on every image
+    g = torch.Generator(device=dev()).manual_seed(45)
+    xb = torch.randn(20000, 32, 32, device=dev(), generator=g)
+    cb = ptwt_amd.wavedec2(xb, "db2", level=3)
+    rec, kids = run_traced(lambda: ptwt_amd.waverec2(cb, "db2"))
+    assert kids == [_engine.KID_INV_SMALL], kids
+    assert float((rec - xb).abs().max()) < 1e-5
+    _engine.set_option(_engine.OPT_PYRAMID_MODE, 2)
+    try:
+        ref, kids2 = run_traced(lambda: ptwt_amd.waverec2(cb, "db2"))
+    finally:
+        _engine.set_option(_engine.OPT_PYRAMID_MODE, 3)
+    assert _engine.KID_INV_SMALL not in kids2
+    assert float(((rec - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)).max()) < 2e-6
+    # leading dims and channels folded into the batch; gradients requested: the per-level (differentiable) route instead
+    cs = ptwt_amd.wavedec2(torch.randn(4, 3, 64, 64, device=dev(), generator=g), "db4", level=2)
+    rec, kids = run_traced(lambda: ptwt_amd.waverec2(cs, "db4"))
+    assert kids == [_engine.KID_INV_SMALL] and rec.shape == (4, 3, 64, 64)
+    cs[0].requires_grad_(True)
+    rec2, kids = run_traced(lambda: ptwt_amd.waverec2(cs, "db4"))
+    assert _engine.KID_INV_SMALL not in kids and rec2.requires_grad
+    assert float((rec2 - rec).abs().max()) < 1e-5

@@ -343,6 +343,49 @@ def test_cabi_pyramid_routes_without_gpu():
     assert lib.mifwt_dwt2_fwd_pyramid(9, None, None, None, None, None, None, None) == -1
 
 
+def test_cabi_inverse_pyramid_envelope_without_gpu():
+    """mifwt_dwt2_inv_pyramid_supported is host arithmetic: which reconstructions the small-plane launch serves."""
+    lib = _engine.load_library()
+
+    def ok(flen, batch, out, nlev, dtype_id=0, crop=0, pitch_pad=0):
+        if crop:  # top-down: every level's output is cropped by `crop` before it becomes the next level's approximation
+            exts = [[10, 12]]
+            for _ in range(nlev):
+                exts.append([2 * m - flen + 2 - crop for m in exts[-1]])
+            exts[-1] = [n + crop for n in exts[-1]]  # (the last output is not cropped)
+        else:      # coefficient extents from the finest output upwards, as wavedec2 would have produced them
+            exts = [list(out)]
+            for _ in range(nlev):
+                exts.append([(n + flen - 1) // 2 for n in exts[-1]])
+            exts = exts[::-1]  # coarsest coefficient extents first, the output last
+        descs = []
+        for l in range(nlev):
+            d = _dense_desc(dtype_id, "zero", flen, batch, exts[l + 1], exts[l])
+            d.detail_stride[1] += pitch_pad
+            descs.append(d)
+        refs = (ctypes.POINTER(type(descs[0])) * nlev)(*[ctypes.pointer(d) for d in descs])
+        return lib.mifwt_dwt2_inv_pyramid_supported(nlev, refs)
+
+    assert ok(4, 4096, (64, 64), 3) == 1
+    assert ok(20, 100, (61, 47), 2) == 1 and ok(4, 4096, (64, 64), 8) == 1
+    assert ok(4, 4096, (64, 64), 3, crop=1) == 1              # the separable containers' crop of the running approximation
+    assert ok(4, 4096, (64, 64), 9) == 0
+    assert ok(4, 4096, (64, 64), 3, dtype_id=1) == 0          # f64: per level
+    assert ok(4, 4096, (64, 64), 3, pitch_pad=2) == 0         # padded rows: per level
+    assert ok(8, 1024, (128, 128), 3) == 1 and ok(8, 256, (128, 128), 3) == 0   # fills a CU's LDS alone: only for big batches
+    assert ok(8, 64, (256, 256), 3) == 0
+    _engine.set_option(_engine.OPT_PYRAMID_MODE, 3)
+    try:
+        assert ok(8, 256, (128, 128), 3) == 1
+    finally:
+        _engine.set_option(_engine.OPT_PYRAMID_MODE, 2)
+    try:
+        assert ok(4, 4096, (64, 64), 3) == 0
+    finally:
+        _engine.set_option(_engine.OPT_PYRAMID_MODE, 0)
+    assert lib.mifwt_dwt2_inv_pyramid(9, None, None, None, None, None, None, None) == -1
+
+
 def test_dwt1_long_plan_and_argument_checks():
     """mifwt_dwt1_fwd_long_levels is host arithmetic (how many levels the chunked 1-D launch fuses); mifwt_dwt1_fwd_long rejects
     bad arguments and level counts it would not fuse before touching the device."""
