@@ -355,3 +355,48 @@ def test_small_planes_reconstruction_separable_big_batches_and_round_trip():
     rec2, kids = run_traced(lambda: ptwt_amd.waverec2(cs, "db4"))
     assert _engine.KID_INV_SMALL not in kids and rec2.requires_grad
     assert float((rec2 - rec).abs().max()) < 1e-5
+
+
+def test_small_plane_kernels_randomised_against_per_level_kernels():
+    """Random plane shapes (1 .. 140 samples per axis: planes shorter than the filter, odd extents, one-row planes), batches, filters
+    of 2 .. 20 taps, all five modes, 1 .. 6 levels through the one-launch analysis and synthesis kernels (ids 20 / 21) against the
+    per-level kernels run in fp64 on the same data (those are pinned against the oracle and the goldens): 1e-6 norm-wise per
+    sub-band, or twice the fp32 per-level kernels' own distance from the fp64 result where that is larger (six levels of a 20-tap
+    filter on a plane of five rows accumulate more rounding than that on either route)."""
+    rng = np.random.default_rng(99)
+    g = torch.Generator(device=dev()).manual_seed(99)
+    ran_f = ran_i = 0
+
+    def rel(a, r):
+        return float((a.double() - r).norm() / r.norm().clamp_min(1e-300))
+
+    for trial in range(80):
+        wavelet = ["haar", "db2", "db3", "db4", "sym6", "db8", "db10"][rng.integers(7)]
+        mode = ALL_MODES[rng.integers(len(ALL_MODES))]
+        h, w = (int(rng.integers(1, 141)) for _ in range(2))
+        if trial % 3 == 0:
+            h, w = min(h, 40), min(w, 40)
+        b = int(rng.integers(1, 40))
+        level = int(rng.integers(1, 7))
+        x = torch.randn(b, h, w, device=dev(), generator=g)
+        _engine.set_option(_engine.OPT_PYRAMID_MODE, 2)
+        try:
+            ref = ptwt_amd.wavedec2(x.double(), wavelet, mode=mode, level=level)
+            lvl = ptwt_amd.wavedec2(x, wavelet, mode=mode, level=level)
+            ref_rec = ptwt_amd.waverec2(ref, wavelet)
+            lvl_rec = ptwt_amd.waverec2(lvl, wavelet)
+            ref_rec32 = ptwt_amd.waverec2([lvl[0].double()] + [type(d)(*(t.double() for t in d)) for d in lvl[1:]], wavelet)
+        except (RuntimeError, ValueError):
+            continue  # the reference's own refusals (reflect pad >= extent, ...)
+        finally:
+            _engine.set_option(_engine.OPT_PYRAMID_MODE, 3)
+        got, kids = run_traced(lambda: ptwt_amd.wavedec2(x, wavelet, mode=mode, level=level))
+        ran_f += kids == [_engine.KID_SMALL]
+        for (n, a), (_, r), (_, l32) in zip(G.flatten_coeffs(got), G.flatten_coeffs(ref), G.flatten_coeffs(lvl)):
+            assert a.shape == r.shape, (trial, wavelet, mode, (b, h, w), level, n)
+            assert rel(a, r) < max(1e-6, 2 * rel(l32, r)), (trial, wavelet, mode, (b, h, w), level, n, kids, rel(a, r), rel(l32, r))
+        rec, kids = run_traced(lambda: ptwt_amd.waverec2(lvl, wavelet))  # the same f32 coefficients through both synthesis routes
+        ran_i += kids == [_engine.KID_INV_SMALL]
+        assert rec.shape == ref_rec.shape == lvl_rec.shape
+        assert rel(rec, ref_rec32) < max(1e-6, 2 * rel(lvl_rec, ref_rec32)), (trial, wavelet, mode, (b, h, w), level, kids)
+    assert ran_f >= 40 and ran_i >= 40, (ran_f, ran_i)
