@@ -306,10 +306,13 @@ bool small_plan(int nlev, const mifwt_level_desc* const* d, SmallPlan* p) {
   if ((cap_a + cap_b) * 4 > kSmallLdsBytes) return false;
   p->cap_a = (int)cap_a;
   p->lds = (int)((cap_a + cap_b) * 4);
-  // resident workgroups per CU by LDS (4 KB of slack: two workgroups of 80.8 KB did NOT share a CU), threads by what they displace
+  // resident workgroups per CU by LDS (4 KB of slack: two workgroups of 80.8 KB did NOT share a CU); 256 threads wherever three or
+  // more images share a CU (4096 x 64^2 db4: 79 us against 97 with 512), 512 for two (2048 x 88^2: 65 against 74 with 256), 1024 for one
   const int slots = 160 * 1024 / (p->lds + 4096);
-  p->threads = slots < 2 ? 1024 : slots < 4 ? 512 : 256;
-  const int per_cu = std::max(1, std::min(slots, 2048 / p->threads));
+  p->threads = slots < 2 ? 1024 : slots < 3 ? 512 : 256;
+  // (the kernel takes up to 128 VGPRs: 16 waves per CU.  A grid of three 512-thread workgroups per CU ran as two and then one:
+  // 4096 x 64^2 db4 108 us against 101 us level by level)
+  const int per_cu = std::max(1, std::min(slots, 1024 / p->threads));
   // A plane that keeps a CU's LDS to itself runs its phases back to back; that pays only when the CU gets several images (the next
   // one's load overlaps: 256 x 131^2, one image per CU, 20 us against 17 us for a launch per level) and the plane is big enough for
   // the per-image fixed costs (2048 x 96^2: 82-97 us against 59-75; 1024 x 112^2 even; 120^2 and up ahead: tools/small_time.py probe).

@@ -28,7 +28,7 @@ namespace {
 constexpr int kISMaxThreads = 1024;
 constexpr int kISMaxLevels = 8;
 constexpr int kISLdsBytes = 160 * 1024;
-constexpr int kISDepth = 5;  // samples of one band plane a lane holds in registers (plane <= kISDepth x threads)
+constexpr int kISDepth = 8;  // samples of one band plane a lane holds in registers (plane <= kISDepth x threads)
 
 template <int L>
 struct ISmallArgs {
@@ -239,12 +239,15 @@ bool ismall_plan(int nlev, const mifwt_level_desc* const* d, ISmallPlan* p) {
   if ((cap_c + cap_x) * 4 > kISLdsBytes) return false;
   p->cap_c = (int)cap_c;
   p->lds = (int)((cap_c + cap_x) * 4);
-  // resident workgroups per CU by LDS (4 KB of slack: two workgroups of 80.8 KB did NOT share a CU), threads by what they displace
+  // resident workgroups per CU by LDS (4 KB of slack: two workgroups of 80.8 KB did NOT share a CU); 256 threads wherever three or
+  // more images share a CU (4096 x 64^2 db4: 79 us against 97 with 512), 512 for two (2048 x 88^2: 65 against 74 with 256), 1024 for one
   const int slots = 160 * 1024 / (p->lds + 4096);
-  p->threads = slots < 2 ? 1024 : slots < 4 ? 512 : 256;
+  p->threads = slots < 2 ? 1024 : slots < 3 ? 512 : 256;
   while (p->threads < kISMaxThreads && plane_max > (int64_t)kISDepth * p->threads) p->threads *= 2;
   if (plane_max > (int64_t)kISDepth * p->threads) return false;
-  const int per_cu = std::max(1, std::min(slots, 2048 / p->threads));
+  // (the kernel takes up to 128 VGPRs: 16 waves per CU.  A grid of three 512-thread workgroups per CU ran as two and then one:
+  // 4096 x 64^2 db4 108 us against 101 us level by level)
+  const int per_cu = std::max(1, std::min(slots, 1024 / p->threads));
   // (as in the analysis kernel: a plane that keeps a CU's LDS to itself pays only when the CU gets several images and the plane is big —
   // 1024 x 128^2 db4 55 us against 63 level by level, 1024 x 120^2 and 112^2 1-3 us behind, 2048 x 96^2 sym4 77 against 55)
   if (per_cu == 1 && (d0->batch < 2 * 256 || p->lds < 128 * 1024) && g_options[MIFWT_OPT_PYRAMID_MODE] != 3) return false;
