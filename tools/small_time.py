@@ -14,7 +14,7 @@ def t(fn, n=20):
         e1.record(); torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / n * 1e3)
     return sorted(res)[1]
-SHAPES = [((4096, 64, 64), 'db2', 3), ((1024, 128, 128), 'db4', 3), ((16384, 32, 32), 'db2', 2), ((2048, 96, 96), 'sym4', 3), ((8192, 48, 48), 'haar', 4), ((512, 128, 128), 'db2', 5)]
+SHAPES = [((4096, 64, 64), 'db2', 3), ((1024, 128, 128), 'db4', 3), ((16384, 32, 32), 'db2', 2), ((2048, 96, 96), 'sym4', 3), ((8192, 48, 48), 'haar', 4), ((512, 128, 128), 'db2', 5), ((32768, 16, 16), 'haar', 2), ((8192, 40, 40), 'db4', 3), ((4096, 64, 64), 'db4', 3), ((4096, 72, 72), 'db2', 3), ((2048, 88, 88), 'db4', 3)]
 if len(sys.argv) > 1 and sys.argv[1] == 'probe':  # the one-workgroup-per-CU boundary
     SHAPES = [((2048, 80, 80), 'sym4', 3), ((2048, 88, 88), 'db4', 3), ((2048, 96, 96), 'db2', 3), ((1024, 112, 112), 'db4', 3), ((1024, 120, 120), 'db2', 3)]
     _engine.set_option(_engine.OPT_PYRAMID_MODE, 3)
