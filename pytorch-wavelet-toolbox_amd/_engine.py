@@ -361,14 +361,15 @@ class HipLevelEngine:
             b = torch.empty(pl.alloc_shape, dtype=x.dtype, device=x.device)
             bufs.append(b if pl.view_last is None else b[..., : pl.view_last])
         # the band-pointer arrays are per thread: cached plans are shared between threads, and ctypes drops the GIL in the call
-        slot = _tls.__dict__.setdefault("pyr", {}).get(key)
+        skey = (key, n_ok)  # (a routing option may change how many levels the same geometry fuses)
+        slot = _tls.__dict__.setdefault("pyr", {}).get(skey)
         if slot is None:
             rows = [(ctypes.c_void_p * 3)() for _ in plans]
             det = (ctypes.POINTER(ctypes.c_void_p) * n_ok)(*[ctypes.cast(r, ctypes.POINTER(ctypes.c_void_p)) for r in rows])
-            slot = _tls.pyr[key] = (rows, det)
+            slot = _tls.pyr[skey] = (rows, det)
             if len(_tls.pyr) > 256:
                 _tls.pyr.clear()
-                _tls.pyr[key] = slot
+                _tls.pyr[skey] = slot
         rows, det = slot
         for r, b, pl in zip(rows, bufs, plans):
             base, pb = b.data_ptr(), pl.plane_bytes

@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(kSmallMaxThreads) dwt2_fwd_small_kernel(const 
           uint32_t j;
           const int r = (int)dv.divmod(it, j);
           const int s = (int)j < P ? (int)j - P : W + (int)j - P;
-          const int src = ext_index(s, W, a.mode);
+          const int src = ext_index_near(s, W, a.mode);  // (no division while the pad is shorter than the plane)
           float* row = A + r * PA + O;
           row[s] = src >= 0 ? row[src] : 0.f;
         }
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(kSmallMaxThreads) dwt2_fwd_small_kernel(const 
           uint32_t c;
           const int j = (int)dv.divmod(it, c);
           const int s = j < P ? j - P : H + j - P;
-          const int src = ext_index(s, H, a.mode);
+          const int src = ext_index_near(s, H, a.mode);
           B[(P + s) * PB + c] = src >= 0 ? B[(P + src) * PB + c] : 0.f;
         }
       }
