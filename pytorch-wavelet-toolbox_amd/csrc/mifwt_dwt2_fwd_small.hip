@@ -6,9 +6,9 @@
 // image: 1024 x 128^2 db4 level 3 took 81 us in three launches for 134 MB of compulsory traffic.  Here a workgroup (256-1024
 // threads by its LDS share) owns one image at a time: it parks the plane in LDS WITH its boundary extension materialised and
 // runs every level on it, so no inner loop ever looks at the boundary:
-//   image A [H][PA]       the plane; sample s of a row sits in column O + s, s in [-(L-2), 2 Wo), the pads filled through the
-//                         boundary index map (one map evaluation per pad SAMPLE; a first version evaluated it per tap of every
-//                         edge output and spent 40 % of its time there)
+//   image A [H][PA]       the plane; sample s of a row sits in column O + s, s in [-(L-2), 2 Wo), the pads copied from the samples the
+//                         boundary index map names (tables of (destination, source) offsets per level, built once per workgroup;
+//                         a first version evaluated the map per tap of every edge output and spent 40 % of its time there)
 //   horizontal pass       (lo, hi)[r][k] = sum_m (h_lo, h_hi)[m] A[r][2k + 1 - m]  ->  image B row L-2 + r, (lo, hi) of a column side by side;
 //                         a lane owns one (r, k): L/2 aligned 8-byte LDS reads, L packed FMAs
 //   image B [2 Ho + L-2][2 Wo]   pad ROWS filled by copying the row the map names
@@ -46,7 +46,7 @@ struct SmallArgs {
   int H[kSmallMaxLevels + 1], W[kSmallMaxLevels + 1];
   int PA[kSmallMaxLevels];                            // row pitch of image A at each level (multiple of 4)
   FastDiv div_park;                                   // by W[0] / 4 (vec) or W[0]
-  FastDiv div_wo[kSmallMaxLevels], div_pc[kSmallMaxLevels], div_pb[kSmallMaxLevels];  // by Wo, by the pad columns of a row of A, by 2 Wo
+  FastDiv div_wo[kSmallMaxLevels], div_pc[kSmallMaxLevels];  // by Wo, by the pad samples of a row of A
   int nlevels, mode, cap_a, vec, dbg;  // cap_a: floats of LDS image A (image B follows)
   int64_t batch;
   f2 tap[L];                           // (dec_lo[m], dec_hi[m])
@@ -58,7 +58,9 @@ static_assert(kParkDepth == 8, "MIFWT_PARK8");
 template <int L>
 __global__ void __launch_bounds__(kSmallMaxThreads) dwt2_fwd_small_kernel(const SmallArgs<L> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char small_lds[];
-  float* A = reinterpret_cast<float*>(small_lds);
+  constexpr int TP = 2 * (L - 2) + 2;  // entries of one pad table (a row of image A has at most 2 (L - 2) + 1 pad samples)
+  int2* const tbl = reinterpret_cast<int2*>(small_lds);  // [level][pad columns of A | pad rows of B][TP] x (destination, source) byte offsets
+  float* A = reinterpret_cast<float*>(small_lds + a.nlevels * 2 * TP * (int)sizeof(int2));
   float* B = A + a.cap_a;
   const uint32_t tid = threadIdx.x, nt = blockDim.x;
   constexpr int P = L - 2;          // samples a window reaches past either end of a row (one more at the far end of odd rows)
@@ -77,6 +79,28 @@ __global__ void __launch_bounds__(kSmallMaxThreads) dwt2_fwd_small_kernel(const 
   const uint32_t pk_g = pk_r * (uint32_t)a.xs_h + 4 * pk_c, pk_l = (pk_r * PA0 + O + 4 * pk_c) * 4;  // floats in HBM, bytes in LDS
   const uint32_t pk_g0 = pk_dr * (uint32_t)a.xs_h + 4 * pk_dc, pk_g1 = pk_g0 + (uint32_t)a.xs_h - W0;
   const uint32_t pk_l0 = (pk_dr * PA0 + 4 * pk_dc) * 4, pk_l1 = pk_l0 + (PA0 - W0) * 4;
+  // The boundary extension of every level, once per workgroup (the geometry is the same for every image): where each pad sample of
+  // a row of image A / each pad row of image B goes and which sample / row the boundary map names for it (-1: zero).  The fills
+  // then cost two LDS accesses and a table entry per pad sample; with the map evaluated per sample they took as long as both filter
+  // passes together (4096 x 64^2 db4: 30 of 80 us).
+  for (int l = 0; l < a.nlevels; ++l) {
+    const int H = a.H[l], W = a.W[l], Ho = a.H[l + 1], Wo = a.W[l + 1];
+    const int npc = (L - 2) + 2 * Wo - W, npr = (L - 2) + 2 * Ho - H, PBb = 2 * Wo * 4;
+    constexpr int P = L - 2, O = (P + 3) & ~3;
+    int2* ta = tbl + l * 2 * TP;
+    int2* tb = ta + TP;
+    for (int j = tid; j < npc; j += nt) {
+      const int s_ = j < P ? j - P : W + j - P;
+      const int src = ext_index(s_, W, a.mode);
+      ta[j] = make_int2((O + s_) * 4, src >= 0 ? (O + src) * 4 : -1);
+    }
+    for (int j = tid; j < npr; j += nt) {
+      const int s_ = j < P ? j - P : H + j - P;
+      const int src = ext_index(s_, H, a.mode);
+      tb[j] = make_int2((P + s_) * PBb, src >= 0 ? (P + src) * PBb : -1);
+    }
+  }
+  __syncthreads();
 #define MIFWT_PARK_DECL(u) float4 q##u = {0.f, 0.f, 0.f, 0.f};
   MIFWT_PARK8(MIFWT_PARK_DECL)
 #undef MIFWT_PARK_DECL
@@ -140,15 +164,23 @@ __global__ void __launch_bounds__(kSmallMaxThreads) dwt2_fwd_small_kernel(const 
       const bool last = l == a.nlevels - 1;
       // ---- pad columns of image A: item = (row r, pad sample j) ---------------------------------------------------------------
       {
-        const int npc = P + 2 * Wo - W;
-        const FastDiv dv = a.div_pc[l];
-        for (uint32_t it = tid; it < (uint32_t)(H * npc); it += nt) {
-          uint32_t j;
-          const int r = (int)dv.divmod(it, j);
-          const int s = (int)j < P ? (int)j - P : W + (int)j - P;
-          const int src = ext_index_near(s, W, a.mode);  // (no division while the pad is shorter than the plane)
-          float* row = A + r * PA + O;
-          row[s] = src >= 0 ? row[src] : 0.f;
+        const uint32_t npc = (uint32_t)(P + 2 * Wo - W);
+        const int2* ta = tbl + l * 2 * TP;
+        uint32_t j;
+        const uint32_t r0 = a.div_pc[l].divmod(tid, j);
+        uint32_t dj;
+        const uint32_t dr = a.div_pc[l].divmod(nt, dj);
+        uint32_t rowb = r0 * PA * 4;
+        const uint32_t rowb0 = dr * PA * 4, rowb1 = rowb0 + PA * 4;
+        char* Ab = reinterpret_cast<char*>(A);
+        for (uint32_t it = tid; it < (uint32_t)((a.dbg & 32) ? 0 : H * (int)npc); it += nt) {
+          const int2 e = ta[j];
+          const float v = e.y >= 0 ? *reinterpret_cast<const float*>(Ab + rowb + e.y) : 0.f;
+          *reinterpret_cast<float*>(Ab + rowb + e.x) = v;
+          j += dj;
+          const bool carry = j >= npc;
+          j -= carry ? npc : 0u;
+          rowb += carry ? rowb1 : rowb0;
         }
       }
       __syncthreads();
@@ -187,16 +219,23 @@ __global__ void __launch_bounds__(kSmallMaxThreads) dwt2_fwd_small_kernel(const 
         }
       }
       __syncthreads();
-      // ---- pad rows of image B: item = (pad row j, column c) ------------------------------------------------------------------
+      // ---- pad rows of image B: item = (pad row j, column c): the (lo, hi) pair of a column at a time ---------------------------
       {
-        const int npr = P + 2 * Ho - H;
-        const FastDiv dv = a.div_pb[l];
-        for (uint32_t it = tid; it < (uint32_t)(npr * PB); it += nt) {
-          uint32_t c;
-          const int j = (int)dv.divmod(it, c);
-          const int s = j < P ? j - P : H + j - P;
-          const int src = ext_index_near(s, H, a.mode);
-          B[(P + s) * PB + c] = src >= 0 ? B[(P + src) * PB + c] : 0.f;
+        const uint32_t npr = (uint32_t)(P + 2 * Ho - H);
+        const int2* tb = tbl + l * 2 * TP + TP;
+        uint32_t c;
+        uint32_t j = a.div_wo[l].divmod(tid, c);
+        uint32_t dc;
+        const uint32_t dj = a.div_wo[l].divmod(nt, dc);
+        char* Bb = reinterpret_cast<char*>(B);
+        for (uint32_t it = tid; it < (uint32_t)((a.dbg & 32) ? 0 : (int)npr * Wo); it += nt) {
+          const int2 e = tb[j];
+          const f2 v = e.y >= 0 ? *reinterpret_cast<const f2*>(Bb + e.y + c * 8) : (f2){0.f, 0.f};
+          *reinterpret_cast<f2*>(Bb + e.x + c * 8) = v;
+          c += dc;
+          const bool carry = c >= (uint32_t)Wo;
+          c -= carry ? (uint32_t)Wo : 0u;
+          j += dj + (carry ? 1u : 0u);
         }
       }
       __syncthreads();
@@ -303,9 +342,10 @@ bool small_plan(int nlev, const mifwt_level_desc* const* d, SmallPlan* p) {
     cap_b = std::max(cap_b, (L - 2 + 2 * Ho) * 2 * Wo);
   }
   cap_a = (cap_a + 3) & ~int64_t(3);
-  if ((cap_a + cap_b) * 4 > kSmallLdsBytes) return false;
+  const int64_t tbl_bytes = (int64_t)nlev * 2 * (2 * (L - 2) + 2) * 8;  // the pad tables (multiple of 16 bytes)
+  if ((cap_a + cap_b) * 4 + tbl_bytes > kSmallLdsBytes) return false;
   p->cap_a = (int)cap_a;
-  p->lds = (int)((cap_a + cap_b) * 4);
+  p->lds = (int)((cap_a + cap_b) * 4 + tbl_bytes);
   // Threads: about four trips of a lane through a filter pass of the finest level (a quarter of its coefficient plane, rounded to
   // a power of two: 64 for 32^2, 128 for 48^2, 256 for 64^2, 512 for 88^2, 1024 for 128^2) — measured with forced counts: more
   // threads idle at the barriers (16384 x 32^2 db2: 59 us with 64 threads against 103 with 256), fewer leave the passes too long
@@ -345,7 +385,6 @@ int launch_small(int nlev, const mifwt_level_desc* const* d, const SmallPlan& p,
     a.PA[l] = (small_origin(L) + 2 * a.W[l + 1] + 3) & ~3;
     a.div_wo[l] = make_fastdiv((uint32_t)a.W[l + 1]);
     a.div_pc[l] = make_fastdiv((uint32_t)std::max(1, L - 2 + 2 * a.W[l + 1] - a.W[l]));
-    a.div_pb[l] = make_fastdiv((uint32_t)(2 * a.W[l + 1]));
   }
   a.approx = static_cast<float*>(approx);
   a.as_b = d[nlev - 1]->approx_stride[0];
