@@ -349,15 +349,15 @@ bool small_plan(int nlev, const mifwt_level_desc* const* d, SmallPlan* p) {
   // Threads: about four trips of a lane through a filter pass of the finest level (a quarter of its coefficient plane, rounded to
   // a power of two: 64 for 32^2, 128 for 48^2, 256 for 64^2, 512 for 88^2, 1024 for 128^2) — measured with forced counts: more
   // threads idle at the barriers (16384 x 32^2 db2: 59 us with 64 threads against 103 with 256), fewer leave the passes too long
-  // (88^2 db4: 65 us with 512 against 74 with 256).  Resident workgroups per CU: by LDS (2 KB + 1/32 of slack: two workgroups of
-  // 80.8 KB did NOT share a CU) and by waves (the kernels take up to 128 VGPRs: 16 waves per CU; a grid of three 512-thread
+  // (88^2 db4: 65 us with 512 against 74 with 256).  Resident workgroups per CU: by LDS (1 KB + 1/64 of slack: two workgroups of
+  // 79.4 KB share a CU, two of 80.8 KB did not) and by waves (the kernels take up to 128 VGPRs: 16 waves per CU; a grid of three 512-thread
   // workgroups per CU ran as two and then one).
   {
     const double quarter = (double)(d0->coef_extent[0] * d0->coef_extent[1]) / 4.0;
     p->threads = 64;
     while (p->threads < 1024 && quarter >= p->threads * 1.4142) p->threads *= 2;
   }
-  const int slots = 160 * 1024 / (p->lds + 2048 + p->lds / 32);
+  const int slots = 160 * 1024 / (p->lds + 1024 + p->lds / 64);
   const int per_cu = std::max(1, std::min(slots, 1024 / p->threads));
   // A plane that keeps a CU's LDS to itself runs its phases back to back; that pays only when the CU gets several images (the next
   // one's load overlaps: 256 x 131^2, one image per CU, 20 us against 17 us for a launch per level) and the plane is big enough for

@@ -21,7 +21,9 @@ if len(sys.argv) > 1 and sys.argv[1] == 'probe':  # the one-workgroup-per-CU bou
 if len(sys.argv) > 6 and sys.argv[1] == 'one':  # one b h w wavelet level [...]
     a_ = sys.argv[2:]
     SHAPES = [((int(a_[i]), int(a_[i + 1]), int(a_[i + 2])), a_[i + 3], int(a_[i + 4])) for i in range(0, len(a_) - 4, 5)]
-MODE = _engine.get_option(_engine.OPT_PYRAMID_MODE) if hasattr(_engine, 'get_option') else (3 if len(sys.argv) > 1 and sys.argv[1] == 'probe' else 0)
+if len(sys.argv) > 1 and sys.argv[1] == 'one':
+    _engine.set_option(_engine.OPT_PYRAMID_MODE, 3)
+MODE = _engine.get_option(_engine.OPT_PYRAMID_MODE) if hasattr(_engine, 'get_option') else (3 if len(sys.argv) > 1 and sys.argv[1] in ('probe', 'one') else 0)
 for shape, wav, lev in SHAPES:
     xs = [torch.randn(*shape, device='cuda') for _ in range(3)]
     cs = [ptwt_amd.wavedec2(x, wav, level=lev) for x in xs]
