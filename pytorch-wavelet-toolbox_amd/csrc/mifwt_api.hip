@@ -219,6 +219,7 @@ size_t route_ws(const mifwt_level_desc* d, int direction, int kid) {
     case kDwt2FwdMfma:
     case kDwt2InvTile:
     case kDwt3FwdTile:
+    case kDwt3InvTile:
     case kDwt2InvStream: return 0;
     case kDwt3FwdStream:
     case kDwt3InvStream: return plane3_ws_bytes(d, direction);
@@ -243,6 +244,7 @@ int pick_kernel(const mifwt_level_desc* d, int direction) {
       const int k2 = dwt2_inv_choice(d);
       if (k2 >= 0) return k2;
     }
+    if (g_options[MIFWT_OPT_TILE_MODE] != 2 && dwt3_inv_tile_supported(d)) return kDwt3InvTile;
     if (plane3_route_ok(d, 1)) return kDwt3InvStream;
     if (rows_route_ok(d, 1)) return kDwt1InvRow;
   }
@@ -365,6 +367,7 @@ static int run_inv(const mifwt_level_desc* desc, const void* approx, const void*
   switch (kid) {
     case kDwt2InvStream: return dwt2_inv_stream(desc, approx, details, y, rec_lo, rec_hi, st);
     case kDwt2InvTile: return dwt2_inv_tile(desc, approx, details, y, rec_lo, rec_hi, st);
+    case kDwt3InvTile: return dwt3_inv_tile(desc, approx, details, y, rec_lo, rec_hi, st);
     case kDwt3InvStream: return plane3_inv(desc, approx, details, y, rec_lo, rec_hi, workspace, st);
     case kDwt1InvRow: return rows_inv(desc, approx, details, y, rec_lo, rec_hi, workspace, st);
     default: break;

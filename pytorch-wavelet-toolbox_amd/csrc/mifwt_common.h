@@ -211,6 +211,10 @@ int dwt2_inv_stream(const mifwt_level_desc* d, const void* approx, const void* c
 bool dwt3_fwd_tile_supported(const mifwt_level_desc* d);
 int dwt3_fwd_tile(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
                   const double* dec_lo, const double* dec_hi, hipStream_t stream);
+// fully fused LDS-brick 3-D synthesis level (mifwt_dwt3_inv_tile.hip): f32, L in {2, 4, 6}
+bool dwt3_inv_tile_supported(const mifwt_level_desc* d);
+int dwt3_inv_tile(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y, const double* lo,
+                  const double* hi, hipStream_t stream);
 
 // ---- composed routes (mifwt_compose.hip) --------------------------------------------------------------------
 bool plane3_route_ok(const mifwt_level_desc* d, int direction);  // ndim 3 f32: fused 2-D planes + depth pass

@@ -322,7 +322,7 @@ def test_stream_routes_selected():
     assert kid(1, torch.float32, "reflect", 8, 4, (1000,)) == 3 and kid(1, torch.float32, "zero", 8, 4, (1000,), direction=1) == 4
     assert kid(1, torch.float64, "reflect", 2, 1, (4096,)) == 3
     assert kid(3, torch.float32, "zero", 4, 8, (256, 256, 256)) == 9  # fully fused LDS-brick 3-D analysis
-    assert kid(3, torch.float32, "zero", 8, 8, (256, 256, 256)) == 5 and kid(3, torch.float32, "zero", 4, 8, (256, 256, 256), direction=1) == 6
+    assert kid(3, torch.float32, "zero", 8, 8, (256, 256, 256)) == 5 and kid(3, torch.float32, "zero", 4, 8, (256, 256, 256), direction=1) == 10 and kid(3, torch.float32, "zero", 8, 8, (256, 256, 256), direction=1) == 6
     assert kid(3, torch.float64, "zero", 4, 2, (33, 34, 35)) == 3  # f64: inner pass + two outer passes
     assert kid(2, torch.float64, "reflect", 8, 2, (64, 64)) == 7 and kid(2, torch.float64, "reflect", 8, 2, (64, 64), direction=1) == 8  # f64 tiles
     assert kid(2, torch.float64, "reflect", 24, 2, (64, 64)) == 3  # f64, long filter: inner + outer pass
@@ -555,6 +555,50 @@ def test_fused_dwt3_tile_vs_oracle_and_composed(wavelet):
                 _engine.set_option(5, 0)
             for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(comp)):
                 assert G.relerr(to_np(a), to_np(b)) < 5e-7, (wavelet, mode, shape, n)
+
+
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3"])
+def test_fused_idwt3_tile_vs_oracle_and_composed(wavelet):
+    """The fully fused LDS-brick 3-D synthesis kernel (kernel id 10) against the fp64 oracle (coefficients of every boundary mode:
+    odd extents, i.e. trimmed outputs; ragged bricks on every axis; tiny volumes; more than one column tile) and against the composed
+    route (fused 2-D planes + depth pass, tile mode 2) on the same f32 coefficients."""
+    rng = np.random.default_rng(len(wavelet) + 11)
+    flen = len(O.filter_bank(wavelet)[0])
+    for shape in [(2, 21, 37, 141), (1, 2 * flen + 1, 2 * flen, 2 * flen + 3), (3, 9, 70, 66), (1, 12, 21, 260), (2, 40, 33, 128)]:
+        x = rng.standard_normal(shape)
+        for mode in MODES:
+            level = 2 if min(shape[1:]) >= 3 * flen else 1
+            try:
+                coeffs = O.wavedec3(x, wavelet, mode=mode, level=level)
+            except RuntimeError:
+                continue
+            cdev = [torch.from_numpy(coeffs[0]).float().to(dev())] + [{k: torch.from_numpy(v).float().to(dev()) for k, v in c.items()} for c in coeffs[1:]]
+            c32 = [cdev[0].cpu().double().numpy()] + [{k: v.cpu().double().numpy() for k, v in c.items()} for c in cdev[1:]]
+            want = O.waverec3(c32, wavelet)
+            _engine.level_events = []
+            try:
+                got = ptwt_amd.waverec3(cdev, wavelet)
+                kids = [e[1] for e in _engine.level_events]
+            finally:
+                _engine.level_events = None
+            assert kids == [10] * level, (wavelet, mode, shape, kids)
+            assert tuple(got.shape) == tuple(want.shape)
+            assert G.relerr(to_np(got), want) < TOL32, (wavelet, mode, shape)
+            _engine.set_option(5, 2)
+            try:
+                comp = ptwt_amd.waverec3(cdev, wavelet)
+            finally:
+                _engine.set_option(5, 0)
+            assert G.relerr(to_np(got), to_np(comp)) < 5e-7, (wavelet, mode, shape)
+    # separable containers (the running approximation is cropped to the detail shape) and coefficient views with foreign strides
+    x = torch.randn(2, 23, 30, 45, device=dev())
+    c = ptwt_amd.fswavedec3(x, wavelet, level=2)
+    rec = ptwt_amd.fswaverec3(c, wavelet)
+    assert (rec[..., :23, :30, :45] - x).abs().max().item() < 1e-5
+    c = ptwt_amd.wavedec3(x, wavelet, level=1)
+    cv = [c[0].transpose(1, 2).contiguous().transpose(1, 2)] + [{k: v.clone() for k, v in c[1].items()}]
+    rec = ptwt_amd.waverec3(cv, wavelet)
+    assert (rec[..., :23, :30, :45] - x).abs().max().item() < 1e-5
 
 
 # ------------------------------------------------------------------ edge cases and the other BASELINE configs at full size
