@@ -21,7 +21,7 @@ namespace mifwt {
 
 namespace {
 
-constexpr int kCZ3 = 2, kCY3 = 4;
+constexpr int kCZ3 = 2;
 
 template <int L>
 struct Idwt3TileArgs {
@@ -39,10 +39,10 @@ struct Idwt3TileArgs {
   f2 tlo[L / 2], thi[L / 2];  // (rec_lo[2j], rec_lo[2j+1]), (rec_hi[2j], rec_hi[2j+1])
 };
 
-template <int L>
+template <int L, int CY>
 __global__ void __launch_bounds__(256, 2) idwt3_tile_kernel(const Idwt3TileArgs<L> a) {
   constexpr int HL = L / 2;
-  constexpr int CZ = kCZ3, CY = kCY3, NQ = 64 - (HL - 1);
+  constexpr int CZ = kCZ3, NQ = 64 - (HL - 1);
   constexpr int IZ = CZ + HL - 1, IY = CY + HL - 1;
   constexpr int SLOT = 4 * IY * 64;  // floats of one output slice's V image: [(H, W) band][row][column]
   static_assert(SLOT >= 2 * CY * 64 * 2, "the (W-low, W-high) image of a slice must fit into the slot it replaces");
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256, 2) idwt3_tile_kernel(const Idwt3TileArgs<
   }
 }
 
-template <int L>
+template <int L, int kCY3>
 int launch_i3(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y, const double* lo, const double* hi,
               hipStream_t stream) {
   constexpr int HL = L / 2, NQ = 64 - (HL - 1), IY = kCY3 + HL - 1;
@@ -188,7 +188,7 @@ int launch_i3(const mifwt_level_desc* d, const void* approx, const void* const* 
   }
   const int64_t ntiles = (int64_t)d->batch * a.tiles_c * a.tiles_r * a.tiles_d;
   if (ntiles > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((idwt3_tile_kernel<L>), dim3((unsigned)ntiles), dim3(256), lds_bytes, stream, a);
+  hipLaunchKernelGGL((idwt3_tile_kernel<L, kCY3>), dim3((unsigned)ntiles), dim3(256), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 
@@ -215,9 +215,10 @@ bool dwt3_inv_tile_supported(const mifwt_level_desc* d) {
 int dwt3_inv_tile(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y, const double* lo,
                   const double* hi, hipStream_t stream) {
   switch (d->filt_len) {
-    case 2: return launch_i3<2>(d, approx, details, y, lo, hi, stream);
-    case 4: return launch_i3<4>(d, approx, details, y, lo, hi, stream);
-    case 6: return launch_i3<6>(d, approx, details, y, lo, hi, stream);
+    // (MIFWT_OPT_TILE_ROWS 8: bricks of 16 output rows instead of 8, A/B)
+    case 2: return g_options[MIFWT_OPT_TILE_ROWS] == 8 ? launch_i3<2, 8>(d, approx, details, y, lo, hi, stream) : launch_i3<2, 4>(d, approx, details, y, lo, hi, stream);
+    case 4: return g_options[MIFWT_OPT_TILE_ROWS] == 8 ? launch_i3<4, 8>(d, approx, details, y, lo, hi, stream) : launch_i3<4, 4>(d, approx, details, y, lo, hi, stream);
+    case 6: return g_options[MIFWT_OPT_TILE_ROWS] == 8 ? launch_i3<6, 8>(d, approx, details, y, lo, hi, stream) : launch_i3<6, 4>(d, approx, details, y, lo, hi, stream);
     default: return MIFWT_ERR_UNSUPPORTED;
   }
 }

@@ -10,8 +10,9 @@ xs = [torch.randn(8, 256, 256, 256, device=dev) for _ in range(3)]
 for lvl in (1, 3):
     cs = [ptwt_amd.wavedec3(x, wav, level=lvl, mode="zero") for x in xs]
     nbytes = 4 * (xs[0].numel() + cs[0][0].numel() + sum(v.numel() for c in cs[0][1:] for v in c.values()))
-    for name, opt5 in (("fused bricks", 0), ("composed", 2), ("fused bricks", 0)):
+    for name, opt5, opt6 in (("fused bricks", 0, 0), ("composed", 2, 0), ("fused bricks", 0, 0), ("bricks 4x16", 0, 8)):
         _engine.set_option(5, opt5)
+        _engine.set_option(6, opt6)
         for i in range(3): ptwt_amd.waverec3(cs[i], wav)
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -21,4 +22,5 @@ for lvl in (1, 3):
         ms = s.elapsed_time(e) / 12
         print(f"waverec3 {wav} level {lvl} {name:13s} {ms:.4f} ms  ({nbytes / ms / 8e9:.3f} of the HBM peak on the compulsory bytes)")
     _engine.set_option(5, 0)
+    _engine.set_option(6, 0)
     del cs
