@@ -287,7 +287,7 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  *          axis); unit innermost stride, f32 / f64 / f16, L in {2..20 even, 24, 32}
  *   5 / 6  3-D analysis / synthesis (f32, even L <= 16; what the brick kernels 9 / 10 do not take): fused 2-D kernel over every
  *          depth slice + one streaming pass along depth
- *   9 / 10 fully fused 3-D analysis / synthesis level, LDS bricks (f32, L in {2, 4, 6})
+ *   9 / 10 fully fused 3-D analysis / synthesis level, LDS bricks (f32, L in {2, 4, 6}; synthesis also 8)
  *   11     fused 2-D analysis level on the matrix cores (banded-Toeplitz MFMA; f16 storage, even L in [18, 32])
  *   12 / 13  two fused 2-D analysis / synthesis levels per launch (mifwt_dwt2_fwd_pair / mifwt_dwt2_inv_pair; never
  *          returned by mifwt_kernel_id, which describes single-level calls)

@@ -13,8 +13,9 @@
 //   2. one barrier; then wave w owns output slice w: H pass from LDS into registers ((W-low, W-high) x 2*CY rows per lane), parked
 //      back into the slice's own slot as (lo, hi) pairs (wave-local ordering only);
 //   3. W pass LDS -> registers -> global: lane = output column pair, one 8-byte store per row.
-// LDS per workgroup = 2*CZ slots of 4 x (CY + L/2 - 1) x 64 floats (L = 4: 20 KB).  Envelope: f32, L in {2, 4, 6}, unit innermost
-// strides; longer filters use the composed route.  Algorithmic traffic: 8*4*B*Md*Mh*Mw read + 4*B*D*H*W written.
+// LDS per workgroup = 2*CZ slots of 4 x (CY + L/2 - 1) x 64 floats (L = 4: 20 KB).  Envelope: f32, L in {2, 4, 6, 8}, unit innermost
+// strides (the halo of a synthesis brick is L/2 - 1 COEFFICIENTS per axis, so eight taps still fit: 28 KB, 70 registers of inputs);
+// longer filters use the composed route.  Algorithmic traffic: 8*4*B*Md*Mh*Mw read + 4*B*D*H*W written.
 #include "mifwt_stream.h"
 
 namespace mifwt {
@@ -197,7 +198,7 @@ int launch_i3(const mifwt_level_desc* d, const void* approx, const void* const* 
 bool dwt3_inv_tile_supported(const mifwt_level_desc* d) {
   if (d->ndim != 3 || d->dtype != MIFWT_F32) return false;
   const int L = d->filt_len;
-  if (L != 2 && L != 4 && L != 6) return false;
+  if (L != 2 && L != 4 && L != 6 && L != 8) return false;
   if (d->sig_stride[3] != 1 || d->approx_stride[3] != 1 || d->detail_stride[3] != 1) return false;
   for (int i = 0; i < 3; ++i) {
     if (d->sig_stride[i] < 0 || d->approx_stride[i] < 0 || d->detail_stride[i] < 0) return false;
@@ -219,6 +220,7 @@ int dwt3_inv_tile(const mifwt_level_desc* d, const void* approx, const void* con
     case 2: return g_options[MIFWT_OPT_TILE_ROWS] == 8 ? launch_i3<2, 8>(d, approx, details, y, lo, hi, stream) : launch_i3<2, 4>(d, approx, details, y, lo, hi, stream);
     case 4: return g_options[MIFWT_OPT_TILE_ROWS] == 8 ? launch_i3<4, 8>(d, approx, details, y, lo, hi, stream) : launch_i3<4, 4>(d, approx, details, y, lo, hi, stream);
     case 6: return g_options[MIFWT_OPT_TILE_ROWS] == 8 ? launch_i3<6, 8>(d, approx, details, y, lo, hi, stream) : launch_i3<6, 4>(d, approx, details, y, lo, hi, stream);
+    case 8: return g_options[MIFWT_OPT_TILE_ROWS] == 8 ? launch_i3<8, 8>(d, approx, details, y, lo, hi, stream) : launch_i3<8, 4>(d, approx, details, y, lo, hi, stream);
     default: return MIFWT_ERR_UNSUPPORTED;
   }
 }

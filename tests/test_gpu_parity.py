@@ -322,7 +322,7 @@ def test_stream_routes_selected():
     assert kid(1, torch.float32, "reflect", 8, 4, (1000,)) == 3 and kid(1, torch.float32, "zero", 8, 4, (1000,), direction=1) == 4
     assert kid(1, torch.float64, "reflect", 2, 1, (4096,)) == 3
     assert kid(3, torch.float32, "zero", 4, 8, (256, 256, 256)) == 9  # fully fused LDS-brick 3-D analysis
-    assert kid(3, torch.float32, "zero", 8, 8, (256, 256, 256)) == 5 and kid(3, torch.float32, "zero", 4, 8, (256, 256, 256), direction=1) == 10 and kid(3, torch.float32, "zero", 8, 8, (256, 256, 256), direction=1) == 6
+    assert kid(3, torch.float32, "zero", 8, 8, (256, 256, 256)) == 5 and kid(3, torch.float32, "zero", 4, 8, (256, 256, 256), direction=1) == 10 and kid(3, torch.float32, "zero", 10, 8, (256, 256, 256), direction=1) == 6
     assert kid(3, torch.float64, "zero", 4, 2, (33, 34, 35)) == 3  # f64: inner pass + two outer passes
     assert kid(2, torch.float64, "reflect", 8, 2, (64, 64)) == 7 and kid(2, torch.float64, "reflect", 8, 2, (64, 64), direction=1) == 8  # f64 tiles
     assert kid(2, torch.float64, "reflect", 24, 2, (64, 64)) == 3  # f64, long filter: inner + outer pass
@@ -557,7 +557,7 @@ def test_fused_dwt3_tile_vs_oracle_and_composed(wavelet):
                 assert G.relerr(to_np(a), to_np(b)) < 5e-7, (wavelet, mode, shape, n)
 
 
-@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3"])
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4"])
 def test_fused_idwt3_tile_vs_oracle_and_composed(wavelet):
     """The fully fused LDS-brick 3-D synthesis kernel (kernel id 10) against the fp64 oracle (coefficients of every boundary mode:
     odd extents, i.e. trimmed outputs; ragged bricks on every axis; tiny volumes; more than one column tile) and against the composed

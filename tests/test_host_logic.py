@@ -227,7 +227,7 @@ def test_cabi_descriptor_validation_and_dispatch():
     assert _engine.kernel_id(3, torch.float32, "zero", 4, 8, (256, 256, 256)) == 9   # fully fused LDS-brick kernel
     assert _engine.kernel_id(3, torch.float32, "zero", 8, 8, (256, 256, 256)) == 5   # fused planes + depth pass
     assert _engine.kernel_id(3, torch.float32, "zero", 4, 8, (256, 256, 256), direction=1) == 10  # fully fused LDS-brick synthesis
-    assert _engine.kernel_id(3, torch.float32, "zero", 8, 8, (256, 256, 256), direction=1) == 6   # fused planes + depth pass
+    assert _engine.kernel_id(3, torch.float32, "zero", 8, 8, (256, 256, 256), direction=1) == 10 and _engine.kernel_id(3, torch.float32, "zero", 10, 8, (256, 256, 256), direction=1) == 6   # ten taps: fused planes + depth pass
     assert _engine.kernel_id(3, torch.float64, "zero", 4, 8, (256, 256, 256), direction=1) != 10
     assert _engine.kernel_id(2, torch.float32, "reflect", 102, 4, (512, 512)) == 0   # coif17 -> generic passes
     assert _engine.kernel_id(2, torch.float32, "reflect", 22, 4, (512, 512)) == 0    # L not in the streaming set
