@@ -486,7 +486,9 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
             if len(outs) == len(folded):
                 cur = fuse(cur, 0, len(folded))
                 pos = len(folded)
-    if ndim == 2 and folded and not (torch.is_grad_enabled() and (tap_t is not None or any(t.requires_grad for t in flat))):
+    # (the finest level's four coefficient planes alone must fit into LDS: 10 240 samples each at most)
+    if (ndim == 2 and folded and folded[-1][0].shape[-1] * folded[-1][0].shape[-2] <= 10240
+            and not (torch.is_grad_enabled() and (tap_t is not None or any(t.requires_grad for t in flat)))):
         # every level of a small plane in one launch, the running approximation kept on chip (mifwt_dwt2_inv_pyramid); every
         # fused trip passes the reference's own checks first
         try:
@@ -542,9 +544,18 @@ def pack_2d(layout: _Layout, approx, bufs):
 
 def pack_dict(layout: _Layout, approx, bufs, keys: Sequence[str]):
     out: list = [layout.unfold(approx)]
+    unfold = layout.unfold
+    keys = tuple(keys)
+    idx = _BAND_OF_KEYS.get(keys)
+    if idx is None:
+        idx = _BAND_OF_KEYS[keys] = tuple(_band(k) for k in keys)  # (the string arithmetic of _band per key and call was 8 us of a wavedec3)
     for b in bufs:
-        out.append({k: layout.unfold(b[:, _band(k)]) for k in keys})
+        planes = b.unbind(1)
+        out.append({k: unfold(planes[i]) for k, i in zip(keys, idx)})
     return tuple(out)
+
+
+_BAND_OF_KEYS: dict = {}
 
 
 def unpack_dict_levels(coeffs, ndim: int, what: str) -> List[List[torch.Tensor]]:
