@@ -383,9 +383,9 @@ class HipLevelEngine:
     def analysis_tail(self, x: torch.Tensor, dec_lo: Sequence[float], dec_hi: Sequence[float], mode_id: int, nlevels: int):
         """The next levels of a 1-D decomposition in ONE launch — all ``nlevels`` remaining ones once a row fits into a workgroup (C
         ABI ``mifwt_dwt1_fwd_tail``), as many as the chunked long-row kernel fuses before that (``mifwt_dwt1_fwd_long``): ``x`` [B, N]
-        -> a list of up to ``nlevels`` buffers [B, 2, M_l] laid out like :meth:`analysis` results, finest first; plane 1 of every buffer
-        holds that level's detail coefficients, plane 0 only of the LAST one its approximation (the others are intermediates
-        that never leave the chip).  Returns None outside the kernel's envelope."""
+        -> a list of up to ``nlevels`` buffers, finest first: [B, 1, M_l] holding that level's detail coefficients, and for the LAST level
+        [B, 2, M] laid out like an :meth:`analysis` result (plane 0 = its approximation, plane 1 = its details); the approximations in
+        between never leave the chip.  Returns None outside the kernel's envelope."""
         _require_gpu(x)
         if x.dim() != 2 or x.dtype not in (torch.float32, torch.float64) or x.stride(1) != 1 or nlevels < 2 or nlevels > 24:
             return None
@@ -406,10 +406,13 @@ class HipLevelEngine:
         for _ in range(nlevels):
             n = (n + flen - 1) // 2
             sizes.append(n)
-        bufs = [torch.empty((rows, 2, m), dtype=x.dtype, device=x.device) for m in sizes]
+        # the last level's buffer carries the approximation in plane 0; the others hold their detail row only (their approximations
+        # never leave the chip: a [B, 2, M] buffer would keep as many dead bytes alive as the coefficients themselves)
+        last = nlevels - 1
+        bufs = [torch.empty((rows, 2 if i == last else 1, m), dtype=x.dtype, device=x.device) for i, m in enumerate(sizes)]
         esz = x.element_size()
-        det = (ctypes.c_void_p * nlevels)(*[b.data_ptr() + sizes[i] * esz for i, b in enumerate(bufs)])
-        det_rs = (ctypes.c_int64 * nlevels)(*[2 * m for m in sizes])
+        det = (ctypes.c_void_p * nlevels)(*[b.data_ptr() + (sizes[i] * esz if i == last else 0) for i, b in enumerate(bufs)])
+        det_rs = (ctypes.c_int64 * nlevels)(*[(2 if i == last else 1) * m for i, m in enumerate(sizes)])
         lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
         p = _Plan()
         p.ws_bytes, p.kid = 0, (KID_LONG if long_rows else KID_TAIL)

@@ -530,7 +530,7 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
 
 # ------------------------------------------------------------------------------------------ containers
 def pack_1d(layout: _Layout, approx, bufs) -> List[torch.Tensor]:
-    return [layout.unfold(approx)] + [layout.unfold(b[:, 1]) for b in bufs]
+    return [layout.unfold(approx)] + [layout.unfold(b[:, -1]) for b in bufs]  # (the detail row is the last plane: [B, 2, M] or [B, 1, M])
 
 
 def pack_2d(layout: _Layout, approx, bufs):

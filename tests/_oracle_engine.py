@@ -21,8 +21,8 @@ class OracleLevelEngine:
         return torch.from_numpy(np.stack([bands[k] for k in keys], axis=1))
 
     def analysis_tail(self, x, dec_lo, dec_hi, mode_id, nlevels):
-        """Stand-in for the fused deep 1-D levels: same return contract as HipLevelEngine.analysis_tail — plane 0 of every
-        buffer but the last is NOT part of it, so it is poisoned here."""
+        """Stand-in for the fused deep 1-D levels: same return contract as HipLevelEngine.analysis_tail — every buffer but the last
+        holds its detail row only ([B, 1, M]), the last one is laid out like an analysis result ([B, 2, M])."""
         if x.dim() != 2 or x.shape[1] > 64 or nlevels < 2:
             return None
         bufs, cur = [], x
@@ -30,9 +30,7 @@ class OracleLevelEngine:
             buf = self.analysis(cur, dec_lo, dec_hi, mode_id)
             bufs.append(buf)
             cur = buf[:, 0].clone()
-        for b in bufs[:-1]:
-            b[:, 0] = float("nan")
-        return bufs
+        return [b[:, 1:].contiguous() for b in bufs[:-1]] + [bufs[-1]]
 
     def analysis_pair(self, x, dec_lo, dec_hi, mode_id):
         """Stand-in for the two-levels-per-launch call: same return contract as HipLevelEngine.analysis_pair — plane 0
