@@ -254,6 +254,21 @@ class HipLevelEngine:
         p.kid = lib.mifwt_kernel_id(p.ref, 0)
         return p
 
+    @staticmethod
+    def _details_only(pl: _Plan) -> _Plan:
+        """Copy of a level plan for a buffer WITHOUT the approximation plane ([B, 2^n - 1, M..]: plane s - 1 = band s): what a level of a
+        multi-level launch gets whose approximation stays on chip (a [B, 2^n, M..] buffer would keep a dead plane alive as long as
+        any of its detail bands lives).  The cached plan itself is shared with the per-level path and is not touched."""
+        q = _Plan()
+        d = LevelDesc()
+        ctypes.memmove(ctypes.addressof(d), ctypes.addressof(pl.desc), ctypes.sizeof(LevelDesc))
+        plane = pl.desc.detail_stride[0] // pl.nb
+        d.detail_stride[0] = d.approx_stride[0] = plane * (pl.nb - 1)
+        q.desc, q.ref = d, ctypes.byref(d)
+        q.alloc_shape = (pl.alloc_shape[0], pl.nb - 1, *pl.alloc_shape[2:])
+        q.view_last, q.nb, q.plane_bytes, q.ws_bytes, q.kid, q.empty = pl.view_last, pl.nb - 1, pl.plane_bytes, pl.ws_bytes, pl.kid, pl.empty
+        return q
+
     def analysis(self, x: torch.Tensor, dec_lo: Sequence[float], dec_hi: Sequence[float], mode_id: int) -> torch.Tensor:
         """``x``: [B, N_0..N_{n-1}] (any strides) -> one buffer [B, 2^n, M_0..] whose plane ``s`` is band ``s``
         (bit (n-1-a) of s set <=> high-pass along axis a; plane 0 = approximation)."""
@@ -323,8 +338,8 @@ class HipLevelEngine:
     def analysis_pyramid(self, x: torch.Tensor, dec_lo: Sequence[float], dec_hi: Sequence[float], mode_id: int, nlevels: int):
         """Several consecutive 2-D analysis levels in one launch (C ABI ``mifwt_dwt2_fwd_pyramid``: up to three through the streaming
         kernel, up to eight — the whole pyramid — for planes that fit into LDS): ``x`` [B, H, W] -> a list of
-        buffers laid out like :meth:`analysis` results, finest first; plane 0 (the approximation) is written only in the LAST one —
-        the others are intermediates that never leave the chip.  Fuses as many of the ``nlevels`` requested levels as the library
+        buffers, finest first: the LAST one laid out like an :meth:`analysis` result ([B, 4, M, M]: approximation + three detail bands),
+        the others [B, 3, M, M] with the detail bands only (ad, da, dd) — their approximations never leave the chip.  Fuses as many of the ``nlevels`` requested levels as the library
         serves for this geometry (possibly fewer); returns None when it serves none."""
         _require_gpu(x)
         if x.dim() != 3 or x.dtype != torch.float32:
@@ -352,6 +367,11 @@ class HipLevelEngine:
                         break
             keep = plans[:n_ok]
             refs = (ctypes.POINTER(LevelDesc) * n_ok)(*[ctypes.pointer(pl.desc) for pl in keep]) if n_ok else None
+            if n_ok > 1:  # every level but the last: detail planes only
+                lean = [self._details_only(pl) for pl in keep[:-1]] + [keep[-1]]
+                lrefs = (ctypes.POINTER(LevelDesc) * n_ok)(*[ctypes.pointer(pl.desc) for pl in lean])
+                if lib.mifwt_dwt2_fwd_pyramid_supported(n_ok, lrefs) == route:
+                    keep, refs = lean, lrefs
             plan = _plans[key] = (keep, n_ok, refs, KID_SMALL if route == 2 else KID_PYRAMID)
         plans, n_ok, refs, kid = plan
         if n_ok == 0:
@@ -372,8 +392,9 @@ class HipLevelEngine:
                 _tls.pyr[skey] = slot
         rows, det = slot
         for r, b, pl in zip(rows, bufs, plans):
-            base, pb = b.data_ptr(), pl.plane_bytes
-            r[0], r[1], r[2] = base + pb, base + 2 * pb, base + 3 * pb
+            pb = pl.plane_bytes
+            base = b.data_ptr() + (pl.nb - 3) * pb  # band ad: plane 1 of a full buffer, plane 0 of a details-only one
+            r[0], r[1], r[2] = base, base + pb, base + 2 * pb
         lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
         lib = _lib
         xp, ap = x.data_ptr(), bufs[-1].data_ptr()

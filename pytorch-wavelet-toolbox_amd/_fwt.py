@@ -537,7 +537,7 @@ def pack_2d(layout: _Layout, approx, bufs):
     out = [layout.unfold(approx)]
     unfold = layout.unfold
     for b in bufs:  # (H, V, D) = ('da', 'ad', 'dd') = bands 2, 1, 3 (one unbind: a third of the host time of three b[:, k])
-        _aa, ad, da, dd = b.unbind(1)
+        ad, da, dd = b.unbind(1)[-3:]  # ([B, 4, ..] with the approximation in plane 0, or [B, 3, ..] from a multi-level launch)
         out.append(WaveletDetailTuple2d(unfold(da), unfold(ad), unfold(dd)))
     return tuple(out)
 
@@ -549,9 +549,11 @@ def pack_dict(layout: _Layout, approx, bufs, keys: Sequence[str]):
     idx = _BAND_OF_KEYS.get(keys)
     if idx is None:
         idx = _BAND_OF_KEYS[keys] = tuple(_band(k) for k in keys)  # (the string arithmetic of _band per key and call was 8 us of a wavedec3)
+    nb = 1 << len(keys[0])
     for b in bufs:
         planes = b.unbind(1)
-        out.append({k: unfold(planes[i]) for k, i in zip(keys, idx)})
+        off = nb - len(planes)  # 1 for a details-only buffer of a multi-level launch (plane s - 1 = band s)
+        out.append({k: unfold(planes[i - off]) for k, i in zip(keys, idx)})
     return tuple(out)
 
 

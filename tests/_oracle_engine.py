@@ -43,8 +43,8 @@ class OracleLevelEngine:
         return buf1, buf2
 
     def analysis_pyramid(self, x, dec_lo, dec_hi, mode_id, nlevels):
-        """Stand-in for the several-levels-per-launch call: same return contract as HipLevelEngine.analysis_pyramid — plane 0
-        of every buffer but the last is NOT part of it, so it is poisoned here.  Like the library it has two routes: planes of at most
+        """Stand-in for the several-levels-per-launch call: same return contract as HipLevelEngine.analysis_pyramid — every buffer but the
+        last holds the three detail bands only.  Like the library it has two routes: planes of at most
         48 x 48 samples get up to eight levels in any mode (the small-plane kernel); bigger ones up to three, rows of a multiple of
         four samples only, every mode but periodic, filters up to 8 taps (the streaming kernel), and may fuse fewer levels than asked."""
         if x.dim() != 3 or x.dtype != torch.float32:
@@ -59,9 +59,7 @@ class OracleLevelEngine:
             buf = self.analysis(cur, dec_lo, dec_hi, mode_id)
             bufs.append(buf)
             cur = buf[:, 0].clone()
-        for b in bufs[:-1]:
-            b[:, 0] = float("nan")
-        return bufs or None
+        return ([b[:, 1:].contiguous() for b in bufs[:-1]] + [bufs[-1]]) or None
 
     def synthesis_pyramid(self, approx, levels, rec_lo, rec_hi, out_extent):
         """Stand-in for the whole-reconstruction-in-one-launch call (same contract as HipLevelEngine.synthesis_pyramid): planes of at
