@@ -17,7 +17,7 @@ os.makedirs("profiles", exist_ok=True)
 
 def short(name):
     name = name.replace("void ", "")
-    for key in ("idwt1_long_kernel", "idwt1_tail_kernel", "dwt2_fwd_pyr_kernel", "dwt2_fwd_roll_kernel", "dwt2_fwd_pair_kernel", "dwt2_fwd_tile_kernel", "dwt2_fwd_stream_kernel", "dwt2_inv_stream_kernel", "outer_fwd_kernel", "outer_inv_kernel", "inner_fwd_kernel", "inner_inv_kernel", "swt_kernel", "axis_adj_kernel", "axis_fwd_kernel", "axis_inv_kernel", "dwt3_", "dwt1_"):
+    for key in ("idwt1_long_kernel", "idwt1_tail_kernel", "idwt2_small_kernel", "idwt3_tile_kernel", "dwt2_fwd_small_kernel", "dwt2_fwd_pyr_kernel", "dwt2_fwd_roll_kernel", "dwt2_fwd_pair_kernel", "dwt2_fwd_tile_kernel", "dwt2_fwd_stream_kernel", "dwt2_inv_stream_kernel", "outer_fwd_kernel", "outer_inv_kernel", "inner_fwd_kernel", "inner_inv_kernel", "swt_kernel", "axis_adj_kernel", "axis_fwd_kernel", "axis_inv_kernel", "dwt3_", "dwt1_"):
         if key in name:
             i = name.index(key)
             j = name.find("(", i)
