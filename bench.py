@@ -66,6 +66,9 @@ WORKLOADS = {
     "fswavedec2_sym16_L5_128x8192x8192_f16": ("fswavedec2", (128, 8192, 8192), "sym16", 5, "reflect", torch.float16),
     # the reference's own 1-D speed test shape (examples/speed_tests/timeitconv_1d.py:16-36)
     "wavedec_db5_L10_32x1000000_f32": ("wavedec", (32, 1000000), "db5", 10, "periodic", torch.float32),
+    # batches of image patches: the whole pyramid in one launch (kernel id 20)
+    "wavedec2_db2_L3_4096x64x64_f32": ("wavedec2", (4096, 64, 64), "db2", 3, "reflect", torch.float32),
+    "wavedec2_db2_L2_16384x32x32_f32": ("wavedec2", (16384, 32, 32), "db2", 2, "reflect", torch.float32),
     # dry runs of the control flow (MIFWT_BENCH_DEVICE=cpu), not a benchmark shape
     "dryrun_wavedec2_db4_L2_6x96x96_f32": ("wavedec2", (6, 96, 96), "db4", 2, "reflect", torch.float32),
 }
@@ -124,7 +127,9 @@ def cpu_baseline(fn, shape, wavelet, level, mode, dtype):
     from oracle import torch_cpu_port as P
 
     cores = os.cpu_count() or 1
-    sample_b = min(shape[0], 64)  # config 2: the whole 64-image batch
+    # config 2: the whole 64-image batch; batches of small planes: as many images as 64 planes of 1024^2 hold, i.e. a sample that
+    # takes the host long enough to be timed
+    sample_b = min(shape[0], max(64, (64 << 20) // max(1, shape[1] * shape[2])))
     x = torch.randn(sample_b, *shape[1:], dtype=dtype)
     # oneDNN's conv does not scale to every core of a big host: probe a few thread counts on a small slice
     # and keep the fastest (reported as "cores")
@@ -150,7 +155,7 @@ def cpu_baseline(fn, shape, wavelet, level, mode, dtype):
         "cores": torch.get_num_threads(),
         "kind": "port",
         "sample": f"{sample_b}x{shape[1]}x{shape[2]} {str(dtype).split('.')[-1]} images, {wavelet} level {level} {mode}, "
-                  f"median of {len(times)} runs (min {min(times):.3f}s, median {med:.3f}s), best of the probed thread counts "
+                  f"median of {len(times)} runs (min {min(times):.4f}s, median {med:.4f}s), best of the probed thread counts "
                   f"on a {cores}-core host; same ATen ops as ptwt's CPU path (pad + dense stride-2 conv2d), "
                   "oracle/torch_cpu_port.py",
     }
@@ -293,7 +298,7 @@ def main():
     if fn_name in ("wavedec2", "fswavedec2", "wavedec3", "wavedec"):
         taps = ptwt_amd._wavelets.host_taps(wavelet)
         mode_id = _engine.MODE_IDS[mode]
-        if first_kid == _engine.KID_PYRAMID:
+        if first_kid in (_engine.KID_PYRAMID, _engine.KID_SMALL):
             fused_levels = len(_engine.ENGINE.analysis_pyramid(bufs[0], taps[0], taps[1], mode_id, level))
             launch = lambda b: _engine.ENGINE.analysis_pyramid(b, taps[0], taps[1], mode_id, level)  # noqa: E731
         elif first_kid == _engine.KID_PAIR:
@@ -363,7 +368,7 @@ def main():
         kid1 = next((kid for (tag, kid, ext, s, e) in events if tuple(ext) == tuple(shape[1:])), -1)
         if kid1 == _engine.KID_PAIR:
             lvl1_b = pair_b
-        if kid1 in (_engine.KID_PYRAMID, _engine.KID_LONG):
+        if kid1 in (_engine.KID_PYRAMID, _engine.KID_LONG, _engine.KID_SMALL):
             # input + the detail bands of the fused levels + the approximation of the last fused one
             lvl1_b = algorithmic_bytes(shape[0], shape[1:], flen, fused_levels, esize)[0]
         klabel = {1: "dwt2_fwd_stream_kernel (level 1)", 7: "dwt2_fwd_tile_kernel (level 1)", 0: "generic axis kernels (level 1)",
@@ -371,7 +376,8 @@ def main():
                   11: "dwt2_fwd_mfma_kernel (level 1)",
                   12: ("dwt2_fwd_roll_kernel" if flen >= 8 else "dwt2_fwd_pair_kernel") + " (levels 1+2 in one launch)",
                   16: f"dwt2_fwd_pyr_kernel (levels 1-{fused_levels} in one launch)",
-                  17: f"dwt1_long_kernel (levels 1-{fused_levels} in one launch)"}.get(kid1, f"kernel id {kid1} (level 1)")
+                  17: f"dwt1_long_kernel (levels 1-{fused_levels} in one launch)",
+                  20: f"dwt2_fwd_small_kernel (levels 1-{fused_levels} in one launch, a workgroup per image)"}.get(kid1, f"kernel id {kid1} (level 1)")
         per_launch_event_ms = sum(lvl1) / max(1, len(lvl1))
         avg_ms = lvl1_b2b_ms if lvl1_b2b_ms else per_launch_event_ms
         achieved = lvl1_b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
