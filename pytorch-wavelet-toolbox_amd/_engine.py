@@ -294,8 +294,8 @@ class HipLevelEngine:
 
     def analysis_pair(self, x: torch.Tensor, dec_lo: Sequence[float], dec_hi: Sequence[float], mode_id: int):
         """TWO consecutive 2-D analysis levels in one launch (C ABI ``mifwt_dwt2_fwd_pair``): ``x`` [B, H, W] ->
-        ``(buf1, buf2)`` laid out like two :meth:`analysis` calls, except that plane 0 of ``buf1`` (the intermediate
-        approximation, which a pyramid does not return) is left unwritten.  Returns None when the library does not
+        ``(buf1, buf2)``: ``buf2`` laid out like an :meth:`analysis` result, ``buf1`` [B, 3, M, M] with the detail bands only (the intermediate
+        approximation, which a pyramid does not return, stays on chip).  Returns None when the library does not
         serve this geometry as a pair; the caller then runs the levels one by one."""
         _require_gpu(x)
         if x.dim() != 3:
@@ -316,6 +316,10 @@ class HipLevelEngine:
                     lvl1 = lvl1[..., : p1.view_last]
                 p2 = self._analysis_plan(lvl1[:, 0], flen, mode_id)
                 ok = (not p2.empty) and bool(lib.mifwt_dwt2_fwd_pair_supported(p1.ref, p2.ref))
+                if ok:  # the first level's buffer: detail planes only (its approximation stays on chip)
+                    lean = self._details_only(p1)
+                    if lib.mifwt_dwt2_fwd_pair_supported(lean.ref, p2.ref):
+                        p1 = lean
             plan = _plans[key] = (p1, p2, ok)
         p1, p2, ok = plan
         if not ok:
@@ -327,7 +331,8 @@ class HipLevelEngine:
         if p2.view_last is not None:
             buf2 = buf2[..., : p2.view_last]
         b1, b2 = buf1.data_ptr(), buf2.data_ptr()
-        ptrs1, ptrs2 = _band_ptrs(b1, p1.plane_bytes, 3), _band_ptrs(b2, p2.plane_bytes, 3)
+        ptrs1 = _band_ptrs(b1 - (4 - p1.nb) * p1.plane_bytes, p1.plane_bytes, 3)  # band ad: plane 1 of a full buffer, plane 0 of a details-only one
+        ptrs2 = _band_ptrs(b2, p2.plane_bytes, 3)
         lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
         lib = _lib
         xp = x.data_ptr()

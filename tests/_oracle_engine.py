@@ -33,14 +33,13 @@ class OracleLevelEngine:
         return [b[:, 1:].contiguous() for b in bufs[:-1]] + [bufs[-1]]
 
     def analysis_pair(self, x, dec_lo, dec_hi, mode_id):
-        """Stand-in for the two-levels-per-launch call: same return contract as HipLevelEngine.analysis_pair — plane 0
-        of the first buffer (the intermediate approximation) is NOT part of it, so it is poisoned here."""
+        """Stand-in for the two-levels-per-launch call: same return contract as HipLevelEngine.analysis_pair — the first
+        buffer holds the three detail bands only."""
         if x.dim() != 3 or min(x.shape[1:]) < 16:
             return None
         buf1 = self.analysis(x, dec_lo, dec_hi, mode_id)
         buf2 = self.analysis(buf1[:, 0], dec_lo, dec_hi, mode_id)
-        buf1[:, 0] = float("nan")
-        return buf1, buf2
+        return buf1[:, 1:].contiguous(), buf2
 
     def analysis_pyramid(self, x, dec_lo, dec_hi, mode_id, nlevels):
         """Stand-in for the several-levels-per-launch call: same return contract as HipLevelEngine.analysis_pyramid — every buffer but the
