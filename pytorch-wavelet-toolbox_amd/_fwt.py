@@ -95,6 +95,19 @@ def _synthesis_tap_grads(g_y, approx, details, rec_lo, rec_hi):
     return g_lo, g_hi
 
 
+def _no_double_backward_through_taps(taps) -> None:
+    """Gradients of any order exist w.r.t. the DATA.  With a learnable filter bank and ``create_graph=True`` (a gradient penalty,
+    say) the mixed terms — d g_x / d taps, and the tap gradients' dependence on the upstream gradient — are not built (the kernels
+    take the taps as host floats); the reference has them from plain ATen ops (src/ptwt/_util.py:115-132).  Refuse instead of
+    silently returning a graph that lacks them."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in taps):
+        raise RuntimeError(
+            "ptwt_amd: double backward (create_graph=True) through a learnable filter bank is not supported: the mixed "
+            "second derivatives w.r.t. the filter taps are not built. Detach the filter bank for this term, or use first-order "
+            "gradients."
+        )
+
+
 def _like(grad64: torch.Tensor, ref: Optional[torch.Tensor]):
     return None if ref is None else grad64.to(device=ref.device, dtype=ref.dtype).reshape(ref.shape)
 
@@ -118,6 +131,7 @@ class _AnalysisLevel(torch.autograd.Function):
     def backward(ctx, g_buf):
         sig_shape, dec_lo, dec_hi, mode_id = ctx.meta
         (x,) = ctx.saved_tensors
+        _no_double_backward_through_taps(ctx.taps)
         # the adjoint is itself a differentiable level op (its derivative is this level again): gradients of any order w.r.t.
         # the data, as the reference has them from plain F.pad + conv.  (The tap gradients below are first order only.)
         g_x = _AnalysisAdjointLevel.apply(g_buf, sig_shape, dec_lo, dec_hi, mode_id) if ctx.needs_input_grad[0] else None
@@ -162,6 +176,7 @@ class _SynthesisLevel(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_y):
         coef_shape, rec_lo, rec_hi, ndet = ctx.meta
+        _no_double_backward_through_taps(ctx.taps)
         g_bands = (None,) * (ndet + 1)
         if any(ctx.needs_input_grad[5:]):
             g = _SynthesisAdjointLevel.apply(g_y, coef_shape, rec_lo, rec_hi)  # differentiable in turn: any order w.r.t. the data

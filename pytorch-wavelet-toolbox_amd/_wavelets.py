@@ -11,7 +11,6 @@ from __future__ import annotations
 import json
 import math
 import os
-import weakref
 from functools import lru_cache
 from typing import List, Sequence, Tuple
 
@@ -64,28 +63,29 @@ def as_wavelet(wavelet):
     return _named(wavelet) if isinstance(wavelet, str) else wavelet
 
 
-_tensor_taps: dict = {}  # id(tensor) -> (weakref, version, data_ptr, floats)
-
-
 def _to_floats(seq) -> Tuple[float, ...]:
     """Host copy of a tap sequence.  The kernels take the taps by value in their launch arguments, so a tensor-valued filter
-    (a learnable parameter on the GPU) costs one small device-to-host copy — once per VALUE: the copy is cached until the
-    tensor is modified in place (optimizer step) or re-pointed, so the many level launches and transform calls between two
-    updates of a learnable wavelet do not synchronise with the device again."""
+    (a learnable parameter on the GPU) is read back on EVERY top-level transform call, like the reference, which always reads the
+    live tensor (src/ptwt/_util.py:115-132).  Nothing is cached across calls: an in-place update through ``p.data`` (hand-written
+    SGD, weight clipping) does not bump ``p._version``, so no cheap validity check exists."""
     if hasattr(seq, "detach"):
-        ent = _tensor_taps.get(id(seq))
-        ver = getattr(seq, "_version", None)
-        if ent is not None and ent[0]() is seq and ent[1] == ver and ent[2] == seq.data_ptr():
-            return ent[3]
-        vals = tuple(float(v) for v in seq.detach().reshape(-1).cpu().tolist())
-        if len(_tensor_taps) > 256:
-            _tensor_taps.clear()
-        try:
-            _tensor_taps[id(seq)] = (weakref.ref(seq), ver, seq.data_ptr(), vals)
-        except TypeError:
-            pass
-        return vals
+        return tuple(float(v) for v in seq.detach().reshape(-1).cpu().tolist())
     return tuple(float(v) for v in seq)
+
+
+def _bank_to_floats(bank):
+    """The four filters of a bank as host floats; tensor-valued banks that live on one device travel in ONE device-to-host copy."""
+    if all(hasattr(t, "detach") for t in bank) and len({(t.device, t.dtype) for t in bank}) == 1 and bank[0].is_cuda:
+        import torch
+
+        flat = torch.cat([t.detach().reshape(-1) for t in bank]).cpu().tolist()
+        out, pos = [], 0
+        for t in bank:
+            n = t.numel()
+            out.append(tuple(float(v) for v in flat[pos:pos + n]))
+            pos += n
+        return tuple(out)
+    return tuple(_to_floats(t) for t in bank)
 
 
 @lru_cache(maxsize=256)
@@ -105,7 +105,7 @@ def host_taps(wavelet) -> Tuple[Tuple[float, ...], Tuple[float, ...], Tuple[floa
     bank = wavelet if isinstance(wavelet, tuple) else wavelet.filter_bank
     if len(bank) != 4:
         raise ValueError("a filter bank must hold (dec_lo, dec_hi, rec_lo, rec_hi)")
-    taps = tuple(_to_floats(t) for t in bank)
+    taps = _bank_to_floats(bank)
     if not (len(taps[0]) == len(taps[1]) and len(taps[2]) == len(taps[3])):
         raise ValueError("low- and high-pass filters must have the same length")
     return taps  # type: ignore[return-value]

@@ -3,12 +3,30 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "mifwt.h"
 
 namespace mifwt {
 
 constexpr int kMaxFilt = MIFWT_MAX_FILT;
 extern int g_options[16];  // mifwt_set_option() switches
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of a kernel ON A DEVICE: set it once per (kernel, device).  One of these
+// as a function-local static next to each launch; safe from threads that call with the GIL released (two racing threads at worst
+// both set the same value).
+struct DynLdsOnce {
+  std::atomic<uint64_t> done{0};
+  bool ensure(const void* fn, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const uint64_t bit = uint64_t(1) << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    done.fetch_or(bit, std::memory_order_release);
+    return true;
+  }
+};
 
 // Boundary extension as an index map (replaces F.pad / _pad_symmetric of the reference:
 // src/ptwt/conv_transform.py:59-66, src/ptwt/_util.py:163-195).  Returns the source index in [0, n) of

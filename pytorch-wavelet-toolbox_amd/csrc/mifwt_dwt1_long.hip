@@ -402,12 +402,8 @@ int launch_long(const LongPlan& p, int mode, int64_t rows, const void* x, int64_
   a.dbg = g_options[MIFWT_OPT_DEBUG];
   for (int m = 0; m < L; ++m) a.tap[m] = (f2){(float)lo[m], (float)hi[m]};
   const size_t lds = (size_t)((a.vec ? p.cap / 4 + 64 : p.cap) + kLongPad + p.cap / 2 + 64 + kLongPad + 2 * (L + (L + 2) * L)) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    const size_t max_lds = 100 * 1024;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt1_long_kernel<L, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
-    attr_set = true;
-  }
+  static DynLdsOnce lds_once;
+  if (!lds_once.ensure(reinterpret_cast<const void*>(&dwt1_long_kernel<L, T>), 100 * 1024)) return MIFWT_ERR_LAUNCH;
   const unsigned grid = (unsigned)(rows * (p.nchunks + 1));
   hipLaunchKernelGGL((dwt1_long_kernel<L, T>), dim3(grid), dim3(T), lds, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
@@ -768,11 +764,8 @@ int launch_inv_long_f64(const InvLongPlan& p, int64_t rows, const int* m, const 
     a.ghi[i] = hi[i];
   }
   const size_t lds = (size_t)(p.cap + kLongPad + p.cap / 2 + 64 + kLongPad) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&idwt1_long_kernel_f64<L, kLongThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    attr_set = true;
-  }
+  static DynLdsOnce lds_once;
+  if (!lds_once.ensure(reinterpret_cast<const void*>(&idwt1_long_kernel_f64<L, kLongThreads>), 100 * 1024)) return MIFWT_ERR_LAUNCH;
   const unsigned grid = (unsigned)(rows * p.nchunks);
   hipLaunchKernelGGL((idwt1_long_kernel_f64<L, kLongThreads>), dim3(grid), dim3(kLongThreads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;

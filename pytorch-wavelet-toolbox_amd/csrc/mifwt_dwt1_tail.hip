@@ -216,15 +216,12 @@ int dwt1_tail(int dtype, int filt_len, int mode, int64_t rows, int64_t n0, int n
   a.cap = (int)n0 < 32 ? 32 : (((int)n0 + 3) & ~3);
   const int m0 = ((int)n0 + filt_len - 1) >> 1;
   const size_t lds = (size_t)(a.cap + (m0 < 32 ? 32 : ((m0 + 3) & ~3))) * esz;
-  static bool attr_set[2] = {false, false};
+  static DynLdsOnce lds_once[2];
   const int ti = dtype == MIFWT_F64 ? 1 : 0;
-  if (!attr_set[ti]) {
+  {
     const int max_lds = (dwt1_tail_max_n(dtype) + (dwt1_tail_max_n(dtype) + kTailMaxTaps) / 2 + 8) * esz;
-    if (ti)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt1_tail_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    else
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt1_tail_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    attr_set[ti] = true;
+    const void* fn = ti ? reinterpret_cast<const void*>(&dwt1_tail_kernel<double>) : reinterpret_cast<const void*>(&dwt1_tail_kernel<float>);
+    if (!lds_once[ti].ensure(fn, max_lds)) return MIFWT_ERR_LAUNCH;
   }
   if (ti)
     hipLaunchKernelGGL((dwt1_tail_kernel<double>), dim3((unsigned)rows), dim3(tail_threads(n0)), lds, stream, a);
@@ -289,15 +286,12 @@ int idwt1_tail(int dtype, int filt_len, int64_t rows, int64_t m0, int nlevels, c
   a.cap = (need_big + 3) & ~3;
   a.cap_small = (need_small + 3) & ~3;
   const size_t lds = (size_t)(a.cap + 2 * a.cap_small) * esz;
-  static bool attr_set[2] = {false, false};
+  static DynLdsOnce lds_once[2];
   const int ti = dtype == MIFWT_F64 ? 1 : 0;
-  if (!attr_set[ti]) {
+  {
     const int max_lds = 2 * (dwt1_tail_max_n(dtype) + 64) * esz;
-    if (ti)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&idwt1_tail_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    else
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&idwt1_tail_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    attr_set[ti] = true;
+    const void* fn = ti ? reinterpret_cast<const void*>(&idwt1_tail_kernel<double>) : reinterpret_cast<const void*>(&idwt1_tail_kernel<float>);
+    if (!lds_once[ti].ensure(fn, max_lds)) return MIFWT_ERR_LAUNCH;
   }
   if (ti)
     hipLaunchKernelGGL((idwt1_tail_kernel<double>), dim3((unsigned)rows), dim3(tail_threads(out_len[nlevels - 1])), lds, stream, a);

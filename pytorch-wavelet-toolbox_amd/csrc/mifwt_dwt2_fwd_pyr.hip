@@ -62,6 +62,7 @@ struct PyrArgs {
   int pitch0, pitch1, pitch2;   // bytes of a staged row / a ring-1 row / a ring-2 row
   int nl1, nl2, nl3;            // waves of level 1 / 2 / 3
   int mode;
+  int xcd_map;
   unsigned long long* prof;
   int dbg;
   f2 tap[L];
@@ -152,6 +153,10 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
     return;  // (a wave that has ended does not take part in the barriers of the others)
 
   int bid = blockIdx.x;
+  if (a.xcd_map) {  // workgroups go to the 8 XCDs round-robin: give every XCD whole images (all row segments of an image share an L2)
+    const int per = gridDim.x >> 3;
+    bid = (bid & 7) * per + (bid >> 3);
+  }
   const int grp = bid % a.ngroups;
   bid /= a.ngroups;
   const int seg = bid % a.nseg, img = bid / a.nseg;
@@ -378,8 +383,13 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
             constexpr int R = (4 * SM + j) % HP;  // its index modulo L/2
             f2 ha[NC1], hb[NC1];
             h_pair(w[2 * jj], w[2 * jj + 1], ha, hb);
+#ifdef MIFWT_PYR_EXP
+            if (!(a.dbg & 64)) acc.template feed<0, R>(tap, ha);
+            if (!(a.dbg & (64 | 8))) acc.template feed<1, R>(tap, hb);
+#else
             acc.template feed<0, R>(tap, ha);
             acc.template feed<1, R>(tap, hb);
+#endif
             const int i = rA[1] + 4 * s + j - (HP - 1);  // the level-1 row it completes
             const f2 (&lo)[NC1] = acc.lo[PyrAcc<L, NC1>::done(R)];
             const f2 (&hi)[NC1] = acc.hi[PyrAcc<L, NC1>::done(R)];
@@ -797,6 +807,8 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
                        const double* hi, hipStream_t stream) {
   PyrPlan p;
   if (!pyr_plan(NLEV, d, &p)) return MIFWT_ERR_UNSUPPORTED;
+  // LDS-DMA moves 16 aligned bytes per lane (the strides are checked in dwt2_fwd_pyr_supported, the base only exists here)
+  if (reinterpret_cast<uintptr_t>(x) & 15) return MIFWT_ERR_UNSUPPORTED;
   PyrArgs<L, NLEV> a;
   a.x = static_cast<const float*>(x);
   a.xs_b = d[0]->sig_stride[0];
@@ -840,21 +852,17 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
   a.mode = d[0]->mode;
   a.dbg = g_options[MIFWT_OPT_DEBUG];
   a.prof = g_pyr_prof;
+  const int64_t nwg_all = d[0]->batch * p.nseg * p.ngroups;
+  a.xcd_map = (a.dbg & 32) && (nwg_all % 8 == 0) ? 1 : 0;
   for (int m = 0; m < L; ++m) a.tap[m] = (f2){(float)lo[m], (float)hi[m]};
   const int64_t nwg = d[0]->batch * p.nseg * p.ngroups;
   if (nwg > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
   // (the per-wave cycle profile of tools/pyr_prof.py exists for the three-level 8-tap kernel only)
   constexpr bool kCanProf = L == 8 && NLEV == 3;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return MIFWT_ERR_LAUNCH;
-    if (kCanProf && hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, kCanProf>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return MIFWT_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static DynLdsOnce lds_once, lds_once_prof;
+  if (!lds_once.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, false>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
+  if (kCanProf && !lds_once_prof.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, kCanProf>), 160 * 1024))
+    return MIFWT_ERR_LAUNCH;
   if (kCanProf && a.prof)
     hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, kCanProf>), dim3((unsigned)nwg), dim3(64 * kPyrWaves), p.lds, stream, a);
   else

@@ -400,11 +400,8 @@ int launch_small(int nlev, const mifwt_level_desc* const* d, const SmallPlan& p,
               : 0;
   a.div_park = make_fastdiv((uint32_t)(a.vec ? a.W[0] / 4 : a.W[0]));
   for (int m = 0; m < L; ++m) a.tap[m] = (f2){(float)lo[m], (float)hi[m]};
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt2_fwd_small_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize, kSmallLdsBytes);
-    attr_set = true;
-  }
+  static DynLdsOnce lds_once;
+  if (!lds_once.ensure(reinterpret_cast<const void*>(&dwt2_fwd_small_kernel<L>), kSmallLdsBytes)) return MIFWT_ERR_LAUNCH;
   hipLaunchKernelGGL((dwt2_fwd_small_kernel<L>), dim3((unsigned)p.grid), dim3(p.threads), p.lds, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }

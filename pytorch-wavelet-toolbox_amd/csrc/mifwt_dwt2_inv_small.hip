@@ -288,11 +288,8 @@ int launch_ismall(int nlev, const mifwt_level_desc* const* d, const ISmallPlan& 
     a.tlo[j] = (f2){(float)lo[2 * j], (float)lo[2 * j + 1]};
     a.thi[j] = (f2){(float)hi[2 * j], (float)hi[2 * j + 1]};
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&idwt2_small_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize, kISLdsBytes);
-    attr_set = true;
-  }
+  static DynLdsOnce lds_once;
+  if (!lds_once.ensure(reinterpret_cast<const void*>(&idwt2_small_kernel<L>), kISLdsBytes)) return MIFWT_ERR_LAUNCH;
   hipLaunchKernelGGL((idwt2_small_kernel<L>), dim3((unsigned)p.grid), dim3(p.threads), p.lds, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }

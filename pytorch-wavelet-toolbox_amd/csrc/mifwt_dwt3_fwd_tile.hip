@@ -607,32 +607,21 @@ int launch3(const mifwt_level_desc* d, const void* x, void* approx, void* const*
     constexpr int ID = 2 * kTailTZ + L - 2, IRY = 2 * kTailTY + L - 2;
     const int nzb = (a.Do + kTailTZ - 1) / kTailTZ, nyb = (a.Ho + kTailTY - 1) / kTailTY;
     const size_t tail_lds = (size_t)(2 * ID * IRY + 4 * ID * kTailTY) * rem * sizeof(float);
-    static bool tail_attr_set = false;
-    if (!tail_attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt3_fwd_tail_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)((size_t)(2 * ID * IRY + 4 * ID * kTailTY) * 8 * sizeof(float)));
-      tail_attr_set = true;
-    }
+    static DynLdsOnce tail_once;
+    if (!tail_once.ensure(reinterpret_cast<const void*>(&dwt3_fwd_tail_kernel<L>), (int)((size_t)(2 * ID * IRY + 4 * ID * kTailTY) * 8 * sizeof(float))))
+      return MIFWT_ERR_LAUNCH;
     const int64_t nblk = (int64_t)d->batch * nzb * nyb;
     if (nblk > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
     hipLaunchKernelGGL((dwt3_fwd_tail_kernel<L>), dim3((unsigned)nblk), dim3(256), tail_lds, stream, a, a.k_limit, rem, nzb, nyb);
     if (hipGetLastError() != hipSuccess) return MIFWT_ERR_LAUNCH;
   }
-  static bool attr_set = false;
+  static DynLdsOnce lds_once;
   if constexpr (kRoll) {
     static_assert(TR == 4, "the slice-per-wave kernel owns 4 rows");
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt3_fwd_slice_kernel<L, TDA>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      attr_set = true;
-    }
+    if (!lds_once.ensure(reinterpret_cast<const void*>(&dwt3_fwd_slice_kernel<L, TDA>), (int)lds_bytes)) return MIFWT_ERR_LAUNCH;
     hipLaunchKernelGGL((dwt3_fwd_slice_kernel<L, TDA>), dim3((unsigned)ntiles), dim3(256), lds_bytes, stream, a);
   } else {
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dwt3_fwd_tile_kernel<L, TD, TR>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-      attr_set = true;
-    }
+    if (!lds_once.ensure(reinterpret_cast<const void*>(&dwt3_fwd_tile_kernel<L, TD, TR>), (int)lds_bytes)) return MIFWT_ERR_LAUNCH;
     hipLaunchKernelGGL((dwt3_fwd_tile_kernel<L, TD, TR>), dim3((unsigned)ntiles), dim3(256), lds_bytes, stream, a);
   }
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;

@@ -97,6 +97,7 @@ class _SwtLevel(torch.autograd.Function):
     def backward(ctx, g_buf):
         lo, hi, dilation, scale = ctx.meta
         (x,) = ctx.saved_tensors
+        _fwt._no_double_backward_through_taps(ctx.taps)
         g_x = _IswtLevel.apply(g_buf[:, 0], g_buf[:, 1], lo[::-1], hi[::-1], dilation, scale) if ctx.needs_input_grad[0] else None
         g_lo = g_hi = None
         if x is not None and (ctx.needs_input_grad[5] or ctx.needs_input_grad[6]):
@@ -126,6 +127,7 @@ class _IswtLevel(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_y):
         lo, hi, dilation, scale = ctx.meta
+        _fwt._no_double_backward_through_taps(ctx.taps)
         g_a = g_d = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             g = _SwtLevel.apply(g_y, lo[::-1], hi[::-1], dilation, scale)

@@ -252,18 +252,36 @@ def test_second_order_gradients_swt():
         assert G.relerr(a.cpu().numpy(), b.cpu().numpy()) < 1e-11
 
 
-def test_tensor_taps_are_read_back_once_per_value():
-    """Tap tensors on the GPU are copied to the host once per value (the kernels take taps by value): repeated calls between two
-    updates of a learnable wavelet reuse the copy, an in-place update invalidates it."""
+def test_double_backward_through_learnable_taps_is_refused():
+    """create_graph=True with a learnable filter bank: the mixed second derivatives w.r.t. the taps are not built, so the backward
+    raises instead of returning a graph that silently lacks them (data-only double backward keeps working: tests above)."""
+    bank = tuple(torch.tensor(v, device=dev(), dtype=torch.float64, requires_grad=True) for v in ptwt_amd._wavelets.host_taps("db2"))
+    x = torch.randn(2, 32, 32, device=dev(), dtype=torch.float64, requires_grad=True)
+    y = sum(c.square().sum() if isinstance(c, torch.Tensor) else sum(t.square().sum() for t in c) for c in ptwt_amd.wavedec2(x, bank, level=1))
+    with pytest.raises(RuntimeError, match="double backward"):
+        torch.autograd.grad(y, x, create_graph=True)
+    (g,) = torch.autograd.grad(y, x)  # first order is fine
+    assert g.shape == x.shape
+
+
+def test_tensor_taps_are_read_live_on_every_call():
+    """Tap tensors on the GPU are read back on every top-level call, like the reference reads the live tensor: an update through
+    ``.data`` (which does not bump the tensor's version counter) must change the next transform."""
     from ptwt_amd import _wavelets
 
     t = torch.tensor([0.5, 0.5], device=dev())
-    a = _wavelets._to_floats(t)
-    assert _wavelets._to_floats(t) is a
+    assert _wavelets._to_floats(t) == (0.5, 0.5)
+    t.data.mul_(2.0)
+    assert _wavelets._to_floats(t) == (1.0, 1.0)
+    p = tuple(torch.nn.Parameter(torch.tensor(v, device=dev(), dtype=torch.float64)) for v in ptwt_amd._wavelets.host_taps("db2"))
+    xx = torch.randn(2, 64, device=dev(), dtype=torch.float64)
     with torch.no_grad():
-        t.mul_(2.0)
-    b = _wavelets._to_floats(t)
-    assert b == (1.0, 1.0) and b is not a
+        before = ptwt_amd.wavedec(xx, p, level=2)
+        for q in p:
+            q.data.mul_(2.0)
+        after = ptwt_amd.wavedec(xx, p, level=2)
+    assert torch.allclose(after[0], 4.0 * before[0], rtol=1e-12, atol=0)  # two levels, every filter doubled
+    assert torch.allclose(after[-1], 2.0 * before[-1], rtol=1e-12, atol=0)
     bank = tuple(torch.tensor(v, device=dev(), dtype=torch.float64) for v in ptwt_amd._wavelets.host_taps("db2"))
     x = torch.randn(2, 64, device=dev(), dtype=torch.float64)
     c1 = ptwt_amd.wavedec(x, bank, level=2)

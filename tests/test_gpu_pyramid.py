@@ -173,6 +173,43 @@ def test_pyramid_declines_what_it_cannot_serve():
     del lib
 
 
+def test_pyramid_misaligned_base_goes_to_another_route():
+    """A storage-offset view whose rows start 4 bytes past a 16-byte boundary (img[..., 1:1025] of a 1028-wide tensor): every stride
+    check of the streaming kernel passes, its LDS-DMA loads (16 aligned bytes per lane) cannot serve it — the engine must hand the call
+    to another route and the C entry point must refuse it.  Results against the oracle either way."""
+    import ctypes
+
+    g = torch.Generator().manual_seed(5)
+    for width in (512, 1024, 1280):
+        big = torch.randn(2, 300, width + 4, generator=g)
+        view = big[..., 1:width + 1]
+        xd = big.to(dev())[..., 1:width + 1]
+        assert xd.data_ptr() % 16 == 4 and xd.stride(1) % 4 == 0
+        got, kids = run_traced(lambda: ptwt_amd.wavedec2(xd, "db4", mode="reflect", level=3))
+        assert _engine.KID_PYRAMID not in kids, kids
+        want = O.wavedec2(view.numpy().astype(np.float64), "db4", mode="reflect", level=3)
+        for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(want)):
+            assert G.relerr(a.cpu().numpy(), b) < TOL32, (width, n)
+        # the aligned view of the same tensor does take the streaming kernel
+        xa = big.to(dev())[..., 4:width + 4]
+        _, kids = run_traced(lambda: ptwt_amd.wavedec2(xa, "db4", mode="reflect", level=3))
+        assert kids[0] == _engine.KID_PYRAMID, kids
+    # C ABI: the launch itself refuses a misaligned base (MIFWT_ERR_UNSUPPORTED = -2), nothing is launched
+    lib = _engine.load_library()
+    xd = torch.randn(2, 300, 1028, device=dev())[..., 1:1025]
+    plans = [_engine.HipLevelEngine._analysis_plan(xd, 8, _engine.MODE_IDS["reflect"])]
+    refs = (ctypes.POINTER(_engine.LevelDesc) * 1)(ctypes.pointer(plans[0].desc))
+    assert lib.mifwt_dwt2_fwd_pyramid_supported(1, refs) == 1
+    buf = torch.empty(plans[0].alloc_shape, device=dev())
+    pb = plans[0].plane_bytes
+    row = (ctypes.c_void_p * 3)(buf.data_ptr() + pb, buf.data_ptr() + 2 * pb, buf.data_ptr() + 3 * pb)
+    det = (ctypes.POINTER(ctypes.c_void_p) * 1)(ctypes.cast(row, ctypes.POINTER(ctypes.c_void_p)))
+    lo, hi = ptwt_amd._fwt.host_taps("db4")[:2]
+    rc = lib.mifwt_dwt2_fwd_pyramid(1, refs, xd.data_ptr(), det, buf.data_ptr(), (ctypes.c_double * 8)(*lo), (ctypes.c_double * 8)(*hi),
+                                    torch._C._cuda_getCurrentRawStream(0))
+    assert rc == -2, rc
+
+
 def test_pyramid_randomised_against_per_level_kernels():
     """Random plane shapes (one to four column groups, odd heights, widths that are multiples of 4), batches, filters, modes, level
     counts and row-segment overrides through the multi-level launch against the per-level kernels on the same data (those are
