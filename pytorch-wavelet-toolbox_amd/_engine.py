@@ -164,6 +164,7 @@ KID_LONG = 17
 KID_INV_LONG = 18
 KID_SMALL = 20
 KID_INV_SMALL = 21
+KID_INV_PYRAMID = 22
 MAX_PYRAMID_LEVELS = 8  # mifwt_dwt2_fwd_pyramid: three for the streaming kernel, eight for the small-plane kernel
 
 
@@ -651,18 +652,22 @@ class HipLevelEngine:
         return y
 
     def synthesis_pyramid(self, approx: torch.Tensor, levels: List[List[torch.Tensor]], rec_lo: Sequence[float],
-                          rec_hi: Sequence[float], out_extent: Sequence[int]):
-        """EVERY level of a 2-D reconstruction of a small plane in one launch (C ABI ``mifwt_dwt2_inv_pyramid``): the coarsest
-        approximation [B, Mh, Mw], ``levels`` = per level (coarsest first) its bands ad, da, dd [B, Mh_l, Mw_l]; the running
+                          rec_hi: Sequence[float], out_extent: Sequence[int], probe: bool = False):
+        """Several levels of a 2-D reconstruction in one launch (C ABI ``mifwt_dwt2_inv_pyramid``): EVERY level of a small plane (kernel
+        id 21), or the up-to-three levels handed over of a big one (kernel id 22, rows streamed through LDS rings).  ``approx``: the
+        coarsest approximation [B, Mh, Mw], ``levels`` = per level (coarsest first) its bands ad, da, dd [B, Mh_l, Mw_l]; the running
         approximation is cropped to the next level's band extents, the finest level's output to ``out_extent``.
-        Returns y [B, *out_extent], or None when the library does not serve this geometry (the caller then goes level by level)."""
-        _require_gpu(approx)
+        Returns y [B, *out_extent], or None when the library does not serve this geometry (the caller then goes level by level).
+        ``probe=True``: nothing is launched, the answer is the route (0 none, 1 small planes, 2 streaming) — ``approx`` may then be a
+        meta tensor."""
+        if not probe:
+            _require_gpu(approx)
         n = len(levels)
         if approx.dim() != 3 or approx.dtype != torch.float32 or n < 1 or n > MAX_PYRAMID_LEVELS:
-            return None
+            return 0 if probe else None
         flen = len(rec_lo)
         batch = approx.shape[0]
-        key = ("invpyr", approx.shape, approx.stride(), tuple((tuple(lv[0].shape[1:]), lv[0].stride(0)) for lv in levels), flen, tuple(out_extent))
+        key = ("invpyr", approx.shape, approx.stride(), tuple((tuple(lv[0].shape[1:]), lv[0].stride()) for lv in levels), flen, tuple(out_extent))
         plan = _plans.get(key)
         if plan is None:
             _trim_plans()
@@ -681,30 +686,29 @@ class HipLevelEngine:
                 for a in range(3):
                     d.sig_stride[a] = ydense[a]
                     d.approx_stride[a] = approx.stride(a) if i == 0 else dense[a]
-                    d.detail_stride[a] = dense[a]
-                d.detail_stride[0] = lv[0].stride(0)
+                    d.detail_stride[a] = lv[0].stride(a)
                 descs.append(d)
             refs = (ctypes.POINTER(LevelDesc) * n)(*[ctypes.pointer(d) for d in descs])
-            ok = tuple(approx.shape[1:]) == tuple(levels[0][0].shape[1:]) and bool(lib.mifwt_dwt2_inv_pyramid_supported(n, refs))
+            route = int(lib.mifwt_dwt2_inv_pyramid_supported(n, refs)) if tuple(approx.shape[1:]) == tuple(levels[0][0].shape[1:]) else 0
             p = _Plan()
             p.desc = descs[-1]
             p.ref = ctypes.byref(descs[-1])
             p.ws_bytes = 0
-            p.kid = KID_INV_SMALL
-            plan = _plans[key] = (p, descs, refs, ok)
-        p, _descs, refs, ok = plan
-        if not ok:
+            p.kid = KID_INV_SMALL if route == 1 else KID_INV_PYRAMID
+            plan = _plans[key] = (p, descs, refs, route)
+        p, _descs, refs, route = plan
+        if probe:
+            return route
+        if not route:
             return None
-        # dense band planes (views into a level buffer are: [B, 4, Mh, Mw] -> batch stride 4 planes); anything else is copied
-        dets = []
+        # the three detail bands of a level share their strides (views into one level buffer do; three separate dense tensors do);
+        # anything else goes level by level
         for lv in levels:
-            m = lv[0].shape[1:]
-            want = (lv[0].stride(0), int(m[1]), 1)
-            dets.append([t if t.stride() == want else None for t in lv])
-        if any(t is None for lv in dets for t in lv) or (approx.stride(1), approx.stride(2)) != (int(approx.shape[2]), 1):
-            return None
+            want = lv[0].stride()
+            if any(t.stride() != want for t in lv[1:]):
+                return None
         y = torch.empty((batch, *out_extent), dtype=approx.dtype, device=approx.device)
-        rows = [(ctypes.c_void_p * 3)(*[t.data_ptr() for t in lv]) for lv in dets]  # per call: plans are shared between threads
+        rows = [(ctypes.c_void_p * 3)(*[t.data_ptr() for t in lv]) for lv in levels]  # per call: plans are shared between threads
         det = (ctypes.POINTER(ctypes.c_void_p) * n)(*[ctypes.cast(r, ctypes.POINTER(ctypes.c_void_p)) for r in rows])
         lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
         lib = _lib

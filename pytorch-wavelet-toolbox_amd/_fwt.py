@@ -501,9 +501,9 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
             if len(outs) == len(folded):
                 cur = fuse(cur, 0, len(folded))
                 pos = len(folded)
+    any_grad = torch.is_grad_enabled() and (tap_t is not None or any(t.requires_grad for t in flat))
     # (the finest level's four coefficient planes alone must fit into LDS: 10 240 samples each at most)
-    if (ndim == 2 and folded and folded[-1][0].shape[-1] * folded[-1][0].shape[-2] <= 10240
-            and not (torch.is_grad_enabled() and (tap_t is not None or any(t.requires_grad for t in flat)))):
+    if ndim == 2 and folded and folded[-1][0].shape[-1] * folded[-1][0].shape[-2] <= 10240 and not any_grad:
         # every level of a small plane in one launch, the running approximation kept on chip (mifwt_dwt2_inv_pyramid); every
         # fused trip passes the reference's own checks first
         try:
@@ -517,14 +517,47 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
             y = _engine.ENGINE.synthesis_pyramid(cur, folded, rec_lo, rec_hi, out_ext)
             if y is not None:
                 return layout.unfold(y)
+    # big planes: the FINEST up to three levels (that is where the bytes are) in one streaming launch (mifwt_dwt2_inv_pyramid's
+    # second kernel); what is coarser goes first, through the loop below.  `tail` = how many levels that launch takes (0: none).
+    tail, tail_ext = 0, None
+    if ndim == 2 and folded and cur.dtype == torch.float32 and not any_grad and folded[-1][0].shape[-1] * folded[-1][0].shape[-2] > 10240:
+        try:
+            shapes, shape = [], tuple(cur.shape)
+            for lv in range(len(folded)):
+                shapes.append(shape)
+                shape = (shape[0], *level_out_extent(shape, lv))
+            final_ext = shape[1:]
+        except (ValueError, RuntimeError, AssertionError):
+            shapes = None  # the per-level loop below raises the reference's error at the level it belongs to
+        if shapes is not None:
+            for k in (3, 2, 1):
+                if k > len(folded):
+                    continue
+                first = len(folded) - k
+                if first == 0:
+                    a0 = cur
+                else:  # the approximation the coarser levels will hand over: dense, cropped to the level's band extents
+                    ext = tuple(min(c, s_) for c, s_ in zip(shapes[first], folded[first][0].shape)) if separable else shapes[first]
+                    a0 = torch.empty(ext, dtype=cur.dtype, device="meta")
+                if separable and first == 0:
+                    a0 = a0[tuple(slice(0, s_) for s_ in folded[0][0].shape)]
+                if _engine.ENGINE.synthesis_pyramid(a0, folded[first:], rec_lo, rec_hi, final_ext, probe=True) == 2:
+                    tail, tail_ext = k, final_ext
+                    break
     while pos < len(folded):
         det = folded[pos]
         if separable:
             cur = cur[tuple(slice(0, s_) for s_ in det[0].shape)]
+        if tail and pos == len(folded) - tail:
+            y = _engine.ENGINE.synthesis_pyramid(cur, folded[pos:], rec_lo, rec_hi, tail_ext)
+            if y is not None:
+                return layout.unfold(y)
+            tail = 0  # (bands that do not share their strides: level by level)
         out_ext = level_out_extent(tuple(cur.shape), pos)
         differentiable = torch.is_grad_enabled() and (cur.requires_grad or any(t.requires_grad for t in det) or tap_t is not None)
-        # levels go in pairs counted from the FINEST one (that is where the bytes are): an odd count starts with a single level
-        if (ndim == 2 and not differentiable and (len(folded) - pos) % 2 == 0
+        # levels go in pairs counted from the FINEST one of those left to this loop (that is where the bytes are): an odd count
+        # starts with a single level
+        if (ndim == 2 and not differentiable and (len(folded) - tail - pos) % 2 == 0 and len(folded) - tail - pos >= 2
                 and not (torch.is_grad_enabled() and any(t.requires_grad for t in folded[pos + 1]))):
             # two levels per launch, the approximation between them kept on chip (mifwt_dwt2_inv_pair); the checks of the
             # second trip are the reference's own and run before anything is launched.  Separable containers: the crop of the

@@ -500,7 +500,8 @@ int mifwt_dwt2_inv_pyramid_supported(int nlevels, const mifwt_level_desc* const*
   if (!descs || nlevels < 1 || nlevels > 8) return 0;
   for (int l = 0; l < nlevels; ++l)
     if (!descs[l] || validate(descs[l], 1) != MIFWT_OK) return 0;
-  return dwt2_inv_small_supported(nlevels, descs) ? 1 : 0;
+  if (dwt2_inv_small_supported(nlevels, descs)) return 1;
+  return nlevels <= 3 && dwt2_inv_pyr_supported(nlevels, descs) ? 2 : 0;
 }
 
 int mifwt_dwt2_inv_pyramid(int nlevels, const mifwt_level_desc* const* descs, const void* approx, const void* const* const* details, void* y,
@@ -517,9 +518,12 @@ int mifwt_dwt2_inv_pyramid(int nlevels, const mifwt_level_desc* const* descs, co
     for (int s = 0; s < 3; ++s)
       if (!details[l][s]) return MIFWT_ERR_BADARG;
   }
-  if (!dwt2_inv_small_supported(nlevels, descs)) return MIFWT_ERR_UNSUPPORTED;
-  if (descs[0]->batch == 0) return MIFWT_OK;
-  return dwt2_inv_small(nlevels, descs, approx, details, y, rec_lo, rec_hi, static_cast<hipStream_t>(stream));
+  if (dwt2_inv_small_supported(nlevels, descs)) {
+    if (descs[0]->batch == 0) return MIFWT_OK;
+    return dwt2_inv_small(nlevels, descs, approx, details, y, rec_lo, rec_hi, static_cast<hipStream_t>(stream));
+  }
+  if (nlevels > 3 || !dwt2_inv_pyr_supported(nlevels, descs)) return MIFWT_ERR_UNSUPPORTED;
+  return dwt2_inv_pyr(nlevels, descs, approx, details, y, rec_lo, rec_hi, static_cast<hipStream_t>(stream));
 }
 // Two consecutive 2-D synthesis levels in one launch (mifwt_idwt2_pair.hip); d2 describes the coarser level, whose
 // (cropped) output is the approximation of d1 and is never materialised.

@@ -173,6 +173,11 @@ bool dwt2_inv_small_supported(int nlevels, const mifwt_level_desc* const* d);
 int dwt2_inv_small(int nlevels, const mifwt_level_desc* const* d, const void* approx, const void* const* const* details, void* y,
                    const double* lo, const double* hi, hipStream_t stream);
 // details[l] = its three detail planes, approx = the last level's approximation
+// up to three consecutive 2-D synthesis levels of a big plane in one launch, rows streamed through registers and LDS rings
+// (mifwt_dwt2_inv_pyr.hip): f32, even L <= 8; d[0] = the coarsest level
+bool dwt2_inv_pyr_supported(int nlev, const mifwt_level_desc* const* d);
+int dwt2_inv_pyr(int nlev, const mifwt_level_desc* const* d, const void* approx, const void* const* const* details, void* y,
+                 const double* rec_lo, const double* rec_hi, hipStream_t stream);
 bool dwt2_fwd_pyr_supported(int nlev, const mifwt_level_desc* const* d);
 int dwt2_fwd_pyr(int nlev, const mifwt_level_desc* const* d, const void* x, void* const* const* details, void* approx,
                  const double* dec_lo, const double* dec_hi, hipStream_t stream);
