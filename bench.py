@@ -69,6 +69,13 @@ WORKLOADS = {
     # batches of image patches: the whole pyramid in one launch (kernel id 20)
     "wavedec2_db2_L3_4096x64x64_f32": ("wavedec2", (4096, 64, 64), "db2", 3, "reflect", torch.float32),
     "wavedec2_db2_L2_16384x32x32_f32": ("wavedec2", (16384, 32, 32), "db2", 2, "reflect", torch.float32),
+    # the round trip's second half on config 2's coefficients: one streaming launch (kernel id 22)
+    "waverec2_db4_L3_64x1024x1024_f32": ("waverec2", (64, 1024, 1024), "db4", 3, "reflect", torch.float32),
+    # the reference's own published 2-D / separable / 3-D speed-test shapes (examples/speed_tests/timeitconv_2d.py:38-57,
+    # timeitconv_2d_separable.py:43-85, timeitconv_3d.py:54-64)
+    "wavedec2_db5_L5_32x1000x1000_f32_periodic": ("wavedec2", (32, 1000, 1000), "db5", 5, "periodic", torch.float32),
+    "fswavedec2_db5_L5_32x1000x1000_f32_periodic": ("fswavedec2", (32, 1000, 1000), "db5", 5, "periodic", torch.float32),
+    "wavedec3_db5_L3_32x100x100x100_f32_periodic": ("wavedec3", (32, 100, 100, 100), "db5", 3, "periodic", torch.float32),
     # dry runs of the control flow (MIFWT_BENCH_DEVICE=cpu), not a benchmark shape
     "dryrun_wavedec2_db4_L2_6x96x96_f32": ("wavedec2", (6, 96, 96), "db4", 2, "reflect", torch.float32),
 }
@@ -121,55 +128,72 @@ def _flatten(coeffs):
 
 
 def cpu_baseline(fn, shape, wavelet, level, mode, dtype):
-    """The reference's CPU op sequence on this host's cores, on a bounded sample of the same workload."""
-    if fn != "wavedec2":
-        return None
+    """The reference's CPU op sequence (oracle/torch_cpu_port.py) on this host's cores, on a bounded sample of the same workload:
+    a slice of the batch sized to about 64 Mi samples (the path is linear in the batch), at most ~20 s of work."""
     from oracle import torch_cpu_port as P
 
+    ports = {"wavedec2": P.wavedec2, "wavedec": P.wavedec, "wavedec3": P.wavedec3, "fswavedec2": P.fswavedec2, "waverec2": P.waverec2}
+    if fn not in ports:
+        return None
+    port = ports[fn]
     cores = os.cpu_count() or 1
-    # config 2: the whole 64-image batch; batches of small planes: as many images as 64 planes of 1024^2 hold, i.e. a sample that
-    # takes the host long enough to be timed
-    sample_b = min(shape[0], max(64, (64 << 20) // max(1, shape[1] * shape[2])))
-    x = torch.randn(sample_b, *shape[1:], dtype=dtype)
+    per_item = prod(shape[1:])
+    sample_b = max(1, min(shape[0], max(8, (64 << 20) // per_item)))
+    cdtype = torch.float32 if dtype == torch.float16 else dtype  # (the reference has no half path on the CPU: conv in fp32)
+    x = torch.randn(sample_b, *shape[1:], dtype=cdtype)
+    if fn == "waverec2":
+        arg = P.wavedec2(x, wavelet, mode=mode, level=level)
+        run = lambda sl: port(tuple([arg[0][sl]] + [tuple(t[sl] for t in lv) for lv in arg[1:]]), wavelet)  # noqa: E731
+    else:
+        run = lambda sl: port(x[sl], wavelet, mode=mode, level=level)  # noqa: E731
     # oneDNN's conv does not scale to every core of a big host: probe a few thread counts on a small slice
     # and keep the fastest (reported as "cores")
+    probe = slice(0, max(1, sample_b // 8))
     best = (float("inf"), cores)
     for nt in sorted({cores, min(cores, 128), min(cores, 64), min(cores, 32), min(cores, 16)}):
         torch.set_num_threads(nt)
-        P.wavedec2(x[:4], wavelet, mode=mode, level=level)  # warm-up (oneDNN primitive creation)
+        run(slice(0, max(1, sample_b // 16)))  # warm-up (oneDNN primitive creation)
         t0 = time.perf_counter()
-        P.wavedec2(x[:8], wavelet, mode=mode, level=level)
+        run(probe)
         best = min(best, (time.perf_counter() - t0, nt))
     torch.set_num_threads(best[1])
-    P.wavedec2(x[:2], wavelet, mode=mode, level=level)
     times = []
     t_end = time.perf_counter() + 20.0
     while len(times) < 5 and (time.perf_counter() < t_end or not times):
         t0 = time.perf_counter()
-        P.wavedec2(x, wavelet, mode=mode, level=level)
+        run(slice(0, sample_b))
         times.append(time.perf_counter() - t0)
     med = statistics.median(times)
     return {
-        "value": round(x.numel() / med / 1e6, 2),
+        "value": round(sample_b * per_item / med / 1e6, 2),
         "unit": "Msamples/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": f"{sample_b}x{shape[1]}x{shape[2]} {str(dtype).split('.')[-1]} images, {wavelet} level {level} {mode}, "
+        "sample": f"{sample_b}x{'x'.join(map(str, shape[1:]))} {str(cdtype).split('.')[-1]} of the {shape[0]} batch elements, {fn} {wavelet} level {level} {mode}, "
                   f"median of {len(times)} runs (min {min(times):.4f}s, median {med:.4f}s), best of the probed thread counts "
-                  f"on a {cores}-core host; same ATen ops as ptwt's CPU path (pad + dense stride-2 conv2d), "
-                  "oracle/torch_cpu_port.py",
+                  f"on a {cores}-core host; the ATen ops of ptwt's CPU path for this function (oracle/torch_cpu_port.py; "
+                  "/root/reference itself cannot travel to the GPU box)",
     }
 
 
 def profiled_traffic(workload, kernel_label=""):
     """(HBM bytes per launch of the dominant kernel, name of the committed PMC summary it comes from): rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 gfx950 correction (tools/gpu_pmc_pyr.sh +
+    FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 gfx950 correction (tools/pmc_workload.sh, tools/gpu_pmc_pyr.sh +
     tools/summarize_prof.py).  PMC counters cannot be collected from inside this process, so the value is the one measured
-    when the newest profile of the SAME kernel under profiles/ was taken; (None, None) if there is none."""
+    when the newest profile of the SAME workload and kernel under profiles/ was taken; (None, None) if there is none."""
+    pdir = os.path.join(ROOT, "profiles")
+    names = sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []
+    for name in names:  # per-workload summaries (round 3 on)
+        if name.endswith(f"_pmc_{workload}.json"):
+            try:
+                with open(os.path.join(pdir, name)) as f:
+                    prof = json.load(f)
+                return prof.get("hbm_traffic_bytes"), "profiles/" + name
+            except Exception:
+                return None, None
     if workload != "wavedec2_db4_L3_64x1024x1024_f32":
         return None, None
-    pdir = os.path.join(ROOT, "profiles")
-    for name in sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []:
+    for name in names:
         if name.endswith("_pmc_level1.json") and not name.startswith("r01a"):
             try:
                 with open(os.path.join(pdir, name)) as f:
@@ -250,10 +274,18 @@ def main():
             out[i] = torch.randn(*shape[1:], dtype=torch.float32, device=dev).to(dtype)
         return out
 
-    bufs = [make_input() for _ in range(max(1, args.buffers))]
+    is_rec = "rec" in fn_name  # a reconstruction: the inputs are coefficient sets (made by the matching analysis, untimed)
+    if is_rec:
+        ana = getattr(ptwt_amd, fn_name.replace("rec", "dec"))
+        bufs = [ana(make_input(), wavelet, mode=mode, level=level) for _ in range(max(1, args.buffers))]
 
-    def step(i):
-        return fn(bufs[i % len(bufs)], wavelet, mode=mode, level=level)
+        def step(i):
+            return fn(bufs[i % len(bufs)], wavelet)
+    else:
+        bufs = [make_input() for _ in range(max(1, args.buffers))]
+
+        def step(i):
+            return fn(bufs[i % len(bufs)], wavelet, mode=mode, level=level)
 
     # spin-up (untimed, reported in the JSON): bring the device out of its idle clocks before the W warm-up steps
     spin_steps = 0
@@ -295,7 +327,13 @@ def main():
     lvl1_b2b_ms = lvl1_b2b_min = None
     fused_levels = 1
     first_kid = events[0][1] if events else -1
-    if fn_name in ("wavedec2", "fswavedec2", "wavedec3", "wavedec"):
+    launch = None
+    if is_rec and events and len({e[2] for e in events}) == 1:
+        # the whole reconstruction is ONE launch (the streaming / small-plane multi-level kernels): the call is the launch
+        first_kid = events[-1][1]
+        fused_levels = level
+        launch = lambda b: fn(b, wavelet)  # noqa: E731
+    elif fn_name in ("wavedec2", "fswavedec2", "wavedec3", "wavedec"):
         taps = ptwt_amd._wavelets.host_taps(wavelet)
         mode_id = _engine.MODE_IDS[mode]
         if first_kid in (_engine.KID_PYRAMID, _engine.KID_SMALL):
@@ -309,6 +347,7 @@ def main():
             launch = lambda b: _engine.ENGINE.analysis_tail(b, taps[0], taps[1], mode_id, level)  # noqa: E731
         else:
             launch = lambda b: _engine.ENGINE.analysis(b, taps[0], taps[1], mode_id)  # noqa: E731
+    if launch is not None:
         for i in range(5):
             launch(bufs[i % len(bufs)])
         sync()
@@ -361,15 +400,18 @@ def main():
         comp_b, perlvl_b, lvl1_b, pair_b = algorithmic_bytes(shape[0], shape[1:], flen, level, esize)
         # dominant kernel = the level-1 analysis launch (largest signal extent); durations from HIP events
         # recorded on the launch stream inside the timed region
-        lvl1 = [s.elapsed_time(e) for (tag, kid, ext, s, e) in events if tag == "fwd" and tuple(ext) == tuple(shape[1:])]
+        lvl1 = [s.elapsed_time(e) for (tag, kid, ext, s, e) in events if tag in ("fwd", "inv") and tuple(ext) == tuple(shape[1:])]
         per_level_ms = {}
         for tag, kid, ext, s, e in events:
             per_level_ms.setdefault("x".join(map(str, ext)), []).append(s.elapsed_time(e))
         kid1 = next((kid for (tag, kid, ext, s, e) in events if tuple(ext) == tuple(shape[1:])), -1)
         if kid1 == _engine.KID_PAIR:
             lvl1_b = pair_b
-        if kid1 in (_engine.KID_PYRAMID, _engine.KID_LONG, _engine.KID_SMALL):
-            # input + the detail bands of the fused levels + the approximation of the last fused one
+        if kid1 == _engine.KID_INV_PYRAMID:
+            fused_levels = min(3, level)
+        if kid1 in (_engine.KID_PYRAMID, _engine.KID_LONG, _engine.KID_SMALL, _engine.KID_INV_PYRAMID, _engine.KID_INV_SMALL):
+            # input + the detail bands of the fused levels + the approximation of the last fused one (a reconstruction: the same bytes,
+            # read and written the other way round)
             lvl1_b = algorithmic_bytes(shape[0], shape[1:], flen, fused_levels, esize)[0]
         klabel = {1: "dwt2_fwd_stream_kernel (level 1)", 7: "dwt2_fwd_tile_kernel (level 1)", 0: "generic axis kernels (level 1)",
                   3: "streaming axis kernels (level 1)", 5: "fused 2-D planes + depth pass (level 1)", 9: "dwt3_fwd_tile_kernel (level 1)",
@@ -377,7 +419,11 @@ def main():
                   12: ("dwt2_fwd_roll_kernel" if flen >= 8 else "dwt2_fwd_pair_kernel") + " (levels 1+2 in one launch)",
                   16: f"dwt2_fwd_pyr_kernel (levels 1-{fused_levels} in one launch)",
                   17: f"dwt1_long_kernel (levels 1-{fused_levels} in one launch)",
-                  20: f"dwt2_fwd_small_kernel (levels 1-{fused_levels} in one launch, a workgroup per image)"}.get(kid1, f"kernel id {kid1} (level 1)")
+                  20: f"dwt2_fwd_small_kernel (levels 1-{fused_levels} in one launch, a workgroup per image)",
+                  22: f"idwt2_pyr_kernel (the {fused_levels} finest synthesis levels in one launch)",
+                  21: f"idwt2_small_kernel (all {fused_levels} synthesis levels in one launch, a workgroup per image)",
+                  13: "idwt2_pair_kernel (two synthesis levels in one launch)", 8: "idwt2_tile_kernel (finest level)",
+                  2: "dwt2_inv_stream_kernel (finest level)"}.get(kid1, f"kernel id {kid1} (level 1)")
         per_launch_event_ms = sum(lvl1) / max(1, len(lvl1))
         avg_ms = lvl1_b2b_ms if lvl1_b2b_ms else per_launch_event_ms
         achieved = lvl1_b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0

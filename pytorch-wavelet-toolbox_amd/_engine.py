@@ -172,6 +172,11 @@ def set_option(key: int, value: int) -> None:
     """Library-wide test/diagnostic switches (e.g. ``OPT_FORCE_GENERIC`` to bypass the fused kernels)."""
     _check(load_library().mifwt_set_option(key, value))
     _plans.clear()  # cached plans hold the scratch size and kernel id of the routing that was in force
+    for c in _routing_caches:
+        c.clear()
+
+
+_routing_caches: list = []  # other modules' per-geometry routing memos (cleared with the plans when an option changes)
 
 
 class _Plan:
@@ -651,23 +656,15 @@ class HipLevelEngine:
         self._run(p, 1, approx2, lambda ws, wsb, stream: lib.mifwt_dwt2_inv_pair(ref2, p.ref, ap, ptrs2, ptrs1, yp, lo, hi, stream))
         return y
 
-    def synthesis_pyramid(self, approx: torch.Tensor, levels: List[List[torch.Tensor]], rec_lo: Sequence[float],
-                          rec_hi: Sequence[float], out_extent: Sequence[int], probe: bool = False):
-        """Several levels of a 2-D reconstruction in one launch (C ABI ``mifwt_dwt2_inv_pyramid``): EVERY level of a small plane (kernel
-        id 21), or the up-to-three levels handed over of a big one (kernel id 22, rows streamed through LDS rings).  ``approx``: the
-        coarsest approximation [B, Mh, Mw], ``levels`` = per level (coarsest first) its bands ad, da, dd [B, Mh_l, Mw_l]; the running
-        approximation is cropped to the next level's band extents, the finest level's output to ``out_extent``.
-        Returns y [B, *out_extent], or None when the library does not serve this geometry (the caller then goes level by level).
-        ``probe=True``: nothing is launched, the answer is the route (0 none, 1 small planes, 2 streaming) — ``approx`` may then be a
-        meta tensor."""
-        if not probe:
-            _require_gpu(approx)
+    def synthesis_pyramid_plan(self, approx: torch.Tensor, levels: List[List[torch.Tensor]], flen: int, out_extent: Sequence[int]):
+        """The cached plan of :meth:`synthesis_pyramid` for this geometry — ``(plan, descs, refs, route)`` with route 0 (the library does
+        not serve it as one launch), 1 (every level of a small plane, kernel id 21) or 2 (the up-to-three levels handed over of a big
+        plane, kernel id 22).  Geometry only: ``approx`` and the bands may be meta tensors."""
         n = len(levels)
         if approx.dim() != 3 or approx.dtype != torch.float32 or n < 1 or n > MAX_PYRAMID_LEVELS:
-            return 0 if probe else None
-        flen = len(rec_lo)
+            return None
         batch = approx.shape[0]
-        key = ("invpyr", approx.shape, approx.stride(), tuple((tuple(lv[0].shape[1:]), lv[0].stride()) for lv in levels), flen, tuple(out_extent))
+        key = ("invpyr", approx.shape, approx.stride(), tuple((lv[0].shape, lv[0].stride()) for lv in levels), flen, tuple(out_extent))
         plan = _plans.get(key)
         if plan is None:
             _trim_plans()
@@ -696,19 +693,33 @@ class HipLevelEngine:
             p.ws_bytes = 0
             p.kid = KID_INV_SMALL if route == 1 else KID_INV_PYRAMID
             plan = _plans[key] = (p, descs, refs, route)
+        return plan
+
+    def synthesis_pyramid(self, approx: torch.Tensor, levels: List[List[torch.Tensor]], rec_lo: Sequence[float],
+                          rec_hi: Sequence[float], out_extent: Sequence[int], plan=None):
+        """Several levels of a 2-D reconstruction in one launch (C ABI ``mifwt_dwt2_inv_pyramid``): EVERY level of a small plane (kernel
+        id 21), or the up-to-three levels handed over of a big one (kernel id 22, rows streamed through LDS rings).  ``approx``: the
+        coarsest approximation [B, Mh, Mw], ``levels`` = per level (coarsest first) its bands ad, da, dd [B, Mh_l, Mw_l]; the running
+        approximation is cropped to the next level's band extents, the finest level's output to ``out_extent``.  ``plan``: what
+        :meth:`synthesis_pyramid_plan` returned for this very geometry (saves the lookup).
+        Returns y [B, *out_extent], or None when the library does not serve this geometry (the caller then goes level by level)."""
+        _require_gpu(approx)
+        if plan is None:
+            plan = self.synthesis_pyramid_plan(approx, levels, len(rec_lo), out_extent)
+            if plan is None:
+                return None
         p, _descs, refs, route = plan
-        if probe:
-            return route
         if not route:
             return None
         # the three detail bands of a level share their strides (views into one level buffer do; three separate dense tensors do);
         # anything else goes level by level
         for lv in levels:
             want = lv[0].stride()
-            if any(t.stride() != want for t in lv[1:]):
+            if lv[1].stride() != want or lv[2].stride() != want:
                 return None
-        y = torch.empty((batch, *out_extent), dtype=approx.dtype, device=approx.device)
-        rows = [(ctypes.c_void_p * 3)(*[t.data_ptr() for t in lv]) for lv in levels]  # per call: plans are shared between threads
+        n = len(levels)
+        y = torch.empty((approx.shape[0], *out_extent), dtype=approx.dtype, device=approx.device)
+        rows = [(ctypes.c_void_p * 3)(lv[0].data_ptr(), lv[1].data_ptr(), lv[2].data_ptr()) for lv in levels]  # per call: plans are shared between threads
         det = (ctypes.POINTER(ctypes.c_void_p) * n)(*[ctypes.cast(r, ctypes.POINTER(ctypes.c_void_p)) for r in rows])
         lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
         lib = _lib

@@ -396,6 +396,10 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
 
 
 # ------------------------------------------------------------------------------------------ synthesis
+_tail_memo: dict = {}  # geometry of a 2-D reconstruction -> (levels the streaming launch takes, final extents, its plan)
+_engine._routing_caches.append(_tail_memo)
+
+
 def _adjust_trim(res_size: int, next_size: int) -> int:
     """src/ptwt/_util.py:231-244 on the already L-2-cropped size."""
     if next_size == res_size:
@@ -519,37 +523,49 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
                 return layout.unfold(y)
     # big planes: the FINEST up to three levels (that is where the bytes are) in one streaming launch (mifwt_dwt2_inv_pyramid's
     # second kernel); what is coarser goes first, through the loop below.  `tail` = how many levels that launch takes (0: none).
-    tail, tail_ext = 0, None
+    # The decision depends on the geometry only and is remembered per geometry.
+    tail, tail_ext, tail_plan = 0, None, None
     if ndim == 2 and folded and cur.dtype == torch.float32 and not any_grad and folded[-1][0].shape[-1] * folded[-1][0].shape[-2] > 10240:
-        try:
-            shapes, shape = [], tuple(cur.shape)
-            for lv in range(len(folded)):
-                shapes.append(shape)
-                shape = (shape[0], *level_out_extent(shape, lv))
-            final_ext = shape[1:]
-        except (ValueError, RuntimeError, AssertionError):
-            shapes = None  # the per-level loop below raises the reference's error at the level it belongs to
-        if shapes is not None:
-            for k in (3, 2, 1):
-                if k > len(folded):
-                    continue
-                first = len(folded) - k
-                if first == 0:
-                    a0 = cur
-                else:  # the approximation the coarser levels will hand over: dense, cropped to the level's band extents
-                    ext = tuple(min(c, s_) for c, s_ in zip(shapes[first], folded[first][0].shape)) if separable else shapes[first]
-                    a0 = torch.empty(ext, dtype=cur.dtype, device="meta")
-                if separable and first == 0:
-                    a0 = a0[tuple(slice(0, s_) for s_ in folded[0][0].shape)]
-                if _engine.ENGINE.synthesis_pyramid(a0, folded[first:], rec_lo, rec_hi, final_ext, probe=True) == 2:
-                    tail, tail_ext = k, final_ext
-                    break
+        tkey = (cur.shape, cur.stride(), tuple((lv[0].shape, lv[0].stride()) for lv in folded), flen, separable)
+        hit = _tail_memo.get(tkey)
+        if hit is None:
+            hit = (0, None, None)
+            try:
+                shapes, shape = [], tuple(cur.shape)
+                for lv in range(len(folded)):
+                    shapes.append(shape)
+                    shape = (shape[0], *level_out_extent(shape, lv))
+                final_ext = shape[1:]
+            except (ValueError, RuntimeError, AssertionError):
+                shapes = None  # the per-level loop below raises the reference's error at the level it belongs to
+            if shapes is not None:
+                for k in (3, 2, 1):
+                    if k > len(folded):
+                        continue
+                    first = len(folded) - k
+                    if first == 0:
+                        a0 = cur
+                    else:  # the approximation the coarser levels will hand over: dense, cropped to the level's band extents
+                        ext = tuple(min(c, s_) for c, s_ in zip(shapes[first], folded[first][0].shape)) if separable else shapes[first]
+                        a0 = torch.empty(ext, dtype=cur.dtype, device="meta")
+                    if separable and first == 0:
+                        a0 = a0[tuple(slice(0, s_) for s_ in folded[0][0].shape)]
+                    pl = _engine.ENGINE.synthesis_pyramid_plan(a0, folded[first:], flen, final_ext)
+                    if pl is not None and pl[3] == 2:
+                        hit = (k, final_ext, pl)
+                        break
+            if len(_tail_memo) > 1024:
+                _tail_memo.clear()
+            _tail_memo[tkey] = hit
+        tail, tail_ext, tail_plan = hit
     while pos < len(folded):
         det = folded[pos]
         if separable:
             cur = cur[tuple(slice(0, s_) for s_ in det[0].shape)]
         if tail and pos == len(folded) - tail:
-            y = _engine.ENGINE.synthesis_pyramid(cur, folded[pos:], rec_lo, rec_hi, tail_ext)
+            # (the plan was made for a dense hand-over approximation; a strided one — a separable crop — is looked up afresh)
+            same = pos == 0 or cur.is_contiguous()
+            y = _engine.ENGINE.synthesis_pyramid(cur, folded[pos:], rec_lo, rec_hi, tail_ext, plan=tail_plan if same else None)
             if y is not None:
                 return layout.unfold(y)
             tail = 0  # (bands that do not share their strides: level by level)

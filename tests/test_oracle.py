@@ -181,3 +181,33 @@ def test_torch_cpu_port_matches_oracle(mode):
     got = P.wavedec2(torch.from_numpy(x), "db4", mode=mode, level=2)
     for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(want)):
         assert G.relerr(a.numpy(), b) < TOL64, (mode, n)
+
+
+@pytest.mark.parametrize("mode", O.MODES)
+def test_torch_cpu_ports_of_the_other_functions_match_oracle(mode):
+    """The cpu_baseline ports of wavedec / wavedec3 / fswavedec2 / waverec2 (the reference's ATen op sequences) equal the oracle."""
+    import torch
+
+    from oracle import torch_cpu_port as P
+
+    rng = np.random.default_rng(6)
+    x1 = rng.standard_normal((3, 101))
+    for a, b in zip(P.wavedec(torch.from_numpy(x1), "db3", mode=mode, level=3), O.wavedec(x1, "db3", mode=mode, level=3)):
+        assert G.relerr(a.numpy(), b) < TOL64, mode
+    x3 = rng.standard_normal((2, 20, 21, 22))
+    got, want = P.wavedec3(torch.from_numpy(x3), "db2", mode=mode, level=2), O.wavedec3(x3, "db2", mode=mode, level=2)
+    assert G.relerr(got[0].numpy(), want[0]) < TOL64
+    for g, w in zip(got[1:], want[1:]):
+        assert list(g) == list(w)
+        for k in w:
+            assert G.relerr(g[k].numpy(), w[k]) < TOL64, (mode, k)
+    x2 = rng.standard_normal((2, 37, 50))
+    got, want = P.fswavedec2(torch.from_numpy(x2), "db3", mode=mode, level=2), O.fswavedec2(x2, "db3", mode=mode, level=2)
+    assert G.relerr(got[0].numpy(), want[0]) < TOL64
+    for g, w in zip(got[1:], want[1:]):
+        for k in w:
+            assert G.relerr(g[k].numpy(), w[k]) < TOL64, (mode, k)
+    for wav in ("haar", "db3", "db4"):
+        c = O.wavedec2(x2, wav, mode=mode, level=3)
+        rec = P.waverec2(tuple([torch.from_numpy(c[0])] + [tuple(torch.from_numpy(v) for v in lv) for lv in c[1:]]), wav)
+        assert G.relerr(rec.numpy(), O.waverec2(c, wav)) < TOL64, (mode, wav)

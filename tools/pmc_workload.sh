@@ -1,0 +1,62 @@
+#!/bin/bash
+# rocprofv3 evidence for ONE bench.py workload: kernel-trace + stats summary, and PMC passes (FETCH_SIZE / WRITE_SIZE each in its own
+# pass, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) condensed into profiles-ready files under gpurun_out/:
+#   <TAG>_kernel_stats_<WL>.csv   per-kernel time of `python bench.py --workload WL` (rocprofv3 --kernel-trace --stats)
+#   <TAG>_pmc_<WL>.json           counters per dispatch of the kernel whose name contains KERNEL (the dominant one)
+# usage: TAG=r03 WL=waverec2_db4_L3_64x1024x1024_f32 KERNEL=idwt2_pyr_kernel bash tools/pmc_workload.sh
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$ROOT/gpurun_out/pmcw_$WL
+rm -rf $OUT; mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+CMD="python $ROOT/bench.py --workload $WL --steps ${STEPS:-60} --warmup 10 --no-cpu-baseline"
+( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $CMD ) > $OUT/kt.log 2>&1; echo "kernel-trace rc=$?"
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" \
+           "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  i=$((i+1))
+  ( timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o p$i -- $CMD ) > $OUT/p$i.log 2>&1; echo "pmc pass $i rc=$?"
+done
+cd $ROOT
+python - <<PY
+import collections, csv, glob, json
+out, kern, wl, tag = "$OUT", "$KERNEL", "$WL", "${TAG:-r03}"
+stats = glob.glob(out + "/kt/**/*kernel_stats.csv", recursive=True)
+if stats:
+    rows = list(csv.DictReader(open(stats[0])))
+    with open(f"gpurun_out/{tag}_kernel_stats_{wl}.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in rows[:12]:
+            w.writerow([r["Name"][:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+# per grid size: the same kernel name can serve launches of very different sizes
+trace = glob.glob(out + "/kt/**/*kernel_trace.csv", recursive=True)
+bygrid = collections.defaultdict(list)
+if trace:
+    for r in csv.DictReader(open(trace[0])):
+        if kern in r["Kernel_Name"]:
+            bygrid[r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", "")].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+pmc, meta = {}, {}
+for p in sorted(glob.glob(out + "/p*/**/*_counter_collection.csv", recursive=True)):
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(p)):
+        if kern not in r["Kernel_Name"]:
+            continue
+        per[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        meta.setdefault("kernel", r["Kernel_Name"][:110]); meta.setdefault("grid_size", r["Grid_Size"]); meta.setdefault("vgpr_count", r["VGPR_Count"])
+    for k, v in per.items():
+        v = v[len(v) // 4:]  # drop the spin-up launches
+        pmc[k] = sum(v) / max(1, len(v))
+res = dict(meta)
+res["workload"] = wl
+res["counters_per_dispatch"] = {k: round(v, 1) for k, v in sorted(pmc.items())}
+res["launch_ns_by_grid"] = {g: {"calls": len(v), "median": sorted(v)[len(v) // 2], "mean_last_half": round(sum(v[len(v) // 2:]) / max(1, len(v) - len(v) // 2), 1)} for g, v in bygrid.items()}
+c = res["counters_per_dispatch"]
+if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+    # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 FETCH_SIZE reports 1/2 of a wide coalesced stream (MI355X_MICROARCH.md, HBM section)
+    res["hbm_read_bytes_corrected"] = int(c["FETCH_SIZE"] * 1024 * 2)
+    res["hbm_write_bytes"] = int(c["WRITE_SIZE"] * 1024)
+    res["hbm_traffic_bytes"] = res["hbm_read_bytes_corrected"] + res["hbm_write_bytes"]
+json.dump(res, open(f"gpurun_out/{tag}_pmc_{wl}.json", "w"), indent=1)
+print(json.dumps(res, indent=1)[:3000])
+PY
