@@ -387,10 +387,6 @@ class HipLevelEngine:
         plans, n_ok, refs, kid = plan
         if n_ok == 0:
             return None
-        if kid == KID_PYRAMID and (x.data_ptr() & 15):
-            # the streaming kernel stages rows with LDS-DMA, 16 aligned bytes per lane: an offset view such as img[..., 1:1025]
-            # goes to the next route (the strides are part of the plan key, the base address is not)
-            return None
         bufs = []
         for pl in plans:
             b = torch.empty(pl.alloc_shape, dtype=x.dtype, device=x.device)

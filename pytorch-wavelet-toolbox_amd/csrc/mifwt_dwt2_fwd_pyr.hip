@@ -30,8 +30,8 @@
 //   * boundary extension: pad columns are filled inside LDS by the waves that read them, right before they do (a row is
 //     complete one barrier after it was written, whoever wrote its columns); out-of-plane rows in zero mode are zero rows.
 // Results agree with the per-level kernels to rounding (different summation order), with the fp64 oracle within 1e-6.
-// f32, even L <= 8, modes zero / constant / reflect / symmetric (periodic needs the far side of the plane), level-0 rows of a
-// multiple of 4 samples that start on 16-byte boundaries.
+// f32, even L <= 8, modes zero / constant / reflect / symmetric (periodic needs the far side of the plane); input rows of any length
+// and alignment.
 // Algorithmic traffic: 4 B H W read + 4 B (3 H1 W1 [+ 3 H2 W2] + 4 H_N W_N) written.
 #include "mifwt_pyr.h"
 
@@ -57,6 +57,7 @@ struct PyrArgs {
   int xs_h, ds_h[NLEV], as_h;
   int H[NLEV + 1], W[NLEV + 1];
   int ngroups, nseg, seg_rows;  // column groups per plane, row segments, level-NLEV rows per segment
+  int seg0_rows;                // ... of the FIRST segment (= seg_rows unless MIFWT_OPT_DEBUG bit 7 asks for a longer one)
   int cpg0, cpg;                // level-NLEV columns of group 0 / of the other groups
   int nchunks, nbuf;            // 1 KiB requests per level-0 row, staging sub-buffers of kPyrSub rows
   int pitch0, pitch1, pitch2;   // bytes of a staged row / a ring-1 row / a ring-2 row
@@ -166,8 +167,8 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
 
   // ---- row ranges of this segment: computed rows [rA, rB) and owned rows [oA, oB) per level (index = level) -------------
   int rA[NLEV + 1], rB[NLEV + 1], oA[NLEV + 1], oB[NLEV + 1];
-  oA[NLEV] = rA[NLEV] = seg * a.seg_rows;
-  oB[NLEV] = rB[NLEV] = seg == a.nseg - 1 ? a.H[NLEV] : min(a.H[NLEV], rA[NLEV] + a.seg_rows);
+  oA[NLEV] = rA[NLEV] = seg == 0 ? 0 : a.seg0_rows + (seg - 1) * a.seg_rows;
+  oB[NLEV] = rB[NLEV] = seg == a.nseg - 1 ? a.H[NLEV] : min(a.H[NLEV], rA[NLEV] + (seg == 0 ? a.seg0_rows : a.seg_rows));
 #pragma unroll
   for (int l = NLEV - 1; l >= 1; --l) {
     oA[l] = 2 * oA[l + 1];
@@ -318,9 +319,12 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
       const int kk = lane / NP, p = lane - kk * NP;
       const bool left = p < HL;
       const int e = left ? p - HL : a.W[0] + (p - HL);
-      if (kk < kPyrSub && !zero_mode && (left ? wlo < 0 : whi >= a.W[0])) {
+      // (zero mode: the pads are zeros from the LDS initialisation — except the right one of rows that are not a multiple of 4
+      // samples long, where the last lane of a row's DMA request brings up to three samples of whatever follows the row)
+      const bool zfix = zero_mode && !left && (a.W[0] & 3) != 0;
+      if (kk < kPyrSub && (!zero_mode || zfix) && (left ? wlo < 0 : whi >= a.W[0])) {
         f_on = true;
-        f_src = (uint32_t)(kk * a.pitch0) + 4u * (uint32_t)(kPyrPad + fold(e, a.W[0]) - g0);
+        f_src = (uint32_t)(kk * a.pitch0) + 4u * (uint32_t)(kPyrPad + (zero_mode ? 0 : fold(e, a.W[0])) - g0);
         f_dst = (uint32_t)(kk * a.pitch0) + 4u * (uint32_t)(kPyrPad + e - g0);
       }
     }
@@ -369,7 +373,7 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
           unsigned char* sb = stage + bi * (kPyrSub * a.pitch0);
           bi = bi + 1 == a.nbuf ? 0 : bi + 1;
           if (f_any) {
-            const float v = *reinterpret_cast<const float*>(sb + f_src);
+            const float v = zero_mode ? 0.f : *reinterpret_cast<const float*>(sb + f_src);
             wave_lds_fence();
             if (f_on) *reinterpret_cast<float*>(sb + f_dst) = v;
             wave_lds_fence();
@@ -663,7 +667,7 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
 struct PyrPlan {
-  int ngroups, nseg, seg_rows, cpg0, cpg, nchunks, nbuf, pitch0, pitch1, pitch2, nl1, nl2, nl3, lds;
+  int ngroups, nseg, seg_rows, seg0_rows, cpg0, cpg, nchunks, nbuf, pitch0, pitch1, pitch2, nl1, nl2, nl3, lds;
 };
 
 // columns of level NLEV a group may own: the level-1 / 2 / 3 lane grids hold 4 x 192 / 3 x 128 / 3 x 64 columns, a staged row
@@ -764,6 +768,21 @@ static bool pyr_plan(int nlev, const mifwt_level_desc* const* d, PyrPlan* p) {
   p->seg_rows = (HN + nseg - 1) / nseg;
   p->nseg = (HN + p->seg_rows - 1) / p->seg_rows;
   if (p->nseg > 1 && HN - (p->nseg - 1) * p->seg_rows < 8) --p->nseg;
+  p->seg0_rows = p->seg_rows;
+  // Every segment but the first streams a prologue of (2^nlev - 1) (L - 2) level-0 rows.  Giving the first one that many rows more
+  // (config 2: 38 + 3 x 32 level-3 rows = 304 / 298 level-0 rows per workgroup, against 272 / 314 / 314 / 298 for equal segments)
+  // was measured SLOWER in the whole kernel, twice: 104.2 against 100.8 us (profiles/r03e_seg0.txt; round 2 saw the same with the
+  // arithmetic alone) — the kernel is bound by the memory system, not by its longest workgroup, and the early finishers of the top
+  // segments hand their bandwidth to the rest.  Equal segments stay the default; MIFWT_OPT_DEBUG bit 7 switches the long first one on.
+  if (p->nseg > 1 && g_options[MIFWT_OPT_PAIR_ROWS] <= 0 && (g_options[MIFWT_OPT_DEBUG] & 128)) {
+    const double halo = ((1 << nlev) - 1) * (double)HL / (double)(1 << nlev);
+    int y = (int)((HN - halo) / p->nseg + 0.5);
+    int x = HN - (p->nseg - 1) * y;
+    if (y >= 8 && x >= y) {
+      p->seg_rows = y;
+      p->seg0_rows = x;
+    }
+  }
   return true;
 }
 
@@ -774,8 +793,7 @@ bool dwt2_fwd_pyr_supported(int nlev, const mifwt_level_desc* const* d) {
   if (d0->ndim != 2 || d0->dtype != MIFWT_F32 || L < 2 || L > 8 || (L & 1)) return false;
   if (d0->mode == MIFWT_MODE_PERIODIC || d0->mode < 0 || d0->mode > MIFWT_MODE_SYMMETRIC) return false;
   if (d0->batch < 1 || d0->sig_stride[2] != 1) return false;
-  // LDS-DMA moves 16 aligned bytes per lane: rows must start on 16-byte boundaries and hold a multiple of 4 samples
-  if ((d0->sig_extent[1] & 3) || (d0->sig_stride[1] & 3) || (d0->sig_stride[0] & 3)) return false;
+  // (rows of any length and alignment: the LDS-DMA engine takes 16 bytes per lane from 4-byte aligned addresses, tools/dma_probe.hip)
   const int64_t lim = int64_t(1) << 29;  // byte offsets inside one image stay below 2^31
   if (d0->sig_extent[0] * d0->sig_stride[1] >= lim) return false;
   for (int l = 0; l < nlev; ++l) {
@@ -807,8 +825,6 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
                        const double* hi, hipStream_t stream) {
   PyrPlan p;
   if (!pyr_plan(NLEV, d, &p)) return MIFWT_ERR_UNSUPPORTED;
-  // LDS-DMA moves 16 aligned bytes per lane (the strides are checked in dwt2_fwd_pyr_supported, the base only exists here)
-  if (reinterpret_cast<uintptr_t>(x) & 15) return MIFWT_ERR_UNSUPPORTED;
   PyrArgs<L, NLEV> a;
   a.x = static_cast<const float*>(x);
   a.xs_b = d[0]->sig_stride[0];
@@ -839,6 +855,7 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
   a.ngroups = p.ngroups;
   a.nseg = p.nseg;
   a.seg_rows = p.seg_rows;
+  a.seg0_rows = p.seg0_rows;
   a.cpg0 = p.cpg0;
   a.cpg = p.cpg;
   a.nchunks = p.nchunks;

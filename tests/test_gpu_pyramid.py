@@ -161,53 +161,35 @@ def test_pyramid_declines_what_it_cannot_serve():
         got = _engine.ENGINE.analysis_pyramid(torch.randn(*shape, device=dev()), *taps, _engine.MODE_IDS["reflect"], 3)
         assert (got is not None) == served, shape
     _engine.set_option(_engine.OPT_PYRAMID_MODE, 1)
-    x = torch.randn(2, 650, 650, device=dev())  # rows of 650 samples are not a multiple of 4 (and too big for the small-plane kernel)
-    assert _engine.ENGINE.analysis_pyramid(x, *ptwt_amd._fwt.host_taps("db4")[:2], _engine.MODE_IDS["reflect"], 3) is None
     x = torch.randn(2, 640, 640, device=dev())  # (a plane too big for the small-plane kernel, which does serve periodic)
     assert _engine.ENGINE.analysis_pyramid(x, *ptwt_amd._fwt.host_taps("db4")[:2], _engine.MODE_IDS["periodic"], 3) is None
     x = torch.randn(2, 128, 128, device=dev())
     assert _engine.ENGINE.analysis_pyramid(x.double(), *ptwt_amd._fwt.host_taps("db4")[:2], _engine.MODE_IDS["reflect"], 3) is None
     # results of unsupported geometries still come from the other kernels
-    got = ptwt_amd.wavedec2(torch.randn(2, 650, 650, device=dev()), "db4", level=2)
-    assert got[0].shape[-1] == 167
+    got = ptwt_amd.wavedec2(torch.randn(2, 640, 640, device=dev()), "db4", level=2, mode="periodic")
+    assert got[0].shape[-1] == 165
     del lib
 
 
-def test_pyramid_misaligned_base_goes_to_another_route():
-    """A storage-offset view whose rows start 4 bytes past a 16-byte boundary (img[..., 1:1025] of a 1028-wide tensor): every stride
-    check of the streaming kernel passes, its LDS-DMA loads (16 aligned bytes per lane) cannot serve it — the engine must hand the call
-    to another route and the C entry point must refuse it.  Results against the oracle either way."""
-    import ctypes
-
+@pytest.mark.parametrize("mode", MODES)
+def test_pyramid_rows_of_any_length_and_alignment(mode):
+    """Rows that are not a multiple of 4 samples long and views whose rows start on 4-byte boundaries only (img[..., 1:1025] of a
+    1028-wide tensor): the LDS-DMA engine takes both (tools/dma_probe.hip); in zero mode the right pad is re-zeroed behind the last
+    lane of a row's request."""
     g = torch.Generator().manual_seed(5)
-    for width in (512, 1024, 1280):
-        big = torch.randn(2, 300, width + 4, generator=g)
-        view = big[..., 1:width + 1]
-        xd = big.to(dev())[..., 1:width + 1]
-        assert xd.data_ptr() % 16 == 4 and xd.stride(1) % 4 == 0
-        got, kids = run_traced(lambda: ptwt_amd.wavedec2(xd, "db4", mode="reflect", level=3))
-        assert _engine.KID_PYRAMID not in kids, kids
-        want = O.wavedec2(view.numpy().astype(np.float64), "db4", mode="reflect", level=3)
+    for shape in ((2, 130, 650), (1, 97, 1001), (2, 64, 515), (1, 200, 1278)):
+        check(torch.randn(*shape, generator=g), "db4", mode, 3 if shape[1] >= 97 else 2, [_engine.KID_PYRAMID])
+        check(torch.randn(*shape, generator=g), "db2", mode, 2, [_engine.KID_PYRAMID])
+    for width, off in ((512, 1), (1024, 3), (1022, 2)):
+        big = torch.randn(2, 150, width + 4, generator=g)
+        view = big[..., off:width + off]
+        xd = big.to(dev())[..., off:width + off]
+        assert xd.data_ptr() % 16 == 4 * off
+        got, kids = run_traced(lambda: ptwt_amd.wavedec2(xd, "db4", mode=mode, level=3))
+        assert kids == [_engine.KID_PYRAMID], kids
+        want = O.wavedec2(view.numpy().astype(np.float64), "db4", mode=mode, level=3)
         for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(want)):
-            assert G.relerr(a.cpu().numpy(), b) < TOL32, (width, n)
-        # the aligned view of the same tensor does take the streaming kernel
-        xa = big.to(dev())[..., 4:width + 4]
-        _, kids = run_traced(lambda: ptwt_amd.wavedec2(xa, "db4", mode="reflect", level=3))
-        assert kids[0] == _engine.KID_PYRAMID, kids
-    # C ABI: the launch itself refuses a misaligned base (MIFWT_ERR_UNSUPPORTED = -2), nothing is launched
-    lib = _engine.load_library()
-    xd = torch.randn(2, 300, 1028, device=dev())[..., 1:1025]
-    plans = [_engine.HipLevelEngine._analysis_plan(xd, 8, _engine.MODE_IDS["reflect"])]
-    refs = (ctypes.POINTER(_engine.LevelDesc) * 1)(ctypes.pointer(plans[0].desc))
-    assert lib.mifwt_dwt2_fwd_pyramid_supported(1, refs) == 1
-    buf = torch.empty(plans[0].alloc_shape, device=dev())
-    pb = plans[0].plane_bytes
-    row = (ctypes.c_void_p * 3)(buf.data_ptr() + pb, buf.data_ptr() + 2 * pb, buf.data_ptr() + 3 * pb)
-    det = (ctypes.POINTER(ctypes.c_void_p) * 1)(ctypes.cast(row, ctypes.POINTER(ctypes.c_void_p)))
-    lo, hi = ptwt_amd._fwt.host_taps("db4")[:2]
-    rc = lib.mifwt_dwt2_fwd_pyramid(1, refs, xd.data_ptr(), det, buf.data_ptr(), (ctypes.c_double * 8)(*lo), (ctypes.c_double * 8)(*hi),
-                                    torch._C._cuda_getCurrentRawStream(0))
-    assert rc == -2, rc
+            assert G.relerr(a.cpu().numpy(), b) < TOL32, (width, off, n)
 
 
 def test_pyramid_randomised_against_per_level_kernels():
