@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libmifwt.so")
+LIB_PATH = os.path.join(_PKG_DIR, os.environ.get("MIFWT_LIB", "libmifwt.so"))  # (MIFWT_LIB: an experiment build next to the product library, tools/ only)
 ABI_VERSION = 1
 
 MODE_IDS = {"zero": 0, "constant": 1, "reflect": 2, "periodic": 3, "symmetric": 4}

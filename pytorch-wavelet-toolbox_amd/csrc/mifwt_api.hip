@@ -256,6 +256,7 @@ int pick_kernel(const mifwt_level_desc* d, int direction) {
 namespace mifwt {
 extern unsigned long long* g_pyr_prof;
 int g_options[16] = {0};
+thread_local BatchSplit g_batch_split = {0, 0};
 }
 
 extern "C" {

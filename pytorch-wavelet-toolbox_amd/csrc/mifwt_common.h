@@ -12,6 +12,13 @@ namespace mifwt {
 constexpr int kMaxFilt = MIFWT_MAX_FILT;
 extern int g_options[16];  // mifwt_set_option() switches
 
+// Two-level batch for ONE call of the LDS-tile 2-D analysis kernel (thread-local, set and cleared by the 3-D composed route around that
+// call): the input images are `inner` slices per volume, `outer_stride` elements between volumes; inner == 0: off.
+struct BatchSplit {
+  int64_t inner, outer_stride;
+};
+extern thread_local BatchSplit g_batch_split;
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of a kernel ON A DEVICE: set it once per (kernel, device).  One of these
 // as a function-local static next to each launch; safe from threads that call with the GIL released (two racing threads at worst
 // both set the same value).

@@ -263,13 +263,25 @@ int plane3_fwd(const mifwt_level_desc* d, const void* x, void* approx, void* con
   float* scratch = static_cast<float*>(ws);  // [B, D, 4, Ho, Wo]
   bool foldable;
   const mifwt_level_desc p = plane_desc(d, D, &foldable);
-  const int64_t nb = foldable ? 1 : d->batch;
-  for (int64_t b = 0; b < nb; ++b) {
-    const float* xb = static_cast<const float*>(x) + b * d->sig_stride[0];
-    float* sb = scratch + b * D * 4 * plane;
-    void* det[3] = {sb + plane, sb + 2 * plane, sb + 3 * plane};
-    const int rc = dwt2_fwd_fused(&p, xb, sb, det, lo, hi, stream);
+  mifwt_level_desc pall = p;  // every slice of every volume in ONE launch: a two-level batch of the tile kernel's input
+  pall.batch = d->batch * D;
+  if (!foldable && dwt2_fwd_tile_supported(&pall) && d->batch * D < (int64_t(1) << 31)) {
+    // (the input of a deeper level is plane 0 of the previous level's [B, 8, D, H, W] buffer: volumes 8 D H W apart, slices H W apart —
+    // one launch per volume cost 32 launches of 5 us each on 32 x 54^3, profiles/r03h_kernel_trace_refshapes.txt)
+    void* det[3] = {scratch + plane, scratch + 2 * plane, scratch + 3 * plane};
+    g_batch_split = {D, d->sig_stride[0]};
+    const int rc = dwt2_fwd_tile(&pall, x, scratch, det, lo, hi, stream);
+    g_batch_split = {0, 0};
     if (rc != MIFWT_OK) return rc;
+  } else {
+    const int64_t nb = foldable ? 1 : d->batch;
+    for (int64_t b = 0; b < nb; ++b) {
+      const float* xb = static_cast<const float*>(x) + b * d->sig_stride[0];
+      float* sb = scratch + b * D * 4 * plane;
+      void* det[3] = {sb + plane, sb + 2 * plane, sb + 3 * plane};
+      const int rc = dwt2_fwd_fused(&p, xb, sb, det, lo, hi, stream);
+      if (rc != MIFWT_OK) return rc;
+    }
   }
   StreamJob jobs[4];
   for (int s = 0; s < 4; ++s) {  // plane band s (axes H, W) -> bands s (depth low) and 4 + s (depth high)

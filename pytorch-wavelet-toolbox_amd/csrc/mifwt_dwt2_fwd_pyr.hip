@@ -405,9 +405,9 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
             const bool own = i >= oA[1] && i < oB[1];
             const uint32_t v2 = own ? sv2 : kPyrOob;
             const uint32_t so = own ? (uint32_t)i * (uint32_t)a.ds_h[0] * 4u : 0u;
-            __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].x, hi[1].x}, rd, v2, so + o0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].y, lo[1].y}, rd, v2, so + o1, 0);
-            __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].y, hi[1].y}, rd, v2, so + o2, 0);
+            __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].x, hi[1].x}, rd, v2, so + o0, MIFWT_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].y, lo[1].y}, rd, v2, so + o1, MIFWT_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].y, hi[1].y}, rd, v2, so + o2, MIFWT_ST_AUX);
             if (rag) {
               const uint32_t v1 = own ? sv1 : kPyrOob;
               pyr_store1(hi[0].x, rd, v1, so + o0);
@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
             }
             if constexpr (NLEV == 1) {
               const uint32_t sa = own ? (uint32_t)i * (uint32_t)a.as_h * 4u : 0u;
-              __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].x, lo[1].x}, ra, v2, sa, 0);
+              __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].x, lo[1].x}, ra, v2, sa, MIFWT_ST_AUX);
               if (rag) pyr_store1(lo[0].x, ra, own ? sv1 : kPyrOob, sa);
             }
           });
@@ -544,9 +544,9 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
               const bool own = i >= oA[2] && i < oB[2];
               const uint32_t v2 = own ? sv2 : kPyrOob;
               const uint32_t so = own ? (uint32_t)i * (uint32_t)a.ds_h[1] * 4u : 0u;
-              __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].x, hi[1].x}, rd, v2, so + o0, 0);
-              __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].y, lo[1].y}, rd, v2, so + o1, 0);
-              __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].y, hi[1].y}, rd, v2, so + o2, 0);
+              __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].x, hi[1].x}, rd, v2, so + o0, MIFWT_ST_AUX);
+              __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].y, lo[1].y}, rd, v2, so + o1, MIFWT_ST_AUX);
+              __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].y, hi[1].y}, rd, v2, so + o2, MIFWT_ST_AUX);
               if (rag) {
                 const uint32_t v1 = own ? sv1 : kPyrOob;
                 pyr_store1(hi[0].x, rd, v1, so + o0);
@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
               }
               if constexpr (NLEV == 2) {
                 const uint32_t sa = own ? (uint32_t)i * (uint32_t)a.as_h * 4u : 0u;
-                __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].x, lo[1].x}, ra, v2, sa, 0);
+                __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].x, lo[1].x}, ra, v2, sa, MIFWT_ST_AUX);
                 if (rag) pyr_store1(lo[0].x, ra, own ? sv1 : kPyrOob, sa);
               }
             });

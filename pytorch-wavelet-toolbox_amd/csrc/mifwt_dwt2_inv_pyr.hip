@@ -157,7 +157,15 @@ __device__ __forceinline__ void ipyr_phase2(int ph, F&& f) {
 // dword (the compiler's hazard table assumes a scalar soffset lifts this hazard; on gfx950 it does not: the ragged-column path's
 // v_cndmask landed in that slot and every few rows a lane's fourth column came out wrong) — the wait states travel with the store
 __device__ __forceinline__ void ipyr_store4(const f4 data, rsrc_t rsrc, uint32_t voff, uint32_t soff) {
+#if MIFWT_ST_AUX == 17
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc0 sc1\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+#elif MIFWT_ST_AUX == 16
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+#elif MIFWT_ST_AUX == 2
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+#else
   asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+#endif
 }
 
 // one LDS-DMA piece: lanes whose 16 bytes start inside the row (voff < limit) move them to LDS [lds + 16 lane)

@@ -27,6 +27,8 @@ struct Dwt2TileArgs {
   const T* x;
   T* out[4];  // bands aa, ad, da, dd
   int64_t xs_b, xs_h;
+  int64_t xs_outer;  // two-level batch of the INPUT (the depth slices of the volumes of a 3-D level whose batch stride is not depth x
+  FastDiv div_in;    // slice stride): image i = outer (i / inner) x xs_outer + (i % inner) x xs_b; div_in.d == 0: one level
   int64_t os_b[4], os_h[4];
   int H, W, Ho, Wo;
   int tiles_c, tiles_r, ntiles;
@@ -35,6 +37,15 @@ struct Dwt2TileArgs {
   int sync_stage;
   typename TileArith<T>::vec2 tap[L];  // (dec_lo[m], dec_hi[m]) in the arithmetic type
 };
+
+// element offset of input image `img` (one- or two-level batch)
+template <typename T, int L>
+__device__ __forceinline__ int64_t tile_image_offset(const Dwt2TileArgs<T, L>& a, int img) {
+  if (a.div_in.d == 0) return (int64_t)img * a.xs_b;
+  uint32_t in;
+  const uint32_t out = a.div_in.divmod((uint32_t)img, in);
+  return (int64_t)out * a.xs_outer + (int64_t)in * a.xs_b;
+}
 
 // workgroups per CU that the tile's LDS footprint admits = waves per SIMD to allocate registers for (a 256-thread
 // workgroup puts one wave on each SIMD)
@@ -84,7 +95,7 @@ __global__ void __launch_bounds__(256, tile_occupancy(L, TR, sizeof(typename Til
   // ---- 1. input tile -> LDS ------------------------------------------------------------------------------------------
   const uint32_t img_bytes = ((uint32_t)(a.H - 1) * (uint32_t)a.xs_h + (uint32_t)a.W) * ES;
   const __amdgpu_buffer_rsrc_t xrsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(a.x + (int64_t)img * a.xs_b), 0, img_bytes, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(a.x + tile_image_offset(a, img)), 0, img_bytes, 0x00020000);
   constexpr uint32_t kOob = 0x80000000u;  // >= num_records: the load returns 0 without a memory request
   // columns / rows the tile's real outputs need (ragged last tiles request nothing beyond them)
   const int nc_need = 2 * (min(k0 + kTC, a.Wo) - k0) + L - 2;
@@ -208,6 +219,12 @@ int launch_tile(const mifwt_level_desc* d, const void* x, void* approx, void* co
   for (int s = 1; s < 4; ++s) a.out[s] = static_cast<T*>(details[s - 1]);
   a.xs_b = d->sig_stride[0];
   a.xs_h = d->sig_stride[1];
+  a.xs_outer = 0;
+  a.div_in.mul = a.div_in.shift = a.div_in.d = 0;
+  if (g_batch_split.inner > 0) {  // (set by the 3-D composed route around this one call: mifwt_compose.hip plane3_fwd)
+    a.div_in = make_fastdiv((uint32_t)g_batch_split.inner);
+    a.xs_outer = g_batch_split.outer_stride;
+  }
   for (int s = 0; s < 4; ++s) {
     a.os_b[s] = s == 0 ? d->approx_stride[0] : d->detail_stride[0];
     a.os_h[s] = s == 0 ? d->approx_stride[1] : d->detail_stride[1];

@@ -867,11 +867,13 @@ def test_idwt_pair_kernel_bit_identical_to_per_level(wavelet):
         for mode in ("reflect", "zero"):
             c = ptwt_amd.wavedec2(x, wavelet, mode=mode, level=level)
             _engine.level_events = []
+            _engine.set_option(_engine.OPT_PYRAMID_MODE, 2)  # (planes from 512 columns on would go to the streaming launch, kernel id 22)
             try:
                 got = ptwt_amd.waverec2(c, wavelet)
                 kids = [e[1] for e in _engine.level_events]
             finally:
                 _engine.level_events = None
+                _engine.set_option(_engine.OPT_PYRAMID_MODE, 0)
             _engine.set_option(_engine.OPT_PAIR_MODE, 2)
             try:
                 want = ptwt_amd.waverec2(c, wavelet)

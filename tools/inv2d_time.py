@@ -6,6 +6,9 @@ from ptwt_amd import _engine
 wav = sys.argv[1] if len(sys.argv) > 1 else 'db4'
 lev = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 shape = tuple(int(v) for v in sys.argv[3].split('x')) if len(sys.argv) > 3 else (64, 1024, 1024)
+import os
+if os.environ.get('MIFWT_NBUF'): _engine.set_option(2, int(os.environ['MIFWT_NBUF']))
+if os.environ.get('MIFWT_DBG'): _engine.set_option(11, int(os.environ['MIFWT_DBG']))
 cs = [ptwt_amd.wavedec2(torch.randn(*shape, device='cuda'), wav, level=lev) for _ in range(3)]
 for i in range(10): ptwt_amd.waverec2(cs[i % 3], wav)
 torch.cuda.synchronize()
@@ -17,7 +20,7 @@ for _ in range(5):
     e1.record(); torch.cuda.synchronize()
     res.append(e0.elapsed_time(e1) / 50 * 1e3)
 res.sort()
-print(f"waverec2 {wav} L{lev} {shape}: median {res[2]:.1f} us min {res[0]:.1f} us")
+print(f"waverec2 {wav} L{lev} {shape} lib={os.environ.get('MIFWT_LIB','-')} nbuf={os.environ.get('MIFWT_NBUF','-')} dbg={os.environ.get('MIFWT_DBG','-')}: median {res[2]:.1f} us min {res[0]:.1f} us")
 _engine.level_events = []
 for i in range(20): ptwt_amd.waverec2(cs[i % 3], wav)
 torch.cuda.synchronize()
