@@ -138,7 +138,7 @@ def cpu_baseline(fn, shape, wavelet, level, mode, dtype):
     port = ports[fn]
     cores = os.cpu_count() or 1
     per_item = prod(shape[1:])
-    sample_b = max(1, min(shape[0], max(8, (64 << 20) // per_item)))
+    sample_b = max(1, min(shape[0], (64 << 20) // per_item))
     cdtype = torch.float32 if dtype == torch.float16 else dtype  # (the reference has no half path on the CPU: conv in fp32)
     x = torch.randn(sample_b, *shape[1:], dtype=cdtype)
     if fn == "waverec2":

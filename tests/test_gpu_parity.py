@@ -632,6 +632,15 @@ def test_full_size_config3_properties():
     want = O.wavedec3(to_np(x[0]).astype(np.float64), "db2", level=3)
     got = tuple([c[0][0]] + [{k: v[0] for k, v in d.items()} for d in c[1:]])
     check_tree(got, want, TOL32, "config 3, batch element 0")
+    # every other batch element: its first sub-volume (the transform of x[b, :96, :96, :96] agrees with the full one wherever the
+    # filters do not reach past the crop: 40^3 / 16^3 / 6^3 coefficients of levels 1 / 2 / 3 from the volume's origin)
+    for b in range(1, 8):
+        wsub = O.wavedec3(to_np(x[b, :96, :96, :96]).astype(np.float64), "db2", level=3)
+        for lvl, n in ((1, 40), (2, 16), (3, 6)):
+            for key, ref in wsub[4 - lvl].items():
+                g = to_np(c[4 - lvl][key][b, :n, :n, :n])
+                assert G.relerr(g, ref[:n, :n, :n]) < TOL32, (b, lvl, key)
+        assert G.relerr(to_np(c[0][b, :6, :6, :6]), wsub[0][:6, :6, :6]) < TOL32, b
     y = torch.randn_like(x)
     cz = ptwt_amd.wavedec3(2 * x + y, "db2", level=3)
     cy = ptwt_amd.wavedec3(y, "db2", level=3)
@@ -647,9 +656,10 @@ def test_full_size_config4_slice_properties():
     x = torch.randn(64, 4096, 4096, device=dev())
     c = ptwt_amd.wavedec2(x, "db8", level=4)
     assert [tuple(t.shape[-2:]) for t in (c[0], c[1][0], c[2][0], c[3][0], c[4][0])] == [(270, 270), (270, 270), (525, 525), (1035, 1035), (2055, 2055)]
-    want = O.wavedec2(to_np(x[63]).astype(np.float64), "db8", level=4)
-    got = tuple([c[0][63]] + [tuple(t[63] for t in det) for det in c[1:]])
-    check_tree(got, want, TOL32, "config 4, image 63")
+    for b in (0, 31, 63):
+        want = O.wavedec2(to_np(x[b]).astype(np.float64), "db8", level=4)
+        got = tuple([c[0][b]] + [tuple(t[b] for t in det) for det in c[1:]])
+        check_tree(got, want, TOL32, f"config 4, image {b}")
     rec = ptwt_amd.waverec2(c, "db8")
     assert rec.shape == x.shape
     assert G.relerr(to_np(rec[:2]), to_np(x[:2])) < 2e-6 and (rec[60:] - x[60:]).abs().max().item() < 2e-5
@@ -676,6 +686,18 @@ def test_full_size_config5_slice_properties():
         w = want[1]["dd"][lo:-lo]
         g = got_dd[512 + lo: 512 + lo + w.shape[0]]
         assert G.relerr(g, w) < 5e-4
+        # levels 1 AND 2 of the same 2048-row band against the numpy oracle (not the on-device f64 transform): level 2 needs the
+        # level-1 approximation the kernels actually stored, i.e. rounded to f16 — feed the oracle that
+        lvl1 = ptwt_amd.fswavedec2(x[0:1, 1024:3072].contiguous(), "sym16", level=1)
+        a1_band = lvl1[0][0].double().cpu().numpy()  # f16-rounded level-1 approximation of the band
+        want2 = O.fswavedec2(a1_band, "sym16", level=1)
+        got2 = ptwt_amd.fswavedec2(lvl1[0], "sym16", level=1)
+        for key in ("ad", "da", "dd"):
+            assert G.relerr(got2[1][key][0].double().cpu().numpy(), want2[1][key]) < 5e-4, key
+        assert G.relerr(got2[0][0].double().cpu().numpy(), want2[0]) < 5e-4
+        want1 = O.fswavedec2(band, "sym16", level=1)
+        for key in ("ad", "da", "dd"):
+            assert G.relerr(lvl1[1][key][0].double().cpu().numpy(), want1[1][key]) < 5e-4, key
         small = x[1, :1024, :1024].contiguous()
         check = ptwt_amd.fswavedec2(small, "sym16", level=5)
         want = O.fswavedec2(small.double().cpu().numpy(), "sym16", level=5)
@@ -920,11 +942,13 @@ def test_idwt_pair_serves_separable_containers():
         for wavelet in ("db2", "db4"):
             c = ptwt_amd.fswavedec2(x, wavelet, level=3)
             _engine.level_events = []
+            _engine.set_option(_engine.OPT_PYRAMID_MODE, 2)  # (planes from 512 columns on would go to the streaming launch, kernel id 22)
             try:
                 got = ptwt_amd.fswaverec2(c, wavelet)
                 kids = [e[1] for e in _engine.level_events]
             finally:
                 _engine.level_events = None
+                _engine.set_option(_engine.OPT_PYRAMID_MODE, 0)
             _engine.set_option(_engine.OPT_PAIR_MODE, 2)
             try:
                 want = ptwt_amd.fswaverec2(c, wavelet)

@@ -133,10 +133,36 @@ def test_pyramid_config2_full_size_all_images():
         num = (a.double() - b).flatten(1).norm(dim=1)
         den = b.flatten(1).norm(dim=1)
         assert float((num / den).max()) < TOL32, n  # per image
-    for i in (0, 21, 42, 63):
-        want = O.wavedec2(x[i : i + 1].numpy().astype(np.float64), "db4", level=3)
+    # sixteen images against the numpy oracle itself (one vectorised oracle call per group of four)
+    for i0 in (0, 20, 40, 60):
+        want = O.wavedec2(x[i0 : i0 + 4].numpy().astype(np.float64), "db4", level=3)
+        for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(want)):
+            for k in range(4):
+                assert G.relerr(a[i0 + k].cpu().numpy(), b[k]) < TOL32, (i0 + k, n)
+
+
+def test_pyramid_batch_beyond_two_gib():
+    """600 x 1024^2 fp32: 2.5 GB of input, 2.5 GB of coefficients — image byte offsets beyond 2^31 through the streaming kernel (64-bit
+    image bases, 32-bit offsets inside an image).  The oracle on the first, one in the middle and the last image; every image of the
+    big batch bit-identical to the same image transformed in a 4-image batch (same kernel, small offsets)."""
+    g = torch.Generator(device=dev()).manual_seed(19)
+    xd = torch.empty(600, 1024, 1024, device=dev())
+    for i in range(0, 600, 50):
+        xd[i : i + 50] = torch.randn(50, 1024, 1024, device=dev(), generator=g)
+    got, kids = run_traced(lambda: ptwt_amd.wavedec2(xd, "db4", level=3))
+    assert kids == [_engine.KID_PYRAMID]
+    for i in (0, 311, 599):
+        want = O.wavedec2(xd[i : i + 1].cpu().numpy().astype(np.float64), "db4", level=3)
         for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(want)):
             assert G.relerr(a[i : i + 1].cpu().numpy(), b) < TOL32, (i, n)
+    for i0 in range(0, 600, 40):
+        small = ptwt_amd.wavedec2(xd[i0 : i0 + 4], "db4", level=3)
+        for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(small)):
+            assert torch.equal(a[i0 : i0 + 4], b), (i0, n)
+    rec, kids = run_traced(lambda: ptwt_amd.waverec2(got, "db4"))  # the streaming synthesis launch over the same offsets
+    assert kids == [_engine.KID_INV_PYRAMID]
+    for i0 in range(0, 600, 100):
+        assert float((rec[i0 : i0 + 100] - xd[i0 : i0 + 100]).abs().max()) < 2e-5
 
 
 def test_pyramid_linearity_and_roundtrip_full_size():
