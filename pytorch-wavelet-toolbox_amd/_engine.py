@@ -715,8 +715,18 @@ class HipLevelEngine:
                 return None
         n = len(levels)
         y = torch.empty((approx.shape[0], *out_extent), dtype=approx.dtype, device=approx.device)
-        rows = [(ctypes.c_void_p * 3)(lv[0].data_ptr(), lv[1].data_ptr(), lv[2].data_ptr()) for lv in levels]  # per call: plans are shared between threads
-        det = (ctypes.POINTER(ctypes.c_void_p) * n)(*[ctypes.cast(r, ctypes.POINTER(ctypes.c_void_p)) for r in rows])
+        # the band-pointer arrays are per thread and reused (cached plans are shared between threads, and ctypes drops the GIL in the
+        # call; fresh ctypes arrays + casts on every call are reference cycles that the garbage collector has to find: a 35 ms
+        # pause every few hundred calls, tools/host_bound.py)
+        slots = _tls.__dict__.setdefault("invpyr", {})
+        slot = slots.get(n)
+        if slot is None:
+            rows = [(ctypes.c_void_p * 3)() for _ in range(n)]
+            det = (ctypes.POINTER(ctypes.c_void_p) * n)(*[ctypes.cast(r, ctypes.POINTER(ctypes.c_void_p)) for r in rows])
+            slot = slots[n] = (rows, det)
+        rows, det = slot
+        for r, lv in zip(rows, levels):
+            r[0], r[1], r[2] = lv[0].data_ptr(), lv[1].data_ptr(), lv[2].data_ptr()
         lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
         lib = _lib
         ap, yp = approx.data_ptr(), y.data_ptr()

@@ -397,7 +397,9 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
 
 # ------------------------------------------------------------------------------------------ synthesis
 _tail_memo: dict = {}  # geometry of a 2-D reconstruction -> (levels the streaming launch takes, final extents, its plan)
+_small_memo: dict = {}  # ... of a small plane -> (final extents, plan of the one-launch reconstruction)
 _engine._routing_caches.append(_tail_memo)
+_engine._routing_caches.append(_small_memo)
 
 
 def _adjust_trim(res_size: int, next_size: int) -> int:
@@ -506,27 +508,38 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
                 cur = fuse(cur, 0, len(folded))
                 pos = len(folded)
     any_grad = torch.is_grad_enabled() and (tap_t is not None or any(t.requires_grad for t in flat))
+    gkey = None
+    if ndim == 2 and folded and not any_grad:
+        # geometry of the call (every band's shape: the reference's shape checks are part of what is remembered)
+        gkey = (cur.shape, cur.stride(), tuple((lv[0].stride(), *[t.shape for t in lv]) for lv in folded), flen, separable)
     # (the finest level's four coefficient planes alone must fit into LDS: 10 240 samples each at most)
-    if ndim == 2 and folded and folded[-1][0].shape[-1] * folded[-1][0].shape[-2] <= 10240 and not any_grad:
+    if gkey is not None and folded[-1][0].shape[-1] * folded[-1][0].shape[-2] <= 10240:
         # every level of a small plane in one launch, the running approximation kept on chip (mifwt_dwt2_inv_pyramid); every
-        # fused trip passes the reference's own checks first
-        try:
-            shape, out_ext = tuple(cur.shape), None
-            for lv in range(len(folded)):
-                out_ext = level_out_extent(shape, lv)
-                shape = (shape[0], *out_ext)
-        except (ValueError, RuntimeError, AssertionError):
-            out_ext = None  # the per-level loop below raises the reference's error at the level it belongs to
-        if out_ext is not None:
-            y = _engine.ENGINE.synthesis_pyramid(cur, folded, rec_lo, rec_hi, out_ext)
+        # fused trip passes the reference's own checks first (remembered per geometry)
+        hit = _small_memo.get(gkey)
+        if hit is None:
+            try:
+                shape, out_ext = tuple(cur.shape), None
+                for lv in range(len(folded)):
+                    out_ext = level_out_extent(shape, lv)
+                    shape = (shape[0], *out_ext)
+            except (ValueError, RuntimeError, AssertionError):
+                out_ext = None  # the per-level loop below raises the reference's error at the level it belongs to
+            pl = _engine.ENGINE.synthesis_pyramid_plan(cur, folded, flen, out_ext) if out_ext is not None and cur.dtype == torch.float32 else None
+            if len(_small_memo) > 1024:
+                _small_memo.clear()
+            hit = _small_memo[gkey] = (out_ext, pl)
+        out_ext, pl = hit
+        if pl is not None and pl[3]:
+            y = _engine.ENGINE.synthesis_pyramid(cur, folded, rec_lo, rec_hi, out_ext, plan=pl)
             if y is not None:
                 return layout.unfold(y)
     # big planes: the FINEST up to three levels (that is where the bytes are) in one streaming launch (mifwt_dwt2_inv_pyramid's
     # second kernel); what is coarser goes first, through the loop below.  `tail` = how many levels that launch takes (0: none).
     # The decision depends on the geometry only and is remembered per geometry.
     tail, tail_ext, tail_plan = 0, None, None
-    if ndim == 2 and folded and cur.dtype == torch.float32 and not any_grad and folded[-1][0].shape[-1] * folded[-1][0].shape[-2] > 10240:
-        tkey = (cur.shape, cur.stride(), tuple((lv[0].shape, lv[0].stride()) for lv in folded), flen, separable)
+    if gkey is not None and cur.dtype == torch.float32 and folded[-1][0].shape[-1] * folded[-1][0].shape[-2] > 10240:
+        tkey = gkey
         hit = _tail_memo.get(tkey)
         if hit is None:
             hit = (0, None, None)

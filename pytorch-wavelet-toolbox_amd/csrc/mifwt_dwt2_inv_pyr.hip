@@ -157,14 +157,13 @@ __device__ __forceinline__ void ipyr_phase2(int ph, F&& f) {
 // dword (the compiler's hazard table assumes a scalar soffset lifts this hazard; on gfx950 it does not: the ragged-column path's
 // v_cndmask landed in that slot and every few rows a lane's fourth column came out wrong) — the wait states travel with the store
 __device__ __forceinline__ void ipyr_store4(const f4 data, rsrc_t rsrc, uint32_t voff, uint32_t soff) {
-#if MIFWT_ST_AUX == 17
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc0 sc1\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-#elif MIFWT_ST_AUX == 16
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-#elif MIFWT_ST_AUX == 2
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-#else
+  // write-through to memory (sc0 sc1): these are full 1-KiB pieces per wave and row, nothing reads them back — 97.8-98.5 against
+  // 100.9-101.0 us per launch on config 2 with the default policy, in one run (profiles/r03g_store_policy_nbuf.txt; a plain copy
+  // kernel gains the same 3 %, profiles/r03f_wbench.txt).  (The analysis kernel's 8-byte stores of partial lines LOSE 6 % with it.)
+#if MIFWT_ST_AUX == 99
   asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+#else
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc0 sc1\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 #endif
 }
 

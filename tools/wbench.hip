@@ -32,6 +32,33 @@ template <int POL> __device__ __forceinline__ f4 ld4(const f4* p) {
   else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
+// 8-byte stores: a wave writes 512 B per instruction (what the analysis kernel's level-1 waves do per band row)
+__global__ void __launch_bounds__(256) k_write8(f2* dst, size_t n_per_wg) {
+  f2* p = dst + (size_t)blockIdx.x * n_per_wg + threadIdx.x;
+  const f2 v = {1.f, (float)threadIdx.x};
+  for (size_t i = 0; i < n_per_wg; i += 256) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p + i), "v"(v) : "memory");
+}
+// the analysis kernel's level-1 pattern: rows of W floats (W = 515: rows start on 4-byte boundaries), three planes, a wave writes 128
+// columns of one row of one plane per instruction (8 bytes per lane), four waves side by side cover 512 columns
+template <int BYTES> __global__ void __launch_bounds__(256) k_rows(float* dst, int W, int H, int planes) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // a workgroup owns rows [r0, r1) of all planes of one image
+  const int img = blockIdx.x >> 2, seg = blockIdx.x & 3;
+  const int r0 = seg * (H / 4), r1 = seg == 3 ? H : r0 + H / 4;
+  float* base = dst + (size_t)img * planes * H * W;
+  for (int r = r0; r < r1; ++r)
+    for (int p = 0; p < planes; ++p) {
+      float* row = base + ((size_t)p * H + r) * W;
+      if (BYTES == 8) {
+        const int c = 128 * wave + 2 * lane;
+        if (c + 1 < W) asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(row + c), "v"((f2){1.f, 2.f}) : "memory");
+      } else {
+        const int c = 256 * (wave & 1) + 4 * lane;  // two waves cover a row, the other two take the next plane's row
+        float* rw = base + ((size_t)(p ^ (wave >> 1)) * H + r) * W;
+        if (c + 3 < W) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(rw + c), "v"((f4){1.f, 2.f, 3.f, 4.f}) : "memory");
+      }
+    }
+}
 // each workgroup streams a contiguous span; per iteration a wave writes 1 KiB
 template <int POL> __global__ void __launch_bounds__(256) k_write(f4* dst, size_t n_per_wg) {
   f4* p = dst + (size_t)blockIdx.x * n_per_wg + threadIdx.x;
@@ -89,6 +116,16 @@ int main() {
     RUNR(0) RUNR(1) RUNR(4) RUNR(7)
 #define RUNC(LP, SP) { float ms = timeit([&](int i) { hipLaunchKernelGGL((k_copy<LP, SP>), dim3(nwg), dim3(256), 0, 0, src[i % 3], dst[i % 3], per); }); printf("copy   [ld %-10s st %-10s] %.4f ms  %6.0f GB/s (r+w)\n", kPol[LP], kPol[SP], ms, 2.0 * bytes / ms / 1e6); }
     RUNC(0, 0) RUNC(1, 0) RUNC(1, 1) RUNC(1, 4) RUNC(1, 7) RUNC(7, 7) RUNC(1, 3) RUNC(1, 2)
+  }
+  { const int nwg = 1024; const size_t per8 = bytes / 8 / nwg;
+    float ms = timeit([&](int i) { hipLaunchKernelGGL(k_write8, dim3(nwg), dim3(256), 0, 0, (f2*)dst[i % 3], per8); }); printf("write 8-byte stores, 1024 workgroups: %.4f ms %6.0f GB/s\n", ms, bytes / ms / 1e6);
+    // 60 images x 4 planes x 512 rows x 516 floats = 254 MB (inside the 256 MiB buffers)
+    const int W = 515, H = 512, P = 4, NI = 60; const double rb = (double)NI * P * H * W * 4;
+    ms = timeit([&](int i) { hipLaunchKernelGGL(k_rows<8>, dim3(4 * NI), dim3(256), 0, 0, (float*)dst[i % 3], W, H, P); }); printf("rows of 515 floats, 8-byte stores, 128 columns per wave:  %.4f ms %6.0f GB/s\n", ms, rb / ms / 1e6);
+    ms = timeit([&](int i) { hipLaunchKernelGGL(k_rows<16>, dim3(4 * NI), dim3(256), 0, 0, (float*)dst[i % 3], W, H, P); }); printf("rows of 515 floats, 16-byte stores, 256 columns per wave: %.4f ms %6.0f GB/s\n", ms, rb / ms / 1e6);
+    const int W2 = 516;
+    ms = timeit([&](int i) { hipLaunchKernelGGL(k_rows<8>, dim3(4 * NI), dim3(256), 0, 0, (float*)dst[i % 3], W2, H, P); }); printf("rows of 516 floats, 8-byte stores:  %.4f ms %6.0f GB/s\n", ms, (double)NI * P * H * W2 * 4 / ms / 1e6);
+    ms = timeit([&](int i) { hipLaunchKernelGGL(k_rows<16>, dim3(4 * NI), dim3(256), 0, 0, (float*)dst[i % 3], W2, H, P); }); printf("rows of 516 floats, 16-byte stores: %.4f ms %6.0f GB/s\n", ms, (double)NI * P * H * W2 * 4 / ms / 1e6);
   }
   // the same output buffer every time (what a benchmark loop over one allocation does)
   { const int nwg = 1024; const size_t per = n / nwg;
