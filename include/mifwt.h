@@ -125,8 +125,8 @@ int mifwt_dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, 
  *   approx   band aa of the last fused level
  * Same sums as nlevels mifwt_dwt_fwd calls (summation order differs: agreement to rounding, not bit for bit).  Two kernels:
  *   (1) kernel id 16, up to THREE levels, rows streamed through registers and LDS rings: f32, even L <= 8, modes zero / constant /
- *       reflect / symmetric, unit innermost strides, input rows of a multiple of 4 samples that start on 16-byte boundaries, every
- *       fused plane at least 2 L samples per axis; in auto mode (MIFWT_OPT_PYRAMID_MODE 0) only for planes of 512 .. 1280 columns,
+ *       reflect / symmetric, unit innermost strides (input rows of any length and alignment), every fused plane at least 2 L
+ *       samples per axis; in auto mode (MIFWT_OPT_PYRAMID_MODE 0) only for planes of 512 .. 1280 columns,
  *       where a workgroup streams whole rows; the three detail planes of a level within 1 GiB of one another;
  *   (2) kernel id 20, up to EIGHT levels — the whole pyramid — of planes small enough to live in LDS (the plane and its
  *       horizontally filtered image, both with their boundary extension, <= 160 KB: 128 x 128 up to 12 taps), a workgroup per
@@ -137,18 +137,25 @@ int mifwt_dwt2_fwd_pyramid_supported(int nlevels, const mifwt_level_desc* const*
 int mifwt_dwt2_fwd_pyramid(int nlevels, const mifwt_level_desc* const* descs, const void* x, void* const* const* details, void* approx,
                            const double* dec_lo, const double* dec_hi, void* stream);
 
-/* EVERY level of a 2-D reconstruction of a small plane in one launch (kernel id 21) — all trips of waverec2's level loop
- * (src/ptwt/conv_transform_2.py:222-249) for planes small enough to live in LDS; the running approximation never reaches HBM.
+/* SEVERAL levels of a 2-D reconstruction in one launch — trips of waverec2's level loop (src/ptwt/conv_transform_2.py:222-249);
+ * the running approximation never reaches HBM.
  * descs[0] describes the COARSEST level, descs[nlevels-1] the finest, each exactly as a mifwt_dwt_inv call would: coef_extent = the
  * level's coefficient extents, detail_stride its bands' strides; approx_stride counts for descs[0] only (the coarsest approximation),
  * sig_extent / sig_stride for the last one only (y).  The output of level l is cropped to descs[l+1]->coef_extent (which must not
  * exceed 2 M - L + 2 per axis): the reference's trims (conv_transform_2.py:240-247) and the separable containers' crop
  * (separable_conv_transform.py:94-97) are both that.
  *   approx   the coarsest approximation        details  HOST array of nlevels HOST arrays of 3 device ptrs: bands ad, da, dd
- * Same sums as nlevels mifwt_dwt_inv calls (summation order differs: agreement to rounding).  f32, even L <= 20, dense coefficient
- * planes (row stride = width), the finest level's coefficients and its vertically synthesised image <= 160 KB (128 x 128 outputs for 8
- * taps); in auto mode planes that keep a CU's LDS to themselves only from 128 KB of LDS images and 512 images upwards
- * (MIFWT_OPT_PYRAMID_MODE 3 lifts that, 2 switches the kernel off).  _supported says 1 / 0; MIFWT_ERR_UNSUPPORTED otherwise, nothing launched. */
+ * Same sums as nlevels mifwt_dwt_inv calls (summation order differs: agreement to rounding).  Two kernels:
+ *   (1) kernel id 21, EVERY level (up to eight) of a plane small enough to live in LDS: f32, even L <= 20, dense coefficient planes
+ *       (row stride = width), the finest level's coefficients and its vertically synthesised image <= 160 KB (128 x 128 outputs for 8
+ *       taps); in auto mode planes that keep a CU's LDS to themselves only from 128 KB of LDS images and 512 images upwards
+ *       (MIFWT_OPT_PYRAMID_MODE 3 lifts that);
+ *   (2) kernel id 22, up to THREE levels of a big plane, coefficient rows streamed through LDS rings (a caller with more levels runs the
+ *       coarser ones first and hands their output over as `approx`): f32, even L <= 8, unit innermost strides, the three detail bands
+ *       of a level sharing their strides (any row / image stride, any alignment), output planes of at least 32 rows whose rows fit a
+ *       workgroup (about 1500 columns); in auto mode (MIFWT_OPT_PYRAMID_MODE 0) planes from 512 columns on.
+ * mifwt_dwt2_inv_pyramid_supported says which one serves the call (0 none, 1, 2; MIFWT_OPT_PYRAMID_MODE 2 switches both off);
+ * MIFWT_ERR_UNSUPPORTED otherwise, nothing launched. */
 int mifwt_dwt2_inv_pyramid_supported(int nlevels, const mifwt_level_desc* const* descs);
 int mifwt_dwt2_inv_pyramid(int nlevels, const mifwt_level_desc* const* descs, const void* approx, const void* const* const* details, void* y,
                            const double* rec_lo, const double* rec_hi, void* stream);
@@ -297,7 +304,8 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  *   17 / 18  several fused 1-D analysis / synthesis levels of long rows, a chunk per workgroup (mifwt_dwt1_fwd_long /
  *          mifwt_dwt1_inv_long; likewise)
  *   20 / 21  every level of a 2-D analysis / synthesis of a small plane in one launch (mifwt_dwt2_fwd_pyramid's second kernel /
- *          mifwt_dwt2_inv_pyramid; likewise) */
+ *          mifwt_dwt2_inv_pyramid; likewise)
+ *   22     up to three fused 2-D synthesis levels of a big plane per launch (mifwt_dwt2_inv_pyramid's second kernel; likewise) */
 int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 
 /* Library-wide diagnostic switches (process-global, meant for tests and A/B measurements).
