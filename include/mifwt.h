@@ -136,6 +136,18 @@ int mifwt_dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, 
 int mifwt_dwt2_fwd_pyramid_supported(int nlevels, const mifwt_level_desc* const* descs);
 int mifwt_dwt2_fwd_pyramid(int nlevels, const mifwt_level_desc* const* descs, const void* x, void* const* const* details, void* approx,
                            const double* dec_lo, const double* dec_hi, void* stream);
+/* The same call with a device WORKSPACE for kernel (1): a plane of few images is cut into row segments, one per workgroup, and a
+ * segment needs, for its deeper levels, approximation rows that depend on input rows above it.  Without a workspace every segment
+ * streams a prologue of (2^nlevels - 1)(L - 2) input rows (42 for three levels of db4: 12 % more reads on 64 x 1024^2, half as many
+ * again on a batch of 16); with one, a segment starts its deeper levels where its own rows suffice and the segment BELOW deposits the
+ * L - 2 (+ 1) approximation rows per level that the end of this one lacks (64-bit flags in the workspace, release / acquire at agent
+ * scope; a flag is set when it holds `call_id`, which must differ from the ids of earlier calls on the same workspace — nothing is
+ * ever cleared).  Identical sums in identical order: bit-identical results.  mifwt_dwt2_fwd_pyramid_workspace() = the bytes it wants
+ * (0: the call would not use one); a smaller or NULL workspace selects the prologue form. */
+size_t mifwt_dwt2_fwd_pyramid_workspace(int nlevels, const mifwt_level_desc* const* descs);
+int mifwt_dwt2_fwd_pyramid_ws(int nlevels, const mifwt_level_desc* const* descs, const void* x, void* const* const* details, void* approx,
+                              const double* dec_lo, const double* dec_hi, void* workspace, size_t workspace_bytes, unsigned long long call_id,
+                              void* stream);
 
 /* SEVERAL levels of a 2-D reconstruction in one launch — trips of waverec2's level loop (src/ptwt/conv_transform_2.py:222-249);
  * the running approximation never reaches HBM.

@@ -7,6 +7,7 @@ raises.  PyTorch is used for device memory (caching allocator) and streams only.
 from __future__ import annotations
 
 import ctypes
+import itertools
 import os
 import threading
 from typing import List, Optional, Sequence, Tuple
@@ -94,6 +95,11 @@ def load_library() -> ctypes.CDLL:
     lib.mifwt_dwt2_inv_pyramid.argtypes = [ctypes.c_int, ctypes.POINTER(desc_p), vp, ctypes.POINTER(vpp), vp, dbl_p, dbl_p, vp]
     lib.mifwt_dwt2_fwd_pyramid.restype = ctypes.c_int
     lib.mifwt_dwt2_fwd_pyramid.argtypes = [ctypes.c_int, ctypes.POINTER(desc_p), vp, ctypes.POINTER(vpp), vp, dbl_p, dbl_p, vp]
+    lib.mifwt_dwt2_fwd_pyramid_ws.restype = ctypes.c_int
+    lib.mifwt_dwt2_fwd_pyramid_ws.argtypes = [ctypes.c_int, ctypes.POINTER(desc_p), vp, ctypes.POINTER(vpp), vp, dbl_p, dbl_p, vp, ctypes.c_size_t,
+                                              ctypes.c_uint64, vp]
+    lib.mifwt_dwt2_fwd_pyramid_workspace.restype = ctypes.c_size_t
+    lib.mifwt_dwt2_fwd_pyramid_workspace.argtypes = [ctypes.c_int, ctypes.POINTER(desc_p)]
     lib.mifwt_dwt2_inv_pair_supported.restype = ctypes.c_int
     lib.mifwt_dwt2_inv_pair_supported.argtypes = [desc_p, desc_p]
     lib.mifwt_dwt2_inv_pair.restype = ctypes.c_int
@@ -197,6 +203,7 @@ def _trim_plans() -> None:
         for k in list(_plans)[:1024]:
             _plans.pop(k, None)
 _tls = threading.local()
+_call_ids = itertools.count((int.from_bytes(os.urandom(7), "little") << 8) | 1)  # ids of launches that use workspace flags
 _taps_cache: dict = {}
 
 
@@ -383,6 +390,10 @@ class HipLevelEngine:
                 lrefs = (ctypes.POINTER(LevelDesc) * n_ok)(*[ctypes.pointer(pl.desc) for pl in lean])
                 if lib.mifwt_dwt2_fwd_pyramid_supported(n_ok, lrefs) == route:
                     keep, refs = lean, lrefs
+            if n_ok and route == 1:
+                # the streaming kernel's row segments hand their first approximation rows over through a small workspace (instead
+                # of each streaming a prologue of input rows): mifwt_dwt2_fwd_pyramid_ws
+                keep[0].ws_bytes = int(lib.mifwt_dwt2_fwd_pyramid_workspace(n_ok, refs))
             plan = _plans[key] = (keep, n_ok, refs, KID_SMALL if route == 2 else KID_PYRAMID)
         plans, n_ok, refs, kid = plan
         if n_ok == 0:
@@ -409,7 +420,8 @@ class HipLevelEngine:
         lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
         lib = _lib
         xp, ap = x.data_ptr(), bufs[-1].data_ptr()
-        self._run(plans[0], 0, x, lambda ws, wsb, stream: lib.mifwt_dwt2_fwd_pyramid(n_ok, refs, xp, det, ap, lo, hi, stream), kid=kid)
+        call_id = next(_call_ids)  # (a flag in the workspace is "set" when it holds this call's id: nothing needs clearing)
+        self._run(plans[0], 0, x, lambda ws, wsb, stream: lib.mifwt_dwt2_fwd_pyramid_ws(n_ok, refs, xp, det, ap, lo, hi, ws, wsb, call_id, stream), kid=kid)
         return bufs
 
     def analysis_tail(self, x: torch.Tensor, dec_lo: Sequence[float], dec_hi: Sequence[float], mode_id: int, nlevels: int):

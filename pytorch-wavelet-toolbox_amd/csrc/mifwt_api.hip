@@ -476,8 +476,9 @@ int mifwt_dwt2_fwd_pyramid_supported(int nlevels, const mifwt_level_desc* const*
   return pyramid_route(nlevels, descs);
 }
 
-int mifwt_dwt2_fwd_pyramid(int nlevels, const mifwt_level_desc* const* descs, const void* x, void* const* const* details, void* approx,
-                           const double* dec_lo, const double* dec_hi, void* stream) {
+int mifwt_dwt2_fwd_pyramid_ws(int nlevels, const mifwt_level_desc* const* descs, const void* x, void* const* const* details, void* approx,
+                              const double* dec_lo, const double* dec_hi, void* workspace, size_t workspace_bytes, unsigned long long call_id,
+                              void* stream) {
   if (!descs || nlevels < 1 || nlevels > 8) return MIFWT_ERR_BADARG;
   for (int l = 0; l < nlevels; ++l) {
     if (!descs[l]) return MIFWT_ERR_BADARG;
@@ -494,7 +495,17 @@ int mifwt_dwt2_fwd_pyramid(int nlevels, const mifwt_level_desc* const* descs, co
   if (route == 0) return MIFWT_ERR_UNSUPPORTED;
   if (descs[0]->batch == 0) return MIFWT_OK;
   if (route == 2) return dwt2_fwd_small(nlevels, descs, x, details, approx, dec_lo, dec_hi, static_cast<hipStream_t>(stream));
-  return dwt2_fwd_pyr(nlevels, descs, x, details, approx, dec_lo, dec_hi, static_cast<hipStream_t>(stream));
+  return dwt2_fwd_pyr(nlevels, descs, x, details, approx, dec_lo, dec_hi, workspace, workspace_bytes, call_id, static_cast<hipStream_t>(stream));
+}
+int mifwt_dwt2_fwd_pyramid(int nlevels, const mifwt_level_desc* const* descs, const void* x, void* const* const* details, void* approx,
+                           const double* dec_lo, const double* dec_hi, void* stream) {
+  return mifwt_dwt2_fwd_pyramid_ws(nlevels, descs, x, details, approx, dec_lo, dec_hi, nullptr, 0, 0, stream);
+}
+size_t mifwt_dwt2_fwd_pyramid_workspace(int nlevels, const mifwt_level_desc* const* descs) {
+  if (!descs || nlevels < 1 || nlevels > 3) return 0;
+  for (int l = 0; l < nlevels; ++l)
+    if (!descs[l] || validate(descs[l], 0) != MIFWT_OK) return 0;
+  return pyramid_route(nlevels, descs) == 1 ? dwt2_fwd_pyr_workspace(nlevels, descs) : 0;
 }
 // Every level of a 2-D reconstruction of a small plane in one launch (mifwt_dwt2_inv_small.hip); descs[0] = the coarsest level.
 int mifwt_dwt2_inv_pyramid_supported(int nlevels, const mifwt_level_desc* const* descs) {

@@ -63,6 +63,14 @@ struct PyrArgs {
   int pitch0, pitch1, pitch2;   // bytes of a staged row / a ring-1 row / a ring-2 row
   int nl1, nl2, nl3;            // waves of level 1 / 2 / 3
   int mode;
+  // HANDOVER between the row segments of an image (a.handover; needs a.ws): a segment starts its deep levels where its own level-1 rows
+  // suffice and takes the last L - 2 (+ 1) approximation rows of levels 1 and 2 it needs from the segment BELOW it, which deposits its
+  // first rows in the workspace — instead of streaming a prologue of (2^NLEV - 1) (L - 2) input rows
+  int handover;
+  unsigned long long nonce;   // value of a set flag of this call
+  unsigned long long* flags;  // [image][segment]
+  float* xrows;               // [image][segment][(L - 1) rows of W1 floats, (L - 1) rows of W2 floats]
+  int xrow_stride;            // floats per (image, segment)
   int xcd_map;
   unsigned long long* prof;
   int dbg;
@@ -87,6 +95,16 @@ __device__ __forceinline__ void pyr_dma_row(const uint32_t (&voff)[3], rsrc_t rs
                  "s_add_u32 m0, m0, 0x800\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %5 offen nt lds\n\t"
                  "s_add_u32 m0, m0, 0x800\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %5 offen nt lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "s"(rsrc), "s"(soff), "s"(lds0) : "memory", "scc");
+  }
+}
+
+// one LDS-DMA piece for rows of any length, past every cache (sc0 sc1: the rows were written by another XCD): lanes whose 16 bytes
+// start inside the row (voff < limit) move them to LDS [lds + 16 lane)
+__device__ __forceinline__ void pyr_dma_masked(uint32_t voff, uint32_t limit, rsrc_t rsrc, uint32_t soff, uint32_t lds) {
+  if (voff < limit) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc0 sc1 lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds) : "memory");
   }
 }
 
@@ -149,6 +167,7 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int role, widx;
   pyr_role(wave, a.nl1, a.nchunks, role, widx);
+  if (wave == 12 && a.handover) role = kRoleXchg;
   if (role < 0 || (role == kRoleL1 && widx >= a.nl1) || (role == kRoleL2 && (NLEV < 2 || widx >= a.nl2)) ||
       (role == kRoleL3 && (NLEV < 3 || widx >= a.nl3)))
     return;  // (a wave that has ended does not take part in the barriers of the others)
@@ -160,35 +179,59 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
   }
   const int grp = bid % a.ngroups;
   bid /= a.ngroups;
-  const int seg = bid % a.nseg, img = bid / a.nseg;
+  // (handover: a segment waits, at its end, for the segment below it, which therefore gets the LOWER block index — workgroups start in
+  // index order, so whatever a workgroup waits for is already running or done)
+  const int seg = a.handover ? a.nseg - 1 - bid % a.nseg : bid % a.nseg, img = bid / a.nseg;
   const bool zero_mode = a.mode == MIFWT_MODE_ZERO;
   Fold1 fold;
   fold.set(a.mode);
 
   // ---- row ranges of this segment: computed rows [rA, rB) and owned rows [oA, oB) per level (index = level) -------------
   int rA[NLEV + 1], rB[NLEV + 1], oA[NLEV + 1], oB[NLEV + 1];
-  oA[NLEV] = rA[NLEV] = seg == 0 ? 0 : a.seg0_rows + (seg - 1) * a.seg_rows;
-  oB[NLEV] = rB[NLEV] = seg == a.nseg - 1 ? a.H[NLEV] : min(a.H[NLEV], rA[NLEV] + (seg == 0 ? a.seg0_rows : a.seg_rows));
+  int lim[NLEV + 1];  // rows of level l below lim[l] come out of this workgroup's own passes (the rest of [rA, rB): handed over)
+  if (!a.handover) {
+    oA[NLEV] = rA[NLEV] = seg == 0 ? 0 : a.seg0_rows + (seg - 1) * a.seg_rows;
+    oB[NLEV] = rB[NLEV] = seg == a.nseg - 1 ? a.H[NLEV] : min(a.H[NLEV], rA[NLEV] + (seg == 0 ? a.seg0_rows : a.seg_rows));
 #pragma unroll
-  for (int l = NLEV - 1; l >= 1; --l) {
-    oA[l] = 2 * oA[l + 1];
-    oB[l] = oB[l + 1] == a.H[l + 1] ? a.H[l] : min(a.H[l], 2 * oB[l + 1]);
-    rA[l] = max(0, 2 * rA[l + 1] - HL);
-    rB[l] = min(a.H[l], 2 * rB[l + 1]);
+    for (int l = NLEV - 1; l >= 1; --l) {
+      oA[l] = 2 * oA[l + 1];
+      oB[l] = oB[l + 1] == a.H[l + 1] ? a.H[l] : min(a.H[l], 2 * oB[l + 1]);
+      rA[l] = max(0, 2 * rA[l + 1] - HL);
+      rB[l] = min(a.H[l], 2 * rB[l + 1]);
+    }
+#pragma unroll
+    for (int l = 1; l <= NLEV; ++l) lim[l] = rB[l];
+  } else {
+    // ownership boundaries bottom-up: the last level as without handover, level l from the first row that level l + 1 of this segment
+    // reads (2 o - (L - 2)): a segment OWNS what it used to compute as its prologue, and stops where the next one starts
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int sg = seg + e;
+      int o = sg == 0 ? 0 : (sg >= a.nseg ? a.H[NLEV] : min(a.H[NLEV], a.seg0_rows + (sg - 1) * a.seg_rows));
+#pragma unroll
+      for (int l = NLEV; l >= 1; --l) {
+        if (l < NLEV) o = sg == 0 ? 0 : (sg >= a.nseg ? a.H[l] : max(0, 2 * o - HL));
+        if (e == 0) oA[l] = rA[l] = o;
+        else oB[l] = lim[l] = o;
+      }
+    }
+    rB[NLEV] = oB[NLEV];
+#pragma unroll
+    for (int l = NLEV - 1; l >= 1; --l) rB[l] = min(a.H[l], 2 * lim[l + 1]);  // (beyond lim[l]: rows the segment below hands over)
   }
   const bool top = seg == 0;
   const int D2 = top ? pyr_lag2(L) : pyr_lag2_inner(L);
   const int D3 = top ? pyr_lag3(L) : pyr_lag3_inner(L);
-  const int E0 = 2 * rA[1] - HL, e0_end = 2 * rB[1];
-  const int npair1 = rB[1] - rA[1] + HP - 1;
+  const int E0 = 2 * rA[1] - HL, e0_end = 2 * lim[1];
+  const int npair1 = lim[1] - rA[1] + HP - 1;  // (pairs of the workgroup's OWN passes: rows from lim[l] on are handed over)
   const int nsteps1 = (npair1 + 3) / 4;
   int nsteps = nsteps1, npair2 = 0, npair3 = 0;
   if constexpr (NLEV >= 2) {
-    npair2 = rB[2] - rA[2] + HP - 1;
+    npair2 = lim[2] - rA[2] + HP - 1;
     nsteps = max(nsteps, D2 + (npair2 + 1) / 2);
   }
   if constexpr (NLEV >= 3) {
-    npair3 = rB[3] - rA[3] + HP - 1;
+    npair3 = lim[3] - rA[3] + HP - 1;
     nsteps = max(nsteps, D3 + npair3);
   }
   const int nsub = 2 * nsteps, nsub1 = 2 * nsteps1;
@@ -296,6 +339,158 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
   __syncthreads();  // ... before the loader's first row lands
 
   // =====================================================================================================================
+  // exchange wave (handover): deposits this segment's first approximation rows of levels 1 and 2 for the segment above, and puts the
+  // rows the segment below deposited into the rings when the level-1 / level-2 waves of this workgroup run out of rows of their own.
+  // It only moves rows between LDS and the workspace; the passes do not know where a ring row came from.
+  if constexpr (NLEV >= 2) {
+    if (role == kRoleXchg) {
+      constexpr int XM = HL + 1;  // rows handed over per level at most
+      const int W1 = a.W[1], W2 = NLEV >= 3 ? a.W[2] : 0;
+      const int nk1 = (W1 + 63) >> 6, nk2 = (W2 + 63) >> 6;
+      const bool produce = seg > 0, consume = seg < a.nseg - 1;
+      if (lane == 0) *reinterpret_cast<volatile unsigned long long*>(smem) = 0;  // (where the flag of the segment below will land)
+      float* const mine = a.xrows + ((int64_t)img * a.nseg + seg) * a.xrow_stride;
+      const float* const theirs = a.xrows + ((int64_t)img * a.nseg + seg + 1) * a.xrow_stride;
+      // deposit: level-1 rows oA[1] + r (r < np1), level-2 rows oA[2] + r (r < np2) — what the segment above lacks
+      const int np1 = produce ? 2 * oA[2] - oA[1] : 0;
+      const int np2 = (produce && NLEV >= 3) ? 2 * oA[NLEV >= 3 ? 3 : 2] - oA[2] : 0;
+      // take over: level-1 rows lim[1] + r (r < nc1), level-2 rows lim[2] + r (r < nc2)
+      const int nc1 = consume ? rB[1] - lim[1] : 0;  // (rB[l] = 2 lim[l + 1]: what the level above needs)
+      const int nc2 = (consume && NLEV >= 3) ? rB[2] - lim[2] : 0;
+      // LDS area the deposited rows of the segment below are copied into (LDS-DMA), behind the rings
+      const int pitchX1 = ((W1 + 3) & ~3) * 4 + 16, pitchX2 = ((W2 + 3) & ~3) * 4 + 16;
+      unsigned char* const xa1 = ring2 + (NLEV >= 3 ? (kPyrRing + 1) * a.pitch2 : 0);
+      unsigned char* const xa2 = xa1 + XM * pitchX1;
+      const uint32_t xa1_off = (uint32_t)(xa1 - smem), xa2_off = (uint32_t)(xa2 - smem);
+      // sub-steps: a level-1 row with sequence number q is written by its level-1 wave during sub-step q / 2, a level-2 row with
+      // sequence number p during sub-step 2 (D2 + p / 2) + 1; a row is readable one barrier later
+      const int q0c = lim[1] - rA[1] + HP - 1;  // sequence number of the first level-1 row taken over
+      const int t_acq = max(0, q0c / 2 - 5);
+      int t_rel = -1;
+      if (produce) {
+        t_rel = (np1 - 1 + HP - 1) / 2 + 1;
+        if (NLEV >= 3 && np2 > 0) t_rel = max(t_rel, 2 * (D2 + (np2 - 1 + HP - 1) / 2) + 2);
+      }
+      const rsrc_t rmine = pyr_rsrc(mine, (uint32_t)a.xrow_stride * 4u);
+      const rsrc_t rtheirs = pyr_rsrc(theirs, (uint32_t)a.xrow_stride * 4u);
+      bool loaded = false;
+#pragma unroll 1
+      for (int t = 0; t < nsub; ++t) {
+        __syncthreads();
+        // ---- deposit -----------------------------------------------------------------------------------------------------
+        if (produce && t <= t_rel + 6) {
+#pragma unroll 1
+          for (int r = 0; r < np1; ++r) {
+            const int q = r + HP - 1;
+            if (t != q / 2 + 1) continue;
+            const unsigned char* row = ring1 + (q & (kPyrRing - 1)) * a.pitch1 + 4 * (kPyrPad + sh1 - cA[1]);
+#pragma unroll 1
+            for (int kk = 0; kk < nk1; ++kk) {
+              const int c = 64 * kk + lane;
+              const float v = *reinterpret_cast<const float*>(row + 4 * min(c, W1 - 1));
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rmine, c < W1 ? 4u * (uint32_t)(r * W1 + c) : kPyrOob, 0, 17);
+            }
+          }
+          if constexpr (NLEV >= 3) {
+#pragma unroll 1
+            for (int r = 0; r < np2; ++r) {
+              const int pq = r + HP - 1;
+              if (t != 2 * (D2 + pq / 2) + 2) continue;
+              const unsigned char* row = ring2 + (pq & (kPyrRing - 1)) * a.pitch2 + 4 * (kPyrPad - cA[2]);
+#pragma unroll 1
+              for (int kk = 0; kk < nk2; ++kk) {
+                const int c = 64 * kk + lane;
+                const float v = *reinterpret_cast<const float*>(row + 4 * min(c, W2 - 1));
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rmine, c < W2 ? 4u * (uint32_t)(XM * W1 + r * W2 + c) : kPyrOob, 0, 17);
+              }
+            }
+          }
+          if (t == t_rel + 6 || (t == nsub - 1 && t_rel + 6 > nsub - 1 && t >= t_rel)) {
+            // Everything was deposited six sub-steps ago (the wait below is over before it starts: a wave that waits in here keeps the
+            // whole workgroup at its next barrier).  The deposits are write-through stores (sc0 sc1: they bypass the XCD's L2, which is not coherent
+            // with the other XCDs'), acknowledged once they are in memory; the flag goes the same way afterwards, and the reader uses
+            // cache-bypassing loads — no cache-wide write-back / invalidate (an agent-scope release / acquire fence does exactly that:
+            // buffer_wbl2 / buffer_inv on an L2 full of dirty output lines cost 19 us per launch, profiles/r03k_handover.txt)
+            pyr_wait_vm<0>();
+            if (lane == 0) __hip_atomic_store(a.flags + (int64_t)img * a.nseg + seg, a.nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+        }
+        // ---- take over ---------------------------------------------------------------------------------------------------
+        if (consume && t_acq >= 4 && t == t_acq - 4) {
+          // the flag of the segment below, requested past the caches into LDS four sub-steps before it is looked at (a wave that waits
+          // for memory in here keeps the whole workgroup at its next barrier)
+          const rsrc_t rf = pyr_rsrc(a.flags + (int64_t)img * a.nseg + seg + 1, 8);
+          if (lane < 2) {
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen sc0 sc1 lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(4u * (uint32_t)lane), "s"(rf), "s"(0u), "s"(0u) : "memory");
+          }
+        }
+        if (consume && t >= t_acq) {
+          if (!loaded) {
+            loaded = true;
+            // the segment below raised its flag long ago (it deposits within its first steps; this is the end of ours)
+            bool seen = false;
+            if (t_acq >= 4) {
+              pyr_wait_vm<0>();
+              seen = *reinterpret_cast<volatile unsigned long long*>(smem) == a.nonce;
+            }
+            if (!seen) {
+              const unsigned long long* f = a.flags + (int64_t)img * a.nseg + seg + 1;
+              int spins = 0;
+              while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.nonce && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(32);
+            }
+            asm volatile("" ::: "memory");  // (the requests below are issued after the flag was seen)
+            const uint32_t lane16 = 16u * (uint32_t)lane;
+#pragma unroll 1
+            for (int r = 0; r < nc1; ++r)
+#pragma unroll 1
+              for (int c = 0; c < (W1 + 255) >> 8; ++c)
+                pyr_dma_masked(lane16 + 1024u * (uint32_t)c, 4u * (uint32_t)W1, rtheirs, 4u * (uint32_t)(r * W1), xa1_off + (uint32_t)(r * pitchX1) + 1024u * (uint32_t)c);
+            if constexpr (NLEV >= 3) {
+#pragma unroll 1
+              for (int r = 0; r < nc2; ++r)
+#pragma unroll 1
+                for (int c = 0; c < (W2 + 255) >> 8; ++c)
+                  pyr_dma_masked(lane16 + 1024u * (uint32_t)c, 4u * (uint32_t)W2, rtheirs, 4u * (uint32_t)(XM * W1 + r * W2),
+                                 xa2_off + (uint32_t)(r * pitchX2) + 1024u * (uint32_t)c);
+            }
+          }
+#pragma unroll 1
+          for (int r = 0; r < nc1; ++r) {
+            const int q = q0c + r;
+            if (t != q / 2) continue;
+            pyr_wait_vm<0>();  // (requested several sub-steps ago)
+            unsigned char* row = ring1 + (q & (kPyrRing - 1)) * a.pitch1 + 4 * (kPyrPad + sh1 - cA[1]);
+#pragma unroll 1
+            for (int kk = 0; kk < nk1; ++kk) {
+              const int c = 64 * kk + lane;
+              const float v = *reinterpret_cast<const float*>(xa1 + r * pitchX1 + 4 * min(c, W1 - 1));
+              if (c < W1) *reinterpret_cast<float*>(row + 4 * c) = v;
+            }
+          }
+          if constexpr (NLEV >= 3) {
+#pragma unroll 1
+            for (int r = 0; r < nc2; ++r) {
+              const int pq = lim[2] - rA[2] + HP - 1 + r;
+              if (t != 2 * (D2 + pq / 2) + 1) continue;
+              pyr_wait_vm<0>();
+              unsigned char* row = ring2 + (pq & (kPyrRing - 1)) * a.pitch2 + 4 * (kPyrPad - cA[2]);
+#pragma unroll 1
+              for (int kk = 0; kk < nk2; ++kk) {
+                const int c = 64 * kk + lane;
+                const float v = *reinterpret_cast<const float*>(xa2 + r * pitchX2 + 4 * min(c, W2 - 1));
+                if (c < W2) *reinterpret_cast<float*>(row + 4 * c) = v;
+              }
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
+
+  // =====================================================================================================================
   // level-1 wave: NC1 columns per lane
   if (role == kRoleL1) {
     const int gmax = (cB[1] - o1 + NC1 - 1) / NC1 - 1;               // last lane of the grid that has a column
@@ -399,8 +594,9 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
             const f2 (&hi)[NC1] = acc.hi[PyrAcc<L, NC1>::done(R)];
             if constexpr (NLEV >= 2) {
               unsigned char* rr = ring1 + ((4 * s + j) & (kPyrRing - 1)) * a.pitch1;
+              const bool mine = i < lim[1];  // (handover: rows from lim[1] on are put into the ring by the exchange wave; float 0 is never read)
 #pragma unroll
-              for (int k = 0; k < NC1; ++k) *reinterpret_cast<float*>(rr + rw[k]) = lo[k].x;
+              for (int k = 0; k < NC1; ++k) *reinterpret_cast<float*>(rr + (mine ? rw[k] : 0u)) = lo[k].x;
             }
             const bool own = i >= oA[1] && i < oB[1];
             const uint32_t v2 = own ? sv2 : kPyrOob;
@@ -538,8 +734,9 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
               const f2 (&hi)[2] = acc.hi[PyrAcc<L, 2>::done(R)];
               if constexpr (NLEV >= 3) {
                 unsigned char* rr = ring2 + (p & (kPyrRing - 1)) * a.pitch2;
-                *reinterpret_cast<float*>(rr + rw[0]) = lo[0].x;
-                *reinterpret_cast<float*>(rr + rw[1]) = lo[1].x;
+                const bool mine = i < lim[2];
+                *reinterpret_cast<float*>(rr + (mine ? rw[0] : 0u)) = lo[0].x;
+                *reinterpret_cast<float*>(rr + (mine ? rw[1] : 0u)) = lo[1].x;
               }
               const bool own = i >= oA[2] && i < oB[2];
               const uint32_t v2 = own ? sv2 : kPyrOob;
@@ -668,6 +865,8 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
 // ---- host side ------------------------------------------------------------------------------------------------------------
 struct PyrPlan {
   int ngroups, nseg, seg_rows, seg0_rows, cpg0, cpg, nchunks, nbuf, pitch0, pitch1, pitch2, nl1, nl2, nl3, lds;
+  int handover, xrow_stride;  // segments hand their first approximation rows over (needs a workspace); floats per (image, segment)
+  size_t ws_bytes;
 };
 
 // columns of level NLEV a group may own: the level-1 / 2 / 3 lane grids hold 4 x 192 / 3 x 128 / 3 x 64 columns, a staged row
@@ -754,6 +953,7 @@ static bool pyr_plan(int nlev, const mifwt_level_desc* const* d, PyrPlan* p) {
   p->lds = kPyrCtl + p->nbuf * kPyrSub * p->pitch0 + rings;
   if (p->lds > 160 * 1024) return false;
   // one workgroup per CU (the segment count below is chosen for that; two small workgroups on one CU leave others idle)
+  const int lds_used = p->lds;
   if (p->lds < 82 * 1024) p->lds = 82 * 1024;
   int dev = 0, ncu = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -769,6 +969,34 @@ static bool pyr_plan(int nlev, const mifwt_level_desc* const* d, PyrPlan* p) {
   p->nseg = (HN + p->seg_rows - 1) / p->seg_rows;
   if (p->nseg > 1 && HN - (p->nseg - 1) * p->seg_rows < 8) --p->nseg;
   p->seg0_rows = p->seg_rows;
+  // handover between the row segments of an image instead of prologues (kernel: exchange wave): two levels at least, more than one
+  // segment, one column group, a spare wave (at most five level-1 waves), room in LDS for the rows taken over
+  p->handover = 0;
+  p->xrow_stride = 0;
+  p->ws_bytes = 0;
+  // MEASURED SLOWER on config 2 and therefore OFF unless MIFWT_OPT_DEBUG bit 8 asks for it: 108.0 against 102.5-104.9 us per launch with
+  // 4.5 % less traffic and 12 % fewer level-1 rows per workgroup (profiles/r03k_handover.txt).  Without prologues every workgroup is in
+  // its full read + write steps at the same time and then all of them drain their deep levels together (7 steps without memory
+  // traffic); with prologues the segments are staggered by what they are — 5 read-only steps at the start of three workgroups in four.
+  if (nlev >= 2 && p->nseg > 1 && p->ngroups == 1 && p->nl1 <= 5 && (g_options[MIFWT_OPT_DEBUG] & 256) && g_options[MIFWT_OPT_PAIR_ROWS] <= 0) {
+    const int W1 = (int)d[0]->coef_extent[1], W2 = nlev >= 3 ? (int)d[1]->coef_extent[1] : 0;
+    const int XM = HL + 1;
+    const int xlds = XM * ((((W1 + 3) & ~3) * 4 + 16) + (nlev >= 3 ? ((W2 + 3) & ~3) * 4 + 16 : 0));
+    // every segment must be long enough for the shifted ownership boundaries (2 (L - 2) rows of the last level is plenty)
+    // the first segment runs with the longer lags of the plane's top (mirrored rows must exist before they are read): it gets that
+    // many rows of the last level fewer, so that the workgroups of an image finish together
+    const int dtop = nlev >= 3 ? pyr_lag3(L) - pyr_lag3_inner(L) : 2 * (pyr_lag2(L) - pyr_lag2_inner(L));
+    const int y = (HN + dtop + p->nseg - 1) / p->nseg, x0 = y - dtop;
+    if (lds_used + xlds <= 160 * 1024 && x0 >= 2 * HL + 4 && y >= 2 * HL + 4 && HN - x0 - (p->nseg - 2) * y >= 2 * HL + 4) {
+      p->seg_rows = y;
+      p->seg0_rows = x0;
+      p->handover = 1;
+      p->lds = std::max(p->lds, lds_used + xlds);
+      p->xrow_stride = (XM * (W1 + W2) + 3) & ~3;
+      const size_t nsegs = (size_t)d[0]->batch * p->nseg;
+      p->ws_bytes = ((nsegs * 8 + 255) & ~size_t(255)) + nsegs * (size_t)p->xrow_stride * 4;
+    }
+  }
   // Every segment but the first streams a prologue of (2^nlev - 1) (L - 2) level-0 rows.  Giving the first one that many rows more
   // (config 2: 38 + 3 x 32 level-3 rows = 304 / 298 level-0 rows per workgroup, against 272 / 314 / 314 / 298 for equal segments)
   // was measured SLOWER in the whole kernel, twice: 104.2 against 100.8 us (profiles/r03e_seg0.txt; round 2 saw the same with the
@@ -822,7 +1050,7 @@ bool dwt2_fwd_pyr_supported(int nlev, const mifwt_level_desc* const* d) {
 
 template <int L, int NLEV>
 static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* const* const* details, void* approx, const double* lo,
-                       const double* hi, hipStream_t stream) {
+                       const double* hi, void* ws, size_t ws_bytes, unsigned long long nonce, hipStream_t stream) {
   PyrPlan p;
   if (!pyr_plan(NLEV, d, &p)) return MIFWT_ERR_UNSUPPORTED;
   PyrArgs<L, NLEV> a;
@@ -871,6 +1099,19 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
   a.prof = g_pyr_prof;
   const int64_t nwg_all = d[0]->batch * p.nseg * p.ngroups;
   a.xcd_map = (a.dbg & 32) && (nwg_all % 8 == 0) ? 1 : 0;
+  a.handover = 0;
+  a.nonce = 0;
+  a.flags = nullptr;
+  a.xrows = nullptr;
+  a.xrow_stride = 0;
+  if (p.handover && ws && ws_bytes >= p.ws_bytes && !a.xcd_map) {
+    const size_t nsegs = (size_t)d[0]->batch * p.nseg;
+    a.handover = 1;
+    a.nonce = nonce;
+    a.flags = static_cast<unsigned long long*>(ws);
+    a.xrows = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + ((nsegs * 8 + 255) & ~size_t(255)));
+    a.xrow_stride = p.xrow_stride;
+  }
   for (int m = 0; m < L; ++m) a.tap[m] = (f2){(float)lo[m], (float)hi[m]};
   const int64_t nwg = d[0]->batch * p.nseg * p.ngroups;
   if (nwg > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
@@ -889,23 +1130,29 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
 
 template <int L>
 static int launch_pyr_l(int nlev, const mifwt_level_desc* const* d, const void* x, void* const* const* details, void* approx,
-                         const double* lo, const double* hi, hipStream_t stream) {
+                         const double* lo, const double* hi, void* ws, size_t ws_bytes, unsigned long long nonce, hipStream_t stream) {
   switch (nlev) {
-    case 1: return launch_pyr<L, 1>(d, x, details, approx, lo, hi, stream);
-    case 2: return launch_pyr<L, 2>(d, x, details, approx, lo, hi, stream);
-    case 3: return launch_pyr<L, 3>(d, x, details, approx, lo, hi, stream);
+    case 1: return launch_pyr<L, 1>(d, x, details, approx, lo, hi, ws, ws_bytes, nonce, stream);
+    case 2: return launch_pyr<L, 2>(d, x, details, approx, lo, hi, ws, ws_bytes, nonce, stream);
+    case 3: return launch_pyr<L, 3>(d, x, details, approx, lo, hi, ws, ws_bytes, nonce, stream);
     default: return MIFWT_ERR_UNSUPPORTED;
   }
 }
 
+size_t dwt2_fwd_pyr_workspace(int nlev, const mifwt_level_desc* const* d) {
+  if (!dwt2_fwd_pyr_supported(nlev, d)) return 0;
+  PyrPlan p;
+  return pyr_plan(nlev, d, &p) ? p.ws_bytes : 0;
+}
+
 int dwt2_fwd_pyr(int nlev, const mifwt_level_desc* const* d, const void* x, void* const* const* details, void* approx,
-                  const double* lo, const double* hi, hipStream_t stream) {
+                  const double* lo, const double* hi, void* ws, size_t ws_bytes, unsigned long long nonce, hipStream_t stream) {
   if (!dwt2_fwd_pyr_supported(nlev, d)) return MIFWT_ERR_UNSUPPORTED;
   switch (d[0]->filt_len) {
-    case 2: return launch_pyr_l<2>(nlev, d, x, details, approx, lo, hi, stream);
-    case 4: return launch_pyr_l<4>(nlev, d, x, details, approx, lo, hi, stream);
-    case 6: return launch_pyr_l<6>(nlev, d, x, details, approx, lo, hi, stream);
-    case 8: return launch_pyr_l<8>(nlev, d, x, details, approx, lo, hi, stream);
+    case 2: return launch_pyr_l<2>(nlev, d, x, details, approx, lo, hi, ws, ws_bytes, nonce, stream);
+    case 4: return launch_pyr_l<4>(nlev, d, x, details, approx, lo, hi, ws, ws_bytes, nonce, stream);
+    case 6: return launch_pyr_l<6>(nlev, d, x, details, approx, lo, hi, ws, ws_bytes, nonce, stream);
+    case 8: return launch_pyr_l<8>(nlev, d, x, details, approx, lo, hi, ws, ws_bytes, nonce, stream);
     default: return MIFWT_ERR_UNSUPPORTED;
   }
 }

@@ -218,6 +218,26 @@ def test_pyramid_rows_of_any_length_and_alignment(mode):
             assert G.relerr(a.cpu().numpy(), b) < TOL32, (width, off, n)
 
 
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4"])
+def test_pyramid_segment_handover_option(wavelet):
+    """MIFWT_OPT_DEBUG bit 8: the row segments of an image hand their first approximation rows over through a workspace instead of
+    streaming prologues (measured slower, hence off by default; the path stays pinned): same sums in the same order — bit-identical to
+    the default form, and against the oracle."""
+    g = torch.Generator().manual_seed(31)
+    for shape, level in (((3, 520, 600), 3), ((1, 1024, 1024), 3), ((2, 333, 517), 2), ((5, 640, 512), 3)):
+        x = torch.randn(*shape, generator=g)
+        for mode in ("reflect", "zero"):
+            ref = ptwt_amd.wavedec2(x.to(dev()), wavelet, mode=mode, level=level)
+            _engine.set_option(_engine.OPT_DEBUG, 256)
+            try:
+                check(x, wavelet, mode, level, [_engine.KID_PYRAMID])
+                got = ptwt_amd.wavedec2(x.to(dev()), wavelet, mode=mode, level=level)
+            finally:
+                _engine.set_option(_engine.OPT_DEBUG, 0)
+            for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(ref)):
+                assert torch.equal(a, b), (shape, wavelet, mode, n)
+
+
 def test_pyramid_randomised_against_per_level_kernels():
     """Random plane shapes (one to four column groups, odd heights, widths that are multiples of 4), batches, filters, modes, level
     counts and row-segment overrides through the multi-level launch against the per-level kernels on the same data (those are

@@ -39,8 +39,11 @@ if trace:
 pmc, meta = {}, {}
 for p in sorted(glob.glob(out + "/p*/**/*_counter_collection.csv", recursive=True)):
     per = collections.defaultdict(list)
-    for r in csv.DictReader(open(p)):
-        if kern not in r["Kernel_Name"]:
+    rows = [r for r in csv.DictReader(open(p)) if kern in r["Kernel_Name"]]
+    # the dominant launch = the biggest grid of that kernel (the same kernel serves the deeper levels with smaller grids)
+    gmax = max((int(r["Grid_Size"]) for r in rows), default=0)
+    for r in rows:
+        if int(r["Grid_Size"]) != gmax:
             continue
         per[r["Counter_Name"]].append(float(r["Counter_Value"]))
         meta.setdefault("kernel", r["Kernel_Name"][:110]); meta.setdefault("grid_size", r["Grid_Size"]); meta.setdefault("vgpr_count", r["VGPR_Count"])
