@@ -146,10 +146,36 @@ __device__ __forceinline__ void ipyr_phase2(int ph, F&& f) {
     if (ph == 0) f(std::integral_constant<int, 0>{});
     else if (ph == 1) f(std::integral_constant<int, 1>{});
     else f(std::integral_constant<int, 2>{});
-  } else {
-    static_assert(HL == 4, "filter lengths up to 8");
+  } else if constexpr (HL == 4) {
     if (ph == 0) f(std::integral_constant<int, 0>{});
     else f(std::integral_constant<int, 2>{});
+  } else {
+    static_assert(HL == 5, "filter lengths up to 10");
+    if (ph == 0) f(std::integral_constant<int, 0>{});
+    else if (ph == 1) f(std::integral_constant<int, 1>{});
+    else if (ph == 2) f(std::integral_constant<int, 2>{});
+    else if (ph == 3) f(std::integral_constant<int, 3>{});
+    else f(std::integral_constant<int, 4>{});
+  }
+}
+
+// f(integral_constant<int, r>) for the runtime r in [0, HL): the phase of a single coefficient row
+template <int HL, typename F>
+__device__ __forceinline__ void ipyr_phase1(int r, F&& f) {
+  if constexpr (HL <= 4) {
+    pyr_dispatch<HL>(r, f);
+  } else {
+    static_assert(HL == 5, "filter lengths up to 10");
+    if (r < 2) {
+      if (r == 0) f(std::integral_constant<int, 0>{});
+      else f(std::integral_constant<int, 1>{});
+    } else if (r == 2) {
+      f(std::integral_constant<int, 2>{});
+    } else if (r == 3) {
+      f(std::integral_constant<int, 3>{});
+    } else {
+      f(std::integral_constant<int, 4>{});
+    }
   }
 }
 
@@ -339,18 +365,32 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
   // the two rows of a block: windows of the four bands, horizontal passes, vertical pass, finished pairs handed to `emit(j, p, slot)`
   auto rows2 = [&](auto r0_tag, const unsigned char* (&src)[2][4], auto&& emit) {
     constexpr int R0 = decltype(r0_tag)::value;
-    f2 w[2][4][NW];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int m = 0; m < NW; ++m) w[j][b][m] = *reinterpret_cast<const f2*>(src[j][b] + 8 * m);
     f2 vl[2][2], vh[2][2];
+    if constexpr (L <= 8) {
+      f2 w[2][4][NW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      ipyr_hsyn<L>(tlo, thi, w[j][0], w[j][1], vl[j]);
-      ipyr_hsyn<L>(tlo, thi, w[j][2], w[j][3], vh[j]);
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int m = 0; m < NW; ++m) w[j][b][m] = *reinterpret_cast<const f2*>(src[j][b] + 8 * m);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        ipyr_hsyn<L>(tlo, thi, w[j][0], w[j][1], vl[j]);
+        ipyr_hsyn<L>(tlo, thi, w[j][2], w[j][3], vh[j]);
+      }
+    } else {  // ten taps: 40 registers of accumulators — one row's windows at a time
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f2 w[4][NW];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int m = 0; m < NW; ++m) w[b][m] = *reinterpret_cast<const f2*>(src[j][b] + 8 * m);
+        ipyr_hsyn<L>(tlo, thi, w[0], w[1], vl[j]);
+        ipyr_hsyn<L>(tlo, thi, w[2], w[3], vh[j]);
+        asm volatile("" ::: "memory");  // (keeps the second row's window loads behind the first row's passes)
+      }
     }
     acc.template feed<R0 % HL>(tlo, thi, vl[0], vh[0]);
     emit(std::integral_constant<int, 0>{}, std::integral_constant<int, IpAcc<L>::done(R0 % HL)>{});
@@ -478,7 +518,7 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
         const int ebp = eb == 0 ? a.nbuf - 1 : eb - 1;
         const unsigned char* e0 = smem + stage_off + ebp * a.entry_bytes + a.offL[2] + win;
         const unsigned char* e1 = smem + stage_off + eb * a.entry_bytes + a.offL[2] + win;
-        pyr_dispatch<HL>(ph, [&](auto r_tag) {
+        ipyr_phase1<HL>(ph, [&](auto r_tag) {
           constexpr int R = decltype(r_tag)::value;
           f2 w[4][NW];
 #pragma unroll
@@ -579,7 +619,7 @@ bool dwt2_inv_pyr_supported(int nlev, const mifwt_level_desc* const* d) {
   if (nlev < 1 || nlev > 3 || g_options[MIFWT_OPT_FORCE_GENERIC] || g_options[MIFWT_OPT_PAIR_MODE] == 2 || g_options[MIFWT_OPT_PYRAMID_MODE] == 2)
     return false;
   const int L = d[0]->filt_len;
-  if (L < 2 || L > 8 || (L & 1)) return false;
+  if (L < 2 || L > 10 || (L & 1)) return false;
   const int64_t lim = int64_t(1) << 29;  // byte offsets inside one image stay below 2^31
   for (int i = 0; i < nlev; ++i) {
     const mifwt_level_desc* dl = d[i];
@@ -669,6 +709,7 @@ int dwt2_inv_pyr(int nlev, const mifwt_level_desc* const* d, const void* approx,
     case 4: return launch_ipyr_l<4>(nlev, d, approx, details, y, lo, hi, stream);
     case 6: return launch_ipyr_l<6>(nlev, d, approx, details, y, lo, hi, stream);
     case 8: return launch_ipyr_l<8>(nlev, d, approx, details, y, lo, hi, stream);
+    case 10: return launch_ipyr_l<10>(nlev, d, approx, details, y, lo, hi, stream);
     default: return MIFWT_ERR_UNSUPPORTED;
   }
 }

@@ -78,20 +78,20 @@ K = _engine.KID_INV_PYRAMID if hasattr(_engine, "KID_INV_PYRAMID") else 22
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4"])
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4", "db5"])
 def test_three_levels_vs_oracle(wavelet, mode):
     check((2, 300, 520), wavelet, mode, 3, [K])
     check((1, 203, 333), wavelet, mode, 3, [K], random_coeffs=True, seed=1)  # odd extents: trims between the levels
 
 
 @pytest.mark.parametrize("level", [1, 2])
-@pytest.mark.parametrize("wavelet", ["db2", "db4"])
+@pytest.mark.parametrize("wavelet", ["db2", "db4", "sym5"])
 def test_one_and_two_levels(wavelet, level):
     check((3, 264, 520), wavelet, "reflect", level, [K])
     check((2, 131, 259), wavelet, "symmetric", level, [K], random_coeffs=True, seed=2)
 
 
-@pytest.mark.parametrize("wavelet", ["haar", "db3", "db4"])
+@pytest.mark.parametrize("wavelet", ["haar", "db3", "db4", "db5"])
 def test_row_segments(wavelet):
     for seg in (32, 40, 64, 104, 1000):
         check((2, 300, 300), wavelet, "reflect", 3, [K], seg_rows=seg, seed=seg)
@@ -154,7 +154,7 @@ def test_randomised_against_per_level_kernels():
     """Random geometries / wavelets / segment lengths against the per-level kernels (bookkeeping net, not oracle evidence)."""
     rng = np.random.default_rng(2024)
     for trial in range(40):
-        wavelet = ["haar", "db2", "db3", "db4", "sym3", "sym4"][int(rng.integers(6))]
+        wavelet = ["haar", "db2", "db3", "db4", "sym3", "sym4", "db5", "sym5"][int(rng.integers(8))]
         level = int(rng.integers(1, 4))
         h, w = int(rng.integers(120, 400)), int(rng.integers(120, 700))  # (planes the one-launch small-plane kernel does not take)
         b = int(rng.integers(1, 4))

@@ -190,7 +190,7 @@ def simulate(coeffs, lo, hi, out_hw, seg_rows, nbuf=5):
 
 
 CASES = [("db4", 3, (200, 190), 64), ("db4", 3, (256, 260), 64), ("db2", 3, (130, 150), 32), ("haar", 3, (128, 96), 32), ("db3", 3, (150, 131), 48),
-         ("db4", 2, (120, 100), 40), ("db3", 2, (97, 110), 32), ("db2", 1, (70, 66), 24), ("db4", 1, (64, 64), 64), ("haar", 2, (64, 80), 16)]
+         ("db5", 3, (260, 210), 64), ("db5", 2, (131, 150), 48), ("sym5", 1, (80, 70), 40), ("db4", 2, (120, 100), 40), ("db3", 2, (97, 110), 32), ("db2", 1, (70, 66), 24), ("db4", 1, (64, 64), 64), ("haar", 2, (64, 80), 16)]
 
 
 @pytest.mark.parametrize("wavelet,level,shape,seg_rows", CASES)
