@@ -163,9 +163,9 @@ int mifwt_dwt2_fwd_pyramid_ws(int nlevels, const mifwt_level_desc* const* descs,
  *       taps); in auto mode planes that keep a CU's LDS to themselves only from 128 KB of LDS images and 512 images upwards
  *       (MIFWT_OPT_PYRAMID_MODE 3 lifts that);
  *   (2) kernel id 22, up to THREE levels of a big plane, coefficient rows streamed through LDS rings (a caller with more levels runs the
- *       coarser ones first and hands their output over as `approx`): f32, even L <= 8, unit innermost strides, the three detail bands
+ *       coarser ones first and hands their output over as `approx`): f32, even L <= 10, unit innermost strides, the three detail bands
  *       of a level sharing their strides (any row / image stride, any alignment), output planes of at least 32 rows whose rows fit a
- *       workgroup (about 1500 columns); in auto mode (MIFWT_OPT_PYRAMID_MODE 0) planes from 512 columns on.
+ *       workgroup (about 1500 columns); in auto mode (MIFWT_OPT_PYRAMID_MODE 0) planes from 384 columns on.
  * mifwt_dwt2_inv_pyramid_supported says which one serves the call (0 none, 1, 2; MIFWT_OPT_PYRAMID_MODE 2 switches both off);
  * MIFWT_ERR_UNSUPPORTED otherwise, nothing launched. */
 int mifwt_dwt2_inv_pyramid_supported(int nlevels, const mifwt_level_desc* const* descs);

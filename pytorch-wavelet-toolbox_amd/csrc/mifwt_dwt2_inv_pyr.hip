@@ -640,8 +640,10 @@ bool dwt2_inv_pyr_supported(int nlev, const mifwt_level_desc* const* d) {
   if (fin->sig_extent[0] < 32) return false;
   IPyrPlan p;
   if (!ipyr_plan(nlev, d, &p)) return false;
-  // where it pays (MIFWT_OPT_PYRAMID_MODE 1 overrides): planes a workgroup streams as whole rows of a useful length
-  if (g_options[MIFWT_OPT_PYRAMID_MODE] != 1 && fin->sig_extent[1] < 512) return false;
+  // where it pays (MIFWT_OPT_PYRAMID_MODE 1 overrides): planes a workgroup streams as whole rows of a useful length — from 384
+  // columns on (256 x 384^2 db4: 80 against 96 us for the per-level / two-level launches; 256^2: 53 against 49; 192^2: 69 against 44,
+  // profiles/r03l_ipyr_where.txt)
+  if (g_options[MIFWT_OPT_PYRAMID_MODE] != 1 && fin->sig_extent[1] < 384) return false;
   return true;
 }
 
