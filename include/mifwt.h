@@ -126,7 +126,7 @@ int mifwt_dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, 
  * Same sums as nlevels mifwt_dwt_fwd calls (summation order differs: agreement to rounding, not bit for bit).  Two kernels:
  *   (1) kernel id 16, up to THREE levels, rows streamed through registers and LDS rings: f32, even L <= 8, modes zero / constant /
  *       reflect / symmetric, unit innermost strides (input rows of any length and alignment), every fused plane at least 2 L
- *       samples per axis; in auto mode (MIFWT_OPT_PYRAMID_MODE 0) only for planes of 512 .. 1280 columns,
+ *       samples per axis; in auto mode (MIFWT_OPT_PYRAMID_MODE 0) only for planes of 448 .. ~2560 columns (one or two column groups),
  *       where a workgroup streams whole rows; the three detail planes of a level within 1 GiB of one another;
  *   (2) kernel id 20, up to EIGHT levels — the whole pyramid — of planes small enough to live in LDS (the plane and its
  *       horizontally filtered image, both with their boundary extension, <= 160 KB: 128 x 128 up to 12 taps), a workgroup per

@@ -511,7 +511,7 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
     gkey = None
     if ndim == 2 and folded and not any_grad:
         # geometry of the call (every band's shape: the reference's shape checks are part of what is remembered)
-        gkey = (cur.shape, cur.stride(), tuple((lv[0].stride(), *[t.shape for t in lv]) for lv in folded), flen, separable)
+        gkey = (cur.dtype, cur.shape, cur.stride(), tuple((lv[0].stride(), *[t.shape for t in lv]) for lv in folded), flen, separable)
     # (the finest level's four coefficient planes alone must fit into LDS: 10 240 samples each at most)
     if gkey is not None and folded[-1][0].shape[-1] * folded[-1][0].shape[-2] <= 10240:
         # every level of a small plane in one launch, the running approximation kept on chip (mifwt_dwt2_inv_pyramid); every

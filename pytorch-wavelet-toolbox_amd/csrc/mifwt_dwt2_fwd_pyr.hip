@@ -1038,12 +1038,11 @@ bool dwt2_fwd_pyr_supported(int nlev, const mifwt_level_desc* const* d) {
   if (dn->approx_stride[2] != 1 || dn->coef_extent[0] * dn->approx_stride[1] >= lim) return false;
   PyrPlan p;
   if (!pyr_plan(nlev, d, &p)) return false;
-  // Where it pays (tools/pyr_matrix.py, tools/pyr_big.py; MIFWT_OPT_PYRAMID_MODE 1 overrides): planes of 512 .. 1280 columns.
-  // A workgroup then reads whole rows, one after the other — contiguous megabytes.  Wider planes are cut into column groups
-  // whose workgroups read 4 KB pieces 16 KB apart: 64 x 4096^2 ran at 0.44 of the HBM peak against 0.65 for the per-level
-  // tile kernel (2-D tiles keep DRAM pages open), independent of segment length and row pitch; narrower planes leave most
-  // lanes of the level-2 / 3 waves idle (256^2: 74 against 50 us).
-  if (g_options[MIFWT_OPT_PYRAMID_MODE] != 1 && (p.ngroups > 1 || d0->sig_extent[1] < 512)) return false;
+  // Where it pays (tools/pyr_where.py, profiles/r03m_pyr_where.txt; round 2: tools/pyr_matrix.py, tools/pyr_big.py;
+  // MIFWT_OPT_PYRAMID_MODE 1 overrides): planes of 448 .. ~2560 columns, i.e. one or two column groups.  A workgroup then reads whole
+  // rows (or halves of them), one after the other.  Four column groups (4096 columns: 4 KB pieces 16 KB apart) ran at 0.44 of the HBM
+  // peak against 0.65 for the per-level tile kernel; narrower planes leave most lanes of the level-2 / 3 waves idle (256^2: 75 against 55 us).
+  if (g_options[MIFWT_OPT_PYRAMID_MODE] != 1 && (p.ngroups > 2 || d0->sig_extent[1] < 448)) return false;
   return true;
 }
 

@@ -25,7 +25,7 @@ def dev():
 
 @pytest.fixture(autouse=True)
 def _pyramid_wherever_it_can_run():
-    """Auto mode keeps the kernel to planes of 512 .. 1280 columns (where it is the fastest route); the parity cases here are
+    """Auto mode keeps the kernel to planes of 448 .. ~2560 columns (where it is the fastest route); the parity cases here are
     mostly smaller or wider, so they switch to "wherever the kernel can run" (MIFWT_OPT_PYRAMID_MODE 1)."""
     _engine.set_option(_engine.OPT_PYRAMID_MODE, 1)
     yield
@@ -181,9 +181,9 @@ def test_pyramid_linearity_and_roundtrip_full_size():
 def test_pyramid_declines_what_it_cannot_serve():
     lib = _engine.load_library()
     taps = ptwt_amd._fwt.host_taps("db4")[:2]
-    # auto mode: only where it is the fastest route — planes of 512 .. 1280 columns (one column group: whole rows per workgroup)
+    # auto mode: only where it is the fastest route — planes of 448 .. ~2560 columns (one or two column groups)
     _engine.set_option(_engine.OPT_PYRAMID_MODE, 0)
-    for shape, served in (((4, 1024, 1024), True), ((4, 600, 512), True), ((4, 256, 256), False), ((2, 512, 2048), False)):
+    for shape, served in (((4, 1024, 1024), True), ((4, 600, 512), True), ((4, 256, 256), False), ((2, 512, 2048), True), ((2, 512, 4096), False)):
         got = _engine.ENGINE.analysis_pyramid(torch.randn(*shape, device=dev()), *taps, _engine.MODE_IDS["reflect"], 3)
         assert (got is not None) == served, shape
     _engine.set_option(_engine.OPT_PYRAMID_MODE, 1)
