@@ -71,6 +71,11 @@ WORKLOADS = {
     "wavedec2_db2_L2_16384x32x32_f32": ("wavedec2", (16384, 32, 32), "db2", 2, "reflect", torch.float32),
     # the round trip's second half on config 2's coefficients: one streaming launch (kernel id 22)
     "waverec2_db4_L3_64x1024x1024_f32": ("waverec2", (64, 1024, 1024), "db4", 3, "reflect", torch.float32),
+    # the other reconstructions (kernel ids 10, 18 / 15, 21)
+    "waverec3_db2_L3_8x256x256x256_f32": ("waverec3", (8, 256, 256, 256), "db2", 3, "zero", torch.float32),
+    "waverec_db5_L10_32x1000000_f32": ("waverec", (32, 1000000), "db5", 10, "periodic", torch.float32),
+    "waverec2_db2_L3_4096x64x64_f32": ("waverec2", (4096, 64, 64), "db2", 3, "reflect", torch.float32),
+    "waverec2_db5_L5_32x1000x1000_f32_periodic": ("waverec2", (32, 1000, 1000), "db5", 5, "periodic", torch.float32),
     # the reference's own published 2-D / separable / 3-D speed-test shapes (examples/speed_tests/timeitconv_2d.py:38-57,
     # timeitconv_2d_separable.py:43-85, timeitconv_3d.py:54-64)
     "wavedec2_db5_L5_32x1000x1000_f32_periodic": ("wavedec2", (32, 1000, 1000), "db5", 5, "periodic", torch.float32),
@@ -132,7 +137,8 @@ def cpu_baseline(fn, shape, wavelet, level, mode, dtype):
     a slice of the batch sized to about 64 Mi samples (the path is linear in the batch), at most ~20 s of work."""
     from oracle import torch_cpu_port as P
 
-    ports = {"wavedec2": P.wavedec2, "wavedec": P.wavedec, "wavedec3": P.wavedec3, "fswavedec2": P.fswavedec2, "waverec2": P.waverec2}
+    ports = {"wavedec2": P.wavedec2, "wavedec": P.wavedec, "wavedec3": P.wavedec3, "fswavedec2": P.fswavedec2, "waverec2": P.waverec2,
+             "waverec": P.waverec, "waverec3": P.waverec3}
     if fn not in ports:
         return None
     port = ports[fn]
@@ -144,6 +150,12 @@ def cpu_baseline(fn, shape, wavelet, level, mode, dtype):
     if fn == "waverec2":
         arg = P.wavedec2(x, wavelet, mode=mode, level=level)
         run = lambda sl: port(tuple([arg[0][sl]] + [tuple(t[sl] for t in lv) for lv in arg[1:]]), wavelet)  # noqa: E731
+    elif fn == "waverec":
+        arg = P.wavedec(x, wavelet, mode=mode, level=level)
+        run = lambda sl: port([t[sl] for t in arg], wavelet)  # noqa: E731
+    elif fn == "waverec3":
+        arg = P.wavedec3(x, wavelet, mode=mode, level=level)
+        run = lambda sl: port(tuple([arg[0][sl]] + [{k: v[sl] for k, v in d.items()} for d in arg[1:]]), wavelet)  # noqa: E731
     else:
         run = lambda sl: port(x[sl], wavelet, mode=mode, level=level)  # noqa: E731
     # oneDNN's conv does not scale to every core of a big host: probe a few thread counts on a small slice
@@ -423,7 +435,9 @@ def main():
                   22: f"idwt2_pyr_kernel (the {fused_levels} finest synthesis levels in one launch)",
                   21: f"idwt2_small_kernel (all {fused_levels} synthesis levels in one launch, a workgroup per image)",
                   13: "idwt2_pair_kernel (two synthesis levels in one launch)", 8: "idwt2_tile_kernel (finest level)",
-                  2: "dwt2_inv_stream_kernel (finest level)"}.get(kid1, f"kernel id {kid1} (level 1)")
+                  2: "dwt2_inv_stream_kernel (finest level)", 10: "idwt3_tile_kernel (finest level)", 6: "depth pass + fused 2-D planes (finest level)",
+                  18: "idwt1_long_kernel (the finest levels in one launch)", 15: "idwt1_tail_kernel (the coarse levels in one launch)",
+                  4: "streaming axis kernels (finest level)"}.get(kid1, f"kernel id {kid1} (level 1)")
         per_launch_event_ms = sum(lvl1) / max(1, len(lvl1))
         avg_ms = lvl1_b2b_ms if lvl1_b2b_ms else per_launch_event_ms
         achieved = lvl1_b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0

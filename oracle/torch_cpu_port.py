@@ -117,6 +117,48 @@ def waverec2(coeffs, wavelet):
     return cur
 
 
+def waverec(coeffs, wavelet):
+    """``[cA_n, cD_n, ..., cD_1]`` of [B, n] CPU tensors -> [B, N] (src/ptwt/conv_transform.py:146-204)."""
+    bank = O.filter_bank(wavelet)
+    dt = coeffs[0].dtype
+    filt = torch.stack([torch.tensor(bank[2].copy(), dtype=dt), torch.tensor(bank[3].copy(), dtype=dt)]).unsqueeze(1)
+    flen = len(bank[2])
+    pad = (2 * flen - 3) // 2
+    cur = coeffs[0]
+    for pos, d in enumerate(coeffs[1:]):
+        res = F.conv_transpose1d(torch.stack([cur, d], 1), filt, stride=2).squeeze(1)
+        pr = pad
+        if pos + 2 < len(coeffs):
+            pr += O.adjust_trim(res.shape[-1] - 2 * pad, coeffs[pos + 2].shape[-1])
+        cur = res[..., pad:res.shape[-1] - pr]
+    return cur
+
+
+def waverec3(coeffs, wavelet):
+    """``(cA, {aad: .., ...}_n, ...)`` of [B, d, h, w] CPU tensors -> [B, D, H, W] (src/ptwt/conv_transform_3.py:148-251)."""
+    bank = O.filter_bank(wavelet)
+    dt = coeffs[0].dtype
+    lo, hi = torch.tensor(bank[2].copy(), dtype=dt), torch.tensor(bank[3].copy(), dtype=dt)
+    filt, keys = [], []
+    for a, fa in (("a", lo), ("d", hi)):
+        for b, fb in (("a", lo), ("d", hi)):
+            for c, fc in (("a", lo), ("d", hi)):
+                filt.append(fa[:, None, None] * fb[None, :, None] * fc[None, None, :])
+                keys.append(a + b + c)
+    bankt = torch.stack(filt).unsqueeze(1)
+    flen = len(bank[2])
+    pad = (2 * flen - 3) // 2
+    cur = coeffs[0]
+    for pos, det in enumerate(coeffs[1:]):
+        res = F.conv_transpose3d(torch.stack([cur] + [det[k] for k in keys[1:]], 1), bankt, stride=2).squeeze(1)
+        trims = [0, 0, 0]
+        if pos + 2 < len(coeffs):
+            nxt = next(iter(coeffs[pos + 2].values())).shape
+            trims = [O.adjust_trim(res.shape[-3 + a] - 2 * pad, nxt[-3 + a]) for a in range(3)]
+        cur = res[..., pad:res.shape[-3] - pad - trims[0], pad:res.shape[-2] - pad - trims[1], pad:res.shape[-1] - pad - trims[2]]
+    return cur
+
+
 def fswavedec2(x: torch.Tensor, wavelet, *, mode: str = "reflect", level: int = 1):
     """``x``: [B, H, W] CPU tensor -> ``(cA, {ad, da, dd}_n, ...)``: one 1-D level along the last axis, then one along the rows of
     both halves, per level (src/ptwt/separable_conv_transform.py:36-72, 187-231)."""

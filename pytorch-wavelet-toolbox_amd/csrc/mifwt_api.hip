@@ -465,7 +465,10 @@ int mifwt_dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, 
 static int pyramid_route(int nlevels, const mifwt_level_desc* const* descs) {
   const bool pyr = nlevels <= 3 && dwt2_fwd_pyr_supported(nlevels, descs);
   if (pyr && g_options[MIFWT_OPT_PYRAMID_MODE] == 1) return 1;
-  if (dwt2_fwd_small_supported(nlevels, descs)) return 2;
+  // (a SINGLE level of a small plane is better off in the per-level tile kernel unless the batch is big: one workgroup per image at a
+  // time — 256 x 67^2: 60.7 us for the call against 54.9, 32 x 70^2: 10.6 against ~6 us for the level; MIFWT_OPT_PYRAMID_MODE 3 lifts it)
+  const bool lone = nlevels == 1 && descs[0]->batch < 1024 && g_options[MIFWT_OPT_PYRAMID_MODE] != 3;
+  if (!lone && dwt2_fwd_small_supported(nlevels, descs)) return 2;
   return pyr ? 1 : 0;
 }
 

@@ -211,3 +211,8 @@ def test_torch_cpu_ports_of_the_other_functions_match_oracle(mode):
         c = O.wavedec2(x2, wav, mode=mode, level=3)
         rec = P.waverec2(tuple([torch.from_numpy(c[0])] + [tuple(torch.from_numpy(v) for v in lv) for lv in c[1:]]), wav)
         assert G.relerr(rec.numpy(), O.waverec2(c, wav)) < TOL64, (mode, wav)
+        c = O.wavedec(x1, wav, mode=mode, level=3)
+        assert G.relerr(P.waverec([torch.from_numpy(t) for t in c], wav).numpy(), O.waverec(c, wav)) < TOL64, (mode, wav)
+        c = O.wavedec3(x3, wav, mode=mode, level=2)
+        rec = P.waverec3(tuple([torch.from_numpy(c[0])] + [{k: torch.from_numpy(v) for k, v in d.items()} for d in c[1:]]), wav)
+        assert G.relerr(rec.numpy(), O.waverec3(c, wav)) < TOL64, (mode, wav)
