@@ -65,21 +65,44 @@ struct IPyrArgs {
   f2 thi[L / 2];
 };
 
+// where the tap pairs live: SGPR pairs (default) or VGPR pairs (experiment build -DMIFWT_IPYR_TAPV: a lone wave issues a packed FMA with
+// an SGPR-pair operand every ~6.9 cycles, with VGPR operands every ~5.3 — tools/ubench.hip — at the price of L registers)
+#ifdef MIFWT_IPYR_TAPV
+#define MIFWT_TAPC "v"
+#else
+#define MIFWT_TAPC "s"
+#endif
+__device__ __forceinline__ void ivfma_lo(f2& acc, const f2 tap, const f2 pair) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : MIFWT_TAPC(tap), "v"(pair));
+}
+__device__ __forceinline__ void ivfma_hi(f2& acc, const f2 tap, const f2 pair) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : MIFWT_TAPC(tap), "v"(pair));
+}
+__device__ __forceinline__ f2 ivmul_lo(const f2 tap, const f2 pair) {
+  f2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : MIFWT_TAPC(tap), "v"(pair));
+  return r;
+}
+__device__ __forceinline__ f2 ivmul_hi(const f2 tap, const f2 pair) {
+  f2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : MIFWT_TAPC(tap), "v"(pair));
+  return r;
+}
 // acc (+)= tap.x * v / tap.y * v with the tap pair in an SGPR pair and BOTH halves of v (two neighbouring columns)
 __device__ __forceinline__ void vfma_tx(f2& acc, const f2 tap, const f2 v) {
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(tap), "v"(v));
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : MIFWT_TAPC(tap), "v"(v));
 }
 __device__ __forceinline__ void vfma_ty(f2& acc, const f2 tap, const f2 v) {
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(tap), "v"(v));
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : MIFWT_TAPC(tap), "v"(v));
 }
 __device__ __forceinline__ f2 vmul_tx(const f2 tap, const f2 v) {
   f2 r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "s"(tap), "v"(v));
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : MIFWT_TAPC(tap), "v"(v));
   return r;
 }
 __device__ __forceinline__ f2 vmul_ty(const f2 tap, const f2 v) {
   f2 r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "s"(tap), "v"(v));
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : MIFWT_TAPC(tap), "v"(v));
   return r;
 }
 
@@ -126,13 +149,13 @@ __device__ __forceinline__ void ipyr_hsyn(const f2 (&tlo)[L / 2], const f2 (&thi
     for (int e = 0; e < 2; ++e) {
       const int u = e + t;
       if (t == 0) {
-        v[e] = (u & 1) ? vmul_hi(tlo[j], cl[u >> 1]) : vmul_lo(tlo[j], cl[u >> 1]);
+        v[e] = (u & 1) ? ivmul_hi(tlo[j], cl[u >> 1]) : ivmul_lo(tlo[j], cl[u >> 1]);
       } else {
-        if (u & 1) vfma_hi(v[e], tlo[j], cl[u >> 1]);
-        else vfma_lo(v[e], tlo[j], cl[u >> 1]);
+        if (u & 1) ivfma_hi(v[e], tlo[j], cl[u >> 1]);
+        else ivfma_lo(v[e], tlo[j], cl[u >> 1]);
       }
-      if (u & 1) vfma_hi(v[e], thi[j], ch[u >> 1]);
-      else vfma_lo(v[e], thi[j], ch[u >> 1]);
+      if (u & 1) ivfma_hi(v[e], thi[j], ch[u >> 1]);
+      else ivfma_lo(v[e], thi[j], ch[u >> 1]);
     }
   }
 }
@@ -366,7 +389,12 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
   auto rows2 = [&](auto r0_tag, const unsigned char* (&src)[2][4], auto&& emit) {
     constexpr int R0 = decltype(r0_tag)::value;
     f2 vl[2][2], vh[2][2];
-    if constexpr (L <= 8) {
+#ifdef MIFWT_IPYR_TAPV
+    constexpr bool kTwoRows = L <= 6;
+#else
+    constexpr bool kTwoRows = L <= 8;
+#endif
+    if constexpr (kTwoRows) {
       f2 w[2][4][NW];
 #pragma unroll
       for (int j = 0; j < 2; ++j)
