@@ -60,6 +60,9 @@ struct IPyrArgs {
   int offL[NLEV];    // byte offset of a level's rows inside a staging entry
   int entry_bytes;
   int nS[NLEV];      // waves per level
+  int tw;            // fast warm-up: entries 0 .. tw - 1 (tw = T1 or 0) have slots of their own (their level-2 / level-3 rows), all
+                     // requested when the workgroup starts; the ring of nbuf entries begins with entry tw
+  int wu2_off, wu3_off;  // LDS byte offsets of those slots: level-2 rows of entries 2 D2 .. tw - 1, level-3 rows of entries 0 .. tw - 1
   int dbg;
   f2 tlo[L / 2];  // (rec_lo[2j], rec_lo[2j+1])
   f2 thi[L / 2];
@@ -279,6 +282,7 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
   }
   const int nsub = T1 + ((rb[1] - ra[1] + 2) >> 1);
   const int ahead = a.nbuf - 2;
+  const int TW = a.tw;
   const uint32_t stage_off = 0;
   const uint32_t ring1_off = stage_off + (uint32_t)(a.nbuf * a.entry_bytes);
   const uint32_t ring2_off = ring1_off + (NLEV >= 2 ? (uint32_t)(kIpRing1 * a.pitchR[0]) : 0u);
@@ -319,8 +323,9 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
       const rsrc_t dead = pyr_rsrc(a.band[0][1], 0);  // every lane out of range: zeros land
       int ib = 0;
       auto issue = [&](int t) {
+        const bool warm = t < TW;  // (the level-1 rows of such an entry are before the segment: nothing to fetch)
         const uint32_t ent = stage_off + (uint32_t)ib * (uint32_t)a.entry_bytes;
-        ib = ib + 1 == a.nbuf ? 0 : ib + 1;
+        if (!warm) ib = ib + 1 == a.nbuf ? 0 : ib + 1;
         pyr_static_for<NMINE>([&](auto k_tag) {
           constexpr int K = decltype(k_tag)::value, I = WI + kIpLoaders * K;
           constexpr int LV = I < N1 ? 1 : (I < N1 + N2 ? 2 : 3);
@@ -332,17 +337,23 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
             r = ra[1] + 2 * (t - T1) + J;
             alive = t >= T1 && r <= rb[1];
             dst = ent + (uint32_t)a.offL[0] + (uint32_t)((2 * SB + J) * a.pitchS[0]);
+            if (warm) return;
           } else if constexpr (LV == 2) {
             constexpr int SB = I - N1;
             r = ra[NLEV >= 2 ? 2 : 1] + t - 2 * D2;
             alive = r >= ra[NLEV >= 2 ? 2 : 1] && r <= rb[NLEV >= 2 ? 2 : 1];
             dst = ent + (uint32_t)a.offL[NLEV >= 2 ? 1 : 0] + (uint32_t)(SB * a.pitchS[NLEV >= 2 ? 1 : 0]);
+            if (warm) {
+              if (t < 2 * D2) return;
+              dst = (uint32_t)a.wu2_off + (uint32_t)(((t - 2 * D2) * NB2 + SB) * a.pitchS[NLEV >= 2 ? 1 : 0]);
+            }
           } else {
             constexpr int SI = I - N1 - N2;
             r = ra[NLEV >= 3 ? 3 : 1] + (t >> 1);
             v = t & 1;
             alive = r <= rb[NLEV >= 3 ? 3 : 1];
             dst = ent + (uint32_t)a.offL[NLEV >= 3 ? 2 : 0] + (uint32_t)(SI * a.pitchS[NLEV >= 3 ? 2 : 0]);
+            if (warm) dst = (uint32_t)a.wu3_off + (uint32_t)((2 * t + SI) * a.pitchS[NLEV >= 3 ? 2 : 0]);
           }
           const int mw = a.Mw[LV - 1];
           const uint32_t limit = 4u * (uint32_t)mw;
@@ -353,15 +364,16 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
           for (int c = 0; c < nch; ++c) ipyr_dma(lane16 + 1024u * (uint32_t)c, limit, rr, soff, dst + 1024u * (uint32_t)c);
         });
       };
-      for (int t = 0; t < ahead; ++t)
+      for (int t = 0; t < TW + ahead; ++t)
         if (t < nsub) issue(t);
 #pragma unroll 1
       for (int t = 0; t < nsub; ++t) {
-        // entry t must have landed; the ones requested after it may still be in flight
-        const int later = min(ahead - 1, nsub - 1 - t);
+        // entry t must have landed; the ones requested after it may still be in flight (before sub-step TW: every warm-up entry —
+        // they were requested first — but none of the ring's entries)
+        const int later = t < TW ? min(ahead, nsub - TW) : min(ahead - 1, nsub - 1 - t);
         ipyr_wait_vm(later * per);
         __syncthreads();
-        if (t + ahead < nsub) issue(t + ahead);  // into the buffer of entry t - 2, which nobody reads any more
+        if (t >= TW && t + ahead < nsub) issue(t + ahead);  // into the buffer of entry t - 2, which nobody reads any more
       }
     };
     if (widx == 0) run(std::integral_constant<int, 0>{});
@@ -477,7 +489,7 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
         });
         ph = (ph + 2) % HL;
       }
-      eb = eb + 1 == a.nbuf ? 0 : eb + 1;
+      if (t >= TW) eb = eb + 1 == a.nbuf ? 0 : eb + 1;
     }
     return;
   }
@@ -502,7 +514,9 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
           const unsigned char* src[2][4];
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
-            const unsigned char* ent = smem + stage_off + (j ? eb : ebp) * a.entry_bytes + a.offL[1];
+            const int e = t - 1 + j;
+            const unsigned char* ent = e < TW ? smem + a.wu2_off + (e - 2 * D2) * NB2 * a.pitchS[1]
+                                              : smem + stage_off + (j ? eb : ebp) * a.entry_bytes + a.offL[1];
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
               if (b == 0 && NLEV >= 3) src[j][b] = smem + ring2_off + ((r2 + j) & (kIpRing2 - 1)) * a.pitchR[1] + win;
@@ -524,7 +538,7 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
           });
           ph = (ph + 2) % HL;
         }
-        eb = eb + 1 == a.nbuf ? 0 : eb + 1;
+        if (t >= TW) eb = eb + 1 == a.nbuf ? 0 : eb + 1;
       }
       return;
     }
@@ -544,8 +558,8 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
       const int r3 = ra[3] + (t >> 1);
       if ((t & 1) && r3 <= rb[3] && !(a.dbg & 4)) {
         const int ebp = eb == 0 ? a.nbuf - 1 : eb - 1;
-        const unsigned char* e0 = smem + stage_off + ebp * a.entry_bytes + a.offL[2] + win;
-        const unsigned char* e1 = smem + stage_off + eb * a.entry_bytes + a.offL[2] + win;
+        const unsigned char* e0 = (t - 1 < TW ? smem + a.wu3_off + 2 * (t - 1) * a.pitchS[2] : smem + stage_off + ebp * a.entry_bytes + a.offL[2]) + win;
+        const unsigned char* e1 = (t < TW ? smem + a.wu3_off + 2 * t * a.pitchS[2] : smem + stage_off + eb * a.entry_bytes + a.offL[2]) + win;
         ipyr_phase1<HL>(ph, [&](auto r_tag) {
           constexpr int R = decltype(r_tag)::value;
           f2 w[4][NW];
@@ -572,14 +586,14 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
         });
         ph = ph + 1 == HL ? 0 : ph + 1;
       }
-      eb = eb + 1 == a.nbuf ? 0 : eb + 1;
+      if (t >= TW) eb = eb + 1 == a.nbuf ? 0 : eb + 1;
     }
   }
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
 struct IPyrPlan {
-  int nseg, seg_rows, nbuf, pitchS[3], pitchR[2], offL[3], entry_bytes, nS[3], lds;
+  int nseg, seg_rows, nbuf, pitchS[3], pitchR[2], offL[3], entry_bytes, nS[3], lds, tw, wu2_off, wu3_off;
 };
 
 // d[0] = the coarsest level, d[nlev - 1] = the finest (the order of mifwt_dwt2_inv_pyramid); level l (1 = finest) = d[nlev - l]
@@ -623,10 +637,20 @@ static bool ipyr_plan(int nlev, const mifwt_level_desc* const* d, IPyrPlan* p) {
     }
     per_max = std::max(per[0], std::max(per[1], per[2]));
   }
+  // fast warm-up (MIFWT_OPT_DEBUG bit 8 switches it off): slots of their own for the level-2 / level-3 rows of the entries before
+  // level 1 starts, if they fit beside at least four ring entries
+  const int t1 = ipyr_t1(L, nlev), d2 = ipyr_d2(L, nlev);
+  const int wu3 = nlev >= 3 ? t1 * 2 * p->pitchS[2] : 0;
+  const int wu2 = nlev >= 2 ? (t1 - 2 * d2) * (nlev == 2 ? 4 : 3) * p->pitchS[1] : 0;
+  int wu = (g_options[MIFWT_OPT_DEBUG] & 8) ? 0 : wu2 + wu3;
+  if (wu && 4 * p->entry_bytes + rings + slack + wu > 160 * 1024) wu = 0;
   p->nbuf = g_options[MIFWT_OPT_PREFETCH_PAIRS] > 3 ? std::min(8, g_options[MIFWT_OPT_PREFETCH_PAIRS]) : 5;
-  while (p->nbuf > 4 && (p->nbuf * p->entry_bytes + rings + slack > 160 * 1024 || (p->nbuf - 2) * per_max > 63)) --p->nbuf;
-  p->lds = p->nbuf * p->entry_bytes + rings + slack;
+  while (p->nbuf > 4 && (p->nbuf * p->entry_bytes + rings + slack + wu > 160 * 1024 || (p->nbuf - 2) * per_max > 63)) --p->nbuf;
+  p->lds = p->nbuf * p->entry_bytes + rings + slack + wu;
   if (p->lds > 160 * 1024 || (p->nbuf - 2) * per_max > 63) return false;
+  p->tw = wu ? t1 : 0;
+  p->wu3_off = p->nbuf * p->entry_bytes + rings + slack;
+  p->wu2_off = p->wu3_off + wu3;
   if (p->lds < 82 * 1024) p->lds = 82 * 1024;  // one workgroup per CU
   int dev = 0, ncu = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -707,6 +731,9 @@ static int launch_ipyr(const mifwt_level_desc* const* d, const void* approx, con
   a.pitchR[0] = p.pitchR[0];
   a.pitchR[1] = p.pitchR[1];
   a.entry_bytes = p.entry_bytes;
+  a.tw = p.tw;
+  a.wu2_off = p.wu2_off;
+  a.wu3_off = p.wu3_off;
   a.dbg = g_options[MIFWT_OPT_DEBUG];
   for (int j = 0; j < L / 2; ++j) {
     a.tlo[j] = (f2){(float)lo[2 * j], (float)lo[2 * j + 1]};
