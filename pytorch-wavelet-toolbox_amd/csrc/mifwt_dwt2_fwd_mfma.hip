@@ -41,6 +41,8 @@ struct MfmaArgs {
   int64_t os_b[4], os_h[4];
   int H, W, Ho, Wo;
   int tiles_c, tiles_r, ntiles;
+  int dbg;                      // walk kernel, MIFWT_OPT_DEBUG: 1 = no stores, 2 = no loads, 4 = no matrix work
+  int seg_tiles, segs, nunits;  // walk kernel: a unit = seg_tiles vertically stacked tiles of one 64-column panel of an image
   int mode, L;
   float lo[32], hi[32];  // dec taps, zero-padded to 32
 };
@@ -265,6 +267,245 @@ __global__ void __launch_bounds__(256, 4) dwt2_fwd_mfma_kernel(const MfmaArgs a)
   }
 }
 
+
+// ---- the same tile, WALKED down a 64-column panel -----------------------------------------------------------------------------
+// Vertically stacked tiles share half of their 64 input rows, and so do their horizontally filtered (lo, hi) images.  A workgroup
+// walks down seg_tiles stacked tiles of one panel: per tile it requests only the 32 NEW input rows (a "chunk"), filters those along
+// the rows (one MFMA job per wave instead of two) into one half of a 64-row ring of the transposed (lo, hi) image, and the vertical
+// pass reads its 64-row window from the ring (older half first).  One extra chunk per unit primes the ring.  Against the tile kernel
+// above: half the window reads (2.5x -> 1.25x of the plane through L2), two thirds of the MFMAs, same sums in the same order
+// (bit-identical results).
+constexpr int kWR = 32;  // input rows of a chunk = 2 kMR
+
+__global__ void __launch_bounds__(256, 4) dwt2_fwd_mfma_walk_kernel(const MfmaArgs a) {
+  __shared__ __attribute__((aligned(16))) _Float16 xt[kWR * kXP];
+  __shared__ __attribute__((aligned(16))) _Float16 ht[2 * kMC * kHP];
+  __shared__ float taps[64];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  __builtin_assume(wave >= 0 && wave < 4);
+  const bool zero_mode = a.mode == MIFWT_MODE_ZERO;
+  Fold1 fold;
+  fold.set(a.mode);
+  const int L = a.L;
+  const int n = lane & 31, half = lane >> 5;
+
+  if (threadIdx.x < 64) taps[threadIdx.x] = threadIdx.x < 32 ? a.lo[threadIdx.x] : a.hi[threadIdx.x - 32];
+  __syncthreads();
+  h8 ahi[4], alo[4];
+  {
+    const int band = n >> 4, kq = n & 15;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = 16 * c + 8 * half + e;
+        const int m = 2 * kq + L - 1 - j;
+        const float t = (m >= 0 && m < L) ? taps[32 * band + m] : 0.f;
+        const _Float16 th = (_Float16)t;
+        ahi[c][e] = th;
+        alo[c][e] = (_Float16)(t - (float)th);
+      }
+    }
+  }
+
+  // units (image, row segment, panel) with the panel index fastest: the blocks of an XCD walk down neighbouring panels (which share
+  // 32 of their 160 columns) at the same time; staggered starting points as in the tile kernel
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, nq = gridDim.x >> 3;
+  const int u_begin = (int)(((int64_t)a.nunits * xcd) >> 3), u_end = (int)(((int64_t)a.nunits * (xcd + 1)) >> 3);
+  const int panel = u_end - u_begin, rot = (int)(((int64_t)panel * xcd) >> 3);
+  constexpr uint32_t kOob = 0x80000000u;
+  const uint32_t row_bytes = (uint32_t)a.xs_h * 2u;
+  const uint32_t img_bytes = (a.dbg & 2) ? 0u : ((uint32_t)(a.H - 1) * (uint32_t)a.xs_h + (uint32_t)a.W) * 2u;
+  const bool aligned4 = (a.xs_h & 1) == 0 && (a.xs_b & 1) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 3) == 0;
+
+  struct Unit {
+    int img, k0, tr0, nt;  // image, first output column, first tile row, tiles
+    bool pairs;
+  };
+  auto locate = [&](int it) -> Unit {
+    int pos = it + rot;
+    if (pos >= panel) pos -= panel;
+    const int idx = u_begin + pos;
+    const int rest = idx / a.tiles_c, tc = idx - rest * a.tiles_c;
+    Unit u;
+    u.img = rest / a.segs;
+    u.tr0 = (rest - u.img * a.segs) * a.seg_tiles;
+    u.nt = min(a.seg_tiles, a.tiles_r - u.tr0);
+    u.k0 = tc * kMC;
+    const int c_first = 2 * u.k0 - (L - 2);
+    u.pairs = aligned4 && c_first >= 0 && c_first + kIC <= a.W;
+    return u;
+  };
+  // chunk g of a unit: extended input rows r_first + 32 g .. + 31 with r_first = 2 kMR tr0 - (L - 2)
+  auto request = [&](const Unit& u, int g, uint32_t (&v)[8][3]) {
+    if (a.dbg & 16) return;
+    const __amdgpu_buffer_rsrc_t xrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.x + (int64_t)u.img * a.xs_b), 0, img_bytes, 0x00020000);
+    const int nc_need = 2 * (min(u.k0 + kMC, a.Wo) - u.k0) + L - 2;
+    const int c_first = 2 * u.k0 - (L - 2), r_first = 2 * kMR * u.tr0 - (L - 2) + kWR * g;
+    const int r_end = 2 * a.Ho;  // extended rows from here on feed no stored output
+    if (u.pairs) {
+      uint32_t poff[2];
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) poff[qq] = lane + 64 * qq < kIC / 2 ? 2u * (uint32_t)(c_first + 2 * (lane + 64 * qq)) : kOob;
+      if (r_first >= 0 && r_first + kWR <= a.H) {
+        uint32_t soff = (uint32_t)(r_first + wave) * row_bytes;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) v[i][qq] = __builtin_amdgcn_raw_buffer_load_b32(xrsrc, poff[qq], soff, 0);
+          soff += 4u * row_bytes;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int ri = r_first + wave + 4 * i;  // wave-uniform
+          const bool dead = ri >= r_end || (zero_mode && (unsigned)ri >= (unsigned)a.H);
+          const uint32_t soff = __builtin_amdgcn_readfirstlane(dead ? 0u : (uint32_t)fold(ri, a.H) * row_bytes);
+#pragma unroll
+          for (int qq = 0; qq < 2; ++qq) v[i][qq] = __builtin_amdgcn_raw_buffer_load_b32(xrsrc, dead ? kOob : poff[qq], soff, 0);
+        }
+      }
+    } else {
+      uint32_t coff[3];
+#pragma unroll
+      for (int qq = 0; qq < 3; ++qq) {
+        const int c = lane + 64 * qq;
+        const int ci = c_first + c;
+        const bool dead = c >= nc_need || (zero_mode && (unsigned)ci >= (unsigned)a.W);
+        coff[qq] = dead ? kOob : 2u * (uint32_t)fold(ci, a.W);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int ri = r_first + wave + 4 * i;
+        const bool dead = ri >= r_end || (zero_mode && (unsigned)ri >= (unsigned)a.H);
+        const uint32_t soff = __builtin_amdgcn_readfirstlane(dead ? 0u : (uint32_t)fold(ri, a.H) * row_bytes);
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq) v[i][qq] = __builtin_amdgcn_raw_buffer_load_b16(xrsrc, dead ? kOob : coff[qq], soff, 0);
+      }
+    }
+  };
+  auto commit = [&](bool pairs, const uint32_t (&v)[8][3]) {
+    if (a.dbg & 8) return;
+    if (pairs) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = wave + 4 * i;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+          if (lane + 64 * qq < kXP / 2) *reinterpret_cast<uint32_t*>(&xt[r * kXP + 2 * (lane + 64 * qq)]) = v[i][qq];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = wave + 4 * i;
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq)
+          if (lane + 64 * qq < kXP) xt[r * kXP + lane + 64 * qq] = __builtin_bit_cast(_Float16, (unsigned short)v[i][qq]);
+      }
+    }
+  };
+
+  // Software pipeline: the chunk AFTER the next one is requested into registers as soon as the next one has been parked in LDS, so
+  // that a request is in flight for a whole step (horizontal pass, vertical pass and both barriers) before anybody waits for it.
+  uint32_t stage[8][3] = {};
+  if (q >= panel) return;
+  int it = q;
+  Unit cur = locate(it);
+  int g = 0;
+  // (unit, chunk) after (u, gg) in this block's sequence; false at the end
+  auto advance = [&](Unit& u, int& gg) -> bool {
+    if (gg < u.nt) {
+      ++gg;
+      return true;
+    }
+    it += nq;
+    if (it >= panel) return false;
+    u = locate(it);
+    gg = 0;
+    return true;
+  };
+  request(cur, 0, stage);
+  commit(cur.pairs, stage);
+  Unit nu = cur;
+  int ng = 0;
+  bool has_next = advance(nu, ng);
+  if (has_next) request(nu, ng, stage);
+  __syncthreads();
+  for (;;) {
+    // ---- horizontal pass of the chunk: wave = output block of 16 columns; D[row][(band, kq)] -> ring half g & 1, transposed
+    {
+      const int kb = wave;
+      f16x acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int c = 0; c < ((a.dbg & 4) ? 0 : 4); ++c) {
+        const h8 xf = *reinterpret_cast<const h8*>(&xt[n * kXP + 32 * kb + 16 * c + 8 * half]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, ahi[c], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, alo[c], acc, 0, 0, 0);
+      }
+      const int band = n >> 4, kq = n & 15;
+      _Float16* hrow = &ht[(band * kMC + kb * 16 + kq) * kHP + 32 * (g & 1) + 4 * half];
+#pragma unroll
+      for (int gg = 0; gg < ((a.dbg & 64) ? 0 : 4); ++gg) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<h4*>(hrow + 8 * gg) =
+            (h4){(_Float16)acc[4 * gg], (_Float16)acc[4 * gg + 1], (_Float16)acc[4 * gg + 2], (_Float16)acc[4 * gg + 3]};
+      }
+    }
+    if (!(a.dbg & 32)) __syncthreads();  // ring half complete, xt released
+
+    Unit nu2 = nu;
+    int ng2 = ng;
+    bool has_next2 = false;
+    if (has_next) {
+      commit(nu.pairs, stage);
+      has_next2 = advance(nu2, ng2);
+      if (has_next2) request(nu2, ng2, stage);
+    }
+
+    // ---- vertical pass of tile tr0 + g - 1: window rows 0 .. 31 = chunk g - 1, 32 .. 63 = chunk g
+    if (g >= 1) {
+      const int bh = wave >> 1, cg = wave & 1;
+      const int old = 32 * ((g - 1) & 1);
+      f16x acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int c = 0; c < ((a.dbg & 4) ? 0 : 4); ++c) {
+        const h8 b = *reinterpret_cast<const h8*>(&ht[(bh * kMC + cg * 32 + n) * kHP + ((16 * c + 8 * half + old) & 63)]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[c], b, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[c], b, acc, 0, 0, 0);
+      }
+      const int k = cur.k0 + cg * 32 + n;
+      const int j0 = (cur.tr0 + g - 1) * kMR;
+      if (k < a.Wo && !(a.dbg & 1)) {
+#pragma unroll
+        for (int bv = 0; bv < 2; ++bv) {
+          const int s = 2 * bv + bh;
+          _Float16* base = a.out[s] + (int64_t)cur.img * a.os_b[s] + (int64_t)(j0 + 4 * half) * a.os_h[s] + k;
+          const int jlim = a.Ho - j0 - 4 * half;
+#pragma unroll
+          for (int gg = 0; gg < 8; ++gg) {
+            const int jr = (gg & 3) + 8 * (gg >> 2);
+            if (jr < jlim) base[(int64_t)jr * a.os_h[s]] = (_Float16)acc[8 * bv + gg];
+          }
+        }
+      }
+    }
+    if (!(a.dbg & 32)) __syncthreads();  // next chunk parked, the older ring half released
+    if (!has_next) break;
+    cur = nu;
+    g = ng;
+    nu = nu2;
+    ng = ng2;
+    has_next = has_next2;
+  }
+}
+
 }  // namespace
 
 bool dwt2_fwd_mfma_supported(const mifwt_level_desc* d) {
@@ -298,6 +539,7 @@ int dwt2_fwd_mfma(const mifwt_level_desc* d, const void* x, void* approx, void* 
   a.Wo = (int)d->coef_extent[1];
   a.mode = d->mode;
   a.L = d->filt_len;
+  a.dbg = g_options[MIFWT_OPT_DEBUG];
   for (int m = 0; m < 32; ++m) {
     a.lo[m] = m < d->filt_len ? (float)lo[m] : 0.f;
     a.hi[m] = m < d->filt_len ? (float)hi[m] : 0.f;
@@ -309,6 +551,22 @@ int dwt2_fwd_mfma(const mifwt_level_desc* d, const void* x, void* approx, void* 
   a.ntiles = (int)ntiles;
   // 4 workgroups per CU (LDS) on 256 CUs; the grid is a multiple of 8 (one contiguous panel of tiles per XCD)
   int64_t grid = 256 * 4;
+  if (g_options[MIFWT_OPT_MFMA_MODE] != 3) {
+    // the walk: units of seg_tiles stacked tiles, about 16 units per workgroup (the priming chunk costs 1 / seg_tiles), at least 4 tiles each
+    const int64_t panels = (int64_t)d->batch * a.tiles_c;
+    int64_t segs = (16 * grid + panels - 1) / panels;
+    segs = std::max<int64_t>(1, std::min<int64_t>(segs, (a.tiles_r + 3) / 4));
+    a.seg_tiles = (int)((a.tiles_r + segs - 1) / segs);
+    if (g_options[MIFWT_OPT_TILE_ROWS] > 0) a.seg_tiles = std::max(1, std::min(a.tiles_r, g_options[MIFWT_OPT_TILE_ROWS]));  // (experiments)
+    a.segs = (a.tiles_r + a.seg_tiles - 1) / a.seg_tiles;
+    const int64_t nunits = panels * a.segs;
+    if (nunits > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
+    a.nunits = (int)nunits;
+    if (nunits < grid) grid = (nunits + 7) & ~int64_t(7);
+    hipLaunchKernelGGL(dwt2_fwd_mfma_walk_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
+  }
+  a.seg_tiles = a.segs = a.nunits = 0;
   if (ntiles < grid) grid = (ntiles + 7) & ~int64_t(7);
   hipLaunchKernelGGL(dwt2_fwd_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;

@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <string.h>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -71,6 +72,12 @@ int main() {
     int bad = 0;
     for (int i = 0; i < 256; ++i) bad += r[256 + lo / 4 + i] != (float)i;
     printf("C M0 offset %2u bytes: mismatches %d (floats at slot start %g %g %g %g %g)\n", lo, bad, r[256], r[257], r[258], r[259], r[260]);
+  }
+  // E: global address only 2-byte aligned (rows of f16 planes with an odd pitch)
+  for (uint32_t goff : {2u, 6u, 10u, 14u, 8222u}) {
+    run(0, goff, 64, 0, N * 4);
+    const int bad = memcmp(&r[256], reinterpret_cast<const char*>(h.data()) + goff, 1024) != 0;
+    printf("E global byte offset %5u (2-byte aligned): %s\n", goff, bad ? "WRONG data" : "right data");
   }
   // D: resource ends 8 bytes into lane 5's piece
   run(0, 0, 64, 0, 5 * 16 + 8);
