@@ -331,7 +331,8 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 #define MIFWT_OPT_NT_STORE 4       /* non-zero: nontemporal stores for the sub-band planes */
 #define MIFWT_OPT_TILE_MODE 5      /* 2-D analysis: 0 = auto (LDS-tile kernel on small planes), 1 = always tile, 2 = never */
 #define MIFWT_OPT_TILE_ROWS 6      /* >0 overrides the tile kernels' output rows per tile */
-#define MIFWT_OPT_MFMA_MODE 7      /* 2-D analysis, f16 storage, 18..32 taps: 0 = matrix-core kernel, 2 = vector tile kernel */
+#define MIFWT_OPT_MFMA_MODE 7      /* 2-D analysis, f16 storage, 18..32 taps: 0 = matrix-core kernels (walk down column panels on big planes, a tile
+                                      at a time on small ones), 2 = vector tile kernel, 3 / 4 = always the tile-at-a-time / the walking one */
 #define MIFWT_OPT_PAIR_MODE 8      /* multi-level launches (mifwt_dwt2_fwd_pyramid, mifwt_dwt2_fwd_pair, mifwt_dwt2_inv_pair, mifwt_dwt1_fwd_tail): 2 = never (they answer
                                       UNSUPPORTED / 0); analysis pairs: 0 = auto (rolling strips for 8 taps, else tiles), 1 = tiles only,
                                       3 = rolling strips wherever they apply */

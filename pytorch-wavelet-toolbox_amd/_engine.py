@@ -241,8 +241,14 @@ class HipLevelEngine:
         # rows of the sub-band planes can be made to start on ROW_ALIGN-byte boundaries (pitch padded, the
         # returned bands are views of the padded buffer).  Measured on MI355X: no gain at 16 B, a loss at 128 B
         # (config 2), so the default is dense rows.
+        # Exception: the matrix-core analysis kernel (f16 storage, 18..32 taps, 2-D) stores 16 bytes per lane; with the dense pitch of
+        # an odd coefficient width every other row starts 2-byte aligned and the stores are split: level 1 of the config-5 slice
+        # 4.3 ms dense, 3.7 ms with 16-byte, 2.76 ms with 128-byte aligned rows (tools/mfma_walk_parts.py) — those planes get 128.
         esz = x.element_size()
-        pitch = -(-coef[-1] * esz // ROW_ALIGN) * ROW_ALIGN // esz if ROW_ALIGN > esz and ndim >= 2 else coef[-1]
+        align = ROW_ALIGN
+        if align <= 1 and ndim == 2 and x.dtype == torch.float16 and 18 <= flen <= 32:
+            align = 128
+        pitch = -(-coef[-1] * esz // align) * align // esz if align > esz and ndim >= 2 else coef[-1]
         p = _Plan()
         p.alloc_shape = (batch, nb, *coef[:-1], pitch)
         p.view_last = coef[-1] if pitch != coef[-1] else None

@@ -21,6 +21,10 @@
 #include "mifwt_stream.h"
 
 namespace mifwt {
+extern unsigned long long* g_pyr_prof;  // (mifwt_dwt2_fwd_pyr.hip; set by mifwt_pyr_profile_buffer)
+}
+
+namespace mifwt {
 
 namespace {
 
@@ -41,6 +45,7 @@ struct MfmaArgs {
   int64_t os_b[4], os_h[4];
   int H, W, Ho, Wo;
   int tiles_c, tiles_r, ntiles;
+  unsigned long long* prof;     // walk kernel, profiling build: 8 counters per wave (tools/mfma_walk_prof.py)
   int dbg;                      // walk kernel, MIFWT_OPT_DEBUG: 1 = no stores, 2 = no loads, 4 = no matrix work
   int seg_tiles, segs, nunits;  // walk kernel: a unit = seg_tiles vertically stacked tiles of one 64-column panel of an image
   int mode, L;
@@ -270,29 +275,247 @@ __global__ void __launch_bounds__(256, 4) dwt2_fwd_mfma_kernel(const MfmaArgs a)
 
 // ---- the same tile, WALKED down a 64-column panel -----------------------------------------------------------------------------
 // Vertically stacked tiles share half of their 64 input rows, and so do their horizontally filtered (lo, hi) images.  A workgroup
-// walks down seg_tiles stacked tiles of one panel: per tile it requests only the 32 NEW input rows (a "chunk"), filters those along
-// the rows (one MFMA job per wave instead of two) into one half of a 64-row ring of the transposed (lo, hi) image, and the vertical
-// pass reads its 64-row window from the ring (older half first).  One extra chunk per unit primes the ring.  Against the tile kernel
-// above: half the window reads (2.5x -> 1.25x of the plane through L2), two thirds of the MFMAs, same sums in the same order
-// (bit-identical results).
-constexpr int kWR = 32;  // input rows of a chunk = 2 kMR
+// walks down seg_tiles stacked tiles of one panel: per tile only the 32 NEW input rows (a "chunk") are fetched and filtered along the
+// rows (one MFMA job per wave instead of two) into one half of a 64-row ring of the transposed (lo, hi) image; the vertical pass reads
+// its 64-row window from the ring (older half first).  One extra chunk per unit primes the ring.  Against the tile kernel above: half
+// the window reads (2.5x -> 1.25x of the plane through L2), two thirds of the MFMAs, the same sums in the same order.
+//
+// The tile kernel and the first version of the walk were bound by instruction issue and by waits, not by the matrix cores or HBM (with
+// loads, stores and MFMAs switched off the launch still took 1.35 of 3.1 ms; tools/mfma_walk_parts.py), so this one is built to issue
+// little:
+//   * a fifth wave is the LOADER: a chunk = 32 rows x 21 sixteen-byte pieces (20 of data, one of padding = the LDS pitch) travels as
+//     11 LDS-DMA requests (buffer_load_dwordx4 ... lds; global addresses need only 2-byte alignment, tools/dma_probe.hip), two chunks
+//     double-buffered; the matrix waves never wait for a load and their stores never delay one;
+//   * columns a panel needs from outside the plane (first / last panel) are patched into the landed chunk by the loader: their
+//     boundary-mapped samples are requested together with the chunk (one 2-byte load per element into registers);
+//   * the vertical pass runs with the operands swapped (D^T): a lane owns ONE output row and four groups of four adjacent columns —
+//     four 8-byte stores per lane and band pair instead of sixteen 2-byte ones (rows of an odd pitch start 2-byte aligned: such
+//     stores work, tools/align_probe.hip).
+constexpr int kWR = 32;                            // input rows of a chunk = 2 kMR
+constexpr int kWPieces = kXP / 8;                  // 16-byte pieces of an LDS row
+constexpr int kWDma = (kWR * kWPieces + 63) / 64;  // requests per chunk
+constexpr int kWChunkBytes = kWR * kXP * 2;
+constexpr int kWLdsBytes = 2 * kWChunkBytes + 2 * kMC * kHP * 2;
+constexpr int kWPatch = 16;                        // patched samples per loader lane requested ahead (32 rows x 32 columns; more: on the spot)
 
-__global__ void __launch_bounds__(256, 4) dwt2_fwd_mfma_walk_kernel(const MfmaArgs a) {
-  __shared__ __attribute__((aligned(16))) _Float16 xt[kWR * kXP];
-  __shared__ __attribute__((aligned(16))) _Float16 ht[2 * kMC * kHP];
-  __shared__ float taps[64];
+__device__ __forceinline__ void mfma_dma16(uint32_t voff, __amdgpu_buffer_rsrc_t rsrc, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
+}
+
+template <bool PROF>
+__global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaArgs a) {
+  unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = PROF ? __builtin_readcyclecounter() : 0;
+  auto lap = [&](int k) {
+    if constexpr (PROF) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      pc[k] += now - pt;
+      pt = now;
+    }
+  };
+  auto dump = [&]() {
+    if constexpr (PROF) {
+      if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 8; ++k) a.prof[((size_t)blockIdx.x * 5 + (threadIdx.x >> 6)) * 8 + k] = pc[k];
+    }
+  };
+  extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+  _Float16* const xt = reinterpret_cast<_Float16*>(wsm);                     // two chunks
+  _Float16* const ht = reinterpret_cast<_Float16*>(wsm + 2 * kWChunkBytes);  // ring of the transposed (lo, hi) image
+  float* const taps = reinterpret_cast<float*>(ht);                          // (until the first horizontal pass)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  __builtin_assume(wave >= 0 && wave < 4);
+  __builtin_assume(wave >= 0 && wave < 5);
   const bool zero_mode = a.mode == MIFWT_MODE_ZERO;
   Fold1 fold;
   fold.set(a.mode);
   const int L = a.L;
-  const int n = lane & 31, half = lane >> 5;
 
+  // units (image, row segment, panel) with the panel index fastest: the blocks of an XCD walk down neighbouring panels (which share
+  // 32 of their 160 columns) at the same time; staggered starting points as in the tile kernel
+  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, nq = gridDim.x >> 3;
+  const int u_begin = (int)(((int64_t)a.nunits * xcd) >> 3), u_end = (int)(((int64_t)a.nunits * (xcd + 1)) >> 3);
+  const int panel = u_end - u_begin, rot = (int)(((int64_t)panel * xcd) >> 3);
+  if (q >= panel) return;
   if (threadIdx.x < 64) taps[threadIdx.x] = threadIdx.x < 32 ? a.lo[threadIdx.x] : a.hi[threadIdx.x - 32];
   __syncthreads();
+  struct Unit {
+    int img, k0, tr0, nt;  // image, first output column, first tile row, tiles
+  };
+  auto locate = [&](int it) -> Unit {
+    int pos = it + rot;
+    if (pos >= panel) pos -= panel;
+    const int idx = u_begin + pos;
+    const int rest = idx / a.tiles_c, tc = idx - rest * a.tiles_c;
+    Unit u;
+    u.img = rest / a.segs;
+    u.tr0 = (rest - u.img * a.segs) * a.seg_tiles;
+    u.nt = min(a.seg_tiles, a.tiles_r - u.tr0);
+    u.k0 = tc * kMC;
+    return u;
+  };
+  int it = q;
+  // (unit, chunk) after (u, gg) in this block's sequence; false at the end.  Chunk g of a unit = extended input rows
+  // r_first + 32 g .. + 31 with r_first = 2 kMR tr0 - (L - 2); tile tr0 + g - 1 needs chunks g - 1 and g.
+  auto advance = [&](Unit& u, int& gg) -> bool {
+    if (gg < u.nt) {
+      ++gg;
+      return true;
+    }
+    it += nq;
+    if (it >= panel) return false;
+    u = locate(it);
+    gg = 0;
+    return true;
+  };
+
+  // =============================================================================================================================
+  if (wave == 4) {
+    constexpr uint32_t kOob = 0x80000000u;
+    const uint32_t row_bytes = (uint32_t)a.xs_h * 2u;
+    const uint32_t img_bytes = (a.dbg & 2) ? 0u : ((uint32_t)(a.H - 1) * (uint32_t)a.xs_h + (uint32_t)a.W) * 2u;
+    // request j of a chunk: lane -> piece 64 j + lane = (row, piece of the row); the padding piece requests nothing, the lanes past
+    // the chunk's end are switched off
+    uint32_t vfast[kWDma];
+#pragma unroll
+    for (int j = 0; j < kWDma; ++j) {
+      const int P = 64 * j + lane, row = P / kWPieces, piece = P - row * kWPieces;
+      vfast[j] = piece == kWPieces - 1 ? kOob : (uint32_t)row * row_bytes + 16u * (uint32_t)piece;
+    }
+    const bool last_live = lane < kWR * kWPieces - 64 * (kWDma - 1);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)xt;  // (LDS offset of the first chunk buffer)
+
+    struct Geo {
+      int c_first, r_first;
+    };
+    auto geo = [&](const Unit& u, int g) -> Geo { return {2 * u.k0 - (L - 2), 2 * kMR * u.tr0 - (L - 2) + kWR * g}; };
+    auto rsrc_of = [&](const Unit& u) {
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.x + (int64_t)u.img * a.xs_b), 0, img_bytes, 0x00020000);
+    };
+    const int r_end = 2 * a.Ho;  // extended rows from here on feed no stored output
+    auto issue_dma = [&](const Unit& u, int g, int buf) {
+      const __amdgpu_buffer_rsrc_t xrsrc = rsrc_of(u);
+      const Geo ge = geo(u, g);
+      const uint32_t dst = lds0 + (uint32_t)(buf * kWChunkBytes);
+      if (ge.r_first >= 0 && ge.r_first + kWR <= a.H) {
+        // (columns left of the plane: the sum wraps into the row above or out of range; those samples are patched)
+        const uint32_t base = (uint32_t)ge.r_first * row_bytes + (uint32_t)(2 * ge.c_first);
+#pragma unroll
+        for (int j = 0; j < kWDma; ++j) {
+          const uint32_t v = vfast[j] == kOob ? kOob : vfast[j] + base;
+          if (j < kWDma - 1 || last_live) mfma_dma16(v, xrsrc, dst + 1024u * (uint32_t)j);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < kWDma; ++j) {
+          const int P = 64 * j + lane, row = P / kWPieces, piece = P - row * kWPieces;
+          const int ri = ge.r_first + row;
+          const bool dead = piece == kWPieces - 1 || ri >= r_end || (zero_mode && (unsigned)ri >= (unsigned)a.H);
+          const uint32_t v = dead ? kOob : (uint32_t)fold(ri, a.H) * row_bytes + (uint32_t)(2 * ge.c_first) + 16u * (uint32_t)piece;
+          if (j < kWDma - 1 || last_live) mfma_dma16(v, xrsrc, dst + 1024u * (uint32_t)j);
+        }
+      }
+    };
+    // Samples outside the plane's columns (first / last panel): element e = lane + 64 t of the list (row, patched column); window
+    // columns [0, nl) on the left, [nr0, 160) on the right.  The first kWPatch per lane are requested a step ahead.
+    uint32_t pv[kWPatch];
+    auto patch_cols = [&](const Geo& ge, int& nl, int& nr0) -> int {
+      // (whole 16-byte pieces on the left: a piece that starts before the plane's first sample is out of range as a whole; whole
+      // dwords on the right: the dword that holds the last sample of an odd-width plane's last row ends out of range)
+      nl = min(kIC, (max(0, -ge.c_first) + 7) & ~7);
+      nr0 = max(nl, min(kIC, (a.W - ge.c_first) & ~1));
+      return nl + (kIC - nr0);
+    };
+    auto patch_off = [&](const Geo& ge, int nl, int nr0, int ncols, int e, int& row, int& wc) -> uint32_t {
+      row = e / ncols;
+      const int ce = e - row * ncols;
+      wc = ce < nl ? ce : nr0 + (ce - nl);
+      const int ri = ge.r_first + row, ci = ge.c_first + wc;
+      const bool dead = row >= kWR || ri >= r_end || (zero_mode && ((unsigned)ri >= (unsigned)a.H || (unsigned)ci >= (unsigned)a.W));
+      return dead ? kOob : (uint32_t)fold(ri, a.H) * row_bytes + 2u * (uint32_t)fold(ci, a.W);
+    };
+    auto issue_patch = [&](const Unit& u, int g) {
+      const Geo ge = geo(u, g);
+      int nl, nr0;
+      const int ncols = patch_cols(ge, nl, nr0);
+      if (ncols == 0) return;
+      const __amdgpu_buffer_rsrc_t xrsrc = rsrc_of(u);
+      const int nt = min(kWPatch, (kWR * ncols + 63) >> 6);
+#pragma unroll
+      for (int t = 0; t < kWPatch; ++t) {
+        if (t < nt) {
+          int row, wc;
+          pv[t] = __builtin_amdgcn_raw_buffer_load_b16(xrsrc, patch_off(ge, nl, nr0, ncols, lane + 64 * t, row, wc), 0, 0);
+        }
+      }
+    };
+    auto write_patch = [&](const Unit& u, int g, int buf) {
+      const Geo ge = geo(u, g);
+      int nl, nr0;
+      const int ncols = patch_cols(ge, nl, nr0);
+      if (ncols == 0) return;
+      _Float16* xb = xt + buf * (kWR * kXP);
+      const int ntot = (kWR * ncols + 63) >> 6, nt = min(kWPatch, ntot);
+#pragma unroll
+      for (int t = 0; t < kWPatch; ++t) {
+        if (t < nt) {
+          int row, wc;
+          (void)patch_off(ge, nl, nr0, ncols, lane + 64 * t, row, wc);
+          if (row < kWR) xb[row * kXP + wc] = __builtin_bit_cast(_Float16, (unsigned short)pv[t]);
+        }
+      }
+      if (ntot > kWPatch) {  // (a last panel that lies mostly outside the plane: the rest on the spot)
+        const __amdgpu_buffer_rsrc_t xrsrc = rsrc_of(u);
+        for (int t = kWPatch; t < ntot; ++t) {
+          int row, wc;
+          const uint32_t v = __builtin_amdgcn_raw_buffer_load_b16(xrsrc, patch_off(ge, nl, nr0, ncols, lane + 64 * t, row, wc), 0, 0);
+          if (row < kWR) xb[row * kXP + wc] = __builtin_bit_cast(_Float16, (unsigned short)v);
+        }
+      }
+    };
+
+    // Chunk s of this block's sequence lives in buffer s & 1.  Two chunks are in flight: chunk s + 2 is requested as soon as barrier
+    // B(s) has released the buffer of chunk s; the patched samples of chunk s + 1 are requested once those of chunk s are written.
+    // Requests complete in order: DMA(s), patch(s), DMA(s + 1) — waiting for all but the last kWDma leaves chunk s complete.
+    Unit u0 = locate(it), u1 = u0, u2;
+    int g0 = 0, g1 = 0, g2;
+    bool has1 = advance(u1, g1);
+    u2 = u1;
+    g2 = g1;
+    bool has2 = has1 && advance(u2, g2);
+    issue_dma(u0, 0, 0);
+    issue_patch(u0, 0);
+    if (has1) issue_dma(u1, g1, 1);
+    lap(0);
+    for (int s = 0;; ++s) {
+      if (has1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWDma) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lap(1);  // waiting for the chunk
+      write_patch(u0, g0, s & 1);
+      if (has1) issue_patch(u1, g1);
+      lap(2);  // patch
+      __syncthreads();  // A(s): chunk s complete in LDS
+      lap(3);
+      __syncthreads();  // B(s): the horizontal pass has read it
+      lap(4);
+      if (!has1) break;
+      if (has2) issue_dma(u2, g2, s & 1);
+      u0 = u1;
+      g0 = g1;
+      u1 = u2;
+      g1 = g2;
+      has1 = has2;
+      if (has2) has2 = advance(u2, g2);
+      lap(5);  // requests + bookkeeping
+    }
+    dump();
+    return;
+  }
+
+  // =============================================================================================================================
+  // matrix waves
+  const int n = lane & 31, half = lane >> 5;
+  // T fragments: T[i][j] = h_band(i)[2 (i & 15) + L - 1 - j] with i = l & 31, j = 16 c + 8 (l >> 5) + e; f16 pairs (t = t_hi + t_lo)
   h8 ahi[4], alo[4];
   {
     const int band = n >> 4, kq = n & 15;
@@ -310,164 +533,47 @@ __global__ void __launch_bounds__(256, 4) dwt2_fwd_mfma_walk_kernel(const MfmaAr
     }
   }
 
-  // units (image, row segment, panel) with the panel index fastest: the blocks of an XCD walk down neighbouring panels (which share
-  // 32 of their 160 columns) at the same time; staggered starting points as in the tile kernel
-  const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, nq = gridDim.x >> 3;
-  const int u_begin = (int)(((int64_t)a.nunits * xcd) >> 3), u_end = (int)(((int64_t)a.nunits * (xcd + 1)) >> 3);
-  const int panel = u_end - u_begin, rot = (int)(((int64_t)panel * xcd) >> 3);
-  constexpr uint32_t kOob = 0x80000000u;
-  const uint32_t row_bytes = (uint32_t)a.xs_h * 2u;
-  const uint32_t img_bytes = (a.dbg & 2) ? 0u : ((uint32_t)(a.H - 1) * (uint32_t)a.xs_h + (uint32_t)a.W) * 2u;
-  const bool aligned4 = (a.xs_h & 1) == 0 && (a.xs_b & 1) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 3) == 0;
-
-  struct Unit {
-    int img, k0, tr0, nt;  // image, first output column, first tile row, tiles
-    bool pairs;
-  };
-  auto locate = [&](int it) -> Unit {
-    int pos = it + rot;
-    if (pos >= panel) pos -= panel;
-    const int idx = u_begin + pos;
-    const int rest = idx / a.tiles_c, tc = idx - rest * a.tiles_c;
-    Unit u;
-    u.img = rest / a.segs;
-    u.tr0 = (rest - u.img * a.segs) * a.seg_tiles;
-    u.nt = min(a.seg_tiles, a.tiles_r - u.tr0);
-    u.k0 = tc * kMC;
-    const int c_first = 2 * u.k0 - (L - 2);
-    u.pairs = aligned4 && c_first >= 0 && c_first + kIC <= a.W;
-    return u;
-  };
-  // chunk g of a unit: extended input rows r_first + 32 g .. + 31 with r_first = 2 kMR tr0 - (L - 2)
-  auto request = [&](const Unit& u, int g, uint32_t (&v)[8][3]) {
-    if (a.dbg & 16) return;
-    const __amdgpu_buffer_rsrc_t xrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.x + (int64_t)u.img * a.xs_b), 0, img_bytes, 0x00020000);
-    const int nc_need = 2 * (min(u.k0 + kMC, a.Wo) - u.k0) + L - 2;
-    const int c_first = 2 * u.k0 - (L - 2), r_first = 2 * kMR * u.tr0 - (L - 2) + kWR * g;
-    const int r_end = 2 * a.Ho;  // extended rows from here on feed no stored output
-    if (u.pairs) {
-      uint32_t poff[2];
-#pragma unroll
-      for (int qq = 0; qq < 2; ++qq) poff[qq] = lane + 64 * qq < kIC / 2 ? 2u * (uint32_t)(c_first + 2 * (lane + 64 * qq)) : kOob;
-      if (r_first >= 0 && r_first + kWR <= a.H) {
-        uint32_t soff = (uint32_t)(r_first + wave) * row_bytes;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-#pragma unroll
-          for (int qq = 0; qq < 2; ++qq) v[i][qq] = __builtin_amdgcn_raw_buffer_load_b32(xrsrc, poff[qq], soff, 0);
-          soff += 4u * row_bytes;
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int ri = r_first + wave + 4 * i;  // wave-uniform
-          const bool dead = ri >= r_end || (zero_mode && (unsigned)ri >= (unsigned)a.H);
-          const uint32_t soff = __builtin_amdgcn_readfirstlane(dead ? 0u : (uint32_t)fold(ri, a.H) * row_bytes);
-#pragma unroll
-          for (int qq = 0; qq < 2; ++qq) v[i][qq] = __builtin_amdgcn_raw_buffer_load_b32(xrsrc, dead ? kOob : poff[qq], soff, 0);
-        }
-      }
-    } else {
-      uint32_t coff[3];
-#pragma unroll
-      for (int qq = 0; qq < 3; ++qq) {
-        const int c = lane + 64 * qq;
-        const int ci = c_first + c;
-        const bool dead = c >= nc_need || (zero_mode && (unsigned)ci >= (unsigned)a.W);
-        coff[qq] = dead ? kOob : 2u * (uint32_t)fold(ci, a.W);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int ri = r_first + wave + 4 * i;
-        const bool dead = ri >= r_end || (zero_mode && (unsigned)ri >= (unsigned)a.H);
-        const uint32_t soff = __builtin_amdgcn_readfirstlane(dead ? 0u : (uint32_t)fold(ri, a.H) * row_bytes);
-#pragma unroll
-        for (int qq = 0; qq < 3; ++qq) v[i][qq] = __builtin_amdgcn_raw_buffer_load_b16(xrsrc, dead ? kOob : coff[qq], soff, 0);
-      }
-    }
-  };
-  auto commit = [&](bool pairs, const uint32_t (&v)[8][3]) {
-    if (a.dbg & 8) return;
-    if (pairs) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int r = wave + 4 * i;
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq)
-          if (lane + 64 * qq < kXP / 2) *reinterpret_cast<uint32_t*>(&xt[r * kXP + 2 * (lane + 64 * qq)]) = v[i][qq];
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int r = wave + 4 * i;
-#pragma unroll
-        for (int qq = 0; qq < 3; ++qq)
-          if (lane + 64 * qq < kXP) xt[r * kXP + lane + 64 * qq] = __builtin_bit_cast(_Float16, (unsigned short)v[i][qq]);
-      }
-    }
-  };
-
-  // Software pipeline: the chunk AFTER the next one is requested into registers as soon as the next one has been parked in LDS, so
-  // that a request is in flight for a whole step (horizontal pass, vertical pass and both barriers) before anybody waits for it.
-  uint32_t stage[8][3] = {};
-  if (q >= panel) return;
-  int it = q;
   Unit cur = locate(it);
-  int g = 0;
-  // (unit, chunk) after (u, gg) in this block's sequence; false at the end
-  auto advance = [&](Unit& u, int& gg) -> bool {
-    if (gg < u.nt) {
-      ++gg;
-      return true;
-    }
-    it += nq;
-    if (it >= panel) return false;
-    u = locate(it);
-    gg = 0;
-    return true;
-  };
-  request(cur, 0, stage);
-  commit(cur.pairs, stage);
-  Unit nu = cur;
-  int ng = 0;
-  bool has_next = advance(nu, ng);
-  if (has_next) request(nu, ng, stage);
-  __syncthreads();
+  int g = 0, s = 0;
+  lap(0);
   for (;;) {
+    Unit un = cur;
+    int gn = g;
+    const bool has_next = advance(un, gn);
+    lap(1);  // bookkeeping
+    __syncthreads();  // A(s): chunk s is in LDS, the ring half it goes to is no longer read
+    lap(2);
     // ---- horizontal pass of the chunk: wave = output block of 16 columns; D[row][(band, kq)] -> ring half g & 1, transposed
     {
       const int kb = wave;
+      const _Float16* xb = xt + (s & 1) * (kWR * kXP);
       f16x acc;
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-      for (int c = 0; c < ((a.dbg & 4) ? 0 : 4); ++c) {
-        const h8 xf = *reinterpret_cast<const h8*>(&xt[n * kXP + 32 * kb + 16 * c + 8 * half]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, ahi[c], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, alo[c], acc, 0, 0, 0);
+      for (int c = 0; c < 4; ++c) {
+        const h8 xf = *reinterpret_cast<const h8*>(&xb[n * kXP + 32 * kb + 16 * c + 8 * half]);
+        if (!(a.dbg & 4)) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, ahi[c], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, alo[c], acc, 0, 0, 0);
+        }
       }
       const int band = n >> 4, kq = n & 15;
       _Float16* hrow = &ht[(band * kMC + kb * 16 + kq) * kHP + 32 * (g & 1) + 4 * half];
 #pragma unroll
-      for (int gg = 0; gg < ((a.dbg & 64) ? 0 : 4); ++gg) {
+      for (int gg = 0; gg < 4; ++gg) {
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
         *reinterpret_cast<h4*>(hrow + 8 * gg) =
             (h4){(_Float16)acc[4 * gg], (_Float16)acc[4 * gg + 1], (_Float16)acc[4 * gg + 2], (_Float16)acc[4 * gg + 3]};
       }
     }
-    if (!(a.dbg & 32)) __syncthreads();  // ring half complete, xt released
+    lap(3);  // horizontal pass
+    __syncthreads();  // B(s): ring half complete, the chunk buffer released
+    lap(4);
 
-    Unit nu2 = nu;
-    int ng2 = ng;
-    bool has_next2 = false;
-    if (has_next) {
-      commit(nu.pairs, stage);
-      has_next2 = advance(nu2, ng2);
-      if (has_next2) request(nu2, ng2, stage);
-    }
-
-    // ---- vertical pass of tile tr0 + g - 1: window rows 0 .. 31 = chunk g - 1, 32 .. 63 = chunk g
+    // ---- vertical pass of tile tr0 + g - 1 (window rows 0 .. 31 = chunk g - 1, 32 .. 63 = chunk g), operands swapped:
+    // D[column i][(vertical band, row) n]: lane (n, half) owns output row n & 15 of vertical band n >> 4 and the columns
+    // cg * 32 + 8 gg + 4 half + (0 .. 3), gg = 0 .. 3
     if (g >= 1) {
       const int bh = wave >> 1, cg = wave & 1;
       const int old = 32 * ((g - 1) & 1);
@@ -475,35 +581,61 @@ __global__ void __launch_bounds__(256, 4) dwt2_fwd_mfma_walk_kernel(const MfmaAr
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-      for (int c = 0; c < ((a.dbg & 4) ? 0 : 4); ++c) {
+      for (int c = 0; c < 4; ++c) {
         const h8 b = *reinterpret_cast<const h8*>(&ht[(bh * kMC + cg * 32 + n) * kHP + ((16 * c + 8 * half + old) & 63)]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[c], b, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[c], b, acc, 0, 0, 0);
+        if (!(a.dbg & 4)) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, ahi[c], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, alo[c], acc, 0, 0, 0);
+        }
       }
-      const int k = cur.k0 + cg * 32 + n;
-      const int j0 = (cur.tr0 + g - 1) * kMR;
-      if (k < a.Wo && !(a.dbg & 1)) {
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+      if (a.dbg & 1) {
+      } else if (cur.k0 + kMC <= a.Wo) {
+        // Transposed through LDS, wave-local: this wave is the only reader of ring columns bh * 64 + cg * 32 + (0 .. 31) in the
+        // vertical pass, and their OLDER half is dead once its fragments above are in registers (the next horizontal pass rewrites it
+        // behind barrier A).  Row r = (vertical band, output row) of the 32 x 32 block goes to the older half of ring column r:
+        // 64 bytes; then every lane stores 16 bytes, four lanes a row.
+        _Float16* colbase = &ht[(bh * kMC + cg * 32) * kHP + old];
 #pragma unroll
-        for (int bv = 0; bv < 2; ++bv) {
-          const int s = 2 * bv + bh;
-          _Float16* base = a.out[s] + (int64_t)cur.img * a.os_b[s] + (int64_t)(j0 + 4 * half) * a.os_h[s] + k;
-          const int jlim = a.Ho - j0 - 4 * half;
+        for (int gg = 0; gg < 4; ++gg)
+          *reinterpret_cast<h4*>(colbase + n * kHP + 8 * gg + 4 * half) =
+              (h4){(_Float16)acc[4 * gg], (_Float16)acc[4 * gg + 1], (_Float16)acc[4 * gg + 2], (_Float16)acc[4 * gg + 3]};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-          for (int gg = 0; gg < 8; ++gg) {
-            const int jr = (gg & 3) + 8 * (gg >> 2);
-            if (jr < jlim) base[(int64_t)jr * a.os_h[s]] = (_Float16)acc[8 * bv + gg];
+        for (int i = 0; i < 2; ++i) {
+          const int r = 16 * i + (lane >> 2), pc = lane & 3;
+          const int sb = 2 * (r >> 4) + bh;  // band: bit 1 = vertical (axis -2) high, bit 0 = horizontal high
+          const int j = (cur.tr0 + g - 1) * kMR + (r & 15);
+          const h8 v = *reinterpret_cast<const h8*>(colbase + r * kHP + 8 * pc);
+          if (j < a.Ho) {
+            _Float16* dst = a.out[sb] + (int64_t)cur.img * a.os_b[sb] + (int64_t)j * a.os_h[sb] + cur.k0 + cg * 32 + 8 * pc;
+            // (16-byte stores to 2-byte aligned addresses — rows of an odd pitch — are fine on this hardware, tools/align_probe.hip;
+            // the compiler would split them)
+            asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
           }
+        }
+      } else {  // the last panel of a plane: column by column
+        const int bv = n >> 4, jr = n & 15;
+        const int sb = 2 * bv + bh;
+        const int j = (cur.tr0 + g - 1) * kMR + jr;
+        const int k = cur.k0 + cg * 32 + 4 * half;
+        if (j < a.Ho) {
+          _Float16* base = a.out[sb] + (int64_t)cur.img * a.os_b[sb] + (int64_t)j * a.os_h[sb] + k;
+#pragma unroll
+          for (int gg = 0; gg < 4; ++gg)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (k + 8 * gg + e < a.Wo) base[8 * gg + e] = (_Float16)acc[4 * gg + e];
         }
       }
     }
-    if (!(a.dbg & 32)) __syncthreads();  // next chunk parked, the older ring half released
+    lap(5);  // vertical pass + stores issued
     if (!has_next) break;
-    cur = nu;
-    g = ng;
-    nu = nu2;
-    ng = ng2;
-    has_next = has_next2;
+    cur = un;
+    g = gn;
+    ++s;
   }
+  dump();
 }
 
 }  // namespace
@@ -551,7 +683,10 @@ int dwt2_fwd_mfma(const mifwt_level_desc* d, const void* x, void* approx, void* 
   a.ntiles = (int)ntiles;
   // 4 workgroups per CU (LDS) on 256 CUs; the grid is a multiple of 8 (one contiguous panel of tiles per XCD)
   int64_t grid = 256 * 4;
-  if (g_options[MIFWT_OPT_MFMA_MODE] != 3) {
+  // the walk pays from about 24 tiles per workgroup on (32 x 2071^2: 0.285 against 0.299 ms; 32 x 1051^2: 0.131 against 0.088 — few
+  // units per workgroup and a priming chunk for every four tiles; MIFWT_OPT_MFMA_MODE 3 / 4 = always the tile kernel / always the walk)
+  const bool walk = g_options[MIFWT_OPT_MFMA_MODE] == 4 || (g_options[MIFWT_OPT_MFMA_MODE] != 3 && ntiles >= 24 * grid);
+  if (walk) {
     // the walk: units of seg_tiles stacked tiles, about 16 units per workgroup (the priming chunk costs 1 / seg_tiles), at least 4 tiles each
     const int64_t panels = (int64_t)d->batch * a.tiles_c;
     int64_t segs = (16 * grid + panels - 1) / panels;
@@ -563,7 +698,9 @@ int dwt2_fwd_mfma(const mifwt_level_desc* d, const void* x, void* approx, void* 
     if (nunits > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
     a.nunits = (int)nunits;
     if (nunits < grid) grid = (nunits + 7) & ~int64_t(7);
-    hipLaunchKernelGGL(dwt2_fwd_mfma_walk_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
+    a.prof = g_pyr_prof;
+    if (a.prof) hipLaunchKernelGGL(dwt2_fwd_mfma_walk_kernel<true>, dim3((unsigned)grid), dim3(320), kWLdsBytes, stream, a);
+    else hipLaunchKernelGGL(dwt2_fwd_mfma_walk_kernel<false>, dim3((unsigned)grid), dim3(320), kWLdsBytes, stream, a);
     return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
   }
   a.seg_tiles = a.segs = a.nunits = 0;

@@ -21,9 +21,9 @@ for shape, wav, mode in [((32, 8192, 8192), 'sym16', 'reflect'), ((32, 4111, 411
     x = torch.randn(*shape, device='cuda').half()
     out = {}
     line = []
-    for m in (3, 0):
+    for m in (3, 4, 0):
         _engine.set_option(7, m)
-        for seg in (segs if m == 0 else [0]):
+        for seg in (segs if m == 4 else [0]):
             _engine.set_option(6, seg)
             c = ptwt_amd.wavedec2(x, wav, mode=mode, level=1)
             torch.cuda.synchronize()
