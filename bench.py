@@ -62,6 +62,8 @@ WORKLOADS = {
     "wavedec2_db8_L4_64x4096x4096_f32": ("wavedec2", (64, 4096, 4096), "db8", 4, "reflect", torch.float32),
     # BASELINE configs[4] at a 32-image slice of the 128 (the path is linear in the batch): f16 storage extension
     "fswavedec2_sym16_L5_32x8192x8192_f16": ("fswavedec2", (32, 8192, 8192), "sym16", 5, "reflect", torch.float16),
+    # ... and its reconstruction (matrix-core synthesis kernel, id 23)
+    "fswaverec2_sym16_L5_32x8192x8192_f16": ("fswaverec2", (32, 8192, 8192), "sym16", 5, "reflect", torch.float16),
     # BASELINE configs[4] at its stated size (17 GB per input buffer)
     "fswavedec2_sym16_L5_128x8192x8192_f16": ("fswavedec2", (128, 8192, 8192), "sym16", 5, "reflect", torch.float16),
     # the reference's own 1-D speed test shape (examples/speed_tests/timeitconv_1d.py:16-36)
@@ -138,7 +140,7 @@ def cpu_baseline(fn, shape, wavelet, level, mode, dtype):
     from oracle import torch_cpu_port as P
 
     ports = {"wavedec2": P.wavedec2, "wavedec": P.wavedec, "wavedec3": P.wavedec3, "fswavedec2": P.fswavedec2, "waverec2": P.waverec2,
-             "waverec": P.waverec, "waverec3": P.waverec3}
+             "waverec": P.waverec, "waverec3": P.waverec3, "fswaverec2": P.fswaverec2}
     if fn not in ports:
         return None
     port = ports[fn]
@@ -150,6 +152,9 @@ def cpu_baseline(fn, shape, wavelet, level, mode, dtype):
     if fn == "waverec2":
         arg = P.wavedec2(x, wavelet, mode=mode, level=level)
         run = lambda sl: port(tuple([arg[0][sl]] + [tuple(t[sl] for t in lv) for lv in arg[1:]]), wavelet)  # noqa: E731
+    elif fn == "fswaverec2":
+        arg = P.fswavedec2(x, wavelet, mode=mode, level=level)
+        run = lambda sl: port(tuple([arg[0][sl]] + [{k: v[sl] for k, v in d.items()} for d in arg[1:]]), wavelet)  # noqa: E731
     elif fn == "waverec":
         arg = P.wavedec(x, wavelet, mode=mode, level=level)
         run = lambda sl: port([t[sl] for t in arg], wavelet)  # noqa: E731
@@ -427,7 +432,7 @@ def main():
             lvl1_b = algorithmic_bytes(shape[0], shape[1:], flen, fused_levels, esize)[0]
         klabel = {1: "dwt2_fwd_stream_kernel (level 1)", 7: "dwt2_fwd_tile_kernel (level 1)", 0: "generic axis kernels (level 1)",
                   3: "streaming axis kernels (level 1)", 5: "fused 2-D planes + depth pass (level 1)", 9: "dwt3_fwd_tile_kernel (level 1)",
-                  11: "dwt2_fwd_mfma_kernel (level 1)",
+                  11: "dwt2_fwd_mfma_walk_kernel (level 1)", 23: "idwt2_mfma_walk_kernel (finest level)",
                   12: ("dwt2_fwd_roll_kernel" if flen >= 8 else "dwt2_fwd_pair_kernel") + " (levels 1+2 in one launch)",
                   16: f"dwt2_fwd_pyr_kernel (levels 1-{fused_levels} in one launch)",
                   17: f"dwt1_long_kernel (levels 1-{fused_levels} in one launch)",

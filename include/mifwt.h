@@ -307,7 +307,8 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  *   5 / 6  3-D analysis / synthesis (f32, even L <= 16; what the brick kernels 9 / 10 do not take): fused 2-D kernel over every
  *          depth slice + one streaming pass along depth
  *   9 / 10 fully fused 3-D analysis / synthesis level, LDS bricks (f32, L in {2, 4, 6}; synthesis also 8)
- *   11     fused 2-D analysis level on the matrix cores (banded-Toeplitz MFMA; f16 storage, even L in [18, 32])
+ *   11 / 23  fused 2-D analysis / synthesis level on the matrix cores (banded-Toeplitz MFMA; f16 storage, even L in [18, 32]; the analysis of small
+ *          planes a tile at a time, of big ones walking down column panels; the synthesis kernel from 512 tiles of 32 x 128 samples per batch on)
  *   12 / 13  two fused 2-D analysis / synthesis levels per launch (mifwt_dwt2_fwd_pair / mifwt_dwt2_inv_pair; never
  *          returned by mifwt_kernel_id, which describes single-level calls)
  *   14 / 15  the deep levels of a 1-D analysis / the coarse levels of a 1-D synthesis in one launch (mifwt_dwt1_fwd_tail /

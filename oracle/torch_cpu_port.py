@@ -174,3 +174,18 @@ def fswavedec2(x: torch.Tensor, wavelet, *, mode: str = "reflect", level: int = 
         cur = aa
         out.append({"ad": ad, "da": da, "dd": dd})
     return (cur, *out[::-1])
+
+
+def fswaverec2(coeffs, wavelet):
+    """``(cA, {ad, da, dd}_n, ...)`` of [B, h, w] CPU tensors -> [B, H, W]: per level one 1-D synthesis level along the rows' axis
+    for (aa, da) and (ad, dd) — the approximation first cut to the details' shape — and one along the last axis for the two results,
+    each over the folded tensor (src/ptwt/separable_conv_transform.py:75-110, 281-313)."""
+    def level1(a, d, axis):
+        a = a[tuple(slice(0, n) for n in d.shape)]
+        ta, td = a.transpose(-1, axis), d.transpose(-1, axis)
+        rec = waverec([ta.reshape(-1, ta.shape[-1]), td.reshape(-1, td.shape[-1])], wavelet)
+        return rec.reshape(*ta.shape[:-1], rec.shape[-1]).transpose(axis, -1)
+    cur = coeffs[0]
+    for det in coeffs[1:]:
+        cur = level1(level1(cur, det["da"], -2), level1(det["ad"], det["dd"], -2), -1)
+    return cur

@@ -218,6 +218,7 @@ size_t route_ws(const mifwt_level_desc* d, int direction, int kid) {
     case kDwt2FwdTile:
     case kDwt2FwdMfma:
     case kDwt2InvTile:
+    case kDwt2InvMfma:
     case kDwt3FwdTile:
     case kDwt3InvTile:
     case kDwt2InvStream: return 0;
@@ -368,6 +369,7 @@ static int run_inv(const mifwt_level_desc* desc, const void* approx, const void*
   switch (kid) {
     case kDwt2InvStream: return dwt2_inv_stream(desc, approx, details, y, rec_lo, rec_hi, st);
     case kDwt2InvTile: return dwt2_inv_tile(desc, approx, details, y, rec_lo, rec_hi, st);
+    case kDwt2InvMfma: return dwt2_inv_mfma(desc, approx, details, y, rec_lo, rec_hi, st);
     case kDwt3InvTile: return dwt3_inv_tile(desc, approx, details, y, rec_lo, rec_hi, st);
     case kDwt3InvStream: return plane3_inv(desc, approx, details, y, rec_lo, rec_hi, workspace, st);
     case kDwt1InvRow: return rows_inv(desc, approx, details, y, rec_lo, rec_hi, workspace, st);

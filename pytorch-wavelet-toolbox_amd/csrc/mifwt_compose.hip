@@ -185,6 +185,7 @@ int dwt2_inv_tile(const mifwt_level_desc* d, const void* approx, const void* con
 
 int dwt2_inv_choice(const mifwt_level_desc* d) {
   const int tm = g_options[MIFWT_OPT_TILE_MODE];  // 0 auto, 1 always tile, 2 never tile
+  if (dwt2_inv_mfma_supported(d)) return kDwt2InvMfma;
   const bool stream_ok = dwt2_inv_stream_supported(d), tile_ok = dwt2_inv_tile_supported(d);
   if (stream_ok && (tm == 2 || !tile_ok)) return kDwt2InvStream;
   if (tile_ok && tm != 2) {
@@ -202,6 +203,7 @@ int dwt2_inv_fused(const mifwt_level_desc* d, const void* approx, const void* co
   switch (dwt2_inv_choice(d)) {
     case kDwt2InvTile: return dwt2_inv_tile(d, approx, details, y, lo, hi, stream);
     case kDwt2InvStream: return dwt2_inv_stream(d, approx, details, y, lo, hi, stream);
+    case kDwt2InvMfma: return dwt2_inv_mfma(d, approx, details, y, lo, hi, stream);
     default: return MIFWT_ERR_UNSUPPORTED;
   }
 }

@@ -492,6 +492,58 @@ def test_mfma_dwt2_long_filters_half(wavelet):
         ptwt_amd.set_half_storage(False)
 
 
+@pytest.mark.parametrize("wavelet", ["db9", "db10", "db12", "db14", "sym16"])
+def test_mfma_idwt2_long_filters_half(wavelet):
+    """The matrix-core synthesis kernel (kernel id 23; f16 storage, 18..32 taps; src/ptwt/conv_transform_2.py:222-249) against the
+    fp64 oracle fed the same f16 coefficients: random coefficient sets (not images of an analysis), ragged tiles in both directions, odd
+    extents (trims), odd and padded pitches, several tiles per workgroup, segments of any length; and the two-level / separable
+    containers.  Tolerance 5e-4 norm-wise per level (f16 output rounding 2.1e-4 + one f16 rounding of the intermediate image)."""
+    rng = np.random.default_rng(len(wavelet) + 300)
+    flen = len(O.filter_bank(wavelet)[0])
+    ptwt_amd.set_half_storage(True)
+    _engine.set_option(7, 4)  # wherever it can run (auto: from 512 tiles of 32 x 128 samples on)
+    try:
+        for shape, seg in [((2, 131, 3 * flen + 70), 0), ((1, 2 * flen, 2 * flen + 1), 0), ((3, 300, 402), 3), ((40, 96, 200), 1), ((1, 700, 1031), 5)]:
+            for mode in ("reflect", "periodic", "zero"):
+                try:
+                    c64 = O.wavedec2(rng.standard_normal(shape), wavelet, mode=mode, level=1)
+                except RuntimeError:
+                    continue
+                cq = [torch.from_numpy(rng.standard_normal(c64[0].shape)).half()] + [tuple(torch.from_numpy(rng.standard_normal(b.shape)).half() for b in c64[1])]
+                want = O.waverec2((cq[0].double().numpy(), tuple(t.double().numpy() for t in cq[1])), wavelet)
+                cdev = (cq[0].to(dev()), tuple(t.to(dev()) for t in cq[1]))
+                _engine.set_option(6, seg)
+                _engine.level_events = []
+                try:
+                    got = ptwt_amd.waverec2(cdev, wavelet)
+                    torch.cuda.synchronize()
+                    kids = [e[1] for e in _engine.level_events]
+                finally:
+                    _engine.level_events = None
+                    _engine.set_option(6, 0)
+                assert kids == [23], kids
+                assert got.dtype == torch.float16 and tuple(got.shape) == tuple(want.shape)
+                assert G.relerr(to_np(got.double()), want) < 5e-4, (wavelet, mode, shape, seg)
+        # views with a padded pitch (what the engine's own analysis returns for these planes) and a two-level separable round trip
+        x = torch.from_numpy(rng.standard_normal((2, 500, 620))).half().to(dev())
+        cs = ptwt_amd.fswavedec2(x, wavelet, mode="symmetric", level=2)
+        assert cs[1]["dd"].stride(-2) != cs[1]["dd"].shape[-1]  # (128-byte aligned rows)
+        _engine.level_events = []
+        rec = ptwt_amd.fswaverec2(cs, wavelet)
+        torch.cuda.synchronize()
+        kids = [e[1] for e in _engine.level_events]
+        _engine.level_events = None
+        assert kids == [23, 23], kids
+        want = O.fswaverec2(tuple([cs[0].double().cpu().numpy()] + [{k: v.double().cpu().numpy() for k, v in d.items()} for d in cs[1:]]), wavelet)
+        assert G.relerr(to_np(rec.double()), want) < 1e-3  # two levels of f16 storage
+        assert G.relerr(to_np(rec.double()[..., :500, :620]), x.double().cpu().numpy()) < 2e-3
+    finally:
+        _engine.set_option(6, 0)
+        _engine.set_option(7, 0)
+        _engine.level_events = None
+        ptwt_amd.set_half_storage(False)
+
+
 @pytest.mark.parametrize("wavelet", FUSED_WAVELETS)
 @pytest.mark.parametrize("tile_rows", [0, 8, 12, 16, 20, 24])
 def test_tile_dwt2_vs_oracle(wavelet, tile_rows):

@@ -185,7 +185,8 @@ def test_torch_cpu_port_matches_oracle(mode):
 
 @pytest.mark.parametrize("mode", O.MODES)
 def test_torch_cpu_ports_of_the_other_functions_match_oracle(mode):
-    """The cpu_baseline ports of wavedec / wavedec3 / fswavedec2 / waverec2 (the reference's ATen op sequences) equal the oracle."""
+    """The cpu_baseline ports of wavedec / wavedec3 / fswavedec2 / waverec2 / fswaverec2 / waverec / waverec3 (the reference's ATen op
+    sequences) equal the oracle."""
     import torch
 
     from oracle import torch_cpu_port as P
@@ -211,6 +212,9 @@ def test_torch_cpu_ports_of_the_other_functions_match_oracle(mode):
         c = O.wavedec2(x2, wav, mode=mode, level=3)
         rec = P.waverec2(tuple([torch.from_numpy(c[0])] + [tuple(torch.from_numpy(v) for v in lv) for lv in c[1:]]), wav)
         assert G.relerr(rec.numpy(), O.waverec2(c, wav)) < TOL64, (mode, wav)
+        c = O.fswavedec2(x2, wav, mode=mode, level=3)
+        rec = P.fswaverec2(tuple([torch.from_numpy(c[0])] + [{k: torch.from_numpy(v) for k, v in d.items()} for d in c[1:]]), wav)
+        assert G.relerr(rec.numpy(), O.fswaverec2(c, wav)) < TOL64, (mode, wav)
         c = O.wavedec(x1, wav, mode=mode, level=3)
         assert G.relerr(P.waverec([torch.from_numpy(t) for t in c], wav).numpy(), O.waverec(c, wav)) < TOL64, (mode, wav)
         c = O.wavedec3(x3, wav, mode=mode, level=2)
