@@ -417,14 +417,16 @@ __global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaAr
       }
     };
     // Samples outside the plane's columns (first / last panel): element e = lane + 64 t of the list (row, patched column); window
-    // columns [0, nl) on the left, [nr0, 160) on the right.  The first kWPatch per lane are requested a step ahead.
+    // columns [0, nl) on the left, [nr0, nr1) on the right; the window columns from nr1 on feed no stored coefficient and are
+    // zeroed.  The first kWPatch per lane are requested a step ahead.
     uint32_t pv[kWPatch];
-    auto patch_cols = [&](const Geo& ge, int& nl, int& nr0) -> int {
+    auto patch_cols = [&](const Unit& u, const Geo& ge, int& nl, int& nr0, int& nr1) -> int {
       // (whole 16-byte pieces on the left: a piece that starts before the plane's first sample is out of range as a whole; whole
       // dwords on the right: the dword that holds the last sample of an odd-width plane's last row ends out of range)
       nl = min(kIC, (max(0, -ge.c_first) + 7) & ~7);
       nr0 = max(nl, min(kIC, (a.W - ge.c_first) & ~1));
-      return nl + (kIC - nr0);
+      nr1 = max(nr0, min(kIC, 2 * (min(u.k0 + kMC, a.Wo) - u.k0) + L - 2));  // (nc_need of the tile kernel)
+      return nl + (nr1 - nr0);
     };
     auto patch_off = [&](const Geo& ge, int nl, int nr0, int ncols, int e, int& row, int& wc) -> uint32_t {
       row = e / ncols;
@@ -436,8 +438,8 @@ __global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaAr
     };
     auto issue_patch = [&](const Unit& u, int g) {
       const Geo ge = geo(u, g);
-      int nl, nr0;
-      const int ncols = patch_cols(ge, nl, nr0);
+      int nl, nr0, nr1;
+      const int ncols = patch_cols(u, ge, nl, nr0, nr1);
       if (ncols == 0) return;
       const __amdgpu_buffer_rsrc_t xrsrc = rsrc_of(u);
       const int nt = min(kWPatch, (kWR * ncols + 63) >> 6);
@@ -451,10 +453,17 @@ __global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaAr
     };
     auto write_patch = [&](const Unit& u, int g, int buf) {
       const Geo ge = geo(u, g);
-      int nl, nr0;
-      const int ncols = patch_cols(ge, nl, nr0);
-      if (ncols == 0) return;
+      int nl, nr0, nr1;
+      const int ncols = patch_cols(u, ge, nl, nr0, nr1);
       _Float16* xb = xt + buf * (kWR * kXP);
+      if (nr1 < kIC) {
+        const int nz = kIC - nr1;
+        for (int e = lane; e < kWR * nz; e += 64) {
+          const int row = e / nz;
+          xb[row * kXP + nr1 + (e - row * nz)] = (_Float16)0.f;
+        }
+      }
+      if (ncols == 0) return;
       const int ntot = (kWR * ncols + 63) >> 6, nt = min(kWPatch, ntot);
 #pragma unroll
       for (int t = 0; t < kWPatch; ++t) {
@@ -683,9 +692,9 @@ int dwt2_fwd_mfma(const mifwt_level_desc* d, const void* x, void* approx, void* 
   a.ntiles = (int)ntiles;
   // 4 workgroups per CU (LDS) on 256 CUs; the grid is a multiple of 8 (one contiguous panel of tiles per XCD)
   int64_t grid = 256 * 4;
-  // the walk pays from about 24 tiles per workgroup on (32 x 2071^2: 0.285 against 0.299 ms; 32 x 1051^2: 0.131 against 0.088 — few
-  // units per workgroup and a priming chunk for every four tiles; MIFWT_OPT_MFMA_MODE 3 / 4 = always the tile kernel / always the walk)
-  const bool walk = g_options[MIFWT_OPT_MFMA_MODE] == 4 || (g_options[MIFWT_OPT_MFMA_MODE] != 3 && ntiles >= 24 * grid);
+  // the walk wins wherever there is a tile or two per workgroup (32 x 8192^2: 2.27 against 3.69 ms; 32 x 1051^2: 0.082 against 0.099;
+  // 32 x 541^2: 0.051 against 0.053; tools/mfma_walk_ab.py; MIFWT_OPT_MFMA_MODE 3 / 4 = always the tile kernel / always the walk)
+  const bool walk = g_options[MIFWT_OPT_MFMA_MODE] == 4 || (g_options[MIFWT_OPT_MFMA_MODE] != 3 && ntiles >= 2048);
   if (walk) {
     // the walk: units of seg_tiles stacked tiles, about 16 units per workgroup (the priming chunk costs 1 / seg_tiles), at least 4 tiles each
     const int64_t panels = (int64_t)d->batch * a.tiles_c;
