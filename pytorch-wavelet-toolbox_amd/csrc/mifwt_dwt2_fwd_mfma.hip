@@ -620,7 +620,11 @@ __global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaAr
             _Float16* dst = a.out[sb] + (int64_t)cur.img * a.os_b[sb] + (int64_t)j * a.os_h[sb] + cur.k0 + cg * 32 + 8 * pc;
             // (16-byte stores to 2-byte aligned addresses — rows of an odd pitch — are fine on this hardware, tools/align_probe.hip;
             // the compiler would split them)
-            asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+            // non-temporal: nothing reads these lines back (config-5 slice, level 1: 2.29 -> 2.15 ms analysis, 2.21 -> 2.18 synthesis;
+            // MIFWT_OPT_DEBUG 8 / 16 = write-through / default policy, tools/mfma_policy_ab.py)
+            if (a.dbg & 8) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+            else if (a.dbg & 16) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
           }
         }
       } else {  // the last panel of a plane: column by column

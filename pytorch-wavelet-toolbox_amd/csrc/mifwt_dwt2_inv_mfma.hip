@@ -289,7 +289,11 @@ __global__ void __launch_bounds__(320, 5) idwt2_mfma_walk_kernel(const MfmaInvAr
           if (row0 + m < a.H) {
             _Float16* dst = a.y + (int64_t)cur.img * a.ys_b + (int64_t)(row0 + m) * a.ys_h + col0 + 8 * pc;
             // (16-byte stores; rows of an odd pitch start 2-byte aligned: works, slowly — tools/align_probe.hip)
-            asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+            // non-temporal: nothing reads these lines back (config-5 slice, level 1: 2.29 -> 2.15 ms analysis, 2.21 -> 2.18 synthesis;
+            // MIFWT_OPT_DEBUG 8 / 16 = write-through / default policy, tools/mfma_policy_ab.py)
+            if (a.dbg & 8) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+            else if (a.dbg & 16) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
           }
         }
       } else if (col0 < a.W) {  // the last columns of a plane: sample by sample
