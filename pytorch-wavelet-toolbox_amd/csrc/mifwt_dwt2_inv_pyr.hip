@@ -214,6 +214,8 @@ __device__ __forceinline__ void ipyr_store4(const f4 data, rsrc_t rsrc, uint32_t
   // kernel gains the same 3 %, profiles/r03f_wbench.txt).  (The analysis kernel's 8-byte stores of partial lines LOSE 6 % with it.)
 #if MIFWT_ST_AUX == 99
   asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+#elif defined(MIFWT_IPYR_ST_NT)
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 #else
   asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc0 sc1\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 #endif
