@@ -49,6 +49,8 @@ for p in sorted(glob.glob(out + "/p*/**/*_counter_collection.csv", recursive=Tru
         meta.setdefault("kernel", r["Kernel_Name"][:110]); meta.setdefault("grid_size", r["Grid_Size"]); meta.setdefault("vgpr_count", r["VGPR_Count"])
     for k, v in per.items():
         v = v[len(v) // 4:]  # drop the spin-up launches
+        # persistent kernels launch the same grid for every level: the dominant launches are the ones with the big counts
+        v = [x for x in v if x >= 0.5 * max(v)] if v and max(v) > 0 else v
         pmc[k] = sum(v) / max(1, len(v))
 res = dict(meta)
 res["workload"] = wl

@@ -3,7 +3,7 @@
 # roofline + traffic (from the PMC summary just taken) + cpu_baseline.  Everything lands under gpurun_out/ (r03x_*); copy to profiles/.
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-TAG=${TAG:-r03x}
+TAG=${TAG:-r03y}
 run_pmc() {  # workload, kernel substring, steps
   TAG=$TAG WL=$1 KERNEL=$2 STEPS=$3 bash tools/pmc_workload.sh > gpurun_out/${TAG}_pmc_$1.log 2>&1
   cp gpurun_out/${TAG}_pmc_$1.json profiles/ 2>/dev/null
@@ -13,7 +13,8 @@ run_pmc wavedec2_db4_L3_64x1024x1024_f32 dwt2_fwd_pyr_kernel 60
 run_pmc waverec2_db4_L3_64x1024x1024_f32 idwt2_pyr_kernel 60
 run_pmc wavedec3_db2_L3_8x256x256x256_f32 dwt3_fwd_slice_kernel 30
 run_pmc wavedec2_db8_L4_64x4096x4096_f32 dwt2_fwd_stream_kernel 10
-run_pmc fswavedec2_sym16_L5_32x8192x8192_f16 dwt2_fwd_mfma_kernel 6
+run_pmc fswavedec2_sym16_L5_32x8192x8192_f16 dwt2_fwd_mfma_walk_kernel 6
+run_pmc fswaverec2_sym16_L5_32x8192x8192_f16 idwt2_mfma_walk_kernel 6
 run_pmc wavedec_db5_L10_32x1000000_f32 dwt1_long_kernel 40
 run_pmc wavedec2_db2_L3_4096x64x64_f32 dwt2_fwd_small_kernel 60
 run_pmc waverec3_db2_L3_8x256x256x256_f32 idwt3_tile_kernel 30
@@ -23,7 +24,7 @@ run_pmc wavedec2_db5_L5_32x1000x1000_f32_periodic dwt2_fwd_tile_kernel 60
 run_pmc waverec2_db5_L5_32x1000x1000_f32_periodic idwt2_pyr_kernel 60
 run_pmc wavedec3_db5_L3_32x100x100x100_f32_periodic dwt2_fwd_tile_kernel 40
 for wl in wavedec2_db4_L3_64x1024x1024_f32 waverec2_db4_L3_64x1024x1024_f32 wavedec3_db2_L3_8x256x256x256_f32 wavedec2_db8_L4_64x4096x4096_f32 \
-          fswavedec2_sym16_L5_32x8192x8192_f16 wavedec_db5_L10_32x1000000_f32 wavedec2_db2_L3_4096x64x64_f32 \
+          fswavedec2_sym16_L5_32x8192x8192_f16 fswaverec2_sym16_L5_32x8192x8192_f16 wavedec_db5_L10_32x1000000_f32 wavedec2_db2_L3_4096x64x64_f32 \
           waverec3_db2_L3_8x256x256x256_f32 waverec_db5_L10_32x1000000_f32 waverec2_db2_L3_4096x64x64_f32 \
           wavedec2_db5_L5_32x1000x1000_f32_periodic waverec2_db5_L5_32x1000x1000_f32_periodic fswavedec2_db5_L5_32x1000x1000_f32_periodic \
           wavedec3_db5_L3_32x100x100x100_f32_periodic; do
