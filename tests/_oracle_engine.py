@@ -60,7 +60,13 @@ class OracleLevelEngine:
             cur = buf[:, 0].clone()
         return ([b[:, 1:].contiguous() for b in bufs[:-1]] + [bufs[-1]]) or None
 
-    def synthesis_pyramid(self, approx, levels, rec_lo, rec_hi, out_extent):
+    def synthesis_pyramid_plan(self, approx, levels, flen, out_extent):
+        """Same contract as HipLevelEngine.synthesis_pyramid_plan: (plan, descriptors, references, route) — route 1 = the
+        whole-reconstruction launch of a small plane (what the stand-in below takes), 0 = no multi-level launch."""
+        ok = approx.dim() == 3 and approx.dtype == torch.float32 and out_extent[0] * out_extent[1] <= 48 * 48
+        return (None, None, None, 1 if ok and tuple(approx.shape) == tuple(levels[0][0].shape) else 0)
+
+    def synthesis_pyramid(self, approx, levels, rec_lo, rec_hi, out_extent, plan=None):
         """Stand-in for the whole-reconstruction-in-one-launch call (same contract as HipLevelEngine.synthesis_pyramid): planes of at
         most 48 x 48 output samples, the running approximation cropped to the next level's band extents."""
         if approx.dim() != 3 or approx.dtype != torch.float32 or out_extent[0] * out_extent[1] > 48 * 48:
