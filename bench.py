@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import gc
 import os
 import statistics
 import sys
@@ -319,6 +320,10 @@ def main():
         dist.barrier()
     sync()
 
+    # (as timeit does: the interpreter's cyclic collector is run now and kept out of the timed steps — a full pass with torch loaded
+    # is a 35-40 ms pause that lands in a 100-step window every few thousand calls, whatever the calls do)
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -327,6 +332,7 @@ def main():
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
 
     # Roofline leg: the same K steps once more with a HIP event pair around every level launch, recorded on
     # the launch stream.  It is a separate pass because hipEventRecord inserts a barrier packet into the
@@ -463,6 +469,7 @@ def main():
             "dtype": {torch.float32: "f32", torch.float64: "f64", torch.float16: "f16 storage / f32 arithmetic"}[dtype],
             "data": "synthetic (torch.randn, %d rotating input buffers resident in HBM)" % len(bufs),
             "spinup_steps": spin_steps,
+            "gc": "cyclic collector run before and disabled during the K timed steps (as timeit does)",
             "config": {
                 "workload": args.workload,
                 "api": f"ptwt_amd.{fn_name}(x, '{wavelet}', mode='{mode}', level={level})",

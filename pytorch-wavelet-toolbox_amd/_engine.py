@@ -23,6 +23,16 @@ _DTYPE_IDS = {torch.float32: 0, torch.float64: 1, torch.float16: 2}
 
 _i64x3 = ctypes.c_int64 * 3
 _i64x4 = ctypes.c_int64 * 4
+_array_types: dict = {}
+
+
+def _arr(base, n: int):
+    """ctypes array TYPE ``base * n``, kept alive: ctypes only holds such types weakly, and a type that dies and is rebuilt on every
+    call is a reference cycle per call (type <-> its own dictionaries) that only the garbage collector's passes free."""
+    t = _array_types.get((base, n))
+    if t is None:
+        t = _array_types[(base, n)] = base * n
+    return t
 
 
 class LevelDesc(ctypes.Structure):
@@ -213,14 +223,14 @@ def _taps_array(taps: Sequence[float]):
     if arr is None:
         if len(_taps_cache) > 512:
             _taps_cache.clear()
-        arr = _taps_cache[key] = (ctypes.c_double * len(key))(*key)
+        arr = _taps_cache[key] = _arr(ctypes.c_double, len(key))(*key)
     return arr
 
 
 def _band_ptrs(base: int, plane_bytes: int, n: int):
     """Device pointers of planes 1 .. n of a level buffer, in a fresh ctypes array: cached plans are shared between threads and
     ctypes releases the GIL during the C call, so a plan never owns an array that calls write to."""
-    return (ctypes.c_void_p * n)(*[base + s * plane_bytes for s in range(1, n + 1)])
+    return _arr(ctypes.c_void_p, n)(*[base + s * plane_bytes for s in range(1, n + 1)])
 
 
 def _raw_stream(dev_index: int) -> int:
@@ -412,8 +422,8 @@ class HipLevelEngine:
         skey = (key, n_ok)  # (a routing option may change how many levels the same geometry fuses)
         slot = _tls.__dict__.setdefault("pyr", {}).get(skey)
         if slot is None:
-            rows = [(ctypes.c_void_p * 3)() for _ in plans]
-            det = (ctypes.POINTER(ctypes.c_void_p) * n_ok)(*[ctypes.cast(r, ctypes.POINTER(ctypes.c_void_p)) for r in rows])
+            rows = [_arr(ctypes.c_void_p, 3)() for _ in plans]
+            det = _arr(ctypes.POINTER(ctypes.c_void_p), n_ok)(*[ctypes.cast(r, ctypes.POINTER(ctypes.c_void_p)) for r in rows])
             slot = _tls.pyr[skey] = (rows, det)
             if len(_tls.pyr) > 256:
                 _tls.pyr.clear()
@@ -461,8 +471,8 @@ class HipLevelEngine:
         last = nlevels - 1
         bufs = [torch.empty((rows, 2 if i == last else 1, m), dtype=x.dtype, device=x.device) for i, m in enumerate(sizes)]
         esz = x.element_size()
-        det = (ctypes.c_void_p * nlevels)(*[b.data_ptr() + (sizes[i] * esz if i == last else 0) for i, b in enumerate(bufs)])
-        det_rs = (ctypes.c_int64 * nlevels)(*[(2 if i == last else 1) * m for i, m in enumerate(sizes)])
+        det = _arr(ctypes.c_void_p, nlevels)(*[b.data_ptr() + (sizes[i] * esz if i == last else 0) for i, b in enumerate(bufs)])
+        det_rs = _arr(ctypes.c_int64, nlevels)(*[(2 if i == last else 1) * m for i, m in enumerate(sizes)])
         lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
         p = _Plan()
         p.ws_bytes, p.kid = 0, (KID_LONG if long_rows else KID_TAIL)
@@ -518,7 +528,7 @@ class HipLevelEngine:
             p.ws_bytes = lib.mifwt_workspace_bytes(p.ref, 1)
             p.kid = lib.mifwt_kernel_id(p.ref, 1)
             _plans[key] = p
-        ptrs = (ctypes.c_void_p * len(details))(*[t.data_ptr() for t in details])
+        ptrs = _arr(ctypes.c_void_p, len(details))(*[t.data_ptr() for t in details])
         lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
         ap, yp = approx.data_ptr(), y.data_ptr()
         self._run(p, 1, approx, lambda ws, wsb, stream: lib.mifwt_dwt_inv(p.ref, ap, ptrs, yp, lo, hi, ws, wsb, stream))
@@ -543,8 +553,8 @@ class HipLevelEngine:
             approx = approx.contiguous()
         details = [t if t.stride(1) == 1 else t.contiguous() for t in details]
         y = torch.empty((rows, int(out_lens[-1])), dtype=approx.dtype, device=approx.device)
-        det = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in details])
-        det_rs = (ctypes.c_int64 * nl)(*[t.stride(0) for t in details])
+        det = _arr(ctypes.c_void_p, nl)(*[t.data_ptr() for t in details])
+        det_rs = _arr(ctypes.c_int64, nl)(*[t.stride(0) for t in details])
         outs = (ctypes.c_int32 * nl)(*[int(v) for v in out_lens])
         lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
         p = _Plan()
@@ -596,8 +606,8 @@ class HipLevelEngine:
             approx = approx.contiguous()
         details = [t if t.stride(1) == 1 else t.contiguous() for t in details]
         y = torch.empty((rows, lens[-1]), dtype=approx.dtype, device=approx.device)
-        det = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in details])
-        det_rs = (ctypes.c_int64 * nl)(*[t.stride(0) for t in details])
+        det = _arr(ctypes.c_void_p, nl)(*[t.data_ptr() for t in details])
+        det_rs = _arr(ctypes.c_int64, nl)(*[t.stride(0) for t in details])
         lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
         p = _Plan()
         p.ws_bytes, p.kid = 0, KID_INV_LONG
@@ -663,8 +673,8 @@ class HipLevelEngine:
         if not ok:
             return None
         y = torch.empty((batch, *out_extent), dtype=approx2.dtype, device=approx2.device)
-        ptrs2 = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in details2])  # per call: plans are shared between threads
-        ptrs1 = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in details1])
+        ptrs2 = _arr(ctypes.c_void_p, 3)(*[t.data_ptr() for t in details2])  # per call: plans are shared between threads
+        ptrs1 = _arr(ctypes.c_void_p, 3)(*[t.data_ptr() for t in details1])
         lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
         ap, yp = approx2.data_ptr(), y.data_ptr()
         self._run(p, 1, approx2, lambda ws, wsb, stream: lib.mifwt_dwt2_inv_pair(ref2, p.ref, ap, ptrs2, ptrs1, yp, lo, hi, stream))
@@ -739,8 +749,8 @@ class HipLevelEngine:
         slots = _tls.__dict__.setdefault("invpyr", {})
         slot = slots.get(n)
         if slot is None:
-            rows = [(ctypes.c_void_p * 3)() for _ in range(n)]
-            det = (ctypes.POINTER(ctypes.c_void_p) * n)(*[ctypes.cast(r, ctypes.POINTER(ctypes.c_void_p)) for r in rows])
+            rows = [_arr(ctypes.c_void_p, 3)() for _ in range(n)]
+            det = _arr(ctypes.POINTER(ctypes.c_void_p), n)(*[ctypes.cast(r, ctypes.POINTER(ctypes.c_void_p)) for r in rows])
             slot = slots[n] = (rows, det)
         rows, det = slot
         for r, lv in zip(rows, levels):

@@ -478,7 +478,7 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
             dets = [lvl[0] for lvl in folded]
             eng = _engine.ENGINE
 
-            def fuse(cur, a, b):
+            def fuse(fuse, cur, a, b):  # (itself as an argument: a closure over its own name would be a reference cycle per call)
                 """Levels a .. b-1 with as few launches as possible: the finest ones in the chunked launch (mifwt_dwt1_inv_long:
                 as many as its halo rule allows), what is coarser first — chunked as well while there are too few rows for one
                 workgroup each, else in the one-workgroup-per-row launch (mifwt_dwt1_inv_tail) while the outputs fit into LDS."""
@@ -487,7 +487,7 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
                     if y is not None:
                         return y
                     if 2 <= k < b - a:
-                        cur = fuse(cur, a, b - k)
+                        cur = fuse(fuse, cur, a, b - k)
                         a = b - k
                         y, _k = eng.synthesis_long(cur, dets[a:b], rec_lo, rec_hi, outs[a:b])
                         if y is not None:
@@ -505,7 +505,7 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
                 return cur
 
             if len(outs) == len(folded):
-                cur = fuse(cur, 0, len(folded))
+                cur = fuse(fuse, cur, 0, len(folded))
                 pos = len(folded)
     any_grad = torch.is_grad_enabled() and (tap_t is not None or any(t.requires_grad for t in flat))
     gkey = None

@@ -65,3 +65,4 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
 json.dump(res, open(f"gpurun_out/{tag}_pmc_{wl}.json", "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])
 PY
+rm -rf $OUT
