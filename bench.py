@@ -313,6 +313,14 @@ def main():
         spin_steps += 1
         if spin_steps % 16 == 0:
             sync()
+    # (as timeit does, the interpreter's cyclic collector is kept out of the timed steps: a full pass with torch loaded is a 35-40 ms
+    # pause, and it lands in a 100-step window every few thousand calls whatever the calls do.  Not preceded by gc.collect(): the 200
+    # steps after a collection ran 10 % slower in every trial — 0.1165 against 0.1036-0.1044 ms per step on config 2, same box,
+    # alternating; MIFWT_BENCH_GC=1 leaves the collector on, =3 collects first)
+    if os.environ.get("MIFWT_BENCH_GC") == "3":
+        gc.collect()
+    if os.environ.get("MIFWT_BENCH_GC") != "1":
+        gc.disable()
     for i in range(args.warmup):
         step(i)
     sync()
@@ -320,10 +328,6 @@ def main():
         dist.barrier()
     sync()
 
-    # (as timeit does: the interpreter's cyclic collector is run now and kept out of the timed steps — a full pass with torch loaded
-    # is a 35-40 ms pause that lands in a 100-step window every few thousand calls, whatever the calls do)
-    gc.collect()
-    gc.disable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -469,7 +473,7 @@ def main():
             "dtype": {torch.float32: "f32", torch.float64: "f64", torch.float16: "f16 storage / f32 arithmetic"}[dtype],
             "data": "synthetic (torch.randn, %d rotating input buffers resident in HBM)" % len(bufs),
             "spinup_steps": spin_steps,
-            "gc": "cyclic collector run before and disabled during the K timed steps (as timeit does)",
+            "gc": "cyclic collector disabled during the warm-up and the K timed steps (as timeit does)",
             "config": {
                 "workload": args.workload,
                 "api": f"ptwt_amd.{fn_name}(x, '{wavelet}', mode='{mode}', level={level})",

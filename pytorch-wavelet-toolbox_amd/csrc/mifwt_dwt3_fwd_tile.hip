@@ -37,6 +37,7 @@ struct Dwt3TileArgs {
   int tiles_c, tiles_r, tiles_d;
   int segd;                     // unused
   FastDiv div_c, div_r, div_d;  // slice-per-wave kernel: by tiles_c, tiles_r, tiles_d
+  int nt;       // non-zero: non-temporal sub-band stores (MIFWT_OPT_NT_STORE)
   int k_limit;  // the brick kernels store columns < k_limit; dwt3_fwd_tail_kernel the few beyond (see launch3)
   int extra;    // slice-per-wave kernel: the last column tile also makes columns k_limit .. k_limit + extra - 1 (<= kExtra3)
   int mode;
@@ -230,8 +231,13 @@ __global__ void __launch_bounds__(256, 2) dwt3_fwd_tile_kernel(const Dwt3TileArg
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int hw = 2 * (c & 1) + (c >> 1);
-        obase[hw][hw == 0 ? off_a : off_d] = acc[c].x;
-        obase[4 + hw][off_d] = acc[c].y;
+        if (a.nt) {
+          __builtin_nontemporal_store(acc[c].x, &obase[hw][hw == 0 ? off_a : off_d]);
+          __builtin_nontemporal_store(acc[c].y, &obase[4 + hw][off_d]);
+        } else {
+          obase[hw][hw == 0 ? off_a : off_d] = acc[c].x;
+          obase[4 + hw][off_d] = acc[c].y;
+        }
       }
     }
   }
@@ -446,8 +452,13 @@ __global__ void __launch_bounds__(256, 2) dwt3_fwd_slice_kernel(const Dwt3TileAr
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int hw = 2 * (c & 1) + (c >> 1);  // component c = (H bit = c & 1, W bit = c >> 1) -> band = 4 depth + 2 H + W
-          obase[hw][hw == 0 ? off_a : off_d] = acc[c].x;
-          obase[4 + hw][off_d] = acc[c].y;
+          if (a.nt) {
+            __builtin_nontemporal_store(acc[c].x, &obase[hw][hw == 0 ? off_a : off_d]);
+            __builtin_nontemporal_store(acc[c].y, &obase[4 + hw][off_d]);
+          } else {
+            obase[hw][hw == 0 ? off_a : off_d] = acc[c].x;
+            obase[4 + hw][off_d] = acc[c].y;
+          }
         }
       }
     }
@@ -567,6 +578,7 @@ int launch3(const mifwt_level_desc* d, const void* x, void* approx, void* const*
   constexpr int ID = 2 * TDA + L - 2, IR = 2 * TR + L - 2, XP = (2 * (kTC3 + (kRoll ? kExtra3 : 0)) + L - 2 + 1) & ~1;
   constexpr size_t lds_bytes = (size_t)ID * IR * XP * sizeof(float);
   Dwt3TileArgs<L> a;
+  a.nt = g_options[MIFWT_OPT_NT_STORE];
   a.x = static_cast<const float*>(x);
   for (int s = 0; s < 8; ++s) {
     a.out[s] = static_cast<float*>(s == 0 ? approx : details[s - 1]);

@@ -37,6 +37,7 @@ struct Idwt3TileArgs {
   int tiles_c, tiles_r, tiles_d;
   FastDiv div_c, div_r, div_d;
   int yvec;  // 8-byte stores into y are aligned
+  int nt;    // non-zero: non-temporal output stores (MIFWT_OPT_NT_STORE)
   f2 tlo[L / 2], thi[L / 2];  // (rec_lo[2j], rec_lo[2j+1]), (rec_hi[2j], rec_hi[2j+1])
 };
 
@@ -142,7 +143,8 @@ __global__ void __launch_bounds__(256, 2) idwt3_tile_kernel(const Idwt3TileArgs<
       if (yo < a.H) {
         float* dst = yb + (int64_t)yo * a.ys_h;
         if (a.yvec && both) {
-          *reinterpret_cast<f2*>(dst) = acc;
+          if (a.nt) __builtin_nontemporal_store(acc, reinterpret_cast<f2*>(dst));
+          else *reinterpret_cast<f2*>(dst) = acc;
         } else {
           dst[0] = acc.x;
           if (both) dst[1] = acc.y;
@@ -158,6 +160,7 @@ int launch_i3(const mifwt_level_desc* d, const void* approx, const void* const* 
   constexpr int HL = L / 2, NQ = 64 - (HL - 1), IY = kCY3 + HL - 1;
   constexpr size_t lds_bytes = (size_t)2 * kCZ3 * 4 * IY * 64 * sizeof(float);
   Idwt3TileArgs<L> a;
+  a.nt = g_options[MIFWT_OPT_NT_STORE];
   for (int s = 0; s < 8; ++s) {
     a.in[s] = static_cast<const float*>(s == 0 ? approx : details[s - 1]);
     a.is_b[s] = s == 0 ? d->approx_stride[0] : d->detail_stride[0];
