@@ -5,6 +5,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 TAG=${TAG:-r03y}
 run_pmc() {  # workload, kernel substring, steps
+  [ -n "$SKIP_PMC" ] && return
   TAG=$TAG WL=$1 KERNEL=$2 STEPS=$3 bash tools/pmc_workload.sh > gpurun_out/${TAG}_pmc_$1.log 2>&1
   cp gpurun_out/${TAG}_pmc_$1.json profiles/ 2>/dev/null
   python -c "import json; d=json.load(open('gpurun_out/${TAG}_pmc_$1.json')); print('$1', d.get('kernel','?')[:60], 'traffic', d.get('hbm_traffic_bytes'), d.get('launch_ns_by_grid'))"
