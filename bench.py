@@ -355,11 +355,13 @@ def main():
     fused_levels = 1
     first_kid = events[0][1] if events else -1
     launch = None
+    call_is_launch = False
     if is_rec and events and len({e[2] for e in events}) == 1:
         # the whole reconstruction is ONE launch (the streaming / small-plane multi-level kernels): the call is the launch
         first_kid = events[-1][1]
         fused_levels = level
         launch = lambda b: fn(b, wavelet)  # noqa: E731
+        call_is_launch = True
     elif fn_name in ("wavedec2", "fswavedec2", "wavedec3", "wavedec"):
         taps = ptwt_amd._wavelets.host_taps(wavelet)
         mode_id = _engine.MODE_IDS[mode]
@@ -455,6 +457,15 @@ def main():
                   4: "streaming axis kernels (finest level)"}.get(kid1, f"kernel id {kid1} (level 1)")
         per_launch_event_ms = sum(lvl1) / max(1, len(lvl1))
         avg_ms = lvl1_b2b_ms if lvl1_b2b_ms else per_launch_event_ms
+        timing_note = ("median of 10 batches of 20 back-to-back launches of that kernel on the launch stream, one HIP event pair per batch "
+                       f"(same rotating inputs; independent of --steps); with an event pair around every launch inside whole calls: {per_launch_event_ms:.4f} ms")
+        if call_is_launch and avg_ms > ms_per_step:
+            # a call that IS one launch: the K timed steps are K back-to-back launches themselves, and the longer loop is the steadier
+            # one (every 20-launch batch starts from an idle queue)
+            timing_note = (f"the K timed steps themselves (a call is this one launch; {args.steps} launches back to back, host clock); the median of 10 "
+                           f"batches of 20 launches between one HIP event pair each was {avg_ms:.4f} ms, with an event pair around every launch "
+                           f"{per_launch_event_ms:.4f} ms")
+            avg_ms = ms_per_step
         achieved = lvl1_b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic, traffic_src = profiled_traffic(args.workload, klabel)
         # the dominant kernel is one launch of a step: its steady-state duration cannot exceed the step's (2 % timer slack)
@@ -498,8 +509,7 @@ def main():
                 "algorithmic_bytes_per_launch": lvl1_b,
                 "avg_launch_ms": round(avg_ms, 4),
                 "min_launch_ms": round(lvl1_b2b_min, 4) if lvl1_b2b_min else None,
-                "timing": "median of 10 batches of 20 back-to-back launches of that kernel on the launch stream, one HIP event pair per batch "
-                          f"(same rotating inputs; independent of --steps); with an event pair around every launch inside whole calls: {per_launch_event_ms:.4f} ms",
+                "timing": timing_note,
                 "traffic": traffic,
                 "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch of this kernel, not measured in this run)") if traffic_src else None,
             },
