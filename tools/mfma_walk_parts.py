@@ -16,7 +16,7 @@ def t(fn, n=5):
         e1.record(); torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / n)
     return min(res)
-for dbg in [int(v) for v in sys.argv[1:]] or (0, 1, 2, 4, 3, 5, 6, 7, 0):
+for dbg in [int(v) for v in sys.argv[1:]] or (0, 1, 2, 4, 3, 5, 6, 7, 0):  # (8 / 16 = store policies, see mfma_policy_ab.py)
     _engine.set_option(_engine.OPT_DEBUG, dbg)
     print(f"debug {dbg} ({'no stores ' if dbg & 1 else ''}{'no loads ' if dbg & 2 else ''}{'no matrix work' if dbg & 4 else ''}): {t(lambda: ptwt_amd.wavedec2(x, 'sym16', mode='reflect', level=1)):.3f} ms", flush=True)
 _engine.set_option(_engine.OPT_DEBUG, 0)
