@@ -523,6 +523,7 @@ __global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaAr
 
   // =============================================================================================================================
   // matrix waves
+  // (wave priorities measured: the loader raised: 2.29 against 2.10 ms; the matrix waves raised: 2.16-2.19 against 2.09-2.20 — none)
   const int n = lane & 31, half = lane >> 5;
   // T fragments: T[i][j] = h_band(i)[2 (i & 15) + L - 1 - j] with i = l & 31, j = 16 c + 8 (l >> 5) + e; f16 pairs (t = t_hi + t_lo)
   h8 ahi[4], alo[4];

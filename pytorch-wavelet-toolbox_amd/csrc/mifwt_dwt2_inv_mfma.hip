@@ -203,6 +203,9 @@ __global__ void __launch_bounds__(320, 5) idwt2_mfma_walk_kernel(const MfmaInvAr
 
   // =============================================================================================================================
   // matrix waves
+  // the matrix waves run above the loader's priority: finest level of the config-5 slice 2.17 -> 1.95 ms with any raised level
+  // (1, 2 or 3), alternating rounds on one box; raising the LOADER instead: 2.33 (MIFWT_OPT_DEBUG 64 = all waves at the default)
+  if (!(a.dbg & 64)) __builtin_amdgcn_s_setprio(1);
   const int n = lane & 31, half = lane >> 5;
   // S fragments: S[m][k], m = n = 2 q + r, k = 16 c + 8 half + e = 32 b + kk: g_b[L - 2 - 2 (kk - q) + r] for 0 <= kk - q < L/2;
   // f16 pairs (t = t_hi + t_lo)

@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
     constexpr int N1 = 2 * NB1, N2 = NLEV >= 2 ? NB2 : 0, N3 = NLEV >= 3 ? 2 : 0;
     constexpr int NITEMS = N1 + N2 + N3;
     const uint32_t lane16 = 16u * (uint32_t)lane;
-    __builtin_amdgcn_s_setprio(3);
+    if (!(a.dbg & 16)) __builtin_amdgcn_s_setprio(3);  // (config 2: 90.8-92.0 us per call with, 93.6-97.1 without, tools/pyr_prio_ab.py)
     auto run = [&](auto w_tag) {
       constexpr int WI = decltype(w_tag)::value;
       // resources of this loader's items (a level-3 item alternates between two bands with the parity of the sub-step)
@@ -440,6 +440,7 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
     emit(std::integral_constant<int, 1>{}, std::integral_constant<int, IpAcc<L>::done((R0 + 1) % HL)>{});
   };
 
+  if (a.dbg & 32) __builtin_amdgcn_s_setprio(1);  // (experiment: the synthesis waves above the default priority as well — no change)
   // ---- level 1 (the finest): output rows to global memory -----------------------------------------------------------------
   if (role == 1) {
     const int nq = (a.W + 3) >> 2;  // lanes with an output column

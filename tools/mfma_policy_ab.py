@@ -18,7 +18,7 @@ def t(fn, n=5):
         res.append(e0.elapsed_time(e1) / n)
     return min(res)
 for rnd in range(2):
-    for dbg in (0, 8, 16):
+    for dbg in (0, 8, 16, 64):
         _engine.set_option(_engine.OPT_DEBUG, dbg)
         ta = t(lambda: ptwt_amd.wavedec2(x, 'sym16', mode='reflect', level=1))
         ts = t(lambda: ptwt_amd.waverec2(cs, 'sym16'))
