@@ -20,6 +20,15 @@
 // Envelope: f16 storage, even L in [18, 32] (shorter filters are HBM-bound in the vector kernels already).
 #include "mifwt_stream.h"
 
+// cache policy of the chunk requests (experiment builds: -DMIFWT_MFMA_DMA_NT=1 non-temporal, =2 sc1)
+#if MIFWT_MFMA_DMA_NT == 1
+#define MIFWT_MFMA_DMA_POLICY " nt"
+#elif MIFWT_MFMA_DMA_NT == 2
+#define MIFWT_MFMA_DMA_POLICY " sc1"
+#else
+#define MIFWT_MFMA_DMA_POLICY ""
+#endif
+
 namespace mifwt {
 extern unsigned long long* g_pyr_prof;  // (mifwt_dwt2_fwd_pyr.hip; set by mifwt_pyr_profile_buffer)
 }
@@ -299,7 +308,7 @@ constexpr int kWLdsBytes = 2 * kWChunkBytes + 2 * kMC * kHP * 2;
 constexpr int kWPatch = 16;                        // patched samples per loader lane requested ahead (32 rows x 32 columns; more: on the spot)
 
 __device__ __forceinline__ void mfma_dma16(uint32_t voff, __amdgpu_buffer_rsrc_t rsrc, uint32_t lds_addr) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen" MIFWT_MFMA_DMA_POLICY " lds" ::"v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
 }
 
 template <bool PROF>

@@ -26,6 +26,15 @@
 // Envelope: f16 storage, even L in [18, 32], unit innermost strides; batches of fewer than 512 tiles stay with the vector tile kernel.
 #include "mifwt_stream.h"
 
+// cache policy of the chunk requests (experiment builds: -DMIFWT_MFMA_DMA_NT=1 non-temporal, =2 sc1)
+#if MIFWT_MFMA_DMA_NT == 1
+#define MIFWT_MFMA_DMA_POLICY " nt"
+#elif MIFWT_MFMA_DMA_NT == 2
+#define MIFWT_MFMA_DMA_POLICY " sc1"
+#else
+#define MIFWT_MFMA_DMA_POLICY ""
+#endif
+
 namespace mifwt {
 
 namespace {
@@ -59,7 +68,7 @@ struct MfmaInvArgs {
 };
 
 __device__ __forceinline__ void imfma_dma16(uint32_t voff, __amdgpu_buffer_rsrc_t rsrc, uint32_t lds_addr) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen" MIFWT_MFMA_DMA_POLICY " lds" ::"v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
 }
 
 __global__ void __launch_bounds__(320, 5) idwt2_mfma_walk_kernel(const MfmaInvArgs a) {
