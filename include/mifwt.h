@@ -307,8 +307,8 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  *   5 / 6  3-D analysis / synthesis (f32, even L <= 16; what the brick kernels 9 / 10 do not take): fused 2-D kernel over every
  *          depth slice + one streaming pass along depth
  *   9 / 10 fully fused 3-D analysis / synthesis level, LDS bricks (f32, L in {2, 4, 6}; synthesis also 8)
- *   11 / 23  fused 2-D analysis / synthesis level on the matrix cores (banded-Toeplitz MFMA; f16 storage, even L in [18, 32]; the analysis of small
- *          planes a tile at a time, of big ones walking down column panels; the synthesis kernel from 512 tiles of 32 x 128 samples per batch on)
+ *   11 / 23  fused 2-D analysis / synthesis level on the matrix cores (banded-Toeplitz MFMA; f16 storage, even L in [18, 32]; both walk down
+ *          column panels; the synthesis kernel from 16 tiles of 32 x 128 samples per call on, the vector tile kernel 8 below that)
  *   12 / 13  two fused 2-D analysis / synthesis levels per launch (mifwt_dwt2_fwd_pair / mifwt_dwt2_inv_pair; never
  *          returned by mifwt_kernel_id, which describes single-level calls)
  *   14 / 15  the deep levels of a 1-D analysis / the coarse levels of a 1-D synthesis in one launch (mifwt_dwt1_fwd_tail /
@@ -332,8 +332,8 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 #define MIFWT_OPT_NT_STORE 4       /* non-zero: nontemporal stores for the sub-band planes */
 #define MIFWT_OPT_TILE_MODE 5      /* 2-D analysis: 0 = auto (LDS-tile kernel on small planes), 1 = always tile, 2 = never */
 #define MIFWT_OPT_TILE_ROWS 6      /* >0 overrides the tile kernels' output rows per tile */
-#define MIFWT_OPT_MFMA_MODE 7      /* 2-D analysis, f16 storage, 18..32 taps: 0 = matrix-core kernels (walk down column panels on big planes, a tile
-                                      at a time on small ones), 2 = vector tile kernel, 3 / 4 = always the tile-at-a-time / the walking one */
+#define MIFWT_OPT_MFMA_MODE 7      /* 2-D analysis, f16 storage, 18..32 taps: 0 = matrix-core kernels (walking down column panels), 2 = vector tile
+                                      kernels, 3 = the tile-at-a-time analysis kernel of round 2 (comparisons), 4 = the synthesis kernel for every size */
 #define MIFWT_OPT_PAIR_MODE 8      /* multi-level launches (mifwt_dwt2_fwd_pyramid, mifwt_dwt2_fwd_pair, mifwt_dwt2_inv_pair, mifwt_dwt1_fwd_tail): 2 = never (they answer
                                       UNSUPPORTED / 0); analysis pairs: 0 = auto (rolling strips for 8 taps, else tiles), 1 = tiles only,
                                       3 = rolling strips wherever they apply */

@@ -75,6 +75,9 @@ __global__ void __launch_bounds__(256, 4) dwt2_fwd_mfma_kernel(const MfmaArgs a)
   fold.set(a.mode);
   const int L = a.L;
   const int n = lane & 31, half = lane >> 5;
+  // (the window starts P = L - 2 + s samples before the first output's pair, as in the walk kernel below: the same sums in the same
+  // order, so that the two kernels agree to the bit)
+  const int P = L - 2 + ((8 - ((L - 2) & 7)) & 7);
 
   // ---- T fragments, once per (persistent) workgroup: T[i][j] = h_band(i)[2 (i & 15) + L - 1 - j] with i = l & 31,
   // j = 16 c + 8 (l >> 5) + e; f16 pairs (t = t_hi + t_lo)
@@ -88,7 +91,7 @@ __global__ void __launch_bounds__(256, 4) dwt2_fwd_mfma_kernel(const MfmaArgs a)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int j = 16 * c + 8 * half + e;
-        const int m = 2 * kq + L - 1 - j;
+        const int m = 2 * kq + P + 1 - j;
         const float t = (m >= 0 && m < L) ? taps[32 * band + m] : 0.f;
         const _Float16 th = (_Float16)t;
         ahi[c][e] = th;
@@ -124,7 +127,7 @@ __global__ void __launch_bounds__(256, 4) dwt2_fwd_mfma_kernel(const MfmaArgs a)
     t.img = trow / a.tiles_r;
     t.k0 = tc * kMC;
     t.j0 = (trow - t.img * a.tiles_r) * kMR;
-    const int c_first = 2 * t.k0 - (L - 2);
+    const int c_first = 2 * t.k0 - P;
     // column pairs as dwords when the tile's columns lie inside the image and every row starts 4-byte aligned
     t.pairs = aligned4 && c_first >= 0 && c_first + kIC <= a.W;
     return t;
@@ -134,9 +137,9 @@ __global__ void __launch_bounds__(256, 4) dwt2_fwd_mfma_kernel(const MfmaArgs a)
   auto request = [&](const Tile& t, uint32_t (&v)[16][3]) {
     const __amdgpu_buffer_rsrc_t xrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.x + (int64_t)t.img * a.xs_b), 0, img_bytes, 0x00020000);
-    const int nc_need = 2 * (min(t.k0 + kMC, a.Wo) - t.k0) + L - 2;
-    const int nr_need = 2 * (min(t.j0 + kMR, a.Ho) - t.j0) + L - 2;
-    const int c_first = 2 * t.k0 - (L - 2), r_first = 2 * t.j0 - (L - 2);
+    const int nc_need = 2 * (min(t.k0 + kMC, a.Wo) - t.k0) + P;
+    const int nr_need = 2 * (min(t.j0 + kMR, a.Ho) - t.j0) + P;
+    const int c_first = 2 * t.k0 - P, r_first = 2 * t.j0 - P;
     if (t.pairs) {
       uint32_t poff[2];
 #pragma unroll
@@ -339,6 +342,10 @@ __global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaAr
   Fold1 fold;
   fold.set(a.mode);
   const int L = a.L;
+  // the window of a tile starts P = L - 2 + s samples before its first output's pair, s = the fewest samples that make P a multiple
+  // of 8: the 16-byte pieces of a chunk row then start on 16-byte boundaries (planes with 16-byte aligned rows); the 64-sample window
+  // of 16 outputs still holds all their taps (2 * 15 + L - 1 + s <= 63 for every L <= 32).  tests/test_mfma_walk_model.py
+  const int P = L - 2 + ((8 - ((L - 2) & 7)) & 7);
 
   // units (image, row segment, panel) with the panel index fastest: the blocks of an XCD walk down neighbouring panels (which share
   // 32 of their 160 columns) at the same time; staggered starting points as in the tile kernel
@@ -365,7 +372,7 @@ __global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaAr
   };
   int it = q;
   // (unit, chunk) after (u, gg) in this block's sequence; false at the end.  Chunk g of a unit = extended input rows
-  // r_first + 32 g .. + 31 with r_first = 2 kMR tr0 - (L - 2); tile tr0 + g - 1 needs chunks g - 1 and g.
+  // r_first + 32 g .. + 31 with r_first = 2 kMR tr0 - P; tile tr0 + g - 1 needs chunks g - 1 and g.
   auto advance = [&](Unit& u, int& gg) -> bool {
     if (gg < u.nt) {
       ++gg;
@@ -397,7 +404,7 @@ __global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaAr
     struct Geo {
       int c_first, r_first;
     };
-    auto geo = [&](const Unit& u, int g) -> Geo { return {2 * u.k0 - (L - 2), 2 * kMR * u.tr0 - (L - 2) + kWR * g}; };
+    auto geo = [&](const Unit& u, int g) -> Geo { return {2 * u.k0 - P, 2 * kMR * u.tr0 - P + kWR * g}; };
     auto rsrc_of = [&](const Unit& u) {
       return __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.x + (int64_t)u.img * a.xs_b), 0, img_bytes, 0x00020000);
     };
@@ -434,7 +441,7 @@ __global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaAr
       // dwords on the right: the dword that holds the last sample of an odd-width plane's last row ends out of range)
       nl = min(kIC, (max(0, -ge.c_first) + 7) & ~7);
       nr0 = max(nl, min(kIC, (a.W - ge.c_first) & ~1));
-      nr1 = max(nr0, min(kIC, 2 * (min(u.k0 + kMC, a.Wo) - u.k0) + L - 2));  // (nc_need of the tile kernel)
+      nr1 = max(nr0, min(kIC, 2 * (min(u.k0 + kMC, a.Wo) - u.k0) + P));  // (nc_need of the tile kernel)
       return nl + (nr1 - nr0);
     };
     auto patch_off = [&](const Geo& ge, int nl, int nr0, int ncols, int e, int& row, int& wc) -> uint32_t {
@@ -534,7 +541,7 @@ __global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaAr
   // matrix waves
   // (wave priorities measured: the loader raised: 2.29 against 2.10 ms; the matrix waves raised: 2.16-2.19 against 2.09-2.20 — none)
   const int n = lane & 31, half = lane >> 5;
-  // T fragments: T[i][j] = h_band(i)[2 (i & 15) + L - 1 - j] with i = l & 31, j = 16 c + 8 (l >> 5) + e; f16 pairs (t = t_hi + t_lo)
+  // T fragments: T[i][j] = h_band(i)[2 (i & 15) + P + 1 - j] with i = l & 31, j = 16 c + 8 (l >> 5) + e; f16 pairs (t = t_hi + t_lo)
   h8 ahi[4], alo[4];
   {
     const int band = n >> 4, kq = n & 15;
@@ -543,7 +550,7 @@ __global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaAr
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int j = 16 * c + 8 * half + e;
-        const int m = 2 * kq + L - 1 - j;
+        const int m = 2 * kq + P + 1 - j;
         const float t = (m >= 0 && m < L) ? taps[32 * band + m] : 0.f;
         const _Float16 th = (_Float16)t;
         ahi[c][e] = th;
@@ -706,9 +713,10 @@ int dwt2_fwd_mfma(const mifwt_level_desc* d, const void* x, void* approx, void* 
   a.ntiles = (int)ntiles;
   // 4 workgroups per CU (LDS) on 256 CUs; the grid is a multiple of 8 (one contiguous panel of tiles per XCD)
   int64_t grid = 256 * 4;
-  // the walk wins wherever there is a tile or two per workgroup (32 x 8192^2: 2.27 against 3.69 ms; 32 x 1051^2: 0.082 against 0.099;
-  // 32 x 541^2: 0.051 against 0.053; tools/mfma_walk_ab.py; MIFWT_OPT_MFMA_MODE 3 / 4 = always the tile kernel / always the walk)
-  const bool walk = g_options[MIFWT_OPT_MFMA_MODE] == 4 || (g_options[MIFWT_OPT_MFMA_MODE] != 3 && ntiles >= 2048);
+  // the walk wins wherever it was measured (32 x 8192^2: 2.0 against 3.6 ms; 32 x 1051^2: 0.080 against 0.098; 32 x 541^2: 0.049 against
+  // 0.051; tools/mfma_walk_ab.py) and serves every call, so that a batch and its images one by one take the same path;
+  // MIFWT_OPT_MFMA_MODE 3 = the tile-at-a-time kernel of round 2 (kept for comparisons: bit-identical results)
+  const bool walk = g_options[MIFWT_OPT_MFMA_MODE] != 3;
   if (walk) {
     // the walk: units of seg_tiles stacked tiles, about 16 units per workgroup (the priming chunk costs 1 / seg_tiles), at least 4 tiles each
     const int64_t panels = (int64_t)d->batch * a.tiles_c;

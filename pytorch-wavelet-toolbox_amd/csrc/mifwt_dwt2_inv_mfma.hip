@@ -23,7 +23,7 @@
 // One extra chunk per unit primes the ring.  Coefficients beyond the planes' extents count as zero (the crop of the reference):
 // rows past the end are requested out of range, columns past the end are zeroed in LDS by the loader (the padding of a row pitch
 // may hold anything).  The intermediate image is rounded to f16 once (5e-4 norm-wise per level, like the analysis kernel).
-// Envelope: f16 storage, even L in [18, 32], unit innermost strides; batches of fewer than 512 tiles stay with the vector tile kernel.
+// Envelope: f16 storage, even L in [18, 32], unit innermost strides; calls of fewer than 16 tiles stay with the vector tile kernel.
 #include "mifwt_stream.h"
 
 // cache policy of the chunk requests (experiment builds: -DMIFWT_MFMA_DMA_NT=1 non-temporal, =2 sc1)
@@ -344,7 +344,7 @@ bool dwt2_inv_mfma_supported(const mifwt_level_desc* d) {
   // where it pays: wherever there is a tile per workgroup or so (32 x 542^2 sym16: 0.026 against 0.205 ms for the vector tile kernel,
   // 32 x 1052^2: 0.049 against 0.172, tools/c5_rec_time.py; MIFWT_OPT_MFMA_MODE 4: always)
   const int64_t ntiles = d->batch * ((d->sig_extent[0] + kSOR - 1) / kSOR) * ((d->sig_extent[1] + kSOC - 1) / kSOC);
-  return g_options[MIFWT_OPT_MFMA_MODE] == 4 || ntiles >= 512;
+  return g_options[MIFWT_OPT_MFMA_MODE] == 4 || ntiles >= 16;  // (from a handful of tiles on: a batch and its images one by one take the same path)
 }
 
 int dwt2_inv_mfma(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y, const double* lo,

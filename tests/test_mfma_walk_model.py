@@ -13,15 +13,23 @@ MR, MC, IC, WR = 16, 64, 160, 32  # analysis: output rows / columns of a tile, w
 SR, SC, SOC = 16, 80, 128         # synthesis: coefficient rows / columns of a chunk, output columns of a tile
 
 
-def analysis_T(dec_lo, dec_hi):
-    """T[(band, k), j] = h_band[2k + L - 1 - j]: 16 low-pass and 16 high-pass outputs from a window of 64 samples that starts L - 2
-    samples before the first output's pair."""
+def window_shift(L):
+    """The window of the walk kernel starts L - 2 + s samples before the first output's pair, s = the fewest samples that make that a
+    multiple of 8 (16-byte pieces of a row then start on 16-byte boundaries); the 64-sample window still holds the 16 outputs' taps."""
+    s = (8 - (L - 2) % 8) % 8
+    assert 2 * 15 + L - 1 + s <= 63
+    return s
+
+
+def analysis_T(dec_lo, dec_hi, shift=0):
+    """T[(band, k), j] = h_band[2k + L - 1 + shift - j]: 16 low-pass and 16 high-pass outputs from a window of 64 samples that starts
+    L - 2 + shift samples before the first output's pair."""
     L = len(dec_lo)
     T = np.zeros((32, 64))
     for band, h in enumerate((dec_lo, dec_hi)):
         for k in range(16):
             for j in range(64):
-                m = 2 * k + L - 1 - j
+                m = 2 * k + L - 1 + shift - j
                 if 0 <= m < L:
                     T[16 * band + k, j] = h[m]
     return T
@@ -76,22 +84,23 @@ def walk_analysis(x, wavelet, mode, seg_tiles):
     L = len(dec_lo)
     H, W = x.shape
     Ho, Wo = (H + L - 1) // 2, (W + L - 1) // 2
-    T = analysis_T(dec_lo, dec_hi)
+    sh = window_shift(L)
+    T = analysis_T(dec_lo, dec_hi, sh)
     out = np.full((4, Ho, Wo), np.nan)
     rmap = lambda e: O.ext_index([e], H, mode)[0]  # noqa: E731  (-1 = an implicit zero)
     cmap = lambda e: O.ext_index([e], W, mode)[0]  # noqa: E731
     r_end = 2 * Ho
     for tc in range((Wo + MC - 1) // MC):
         k0 = tc * MC
-        c_first = 2 * k0 - (L - 2)
+        c_first = 2 * k0 - (L - 2) - sh
         # the patch ranges of csrc/mifwt_dwt2_fwd_mfma.hip:patch_cols
         nl = min(IC, (max(0, -c_first) + 7) & ~7)
         nr0 = max(nl, min(IC, (W - c_first) & ~1))
-        nr1 = max(nr0, min(IC, 2 * (min(k0 + MC, Wo) - k0) + L - 2))
+        nr1 = max(nr0, min(IC, 2 * (min(k0 + MC, Wo) - k0) + L - 2 + sh))
         for tr0, nt in units_of((Ho + MR - 1) // MR, seg_tiles):
             ring = np.full((2, MC, 64), np.nan)  # [horizontal band][output column][ring row]
             for g in range(nt + 1):  # chunk g; chunk 0 primes the ring
-                r_first = 2 * MR * tr0 - (L - 2) + WR * g
+                r_first = 2 * MR * tr0 - (L - 2) - sh + WR * g
                 chunk = np.zeros((WR, IC))
                 for r in range(WR):
                     ri = r_first + r
