@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define MIFWT_ABI_VERSION 1
+#define MIFWT_ABI_VERSION 2
 #define MIFWT_MAX_NDIM 3
 #define MIFWT_MAX_FILT 128 /* longest PyWavelets discrete filter is coif17 = 102 taps */
 
@@ -346,6 +346,14 @@ int mifwt_set_option(int key, int value);
 /* Diagnostic: a device buffer of 2 x uint64 per wave of every workgroup that later mifwt_dwt2_fwd_pyramid launches fill with
  * (cycles alive, cycles spent in workgroup barriers); NULL switches it off again. */
 int mifwt_pyr_profile_buffer(void* device_buffer);
+
+/* Diagnostic: how many launches of a kernel VARIANT this process has enqueued — variants that share a kernel id (what the tests use to
+ * pin "this code path ran"; `variant` out of range: 0). */
+#define MIFWT_VARIANT_FWD_MFMA_WALK 0 /* id 11: the analysis kernel that walks down column panels */
+#define MIFWT_VARIANT_FWD_MFMA_TILE 1 /* id 11: the tile-at-a-time analysis kernel of round 2 (MIFWT_OPT_MFMA_MODE 3) */
+#define MIFWT_VARIANT_FWD_PYR_ST16 2  /* id 16: 16-byte stores after a lane-pair exchange (planes with 16-byte aligned rows) */
+#define MIFWT_VARIANT_FWD_PYR_ST8 3   /* id 16: 8-byte stores (any row pitch) */
+unsigned long long mifwt_launch_count(int variant);
 
 const char* mifwt_strerror(int code);
 int mifwt_abi_version(void);

@@ -16,7 +16,11 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, os.environ.get("MIFWT_LIB", "libmifwt.so"))  # (MIFWT_LIB: an experiment build next to the product library, tools/ only)
-ABI_VERSION = 1
+if "MIFWT_LIB" in os.environ:
+    import warnings
+
+    warnings.warn(f"ptwt_amd: MIFWT_LIB is set — running on the experiment build {LIB_PATH}, not on the product library", RuntimeWarning)
+ABI_VERSION = 2
 
 MODE_IDS = {"zero": 0, "constant": 1, "reflect": 2, "periodic": 3, "symmetric": 4}
 _DTYPE_IDS = {torch.float32: 0, torch.float64: 1, torch.float16: 2}
@@ -132,9 +136,13 @@ def load_library() -> ctypes.CDLL:
     lib.mifwt_dwt1_inv_tail.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, vp, ctypes.c_int64,
                                         ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32), vp,
                                         ctypes.c_int64, dbl_p, dbl_p, vp]
+    experiment = "MIFWT_LIB" in os.environ  # (tools/: an older build for a same-run comparison may lack the newest entry points)
+    if not experiment or hasattr(lib, "mifwt_launch_count"):
+        lib.mifwt_launch_count.restype = ctypes.c_uint64
+        lib.mifwt_launch_count.argtypes = [ctypes.c_int]
     lib.mifwt_set_option.restype = ctypes.c_int
     lib.mifwt_set_option.argtypes = [ctypes.c_int, ctypes.c_int]
-    if lib.mifwt_abi_version() != ABI_VERSION:
+    if lib.mifwt_abi_version() != ABI_VERSION and not experiment:
         raise RuntimeError("ptwt_amd: libmifwt.so ABI version mismatch; rebuild the extension")
     _lib = lib
     return lib
@@ -159,6 +167,11 @@ def _require_gpu(t: torch.Tensor) -> None:
 level_events: Optional[list] = None
 
 ROW_ALIGN = int(os.environ.get("MIFWT_ROW_ALIGN", "1"))  # bytes; 1 = dense rows
+# Row alignment (bytes) of the planes the streaming multi-level analysis kernel writes; 1 = dense.  MEASURED (round 4, config 2, same run,
+# profiles/r04b_st16_ab.txt): rows padded to 16 bytes (515 -> 516 floats) cost 20 us per call with rotating output sets whatever the
+# store width (126 us dense, 147-150 padded with 8-byte stores, 141-166 with 16-byte stores) — a memory-channel effect of the pitch,
+# as on the 3-D planes.  Dense stays the default; the kernel's 16-byte store path serves planes whose dense rows are 16-byte aligned.
+PYRAMID_ROW_ALIGN = int(os.environ.get("MIFWT_PYRAMID_ROW_ALIGN", "1"))
 
 OPT_FORCE_GENERIC = 0
 OPT_ROWS_PER_CHUNK = 1
@@ -182,6 +195,14 @@ KID_SMALL = 20
 KID_INV_SMALL = 21
 KID_INV_PYRAMID = 22
 MAX_PYRAMID_LEVELS = 8  # mifwt_dwt2_fwd_pyramid: three for the streaming kernel, eight for the small-plane kernel
+
+
+VARIANT_FWD_MFMA_WALK, VARIANT_FWD_MFMA_TILE, VARIANT_FWD_PYR_ST16, VARIANT_FWD_PYR_ST8 = 0, 1, 2, 3
+
+
+def launch_count(variant: int) -> int:
+    """Launches of a kernel variant enqueued by this process so far (variants share a kernel id; tests pin "this path ran" with it)."""
+    return int(load_library().mifwt_launch_count(variant))
 
 
 def set_option(key: int, value: int) -> None:
@@ -241,7 +262,7 @@ class HipLevelEngine:
     """One decomposition / reconstruction level for a folded batch, on the GPU, through the C ABI."""
 
     @staticmethod
-    def _analysis_plan(x: torch.Tensor, flen: int, mode_id: int) -> _Plan:
+    def _analysis_plan(x: torch.Tensor, flen: int, mode_id: int, min_align: int = 1) -> _Plan:
         lib = load_library()
         ndim = x.dim() - 1
         batch = x.shape[0]
@@ -255,7 +276,7 @@ class HipLevelEngine:
         # an odd coefficient width every other row starts 2-byte aligned and the stores are split: level 1 of the config-5 slice
         # 4.3 ms dense, 3.7 ms with 16-byte, 2.76 ms with 128-byte aligned rows (tools/mfma_walk_parts.py) — those planes get 128.
         esz = x.element_size()
-        align = ROW_ALIGN
+        align = max(ROW_ALIGN, min_align)
         if align <= 1 and ndim == 2 and x.dtype == torch.float16 and 18 <= flen <= 32:
             align = 128
         pitch = -(-coef[-1] * esz // align) * align // esz if align > esz and ndim >= 2 else coef[-1]
@@ -379,26 +400,39 @@ class HipLevelEngine:
         if x.dim() != 3 or x.dtype != torch.float32:
             return None
         flen = len(dec_lo)
-        key = ("pyr", x.shape, x.stride(), mode_id, flen, min(nlevels, MAX_PYRAMID_LEVELS), ROW_ALIGN)
+        key = ("pyr", x.shape, x.stride(), mode_id, flen, min(nlevels, MAX_PYRAMID_LEVELS), ROW_ALIGN, PYRAMID_ROW_ALIGN)
         plan = _plans.get(key)
         if plan is None:
             _trim_plans()
             lib = load_library()
-            plans = [self._analysis_plan(x, flen, mode_id)]
-            while len(plans) < min(nlevels, MAX_PYRAMID_LEVELS) and not plans[-1].empty:
-                pl = plans[-1]
-                lvl = torch.empty(pl.alloc_shape, dtype=x.dtype, device="meta")
-                if pl.view_last is not None:
-                    lvl = lvl[..., : pl.view_last]
-                plans.append(self._analysis_plan(lvl[:, 0], flen, mode_id))
-            n_ok, route = 0, 0
-            if not any(pl.empty for pl in plans):
-                for n in range(len(plans), 0, -1):
-                    refs = (ctypes.POINTER(LevelDesc) * n)(*[ctypes.pointer(pl.desc) for pl in plans[:n]])
-                    route = lib.mifwt_dwt2_fwd_pyramid_supported(n, refs)
-                    if route:
-                        n_ok = n
-                        break
+
+            def chain(min_align):
+                plans = [self._analysis_plan(x, flen, mode_id, min_align)]
+                while len(plans) < min(nlevels, MAX_PYRAMID_LEVELS) and not plans[-1].empty:
+                    pl = plans[-1]
+                    lvl = torch.empty(pl.alloc_shape, dtype=x.dtype, device="meta")
+                    if pl.view_last is not None:
+                        lvl = lvl[..., : pl.view_last]
+                    plans.append(self._analysis_plan(lvl[:, 0], flen, mode_id, min_align))
+                n_ok, route = 0, 0
+                if not any(pl.empty for pl in plans):
+                    for n in range(len(plans), 0, -1):
+                        refs = (ctypes.POINTER(LevelDesc) * n)(*[ctypes.pointer(pl.desc) for pl in plans[:n]])
+                        route = lib.mifwt_dwt2_fwd_pyramid_supported(n, refs)
+                        if route:
+                            n_ok = n
+                            break
+                return plans, n_ok, route
+
+            plans, n_ok, route = chain(1)
+            if n_ok and route == 1 and PYRAMID_ROW_ALIGN > 1:
+                # the streaming kernel stores 16 bytes per lane when the rows of every plane it writes start on 16-byte boundaries
+                # (lane pairs exchange rows in front of the store, csrc/mifwt_pyr.h): its planes get a row pitch of a multiple of four
+                # floats (config 2: 515 -> 516); the returned bands are views with that pitch.  The small-plane kernel (route 2) keeps
+                # dense planes.
+                plans_a, n_a, route_a = chain(PYRAMID_ROW_ALIGN)
+                if n_a == n_ok and route_a == route:
+                    plans = plans_a
             keep = plans[:n_ok]
             refs = (ctypes.POINTER(LevelDesc) * n_ok)(*[ctypes.pointer(pl.desc) for pl in keep]) if n_ok else None
             if n_ok > 1:  # every level but the last: detail planes only

@@ -257,6 +257,7 @@ int pick_kernel(const mifwt_level_desc* d, int direction) {
 namespace mifwt {
 extern unsigned long long* g_pyr_prof;
 int g_options[16] = {0};
+unsigned long long g_launch_counts[16] = {0};
 thread_local BatchSplit g_batch_split = {0, 0};
 }
 
@@ -269,6 +270,10 @@ int mifwt_set_option(int key, int value) {
 }
 
 int mifwt_abi_version(void) { return MIFWT_ABI_VERSION; }
+
+unsigned long long mifwt_launch_count(int variant) {
+  return variant >= 0 && variant < 16 ? __atomic_load_n(&g_launch_counts[variant], __ATOMIC_RELAXED) : 0ull;
+}
 
 // diagnostic: device buffer of 2 x uint64 per wave of every workgroup of mifwt_dwt2_fwd_pyramid launches (NULL = off)
 int mifwt_pyr_profile_buffer(void* device_buffer) {

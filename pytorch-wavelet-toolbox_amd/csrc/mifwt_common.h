@@ -11,6 +11,8 @@ namespace mifwt {
 
 constexpr int kMaxFilt = MIFWT_MAX_FILT;
 extern int g_options[16];  // mifwt_set_option() switches
+extern unsigned long long g_launch_counts[16];  // mifwt_launch_count(): launches per kernel variant (MIFWT_VARIANT_*)
+inline void count_launch(int variant) { __atomic_fetch_add(&g_launch_counts[variant], 1ull, __ATOMIC_RELAXED); }
 
 // Two-level batch for ONE call of the LDS-tile 2-D analysis kernel (thread-local, set and cleared by the 3-D composed route around that
 // call): the input images are `inner` slices per volume, `outer_stride` elements between volumes; inner == 0: off.

@@ -730,12 +730,14 @@ int dwt2_fwd_mfma(const mifwt_level_desc* d, const void* x, void* approx, void* 
     a.nunits = (int)nunits;
     if (nunits < grid) grid = (nunits + 7) & ~int64_t(7);
     a.prof = g_pyr_prof;
+    count_launch(MIFWT_VARIANT_FWD_MFMA_WALK);
     if (a.prof) hipLaunchKernelGGL(dwt2_fwd_mfma_walk_kernel<true>, dim3((unsigned)grid), dim3(320), kWLdsBytes, stream, a);
     else hipLaunchKernelGGL(dwt2_fwd_mfma_walk_kernel<false>, dim3((unsigned)grid), dim3(320), kWLdsBytes, stream, a);
     return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
   }
   a.seg_tiles = a.segs = a.nunits = 0;
   if (ntiles < grid) grid = (ntiles + 7) & ~int64_t(7);
+  count_launch(MIFWT_VARIANT_FWD_MFMA_TILE);
   hipLaunchKernelGGL(dwt2_fwd_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }

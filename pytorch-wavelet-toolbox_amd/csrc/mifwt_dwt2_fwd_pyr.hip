@@ -156,7 +156,7 @@ __device__ __forceinline__ void pyr_role(int wave, int nl1, int nchunks, int& ro
   }
 }
 
-template <int L, int NLEV, bool PROF>
+template <int L, int NLEV, bool PROF, bool ST16>
 __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrArgs<L, NLEV> a) {
   constexpr int HL = L - 2, HP = L / 2;
   constexpr int NC1 = 2;          // columns per level-1 lane (three were measured: 112.6 against 108.5 us on config 2)
@@ -494,8 +494,11 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
   // level-1 wave: NC1 columns per lane
   if (role == kRoleL1) {
     const int gmax = (cB[1] - o1 + NC1 - 1) / NC1 - 1;               // last lane of the grid that has a column
-    const int G = min(64 * widx + lane, gmax);                // (lanes beyond it repeat that one and store nothing)
-    const bool real = 64 * widx + lane <= gmax;
+    // 16-byte stores: lanes l and l + 32 hold neighbouring column pairs (they exchange rows in front of a store, pyr_swap_rows)
+    constexpr bool st16 = ST16;
+    const int glane = 64 * widx + (st16 ? 2 * (lane & 31) + (lane >> 5) : lane);
+    const int G = min(glane, gmax);                           // (lanes beyond it repeat that one and store nothing)
+    const bool real = glane <= gmax;
     const int c0 = o1 + NC1 * G;
     const uint32_t win = 4u * (uint32_t)(kPyrPad - HL + 2 * o1 - g0 + 2 * NC1 * G);  // the lane's L - 2 + 2 NC1 staged samples
     const bool full = real && c0 >= pA[1] && c0 + 1 < pB[1];
@@ -531,6 +534,12 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
     const rsrc_t rd = pyr_rsrc(a.det[0] + (int64_t)img * a.ds_b[0], dbytes);
     const rsrc_t ra = pyr_rsrc(a.approx + (int64_t)img * a.as_b, NLEV == 1 ? abytes : 0u);
     const uint32_t o0 = a.doff[0][0], o1 = a.doff[0][1], o2 = a.doff[0][2];
+    PyrSt16 gd, ga;  // detail planes / approximation plane (one level only)
+    const uint32_t dpitch = (uint32_t)a.ds_h[0] * 4u, apitch = (uint32_t)a.as_h * 4u;
+    if constexpr (st16) {
+      gd.set(lane, NC1 * 64 * widx, pB[1]);  // (one column group: the lane grid starts at column 0)
+      if constexpr (NLEV == 1) ga = gd;
+    }
 
     PyrAcc<L, NC1> acc;
     acc.clear();
@@ -576,6 +585,7 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
           f2 w[kPyrSub][NW2];
 #pragma unroll
           for (int kk = 0; kk < kPyrSub; ++kk) load_win(sb + kk * a.pitch0 + win, w[kk]);
+          float k_ad[2], k_da[2], k_dd[2], k_aa[2];  // (16-byte stores: the first row of the half step waits for the second)
           pyr_static_for<kPyrSub / 2>([&](auto jj_tag) {
             constexpr int jj = decltype(jj_tag)::value;
             constexpr int j = 2 * half + jj;      // pair of the step
@@ -598,22 +608,40 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
 #pragma unroll
               for (int k = 0; k < NC1; ++k) *reinterpret_cast<float*>(rr + (mine ? rw[k] : 0u)) = lo[k].x;
             }
-            const bool own = i >= oA[1] && i < oB[1];
-            const uint32_t v2 = own ? sv2 : kPyrOob;
-            const uint32_t so = own ? (uint32_t)i * (uint32_t)a.ds_h[0] * 4u : 0u;
-            __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].x, hi[1].x}, rd, v2, so + o0, MIFWT_ST_AUX);
-            __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].y, lo[1].y}, rd, v2, so + o1, MIFWT_ST_AUX);
-            __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].y, hi[1].y}, rd, v2, so + o2, MIFWT_ST_AUX);
-            if (rag) {
-              const uint32_t v1 = own ? sv1 : kPyrOob;
-              pyr_store1(hi[0].x, rd, v1, so + o0);
-              pyr_store1(lo[0].y, rd, v1, so + o1);
-              pyr_store1(hi[0].y, rd, v1, so + o2);
-            }
-            if constexpr (NLEV == 1) {
-              const uint32_t sa = own ? (uint32_t)i * (uint32_t)a.as_h * 4u : 0u;
-              __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].x, lo[1].x}, ra, v2, sa, MIFWT_ST_AUX);
-              if (rag) pyr_store1(lo[0].x, ra, own ? sv1 : kPyrOob, sa);
+            if constexpr (st16) {
+              if constexpr (jj == 0) {
+                k_ad[0] = hi[0].x, k_ad[1] = hi[1].x, k_da[0] = lo[0].y, k_da[1] = lo[1].y, k_dd[0] = hi[0].y, k_dd[1] = hi[1].y;
+                if constexpr (NLEV == 1) k_aa[0] = lo[0].x, k_aa[1] = lo[1].x;
+              } else {
+                uint32_t v4, dx, so;
+                bool mine;
+                gd.rows(lane, i - 1, oA[1], oB[1], dpitch, v4, dx, mine, so);
+                gd.band(lane, v4, dx, mine, k_ad[0], k_ad[1], hi[0].x, hi[1].x, rd, so + o0);
+                gd.band(lane, v4, dx, mine, k_da[0], k_da[1], lo[0].y, lo[1].y, rd, so + o1);
+                gd.band(lane, v4, dx, mine, k_dd[0], k_dd[1], hi[0].y, hi[1].y, rd, so + o2);
+                if constexpr (NLEV == 1) {
+                  ga.rows(lane, i - 1, oA[1], oB[1], apitch, v4, dx, mine, so);
+                  ga.band(lane, v4, dx, mine, k_aa[0], k_aa[1], lo[0].x, lo[1].x, ra, so);
+                }
+              }
+            } else {
+              const bool own = i >= oA[1] && i < oB[1];
+              const uint32_t v2 = own ? sv2 : kPyrOob;
+              const uint32_t so = own ? (uint32_t)i * (uint32_t)a.ds_h[0] * 4u : 0u;
+              __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].x, hi[1].x}, rd, v2, so + o0, MIFWT_ST_AUX);
+              __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].y, lo[1].y}, rd, v2, so + o1, MIFWT_ST_AUX);
+              __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].y, hi[1].y}, rd, v2, so + o2, MIFWT_ST_AUX);
+              if (rag) {
+                const uint32_t v1 = own ? sv1 : kPyrOob;
+                pyr_store1(hi[0].x, rd, v1, so + o0);
+                pyr_store1(lo[0].y, rd, v1, so + o1);
+                pyr_store1(hi[0].y, rd, v1, so + o2);
+              }
+              if constexpr (NLEV == 1) {
+                const uint32_t sa = own ? (uint32_t)i * (uint32_t)a.as_h * 4u : 0u;
+                __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].x, lo[1].x}, ra, v2, sa, MIFWT_ST_AUX);
+                if (rag) pyr_store1(lo[0].x, ra, own ? sv1 : kPyrOob, sa);
+              }
             }
           });
         }
@@ -638,8 +666,10 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
   if constexpr (NLEV >= 2) {
     if (role == kRoleL2) {
       const int gmax = (cB[2] - cA[2] + 1) / 2 - 1;
-      const int G = min(64 * widx + lane, gmax);
-      const bool real = 64 * widx + lane <= gmax;
+      constexpr bool st16 = ST16;  // (as at level 1)
+      const int glane = 64 * widx + (st16 ? 2 * (lane & 31) + (lane >> 5) : lane);
+      const int G = min(glane, gmax);
+      const bool real = glane <= gmax;
       const int c0 = cA[2] + 2 * G;  // (pA2 - cA2 is even: a lane lies inside or outside the owned range)
       const uint32_t win = 4u * (uint32_t)(kPyrPad + sh1 - HL + 2 * c0 - cA[1]);
       const bool full = real && c0 >= pA[2] && c0 + 1 < pB[2];
@@ -670,6 +700,12 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
       const rsrc_t rd = pyr_rsrc(a.det[1] + (int64_t)img * a.ds_b[1], dbytes);
       const rsrc_t ra = pyr_rsrc(a.approx + (int64_t)img * a.as_b, NLEV == 2 ? abytes : 0u);
       const uint32_t o0 = a.doff[1][0], o1 = a.doff[1][1], o2 = a.doff[1][2];
+      PyrSt16 gd, ga;
+      const uint32_t dpitch = (uint32_t)a.ds_h[1] * 4u, apitch = (uint32_t)a.as_h * 4u;
+      if constexpr (st16) {
+        gd.set(lane, 128 * widx, pB[2]);
+        if constexpr (NLEV == 2) ga = gd;
+      }
       const int ro1 = HP - 1 - rA[1];
       const int E1 = 2 * rA[2] - HL;
       PyrAcc<L, 2> acc;
@@ -718,12 +754,22 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
           }
           pyr_dispatch<HP>(ph, [&](auto r0_tag) {
             constexpr int R0 = decltype(r0_tag)::value;  // (2 (s - D2)) mod L/2
+            // (16-byte stores of 8-tap filters: the first row of a step waits in registers for the second — the windows of a
+            // step's two row pairs are requested pair by pair then, the wave has no registers for all four next to them)
+            constexpr bool kSplit = st16 && L >= 8;
             f2 w[4][NW2];
+            if constexpr (!kSplit) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) load_win(ring1 + so_r[r] + win, w[r]);
+              for (int r = 0; r < 4; ++r) load_win(ring1 + so_r[r] + win, w[r]);
+            }
+            float k_ad[2], k_da[2], k_dd[2], k_aa[2];
             pyr_static_for<2>([&](auto jj_tag) {
               constexpr int jj = decltype(jj_tag)::value;
               constexpr int R = (R0 + jj) % HP;
+              if constexpr (kSplit) {
+                load_win(ring1 + so_r[2 * jj] + win, w[2 * jj]);
+                load_win(ring1 + so_r[2 * jj + 1] + win, w[2 * jj + 1]);
+              }
               f2 ha[2], hb[2];
               h_pair(w[2 * jj], w[2 * jj + 1], ha, hb);
               acc.template feed<0, R>(tap, ha);
@@ -738,22 +784,40 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
                 *reinterpret_cast<float*>(rr + (mine ? rw[0] : 0u)) = lo[0].x;
                 *reinterpret_cast<float*>(rr + (mine ? rw[1] : 0u)) = lo[1].x;
               }
-              const bool own = i >= oA[2] && i < oB[2];
-              const uint32_t v2 = own ? sv2 : kPyrOob;
-              const uint32_t so = own ? (uint32_t)i * (uint32_t)a.ds_h[1] * 4u : 0u;
-              __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].x, hi[1].x}, rd, v2, so + o0, MIFWT_ST_AUX);
-              __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].y, lo[1].y}, rd, v2, so + o1, MIFWT_ST_AUX);
-              __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].y, hi[1].y}, rd, v2, so + o2, MIFWT_ST_AUX);
-              if (rag) {
-                const uint32_t v1 = own ? sv1 : kPyrOob;
-                pyr_store1(hi[0].x, rd, v1, so + o0);
-                pyr_store1(lo[0].y, rd, v1, so + o1);
-                pyr_store1(hi[0].y, rd, v1, so + o2);
-              }
-              if constexpr (NLEV == 2) {
-                const uint32_t sa = own ? (uint32_t)i * (uint32_t)a.as_h * 4u : 0u;
-                __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].x, lo[1].x}, ra, v2, sa, MIFWT_ST_AUX);
-                if (rag) pyr_store1(lo[0].x, ra, own ? sv1 : kPyrOob, sa);
+              if constexpr (st16) {
+                if constexpr (jj == 0) {
+                  k_ad[0] = hi[0].x, k_ad[1] = hi[1].x, k_da[0] = lo[0].y, k_da[1] = lo[1].y, k_dd[0] = hi[0].y, k_dd[1] = hi[1].y;
+                  if constexpr (NLEV == 2) k_aa[0] = lo[0].x, k_aa[1] = lo[1].x;
+                } else {
+                  uint32_t v4, dx, so;
+                  bool mine;
+                  gd.rows(lane, i - 1, oA[2], oB[2], dpitch, v4, dx, mine, so);
+                  gd.band(lane, v4, dx, mine, k_ad[0], k_ad[1], hi[0].x, hi[1].x, rd, so + o0);
+                  gd.band(lane, v4, dx, mine, k_da[0], k_da[1], lo[0].y, lo[1].y, rd, so + o1);
+                  gd.band(lane, v4, dx, mine, k_dd[0], k_dd[1], hi[0].y, hi[1].y, rd, so + o2);
+                  if constexpr (NLEV == 2) {
+                    ga.rows(lane, i - 1, oA[2], oB[2], apitch, v4, dx, mine, so);
+                    ga.band(lane, v4, dx, mine, k_aa[0], k_aa[1], lo[0].x, lo[1].x, ra, so);
+                  }
+                }
+              } else {
+                const bool own = i >= oA[2] && i < oB[2];
+                const uint32_t v2 = own ? sv2 : kPyrOob;
+                const uint32_t so = own ? (uint32_t)i * (uint32_t)a.ds_h[1] * 4u : 0u;
+                __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].x, hi[1].x}, rd, v2, so + o0, MIFWT_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].y, lo[1].y}, rd, v2, so + o1, MIFWT_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].y, hi[1].y}, rd, v2, so + o2, MIFWT_ST_AUX);
+                if (rag) {
+                  const uint32_t v1 = own ? sv1 : kPyrOob;
+                  pyr_store1(hi[0].x, rd, v1, so + o0);
+                  pyr_store1(lo[0].y, rd, v1, so + o1);
+                  pyr_store1(hi[0].y, rd, v1, so + o2);
+                }
+                if constexpr (NLEV == 2) {
+                  const uint32_t sa = own ? (uint32_t)i * (uint32_t)a.as_h * 4u : 0u;
+                  __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].x, lo[1].x}, ra, v2, sa, MIFWT_ST_AUX);
+                  if (rag) pyr_store1(lo[0].x, ra, own ? sv1 : kPyrOob, sa);
+                }
               }
             });
           });
@@ -1098,6 +1162,18 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
   a.prof = g_pyr_prof;
   const int64_t nwg_all = d[0]->batch * p.nseg * p.ngroups;
   a.xcd_map = (a.dbg & 32) && (nwg_all % 8 == 0) ? 1 : 0;
+  // 16-byte stores (lane-pair exchange): one column group, and every plane the level's waves write has rows, images and bands on
+  // 16-byte boundaries (the host layer pads the row pitch of these planes to a multiple of four floats; dense odd-width planes of
+  // other callers keep the 8-byte stores).  MIFWT_OPT_DEBUG bit 9 switches them off (A/B runs).
+  bool st16 = p.ngroups == 1 && !(a.dbg & 512) && !p.handover;
+  {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    for (int l = 0; l < NLEV && l < 2; ++l) {
+      st16 = st16 && al16(a.det[l]) && a.ds_h[l] % 4 == 0 && a.ds_b[l] % 4 == 0;
+      for (int b = 0; b < 3; ++b) st16 = st16 && (a.doff[l][b] & 15) == 0;
+      if (l + 1 == NLEV) st16 = st16 && al16(a.approx) && a.as_h % 4 == 0 && a.as_b % 4 == 0;
+    }
+  }
   a.handover = 0;
   a.nonce = 0;
   a.flags = nullptr;
@@ -1116,14 +1192,20 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
   if (nwg > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
   // (the per-wave cycle profile of tools/pyr_prof.py exists for the three-level 8-tap kernel only)
   constexpr bool kCanProf = L == 8 && NLEV == 3;
-  static DynLdsOnce lds_once, lds_once_prof;
-  if (!lds_once.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, false>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
-  if (kCanProf && !lds_once_prof.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, kCanProf>), 160 * 1024))
+  static DynLdsOnce lds_once, lds_once16, lds_once_prof;
+  if (!lds_once.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, false, false>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
+  if (!lds_once16.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, false, true>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
+  if (kCanProf && !lds_once_prof.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, false>), 160 * 1024))
     return MIFWT_ERR_LAUNCH;
   if (kCanProf && a.prof)
-    hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, kCanProf>), dim3((unsigned)nwg), dim3(64 * kPyrWaves), p.lds, stream, a);
-  else
-    hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, false>), dim3((unsigned)nwg), dim3(64 * kPyrWaves), p.lds, stream, a);
+    hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, false>), dim3((unsigned)nwg), dim3(64 * kPyrWaves), p.lds, stream, a);
+  else if (st16) {
+    count_launch(MIFWT_VARIANT_FWD_PYR_ST16);
+    hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, false, true>), dim3((unsigned)nwg), dim3(64 * kPyrWaves), p.lds, stream, a);
+  } else {
+    count_launch(MIFWT_VARIANT_FWD_PYR_ST8);
+    hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, false, false>), dim3((unsigned)nwg), dim3(64 * kPyrWaves), p.lds, stream, a);
+  }
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 

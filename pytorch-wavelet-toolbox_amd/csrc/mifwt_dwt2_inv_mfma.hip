@@ -343,8 +343,10 @@ bool dwt2_inv_mfma_supported(const mifwt_level_desc* d) {
     if (d->sig_extent[ax] < 1 || d->sig_extent[ax] > 2 * d->coef_extent[ax] - L + 2) return false;
   // where it pays: wherever there is a tile per workgroup or so (32 x 542^2 sym16: 0.026 against 0.205 ms for the vector tile kernel,
   // 32 x 1052^2: 0.049 against 0.172, tools/c5_rec_time.py; MIFWT_OPT_MFMA_MODE 4: always)
-  const int64_t ntiles = d->batch * ((d->sig_extent[0] + kSOR - 1) / kSOR) * ((d->sig_extent[1] + kSOC - 1) / kSOC);
-  return g_options[MIFWT_OPT_MFMA_MODE] == 4 || ntiles >= 16;  // (from a handful of tiles on: a batch and its images one by one take the same path)
+  // The threshold looks at ONE image's tiles, never at the batch: this kernel rounds the intermediate image to f16, the vector tile
+  // kernel keeps it in f32 — a batch and its images one by one must take the same path to agree to the bit.
+  const int64_t tiles_per_image = ((d->sig_extent[0] + kSOR - 1) / kSOR) * ((d->sig_extent[1] + kSOC - 1) / kSOC);
+  return g_options[MIFWT_OPT_MFMA_MODE] == 4 || tiles_per_image >= 4;
 }
 
 int dwt2_inv_mfma(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y, const double* lo,

@@ -37,6 +37,68 @@ __device__ __forceinline__ rsrc_t pyr_rsrc(const void* p, uint32_t bytes) {
 __device__ __forceinline__ void pyr_store1(float v, rsrc_t rsrc, uint32_t voff, uint32_t soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rsrc, voff, soff, MIFWT_ST_AUX);
 }
+// 16-byte store, non-temporal (measured on config 2 with 516-float rows and rotating output sets, profiles/r04b_st16_ab.txt: nt 141 us,
+// default policy 150, write-through sc0 sc1 166 — against 148 for the 8-byte stores on the same planes; the policy is a build-time
+// switch for A/B runs).  The wait states behind it: a VALU write of the store's LAST data register in the next cycle
+// corrupts that dword on gfx950 (mifwt_dwt2_inv_pyr.hip, ipyr_store4)
+#ifndef MIFWT_PYR_ST16_POLICY
+#define MIFWT_PYR_ST16_POLICY "nt"
+#endif
+__device__ __forceinline__ void pyr_store4(const f4 data, rsrc_t rsrc, uint32_t voff, uint32_t soff) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen " MIFWT_PYR_ST16_POLICY "\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+// Lane-pair exchange in front of a 16-byte store (v_permlane32_swap, new on gfx950: lanes 32-63 of the first operand change places with
+// lanes 0-31 of the second).  Lane l < 32 and lane l + 32 hold NEIGHBOURING column pairs (l: columns c, c + 1; l + 32: c + 2, c + 3) of
+// the same two rows: a = row i, b = row i + 1.  Afterwards lane l holds columns c .. c + 3 of row i, lane l + 32 columns c .. c + 3 of
+// row i + 1: one buffer_store_dwordx4 per lane writes 512 contiguous bytes of each of the two rows.
+// (inline assembly: hipcc 7.2 folds the two results of __builtin_amdgcn_permlane32_swap into one register inside this kernel — the
+// store data came out as (x, y, x, y).  Two wait states in front: a VALU write of either operand must be two instructions old.)
+__device__ __forceinline__ void pyr_permlane32_swap(float& x, float& y) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 0" : "+v"(x), "+v"(y));
+}
+__device__ __forceinline__ f4 pyr_swap_rows(float a0, float a1, float b0, float b1) {
+  pyr_permlane32_swap(a0, b0);
+  pyr_permlane32_swap(a1, b1);
+  return (f4){a0, a1, b0, b1};
+}
+// Per-lane constants of the 16-byte store path of one output plane family (one row pitch): the lane pair (l, l + 32) owns columns
+// cq .. cq + 3 of the two rows a half step completes.  Full groups leave as one 16-byte store per lane, a ragged last group (1 .. 3
+// columns inside the plane) as single dwords; rows a segment does not own go to an offset beyond every resource.
+struct PyrSt16 {
+  uint32_t v16;  // byte offset of the lane's four columns if all of them lie inside the plane, else beyond every resource
+  int cq0, wend;  // (uniform) first column of the wave's lane grid, end of the plane's columns
+  bool rag;      // (uniform) some lane of the wave holds a ragged group
+  // (everything else is recomputed where it is needed: the level-1 / level-2 waves of the 8-tap kernel have no registers to spare)
+  __device__ __forceinline__ void set(int lane, int cq0_, int wend_) {
+    cq0 = cq0_;
+    wend = wend_;
+    const int cq = cq0 + 4 * (lane & 31), nin = wend - cq;
+    v16 = nin >= 4 ? 4u * (uint32_t)cq : kPyrOob;
+    rag = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(nin > 0 && nin < 4) != 0);
+  }
+  // rows i0 (lanes 0-31) and i0 + 1 (lanes 32-63) of a plane whose segment owns rows [oA, oB): the lane's row is `dx` bytes
+  // behind the scalar row offset `so` (`mine`: the segment owns the lane's row)
+  __device__ __forceinline__ void rows(int lane, int i0, int oA, int oB, uint32_t pitch_bytes, uint32_t& v4, uint32_t& dx, bool& mine, uint32_t& so) const {
+    const bool own0 = i0 >= oA && i0 < oB, own1 = i0 + 1 >= oA && i0 + 1 < oB, upper = lane >= 32;
+    so = (own0 || own1) ? (uint32_t)(own0 ? i0 : i0 + 1) * pitch_bytes : 0u;
+    mine = upper ? own1 : own0;
+    dx = (upper && own0) ? pitch_bytes : 0u;
+    v4 = mine ? v16 + dx : kPyrOob;  // (kPyrOob + a pitch is still beyond every resource)
+  }
+  // one band: a = the lane's two columns of row i0, b = of row i0 + 1
+  __device__ __forceinline__ void band(int lane, uint32_t v4, uint32_t dx, bool mine, float a0, float a1, float b0, float b1, rsrc_t r, uint32_t soff) const {
+    const f4 t = pyr_swap_rows(a0, a1, b0, b1);
+    pyr_store4(t, r, v4, soff);
+    if (rag) {
+      const int cq = cq0 + 4 * (lane & 31), nin = wend - cq;
+      const uint32_t vrl = (mine && nin > 0 && nin < 4) ? 4u * (uint32_t)cq + dx : kPyrOob;
+      pyr_store1(t.x, r, vrl, soff);
+      pyr_store1(t.y, r, nin >= 2 ? vrl : kPyrOob, soff + 4u);
+      pyr_store1(t.z, r, nin >= 3 ? vrl : kPyrOob, soff + 8u);
+    }
+  }
+};
+
 // workgroup barrier; with profiling on, the cycles spent in it are added to `waited`
 template <bool PROF>
 __device__ __forceinline__ void pyr_barrier(unsigned long long& waited) {

@@ -462,7 +462,11 @@ def test_mfma_dwt2_long_filters_half(wavelet):
                     want = O.wavedec2(xq.double().numpy(), wavelet, mode=mode, level=level)
                 except RuntimeError:
                     continue
+                n_walk, n_tile = _engine.launch_count(_engine.VARIANT_FWD_MFMA_WALK), _engine.launch_count(_engine.VARIANT_FWD_MFMA_TILE)
                 got = ptwt_amd.wavedec2(xq.to(dev()), wavelet, mode=mode, level=level)
+                # kernel id 11 is answered by two kernels: the one that walks down column panels must have served every level
+                assert _engine.launch_count(_engine.VARIANT_FWD_MFMA_WALK) - n_walk == level, (wavelet, mode, shape)
+                assert _engine.launch_count(_engine.VARIANT_FWD_MFMA_TILE) == n_tile
                 vec = got
                 if flen in (18, 20, 24, 32):  # lengths the vector tile kernel is instantiated for
                     _engine.set_option(7, 2)
@@ -755,6 +759,73 @@ def test_full_size_config5_slice_properties():
         want = O.fswavedec2(small.double().cpu().numpy(), "sym16", level=5)
         for (n, a), (_, b) in zip(G.flatten_coeffs(check), G.flatten_coeffs(want)):
             assert G.relerr(to_np(a.double()), b) < 2e-3, n  # five levels of f16 storage
+    finally:
+        ptwt_amd.set_half_storage(False)
+
+
+def test_full_size_config5_slice_reconstruction():
+    """BASELINE configs[4] the other way round, at the benchmark's geometry: `fswaverec2` of a 20-image slice (20 x 8192^2 fp16: image byte
+    offsets beyond 2^31; sym16, level 5) with AUTO routing.  (1) the matrix-core synthesis kernel (id 23, csrc/mifwt_dwt2_inv_mfma.hip;
+    replaces src/ptwt/separable_conv_transform.py:281-313 / conv_transform_2.py:222-249) serves every level; (2) the finest level of a
+    band of coefficient rows against the numpy oracle (hundreds of stacked tiles per panel, units dealt per XCD); (3) round trip
+    <= 2e-3 on all images (five levels of f16 storage); (4) images of the batch call bit-identical to one-image calls (first, middle,
+    last: the last one lies beyond 2^31 bytes)."""
+    ptwt_amd.set_half_storage(True)
+    try:
+        torch.manual_seed(6)
+        nimg = 20
+        x = torch.randn(nimg, 8192, 8192, device=dev()).half()
+        c = ptwt_amd.fswavedec2(x, "sym16", level=5)
+        _engine.level_events = []
+        try:
+            rec = ptwt_amd.fswaverec2(c, "sym16")
+            torch.cuda.synchronize()
+            kids = [e[1] for e in _engine.level_events]
+        finally:
+            _engine.level_events = None
+        assert kids == [23] * 5, kids
+        assert rec.dtype == torch.float16 and tuple(rec.shape) == tuple(x.shape)
+        for b in range(nimg):
+            err = float((rec[b].float() - x[b].float()).norm() / x[b].float().norm())
+            assert err < 2e-3, (b, err)
+        # (4) batch slices against one-image calls
+        for b in (0, nimg // 2, nimg - 1):
+            cb = tuple([c[0][b : b + 1]] + [{k: v[b : b + 1] for k, v in d.items()} for d in c[1:]])
+            one = ptwt_amd.fswaverec2(cb, "sym16")
+            assert torch.equal(one[0], rec[b]), b
+        # (2) the finest level alone: approximation = the f16 level-1 approximation the kernels stored, details = c[-1]
+        lvl1 = ptwt_amd.fswavedec2(x, "sym16", level=1)
+        _engine.level_events = []
+        try:
+            fine = ptwt_amd.fswaverec2(lvl1, "sym16")
+            torch.cuda.synchronize()
+            kids = [e[1] for e in _engine.level_events]
+        finally:
+            _engine.level_events = None
+        assert kids == [23], kids
+        for b, k0 in ((0, 1000), (nimg - 1, 3050)):  # coefficient rows [k0, k0 + 600) of two images, all 4111 columns
+            nk, lo = 600, 64
+            band = tuple([lvl1[0][b, k0 : k0 + nk].double().cpu().numpy()] + [{k: v[b, k0 : k0 + nk].double().cpu().numpy() for k, v in lvl1[1].items()}])
+            want = O.fswaverec2(band, "sym16")  # rows m of it = rows m + 2 k0 of the image's reconstruction, away from the band's ends
+            got = fine[b, 2 * k0 + lo : 2 * k0 + want.shape[0] - lo].double().cpu().numpy()
+            assert G.relerr(got, want[lo:-lo, :8192]) < 5e-4, (b, k0)
+    finally:
+        ptwt_amd.set_half_storage(False)
+
+
+def test_mfma_idwt2_batch_and_single_images_agree():
+    """The routing of the f16 long-filter reconstruction looks at ONE image's geometry (a batch took the matrix-core kernel,
+    which rounds the intermediate image to f16, where its images one by one took the vector kernel): bit-identical either way."""
+    ptwt_amd.set_half_storage(True)
+    try:
+        rng = np.random.default_rng(77)
+        for shape in ((4, 100, 100), (4, 40, 52), (40, 96, 200), (3, 300, 402)):
+            x = torch.from_numpy(rng.standard_normal(shape)).half().to(dev())
+            c = ptwt_amd.wavedec2(x, "sym16", mode="symmetric", level=1)
+            rec = ptwt_amd.waverec2(c, "sym16")
+            for b in range(shape[0]):
+                one = ptwt_amd.waverec2((c[0][b : b + 1], tuple(t[b : b + 1] for t in c[1])), "sym16")
+                assert torch.equal(one[0], rec[b]), (shape, b)
     finally:
         ptwt_amd.set_half_storage(False)
 

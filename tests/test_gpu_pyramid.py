@@ -23,12 +23,17 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(autouse=True)
-def _pyramid_wherever_it_can_run():
+@pytest.fixture(autouse=True, params=[16, 1], ids=["rows16", "dense"])
+def _pyramid_wherever_it_can_run(request):
     """Auto mode keeps the kernel to planes of 448 .. ~2560 columns (where it is the fastest route); the parity cases here are
-    mostly smaller or wider, so they switch to "wherever the kernel can run" (MIFWT_OPT_PYRAMID_MODE 1)."""
+    mostly smaller or wider, so they switch to "wherever the kernel can run" (MIFWT_OPT_PYRAMID_MODE 1).  Every case runs twice: with
+    the streaming kernel's planes on 16-byte aligned rows (16-byte stores after a lane-pair exchange) and with dense planes (the
+    default: 8-byte stores wherever a width is not a multiple of four)."""
+    old = _engine.PYRAMID_ROW_ALIGN
+    _engine.PYRAMID_ROW_ALIGN = request.param
     _engine.set_option(_engine.OPT_PYRAMID_MODE, 1)
     yield
+    _engine.PYRAMID_ROW_ALIGN = old
     _engine.set_option(_engine.OPT_PYRAMID_MODE, 0)
 
 
@@ -90,6 +95,25 @@ def test_pyramid_row_segments(wavelet):
     for mode in ("reflect", "symmetric", "zero"):
         check(x, wavelet, mode, 3, want_kids=[_engine.KID_PYRAMID], seg_rows=8)
         check(x, wavelet, mode, 2, want_kids=[_engine.KID_PYRAMID], seg_rows=16)
+
+
+def test_pyramid_store_paths_ragged_widths():
+    """Both store paths of the streaming kernel against the oracle on level-1 / level-2 widths of every residue modulo four (a ragged
+    last lane pair stores 1 .. 3 single columns), with short row segments (rows a lane pair stores belong to different segments at
+    odd ownership boundaries); `mifwt_launch_count` pins which variant ran."""
+    g = torch.Generator().manual_seed(21)
+    st16 = _engine.PYRAMID_ROW_ALIGN >= 16
+    for width in (512, 514, 516, 518, 1024, 1030):
+        x = torch.randn(2, 140, width, generator=g, dtype=torch.float32)
+        for wavelet, level in (("haar", 3), ("db2", 2), ("db3", 3), ("db4", 3), ("db4", 1)):
+            n16, n8 = _engine.launch_count(_engine.VARIANT_FWD_PYR_ST16), _engine.launch_count(_engine.VARIANT_FWD_PYR_ST8)
+            check(x, wavelet, "symmetric", level, want_kids=[_engine.KID_PYRAMID])
+            check(x, wavelet, "zero", level, want_kids=[_engine.KID_PYRAMID], seg_rows=8)
+            d16, d8 = _engine.launch_count(_engine.VARIANT_FWD_PYR_ST16) - n16, _engine.launch_count(_engine.VARIANT_FWD_PYR_ST8) - n8
+            if st16:
+                assert (d16, d8) == (2, 0), (width, wavelet, level, d16, d8)
+            else:
+                assert d16 + d8 == 2
 
 
 def test_pyramid_many_strips_two_groups():

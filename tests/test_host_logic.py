@@ -201,7 +201,7 @@ def test_cabi_library_exports_every_declared_symbol():
             "mifwt_abi_version", "mifwt_set_option"} <= set(syms)
     for s in syms:
         assert getattr(lib, s) is not None
-    assert lib.mifwt_abi_version() == 1
+    assert lib.mifwt_abi_version() == _engine.ABI_VERSION == 2 and lib.mifwt_launch_count(99) == 0
     assert lib.mifwt_strerror(0) == b"ok" and b"argument" in lib.mifwt_strerror(-1)
 
 
