@@ -276,10 +276,12 @@ class HipLevelEngine:
         # an odd coefficient width every other row starts 2-byte aligned and the stores are split: level 1 of the config-5 slice
         # 4.3 ms dense, 3.7 ms with 16-byte, 2.76 ms with 128-byte aligned rows (tools/mfma_walk_parts.py) — those planes get 128.
         esz = x.element_size()
-        align = max(ROW_ALIGN, min_align)
+        align = max(ROW_ALIGN, min_align, 1)
         if align <= 1 and ndim == 2 and x.dtype == torch.float16 and 18 <= flen <= 32:
             align = 128
         pitch = -(-coef[-1] * esz // align) * align // esz if align > esz and ndim >= 2 else coef[-1]
+        if min_align < 0 and ndim >= 2:  # (experiments, tools/pitch_sweep.py: -k = k extra elements per row, whatever the alignment)
+            pitch = coef[-1] - min_align
         p = _Plan()
         p.alloc_shape = (batch, nb, *coef[:-1], pitch)
         p.view_last = coef[-1] if pitch != coef[-1] else None
@@ -425,7 +427,7 @@ class HipLevelEngine:
                 return plans, n_ok, route
 
             plans, n_ok, route = chain(1)
-            if n_ok and route == 1 and PYRAMID_ROW_ALIGN > 1:
+            if n_ok and route == 1 and (PYRAMID_ROW_ALIGN > 1 or PYRAMID_ROW_ALIGN < 0):
                 # the streaming kernel stores 16 bytes per lane when the rows of every plane it writes start on 16-byte boundaries
                 # (lane pairs exchange rows in front of the store, csrc/mifwt_pyr.h): its planes get a row pitch of a multiple of four
                 # floats (config 2: 515 -> 516); the returned bands are views with that pitch.  The small-plane kernel (route 2) keeps
