@@ -75,6 +75,9 @@ WORKLOADS = {
     # the round trip's second half on config 2's coefficients: one streaming launch (kernel id 22)
     "waverec2_db4_L3_64x1024x1024_f32": ("waverec2", (64, 1024, 1024), "db4", 3, "reflect", torch.float32),
     "waverec2_db8_L4_64x4096x4096_f32": ("waverec2", (64, 4096, 4096), "db8", 4, "reflect", torch.float32),
+    # config 2 with gradients: forward (one launch, kernel 16, as a differentiable op) + backward w.r.t. the data (per-level adjoints)
+    "wavedec2_bwd_db4_L3_64x1024x1024_f32": ("wavedec2_bwd", (64, 1024, 1024), "db4", 3, "reflect", torch.float32),
+    "wavedec2_bwd_db4_L3_64x1024x1024_f32_zero": ("wavedec2_bwd", (64, 1024, 1024), "db4", 3, "zero", torch.float32),
     # the other reconstructions (kernel ids 10, 18 / 15, 21)
     "waverec3_db2_L3_8x256x256x256_f32": ("waverec3", (8, 256, 256, 256), "db2", 3, "zero", torch.float32),
     "waverec_db5_L10_32x1000000_f32": ("waverec", (32, 1000000), "db5", 10, "periodic", torch.float32),
@@ -143,6 +146,9 @@ def cpu_baseline(fn, shape, wavelet, level, mode, dtype):
 
     ports = {"wavedec2": P.wavedec2, "wavedec": P.wavedec, "wavedec3": P.wavedec3, "fswavedec2": P.fswavedec2, "waverec2": P.waverec2,
              "waverec": P.waverec, "waverec3": P.waverec3, "fswaverec2": P.fswaverec2}
+    bwd = fn.endswith("_bwd")
+    if bwd:
+        fn = fn[:-4]
     if fn not in ports:
         return None
     port = ports[fn]
@@ -163,6 +169,11 @@ def cpu_baseline(fn, shape, wavelet, level, mode, dtype):
     elif fn == "waverec3":
         arg = P.wavedec3(x, wavelet, mode=mode, level=level)
         run = lambda sl: port(tuple([arg[0][sl]] + [{k: v[sl] for k, v in d.items()} for d in arg[1:]]), wavelet)  # noqa: E731
+    elif bwd:
+        def run(sl):  # forward + backward w.r.t. the data through ATen's autograd, as the reference does it
+            xs = x[sl].clone().requires_grad_(True)
+            outs = [t for _, t in _flatten(port(xs, wavelet, mode=mode, level=level))]
+            torch.autograd.grad(outs, xs, [torch.ones_like(t) for t in outs])
     else:
         run = lambda sl: port(x[sl], wavelet, mode=mode, level=level)  # noqa: E731
     # oneDNN's conv does not scale to every core of a big host: probe a few thread counts on a small slice
@@ -229,7 +240,7 @@ def profiled_traffic(workload, kernel_label=""):
 # What else the default run times after the headline line's own measurements (whole calls, a few seconds in total): the other
 # BASELINE configs' per-GPU shapes, both directions, so that they are driver-timed figures and not builder-run ones.
 SECONDARY = ["waverec2_db4_L3_64x1024x1024_f32", "wavedec3_db2_L3_8x256x256x256_f32", "waverec3_db2_L3_8x256x256x256_f32",
-             "wavedec2_db8_L4_64x4096x4096_f32", "waverec2_db8_L4_64x4096x4096_f32"]
+             "wavedec2_db8_L4_64x4096x4096_f32", "waverec2_db8_L4_64x4096x4096_f32", "wavedec2_bwd_db4_L3_64x1024x1024_f32"]
 
 
 def secondary_lines(dev, steps=20, warmup=5, buffers=3):
@@ -242,9 +253,15 @@ def secondary_lines(dev, steps=20, warmup=5, buffers=3):
         fn_name, shape, wavelet, level, mode, dtype = WORKLOADS[name]
         t_all = time.perf_counter()
         try:
-            fn = getattr(ptwt_amd, fn_name)
+            bwd = fn_name.endswith("_bwd")
+            fn = getattr(ptwt_amd, fn_name[:-4] if bwd else fn_name)
             xs = [torch.randn(*shape, dtype=dtype, device=dev) for _ in range(buffers)]
-            if "rec" in fn_name:
+            if bwd:
+                args_ = [x.requires_grad_(True) for x in xs]
+                with torch.no_grad():
+                    gouts = [torch.randn_like(t) for _, t in _flatten(fn(xs[0], wavelet, mode=mode, level=level))]
+                call = lambda a: torch.autograd.grad([t for _, t in _flatten(fn(a, wavelet, mode=mode, level=level))], a, gouts)  # noqa: E731
+            elif "rec" in fn_name:
                 ana = getattr(ptwt_amd, fn_name.replace("rec", "dec"))
                 args_ = [ana(x, wavelet, mode=mode, level=level) for x in xs]
                 del xs
@@ -261,7 +278,7 @@ def secondary_lines(dev, steps=20, warmup=5, buffers=3):
             sync()
             ms = (time.perf_counter() - t0) / steps * 1e3
             flen = len(ptwt_amd._wavelets.as_wavelet(wavelet))
-            comp_b = algorithmic_bytes(shape[0], shape[1:], flen, level, torch.empty(0, dtype=dtype).element_size())[0]
+            comp_b = algorithmic_bytes(shape[0], shape[1:], flen, level, torch.empty(0, dtype=dtype).element_size())[0] * (2 if bwd else 1)
             out.append({"workload": name, "ms_per_step": round(ms, 4), "steps": steps, "compulsory_bytes": comp_b,
                         "Msamples_per_s": round(prod(shape) / ms / 1e3, 1),
                         "frac": round(comp_b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "wall_s": round(time.perf_counter() - t_all, 2)})
@@ -328,7 +345,8 @@ def main():
     from ptwt_amd import _engine
 
     fn_name, shape, wavelet, level, mode, dtype = WORKLOADS[args.workload]
-    fn = getattr(ptwt_amd, fn_name)
+    is_bwd = fn_name.endswith("_bwd")
+    fn = getattr(ptwt_amd, fn_name[:-4] if is_bwd else fn_name)
     if dtype == torch.float16:
         ptwt_amd.set_half_storage(True)
     flen = len(ptwt_amd._wavelets.as_wavelet(wavelet))
@@ -348,6 +366,16 @@ def main():
 
         def step(i):
             return fn(bufs[i % len(bufs)], wavelet)
+    elif is_bwd:
+        # forward + backward w.r.t. the data: the coefficients' gradients (one fixed set, resident) in, the input's gradient out
+        bufs = [make_input().requires_grad_(True) for _ in range(max(1, args.buffers))]
+        with torch.no_grad():
+            gouts = [torch.randn_like(t) for _, t in _flatten(fn(bufs[0], wavelet, mode=mode, level=level))]
+
+        def step(i):
+            xb = bufs[i % len(bufs)]
+            outs = [t for _, t in _flatten(fn(xb, wavelet, mode=mode, level=level))]
+            return torch.autograd.grad(outs, xb, gouts)
     else:
         bufs = [make_input() for _ in range(max(1, args.buffers))]
 
@@ -434,8 +462,10 @@ def main():
         fused_levels = level
         launch = lambda b: fn(b, wavelet)  # noqa: E731
         call_is_launch = True
-    elif fn_name in ("wavedec2", "fswavedec2", "wavedec3", "wavedec"):
+    elif fn_name in ("wavedec2", "fswavedec2", "wavedec3", "wavedec", "wavedec2_bwd"):
         taps = ptwt_amd._wavelets.host_taps(wavelet)
+        if is_bwd:
+            bufs = [b.detach() for b in bufs]  # (the launch leg below calls the engine directly)
         mode_id = _engine.MODE_IDS[mode]
         if first_kid in (_engine.KID_PYRAMID, _engine.KID_SMALL):
             fused_levels = len(_engine.ENGINE.analysis_pyramid(bufs[0], taps[0], taps[1], mode_id, level))
@@ -499,13 +529,15 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         esize = torch.empty(0, dtype=dtype).element_size()
         comp_b, perlvl_b, lvl1_b, pair_b = algorithmic_bytes(shape[0], shape[1:], flen, level, esize)
+        if is_bwd:  # the backward reads every coefficient's gradient once and writes the input's gradient once: the same bytes again
+            comp_b, perlvl_b = 2 * comp_b, 2 * perlvl_b
         # dominant kernel = the level-1 analysis launch (largest signal extent); durations from HIP events
         # recorded on the launch stream inside the timed region
         lvl1 = [s.elapsed_time(e) for (tag, kid, ext, s, e) in events if tag in ("fwd", "inv") and tuple(ext) == tuple(shape[1:])]
         per_level_ms = {}
         for tag, kid, ext, s, e in events:
-            per_level_ms.setdefault("x".join(map(str, ext)), []).append(s.elapsed_time(e))
-        kid1 = next((kid for (tag, kid, ext, s, e) in events if tuple(ext) == tuple(shape[1:])), -1)
+            per_level_ms.setdefault(("adjoint " if tag.endswith("_adj") else "") + "x".join(map(str, ext)), []).append(s.elapsed_time(e))
+        kid1 = next((kid for (tag, kid, ext, s, e) in events if tag in ("fwd", "inv") and tuple(ext) == tuple(shape[1:])), -1)
         if kid1 == _engine.KID_PAIR:
             lvl1_b = pair_b
         if kid1 == _engine.KID_INV_PYRAMID:
@@ -554,7 +586,8 @@ def main():
             "gc": "cyclic collector disabled during the warm-up and the K timed steps (as timeit does)",
             "config": {
                 "workload": args.workload,
-                "api": f"ptwt_amd.{fn_name}(x, '{wavelet}', mode='{mode}', level={level})",
+                "api": (f"torch.autograd.grad(ptwt_amd.{fn_name[:-4]}(x, '{wavelet}', mode='{mode}', level={level}), x, grad_outputs)" if is_bwd
+                        else f"ptwt_amd.{fn_name}(x, '{wavelet}', mode='{mode}', level={level})"),
                 "per_gpu_shape": list(shape),
                 "parallelism": f"batch-sharded x{world}, no data-path collective",
             },

@@ -402,6 +402,45 @@ class HipLevelEngine:
         if x.dim() != 3 or x.dtype != torch.float32:
             return None
         flen = len(dec_lo)
+        key, plan = self._pyramid_plan(x, flen, mode_id, nlevels)
+        plans, n_ok, refs, kid = plan
+        if n_ok == 0:
+            return None
+        bufs = []
+        for pl in plans:
+            b = torch.empty(pl.alloc_shape, dtype=x.dtype, device=x.device)
+            bufs.append(b if pl.view_last is None else b[..., : pl.view_last])
+        # the band-pointer arrays are per thread: cached plans are shared between threads, and ctypes drops the GIL in the call
+        skey = (key, n_ok)  # (a routing option may change how many levels the same geometry fuses)
+        slot = _tls.__dict__.setdefault("pyr", {}).get(skey)
+        if slot is None:
+            rows = [_arr(ctypes.c_void_p, 3)() for _ in plans]
+            det = _arr(ctypes.POINTER(ctypes.c_void_p), n_ok)(*[ctypes.cast(r, ctypes.POINTER(ctypes.c_void_p)) for r in rows])
+            slot = _tls.pyr[skey] = (rows, det)
+            if len(_tls.pyr) > 256:
+                _tls.pyr.clear()
+                _tls.pyr[skey] = slot
+        rows, det = slot
+        for r, b, pl in zip(rows, bufs, plans):
+            pb = pl.plane_bytes
+            base = b.data_ptr() + (pl.nb - 3) * pb  # band ad: plane 1 of a full buffer, plane 0 of a details-only one
+            r[0], r[1], r[2] = base, base + pb, base + 2 * pb
+        lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
+        lib = _lib
+        xp, ap = x.data_ptr(), bufs[-1].data_ptr()
+        call_id = next(_call_ids)  # (a flag in the workspace is "set" when it holds this call's id: nothing needs clearing)
+        self._run(plans[0], 0, x, lambda ws, wsb, stream: lib.mifwt_dwt2_fwd_pyramid_ws(n_ok, refs, xp, det, ap, lo, hi, ws, wsb, call_id, stream), kid=kid)
+        return bufs
+
+    def pyramid_levels(self, x: torch.Tensor, flen: int, mode_id: int, nlevels: int) -> int:
+        """How many of the next ``nlevels`` 2-D analysis levels :meth:`analysis_pyramid` would take in one launch for this geometry
+        (0: none); nothing is launched."""
+        if x.dim() != 3 or x.dtype != torch.float32 or not x.is_cuda:
+            return 0
+        return self._pyramid_plan(x, flen, mode_id, nlevels)[1][1]
+
+    def _pyramid_plan(self, x: torch.Tensor, flen: int, mode_id: int, nlevels: int):
+        """(cache key, (level plans, levels served, descriptor array, kernel id)) of :meth:`analysis_pyramid` for a geometry."""
         key = ("pyr", x.shape, x.stride(), mode_id, flen, min(nlevels, MAX_PYRAMID_LEVELS), ROW_ALIGN, PYRAMID_ROW_ALIGN)
         plan = _plans.get(key)
         if plan is None:
@@ -447,34 +486,7 @@ class HipLevelEngine:
                 # of each streaming a prologue of input rows): mifwt_dwt2_fwd_pyramid_ws
                 keep[0].ws_bytes = int(lib.mifwt_dwt2_fwd_pyramid_workspace(n_ok, refs))
             plan = _plans[key] = (keep, n_ok, refs, KID_SMALL if route == 2 else KID_PYRAMID)
-        plans, n_ok, refs, kid = plan
-        if n_ok == 0:
-            return None
-        bufs = []
-        for pl in plans:
-            b = torch.empty(pl.alloc_shape, dtype=x.dtype, device=x.device)
-            bufs.append(b if pl.view_last is None else b[..., : pl.view_last])
-        # the band-pointer arrays are per thread: cached plans are shared between threads, and ctypes drops the GIL in the call
-        skey = (key, n_ok)  # (a routing option may change how many levels the same geometry fuses)
-        slot = _tls.__dict__.setdefault("pyr", {}).get(skey)
-        if slot is None:
-            rows = [_arr(ctypes.c_void_p, 3)() for _ in plans]
-            det = _arr(ctypes.POINTER(ctypes.c_void_p), n_ok)(*[ctypes.cast(r, ctypes.POINTER(ctypes.c_void_p)) for r in rows])
-            slot = _tls.pyr[skey] = (rows, det)
-            if len(_tls.pyr) > 256:
-                _tls.pyr.clear()
-                _tls.pyr[skey] = slot
-        rows, det = slot
-        for r, b, pl in zip(rows, bufs, plans):
-            pb = pl.plane_bytes
-            base = b.data_ptr() + (pl.nb - 3) * pb  # band ad: plane 1 of a full buffer, plane 0 of a details-only one
-            r[0], r[1], r[2] = base, base + pb, base + 2 * pb
-        lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
-        lib = _lib
-        xp, ap = x.data_ptr(), bufs[-1].data_ptr()
-        call_id = next(_call_ids)  # (a flag in the workspace is "set" when it holds this call's id: nothing needs clearing)
-        self._run(plans[0], 0, x, lambda ws, wsb, stream: lib.mifwt_dwt2_fwd_pyramid_ws(n_ok, refs, xp, det, ap, lo, hi, ws, wsb, call_id, stream), kid=kid)
-        return bufs
+        return key, plan
 
     def analysis_tail(self, x: torch.Tensor, dec_lo: Sequence[float], dec_hi: Sequence[float], mode_id: int, nlevels: int):
         """The next levels of a 1-D decomposition in ONE launch — all ``nlevels`` remaining ones once a row fits into a workgroup (C
@@ -836,6 +848,51 @@ class HipLevelEngine:
         lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
         gp = g_x.data_ptr()
         self._run(p, 2, g_buf, lambda ws, wsb, stream: lib.mifwt_dwt_fwd_adjoint(p.ref, base, ptrs, gp, lo, hi, ws, wsb, stream))
+        return g_x
+
+    def analysis_adjoint_bands(self, g_approx: torch.Tensor, g_details: Sequence[torch.Tensor], sig_shape: Sequence[int], dec_lo: Sequence[float],
+                               dec_hi: Sequence[float], mode_id: int) -> torch.Tensor:
+        """:meth:`analysis_adjoint` with the gradient of every band in a tensor of its own, ``g_approx`` and the 2^n - 1 ``g_details``
+        [B, M_0..] each (what the backward of a multi-level launch is handed: the approximation's gradient is the result of the coarser
+        level's adjoint, the details' gradients come from the caller one by one) — no concatenation; the C ABI takes a pointer per band."""
+        _require_gpu(g_approx)
+        lib = load_library()
+        if g_approx.stride(-1) != 1:
+            g_approx = g_approx.contiguous()
+        ref_stride = g_details[0].stride()
+        if ref_stride[-1] != 1 or any(t.stride() != ref_stride for t in g_details):
+            g_details = [t.contiguous() for t in g_details]
+        ndim = g_approx.dim() - 1
+        flen = len(dec_lo)
+        batch = g_approx.shape[0]
+        g_x = torch.empty((batch, *sig_shape), dtype=g_approx.dtype, device=g_approx.device)
+        if g_x.numel() == 0:
+            return g_x
+        gd0 = g_details[0]
+        key = ("fwd_adjb", g_approx.shape, g_approx.stride(), gd0.stride(), tuple(sig_shape), g_approx.dtype, mode_id, flen)
+        p = _plans.get(key)
+        if p is None:
+            p = _Plan()
+            d = LevelDesc()
+            d.ndim, d.dtype, d.mode, d.filt_len, d.batch = ndim, _DTYPE_IDS[g_approx.dtype], mode_id, flen, batch
+            for a in range(ndim):
+                d.sig_extent[a] = int(sig_shape[a])
+                d.coef_extent[a] = int(g_approx.shape[1 + a])
+                d.sig_stride[1 + a] = g_x.stride(1 + a)
+                d.approx_stride[1 + a] = g_approx.stride(1 + a)
+                d.detail_stride[1 + a] = gd0.stride(1 + a)
+            d.sig_stride[0] = g_x.stride(0)
+            d.approx_stride[0] = g_approx.stride(0)
+            d.detail_stride[0] = gd0.stride(0)
+            p.desc, p.ref = d, ctypes.byref(d)
+            p.nb = 1 << ndim
+            p.ws_bytes = lib.mifwt_workspace_bytes(p.ref, 2)
+            p.kid = lib.mifwt_kernel_id(p.ref, 2)
+            _plans[key] = p
+        ptrs = _arr(ctypes.c_void_p, p.nb - 1)(*[t.data_ptr() for t in g_details])
+        lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
+        ap, gp = g_approx.data_ptr(), g_x.data_ptr()
+        self._run(p, 2, g_approx, lambda ws, wsb, stream: lib.mifwt_dwt_fwd_adjoint(p.ref, ap, ptrs, gp, lo, hi, ws, wsb, stream))
         return g_x
 
     def synthesis_adjoint(self, g_y: torch.Tensor, coef_shape: Sequence[int], rec_lo: Sequence[float],

@@ -157,6 +157,51 @@ class _AnalysisAdjointLevel(torch.autograd.Function):
         return _AnalysisLevel.apply(gg_x, dec_lo, dec_hi, mode_id, None, None), None, None, None, None
 
 
+class _AnalysisAdjointBands(torch.autograd.Function):
+    """:class:`_AnalysisAdjointLevel` with the gradient of every band in a tensor of its own (no concatenation: the C ABI takes a
+    pointer per band); linear as well, its backward is the analysis level."""
+
+    @staticmethod
+    def forward(ctx, sig_shape, dec_lo, dec_hi, mode_id, g_approx, *g_details):
+        ctx.meta = (dec_lo, dec_hi, mode_id, len(g_details))
+        return _engine.ENGINE.analysis_adjoint_bands(g_approx, g_details, sig_shape, dec_lo, dec_hi, mode_id)
+
+    @staticmethod
+    def backward(ctx, gg_x):
+        dec_lo, dec_hi, mode_id, ndet = ctx.meta
+        buf = _AnalysisLevel.apply(gg_x, dec_lo, dec_hi, mode_id, None, None)
+        return (None, None, None, None) + tuple(buf[:, s] for s in range(ndet + 1))
+
+
+class _AnalysisPyramid(torch.autograd.Function):
+    """Several 2-D analysis levels in ONE launch as a differentiable op w.r.t. the data (C ABI ``mifwt_dwt2_fwd_pyramid``: the streaming
+    three-level kernel / the small-plane kernel; src/ptwt/conv_transform_2.py:142-149 per trip): the forward of a call that asks for
+    gradients runs on the same fused kernels as one that does not, and saves nothing.  The outputs are the BANDS (views of the level
+    buffers): the approximation of the last fused level, then (ad, da, dd) per level, finest first — autograd hands the backward one
+    gradient per band, no buffer is assembled.  The backward composes the per-level adjoints coarse to fine (each a differentiable op in
+    turn: gradients of any order)."""
+
+    @staticmethod
+    def forward(ctx, x, dec_lo, dec_hi, mode_id, want):
+        bufs = _engine.ENGINE.analysis_pyramid(x, dec_lo, dec_hi, mode_id, want)
+        shapes, n = [], list(x.shape[1:])
+        out = [bufs[-1][:, 0]]
+        for b in bufs:
+            shapes.append(tuple(n))
+            n = list(b.shape[2:])
+            out.extend(b.unbind(1)[-3:])
+        ctx.meta = (shapes, dec_lo, dec_hi, mode_id)
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, g_approx, *g_bands):
+        shapes, dec_lo, dec_hi, mode_id = ctx.meta
+        g = g_approx
+        for lvl in range(len(shapes) - 1, -1, -1):
+            g = _AnalysisAdjointBands.apply(shapes[lvl], dec_lo, dec_hi, mode_id, g, *g_bands[3 * lvl : 3 * lvl + 3])
+        return g, None, None, None, None
+
+
 class _SynthesisLevel(torch.autograd.Function):
     """One synthesis level, differentiable w.r.t. the approximation, every detail band and (optionally) the rec taps
     (backward: ``mifwt_dwt_inv_adjoint`` + ``mifwt_tap_correlate``; reference: autograd through torch.stack +
@@ -344,7 +389,7 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
         mode_id = _mode_id(mode)
         _check_pad(cur.shape[1:], flen, "reflect" if mode is None else mode)
         differentiable = torch.is_grad_enabled() and (cur.requires_grad or tap_t is not None)
-        if ndim == 2 and not differentiable:
+        if ndim == 2 and (not differentiable or tap_t is None):
             # several levels per launch (three of a big plane, the whole pyramid of a small one), the approximations between them kept
             # on chip (mifwt_dwt2_fwd_pyramid); the pad
             # checks of the fused trips are the reference's own and run before anything is launched
@@ -353,12 +398,23 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
             for _l in range(want):
                 _check_pad(ns, flen, "reflect" if mode is None else mode)
                 ns = [(n + flen - 1) // 2 for n in ns]
-            pyr = _engine.ENGINE.analysis_pyramid(cur, dec_lo, dec_hi, mode_id, want)
-            if pyr is not None:
-                bufs.extend(pyr)
-                cur = pyr[-1][:, 0]
-                done += len(pyr)
-                continue
+            if differentiable:
+                # gradients w.r.t. the data only (a learnable filter bank takes the per-level ops, which also produce tap gradients):
+                # the same launch as a differentiable op
+                if _engine.ENGINE.pyramid_levels(cur, flen, mode_id, want) > 0:
+                    bands = _AnalysisPyramid.apply(cur, dec_lo, dec_hi, mode_id, want)
+                    cur = bands[0]
+                    nfused = (len(bands) - 1) // 3
+                    bufs.extend(bands[1 + 3 * l : 4 + 3 * l] for l in range(nfused))  # (a level as its three bands: pack_2d / pack_dict take either form)
+                    done += nfused
+                    continue
+            else:
+                pyr = _engine.ENGINE.analysis_pyramid(cur, dec_lo, dec_hi, mode_id, want)
+                if pyr is not None:
+                    bufs.extend(pyr)
+                    cur = pyr[-1][:, 0]
+                    done += len(pyr)
+                    continue
         if ndim == 2 and level - done >= 2 and not differentiable:
             # two levels per launch, the approximation between them kept on chip (mifwt_dwt2_fwd_pair); the second
             # level's reflect / periodic pad check is the reference's own (it would raise inside the next trip)
@@ -614,7 +670,8 @@ def pack_2d(layout: _Layout, approx, bufs):
     out = [layout.unfold(approx)]
     unfold = layout.unfold
     for b in bufs:  # (H, V, D) = ('da', 'ad', 'dd') = bands 2, 1, 3 (one unbind: a third of the host time of three b[:, k])
-        ad, da, dd = b.unbind(1)[-3:]  # ([B, 4, ..] with the approximation in plane 0, or [B, 3, ..] from a multi-level launch)
+        # ([B, 4, ..] with the approximation in plane 0, [B, 3, ..] from a multi-level launch, or the three bands of a differentiable one)
+        ad, da, dd = b if isinstance(b, tuple) else b.unbind(1)[-3:]
         out.append(WaveletDetailTuple2d(unfold(da), unfold(ad), unfold(dd)))
     return tuple(out)
 
@@ -628,7 +685,7 @@ def pack_dict(layout: _Layout, approx, bufs, keys: Sequence[str]):
         idx = _BAND_OF_KEYS[keys] = tuple(_band(k) for k in keys)  # (the string arithmetic of _band per key and call was 8 us of a wavedec3)
     nb = 1 << len(keys[0])
     for b in bufs:
-        planes = b.unbind(1)
+        planes = b if isinstance(b, tuple) else b.unbind(1)
         off = nb - len(planes)  # 1 for a details-only buffer of a multi-level launch (plane s - 1 = band s)
         out.append({k: unfold(planes[i - off]) for k, i in zip(keys, idx)})
     return tuple(out)

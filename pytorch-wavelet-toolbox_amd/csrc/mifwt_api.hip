@@ -302,7 +302,8 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction) {
   if (direction == 2) {
     const int rc = validate(desc, 0);
     if (rc != MIFWT_OK) return rc;
-    return desc->mode == MIFWT_MODE_ZERO ? pick_kernel(desc, 1) : kGeneric;
+    // (boundary extensions: the same launch over the whole signal + the border kernel, mifwt_adjoint_border.hip)
+    return desc->mode == MIFWT_MODE_ZERO || adjoint_border_supported(desc) ? pick_kernel(desc, 1) : kGeneric;
   }
   if (direction == 3) {
     const mifwt_level_desc z = as_zero_mode(desc);
@@ -321,7 +322,7 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction) {
 size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction) {
   if (direction == 2) {
     if (validate(desc, 0) != MIFWT_OK) return 0;
-    if (desc->mode == MIFWT_MODE_ZERO) return route_ws(desc, 1, pick_kernel(desc, 1));
+    if (desc->mode == MIFWT_MODE_ZERO || adjoint_border_supported(desc)) return route_ws(desc, 1, pick_kernel(desc, 1));
     return generic_ws(desc, 1);
   }
   if (direction == 3) {
@@ -402,7 +403,8 @@ int mifwt_dwt_fwd_adjoint(const mifwt_level_desc* desc, const void* g_approx, co
   if (rc != MIFWT_OK) return rc;
   if (!g_x || !g_approx || !g_details || !dec_lo || !dec_hi) return MIFWT_ERR_BADARG;
   const int L = desc->filt_len;
-  if (desc->mode == MIFWT_MODE_ZERO) {
+  const bool fold_back = desc->mode != MIFWT_MODE_ZERO && adjoint_border_supported(desc);
+  if (desc->mode == MIFWT_MODE_ZERO || fold_back) {
     // u[n] = sum_k a[k] h[2k + 1 - n] is the synthesis formula with g[j] = h[L - 1 - j]; its cropped interior
     // [0, 2M - L + 2 - N%2) is exactly [0, N)
     double lo[MIFWT_MAX_FILT], hi[MIFWT_MAX_FILT];
@@ -410,7 +412,15 @@ int mifwt_dwt_fwd_adjoint(const mifwt_level_desc* desc, const void* g_approx, co
       lo[j] = dec_lo[L - 1 - j];
       hi[j] = dec_hi[L - 1 - j];
     }
-    return run_inv(desc, g_approx, g_details, g_x, lo, hi, workspace, workspace_bytes, stream);
+    if (!fold_back) return run_inv(desc, g_approx, g_details, g_x, lo, hi, workspace, workspace_bytes, stream);
+    // a boundary extension: the interior of the adjoint is the zero-mode adjoint (a sample away from the borders has no pad position
+    // mapped onto it); the samples near a border are recomputed with the pad positions folded back (mifwt_adjoint_border.hip)
+    for (int s = 1; s < (1 << desc->ndim); ++s)
+      if (!g_details[s - 1]) return MIFWT_ERR_BADARG;
+    const mifwt_level_desc z = as_zero_mode(desc);
+    rc = run_inv(&z, g_approx, g_details, g_x, lo, hi, workspace, workspace_bytes, stream);
+    if (rc != MIFWT_OK || desc->batch == 0) return rc;
+    return adjoint_border(desc, g_approx, g_details, g_x, dec_lo, dec_hi, static_cast<hipStream_t>(stream));
   }
   for (int s = 1; s < (1 << desc->ndim); ++s)
     if (!g_details[s - 1]) return MIFWT_ERR_BADARG;

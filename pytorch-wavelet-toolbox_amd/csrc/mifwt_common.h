@@ -172,6 +172,12 @@ int dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, const 
 
 // the same two levels as rolling column strips (mifwt_dwt2_fwd_roll.hip): needs a level-1 plane of >= 32 rows
 bool dwt2_fwd_roll_supported(const mifwt_level_desc* d1, const mifwt_level_desc* d2);
+
+// boundary part of the adjoint of an analysis level with a boundary extension (mifwt_adjoint_border.hip): recomputes the samples near
+// the borders of g_x, pad positions folded back, after the zero-mode adjoint (a synthesis launch) has written all of g_x
+bool adjoint_border_supported(const mifwt_level_desc* d);
+int adjoint_border(const mifwt_level_desc* d, const void* g_approx, const void* const* g_details, void* g_x, const double* dec_lo,
+                   const double* dec_hi, hipStream_t stream);
 int dwt2_fwd_roll(const mifwt_level_desc* d1, const mifwt_level_desc* d2, const void* x, void* const* details1,
                   void* approx2, void* const* details2, const double* dec_lo, const double* dec_hi, hipStream_t stream);
 

@@ -84,6 +84,94 @@ def test_adjoint_identities_fp32(mode, fn, rec, shape):
     assert abs(lhs.item() - rhs.item()) <= 2e-5 * max(1.0, abs(rhs.item())) + 2e-2, (lhs.item(), rhs.item())
 
 
+@pytest.mark.parametrize("mode", ["zero", "reflect", "symmetric", "constant"])
+@pytest.mark.parametrize("shape,wavelet,level,pmode", [((2, 300, 520), "db4", 3, 1), ((3, 203, 610), "db2", 3, 1), ((6, 96, 80), "db3", 3, 3),
+                                                        ((2, 512, 512), "haar", 5, 0)])
+def test_fused_forward_of_differentiable_calls(mode, shape, wavelet, level, pmode):
+    """A `wavedec2` that asks for gradients w.r.t. the data runs its forward on the multi-level launches (kernel ids 16 / 20:
+    `_fwt._AnalysisPyramid`; src/ptwt/conv_transform_2.py:142-149), not level by level: same kernel ids as the plain call, coefficients
+    bit-identical to it; gradients equal to those of the per-level ops (pyramid launches switched off) within fp32 rounding, the
+    adjoint identity, and a Hessian-vector product through the fused op (its backward is made of differentiable level ops)."""
+    torch.manual_seed(9)
+    x = torch.randn(*shape, device=dev(), requires_grad=True)
+    _engine.set_option(_engine.OPT_PYRAMID_MODE, pmode)
+    try:
+        _engine.level_events = []
+        coeffs = ptwt_amd.wavedec2(x, wavelet, mode=mode, level=level)
+        torch.cuda.synchronize()
+        kids = [e[1] for e in _engine.level_events]
+        _engine.level_events = None
+        assert kids[0] in (_engine.KID_PYRAMID, _engine.KID_SMALL), kids
+        with torch.no_grad():
+            _engine.level_events = []
+            plain = ptwt_amd.wavedec2(x, wavelet, mode=mode, level=level)
+            torch.cuda.synchronize()
+            assert [e[1] for e in _engine.level_events][0] == kids[0]  # (the levels after the fused ones may pair up in the plain call)
+            _engine.level_events = None
+        fl = flat(coeffs)
+        for a, b in zip(fl, flat(plain)):
+            assert a.requires_grad and torch.equal(a.detach(), b)
+        ws = [torch.randn_like(t) for t in fl]
+        lhs = sum((w * t).sum() for w, t in zip(ws, fl))
+        (gx,) = torch.autograd.grad(lhs, x, retain_graph=True)
+        rhs = (gx.double() * x.detach().double()).sum()
+        assert abs(lhs.item() - rhs.item()) <= 2e-5 * max(1.0, abs(rhs.item())) + 2e-2, (lhs.item(), rhs.item())
+        # Hessian-vector product of f = sum w c^2 / 2 through the fused op against the first-order gradient of f at v
+        v = torch.randn_like(x)
+
+        def f(t):
+            return sum((w * c.square()).sum() for w, c in zip(ws, flat(ptwt_amd.wavedec2(t, wavelet, mode=mode, level=level)))) / 2
+
+        (g,) = torch.autograd.grad(f(x), x, create_graph=True)
+        (hv,) = torch.autograd.grad((g * v).sum(), x)
+        vv = v.clone().requires_grad_(True)
+        (want_hv,) = torch.autograd.grad(f(vv), vv)
+        assert G.relerr(hv.cpu().numpy(), want_hv.cpu().numpy()) < 2e-6
+    finally:
+        _engine.level_events = None
+        _engine.set_option(_engine.OPT_PYRAMID_MODE, 0)
+    # the per-level ops (every multi-level launch off)
+    _engine.set_option(_engine.OPT_PYRAMID_MODE, 2)
+    _engine.set_option(_engine.OPT_PAIR_MODE, 2)
+    try:
+        x2 = x.detach().clone().requires_grad_(True)
+        fl2 = flat(ptwt_amd.wavedec2(x2, wavelet, mode=mode, level=level))
+        (gx2,) = torch.autograd.grad(sum((w * t).sum() for w, t in zip(ws, fl2)), x2)
+    finally:
+        _engine.set_option(_engine.OPT_PYRAMID_MODE, 0)
+        _engine.set_option(_engine.OPT_PAIR_MODE, 0)
+    assert G.relerr(gx.cpu().numpy(), gx2.cpu().numpy()) < 2e-6
+
+
+def test_fused_forward_gradients_at_config2_size():
+    """Forward + backward of `wavedec2` db4 level 3 on 64 x 1024^2 (BASELINE config 2 with gradients; the benchmark workload
+    `wavedec2_bwd_...`): one forward launch (kernel 16), gradient against the per-level ops on every image, adjoint identity."""
+    torch.manual_seed(10)
+    x = torch.randn(64, 1024, 1024, device=dev(), requires_grad=True)
+    _engine.level_events = []
+    fl = flat(ptwt_amd.wavedec2(x, "db4", level=3))
+    torch.cuda.synchronize()
+    kids = [e[1] for e in _engine.level_events]
+    _engine.level_events = None
+    assert kids == [_engine.KID_PYRAMID], kids
+    ws = [torch.randn_like(t) for t in fl]
+    lhs = sum((w * t).sum(dtype=torch.float64) for w, t in zip(ws, fl))
+    (gx,) = torch.autograd.grad(lhs, x)
+    rhs = (gx.double() * x.detach().double()).sum()
+    assert abs(lhs.item() - rhs.item()) <= 2e-5 * abs(rhs.item()) + 1.0, (lhs.item(), rhs.item())
+    _engine.set_option(_engine.OPT_PYRAMID_MODE, 2)
+    _engine.set_option(_engine.OPT_PAIR_MODE, 2)
+    try:
+        x2 = x.detach().clone().requires_grad_(True)
+        fl2 = flat(ptwt_amd.wavedec2(x2, "db4", level=3))
+        (gx2,) = torch.autograd.grad(sum((w * t).sum(dtype=torch.float64) for w, t in zip(ws, fl2)), x2)
+    finally:
+        _engine.set_option(_engine.OPT_PYRAMID_MODE, 0)
+        _engine.set_option(_engine.OPT_PAIR_MODE, 0)
+    err = (gx - gx2).flatten(1).norm(dim=1) / gx2.flatten(1).norm(dim=1)
+    assert float(err.max()) < 2e-6, float(err.max())
+
+
 def test_backward_routes():
     """Zero-mode analysis adjoints and all synthesis adjoints ride on the fast kernels (kernel ids through the C ABI)."""
     import ctypes
@@ -99,8 +187,46 @@ def test_backward_routes():
     assert lib.mifwt_kernel_id(ctypes.byref(d), 2) == 2  # adjoint of a zero-mode analysis = fused synthesis kernel
     assert lib.mifwt_kernel_id(ctypes.byref(d), 3) == 7  # adjoint of a synthesis = fused zero-mode analysis kernel
     d.mode = 2
-    assert lib.mifwt_kernel_id(ctypes.byref(d), 2) == 0  # reflect: generic adjoint passes (halo fold-back)
+    assert lib.mifwt_kernel_id(ctypes.byref(d), 2) == 2  # reflect: the same launch + the border kernel (round 4; was: generic passes)
     assert lib.mifwt_kernel_id(ctypes.byref(d), 3) == 7
+    _engine.set_option(_engine.OPT_DEBUG, 1024)
+    try:
+        assert lib.mifwt_kernel_id(ctypes.byref(d), 2) == 0  # the generic adjoint passes (halo fold-back), kept for short axes / long filters
+    finally:
+        _engine.set_option(_engine.OPT_DEBUG, 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("mode", ["reflect", "symmetric", "periodic", "constant"])
+def test_analysis_adjoint_fast_route_vs_generic_passes(mode, dtype):
+    """The adjoint of an analysis level with a boundary extension (the backward of F.pad + F.conv*d, src/ptwt/conv_transform.py:135-139
+    and the 2-D / 3-D twins) on its fast route — zero-mode adjoint over the whole signal + border kernel (csrc/mifwt_adjoint_border.hip)
+    — against the generic per-axis adjoint passes (pinned by the reference's autograd goldens): 1-3 axes, odd / even extents, 2 .. 20
+    taps, batches; and the adjoint identity <A x, g> = <x, A^T g> against the forward kernels."""
+    rng = np.random.default_rng(41)
+    eng = _engine.ENGINE
+    tol = 2e-6 if dtype == torch.float32 else 1e-12
+    for shape, wavelet in [((3, 200), "db4"), ((2, 201), "haar"), ((5, 96), "db10"), ((2, 64, 70), "db4"), ((3, 61, 128), "db2"), ((1, 300, 301), "sym8"),
+                           ((2, 24, 26, 31), "db2"), ((1, 40, 33, 36), "db3"), ((2, 18, 20, 19), "haar")]:
+        dec_lo, dec_hi, _, _ = ptwt_amd._wavelets.host_taps(wavelet)
+        flen, nd = len(dec_lo), len(shape) - 1
+        x = torch.from_numpy(rng.standard_normal(shape)).to(dtype).to(dev())
+        buf = eng.analysis(x, dec_lo, dec_hi, _engine.MODE_IDS[mode])
+        g = torch.from_numpy(rng.standard_normal(tuple(buf.shape))).to(dtype).to(dev())
+        fast = eng.analysis_adjoint(g, shape[1:], dec_lo, dec_hi, _engine.MODE_IDS[mode])
+        bands = eng.analysis_adjoint_bands(g[:, 0].contiguous(), [g[:, s].contiguous() for s in range(1, 1 << nd)], shape[1:], dec_lo, dec_hi,
+                                           _engine.MODE_IDS[mode])
+        _engine.set_option(_engine.OPT_DEBUG, 1024)
+        try:
+            slow = eng.analysis_adjoint(g, shape[1:], dec_lo, dec_hi, _engine.MODE_IDS[mode])
+        finally:
+            _engine.set_option(_engine.OPT_DEBUG, 0)
+        assert G.relerr(fast.cpu().numpy(), slow.cpu().numpy()) < tol, (shape, wavelet)
+        assert float((fast - slow).abs().max()) < 50 * tol * float(slow.abs().max()), (shape, wavelet)  # (every border sample, not only the norm)
+        assert G.relerr(bands.cpu().numpy(), slow.cpu().numpy()) < tol, (shape, wavelet, "per-band entry")
+        lhs, rhs = (buf.double() * g.double()).sum().item(), (x.double() * fast.double()).sum().item()
+        # (sums of up to 1e5 products of unit-variance numbers: |lhs| ~ 3e2, fp32 rounding of the terms ~ 1e-2 in all)
+        assert abs(lhs - rhs) <= ((2e-5, 2e-2) if dtype == torch.float32 else (1e-12, 1e-9))[0] * abs(rhs) + ((2e-5, 2e-2) if dtype == torch.float32 else (1e-12, 1e-9))[1], (shape, wavelet, lhs, rhs)
 
 
 def test_no_grad_and_detached_paths_unchanged():
