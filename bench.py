@@ -78,6 +78,8 @@ WORKLOADS = {
     # config 2 with gradients: forward (one launch, kernel 16, as a differentiable op) + backward w.r.t. the data (per-level adjoints)
     "wavedec2_bwd_db4_L3_64x1024x1024_f32": ("wavedec2_bwd", (64, 1024, 1024), "db4", 3, "reflect", torch.float32),
     "wavedec2_bwd_db4_L3_64x1024x1024_f32_zero": ("wavedec2_bwd", (64, 1024, 1024), "db4", 3, "zero", torch.float32),
+    # ... and the reconstruction with gradients w.r.t. every coefficient tensor (forward: kernel 22; backward: zero-mode analysis kernels)
+    "waverec2_bwd_db4_L3_64x1024x1024_f32": ("waverec2_bwd", (64, 1024, 1024), "db4", 3, "reflect", torch.float32),
     # the other reconstructions (kernel ids 10, 18 / 15, 21)
     "waverec3_db2_L3_8x256x256x256_f32": ("waverec3", (8, 256, 256, 256), "db2", 3, "zero", torch.float32),
     "waverec_db5_L10_32x1000000_f32": ("waverec", (32, 1000000), "db5", 10, "periodic", torch.float32),
@@ -157,7 +159,7 @@ def cpu_baseline(fn, shape, wavelet, level, mode, dtype):
     sample_b = max(1, min(shape[0], (64 << 20) // per_item))
     cdtype = torch.float32 if dtype == torch.float16 else dtype  # (the reference has no half path on the CPU: conv in fp32)
     x = torch.randn(sample_b, *shape[1:], dtype=cdtype)
-    if fn == "waverec2":
+    if fn == "waverec2" and not bwd:
         arg = P.wavedec2(x, wavelet, mode=mode, level=level)
         run = lambda sl: port(tuple([arg[0][sl]] + [tuple(t[sl] for t in lv) for lv in arg[1:]]), wavelet)  # noqa: E731
     elif fn == "fswaverec2":
@@ -169,6 +171,13 @@ def cpu_baseline(fn, shape, wavelet, level, mode, dtype):
     elif fn == "waverec3":
         arg = P.wavedec3(x, wavelet, mode=mode, level=level)
         run = lambda sl: port(tuple([arg[0][sl]] + [{k: v[sl] for k, v in d.items()} for d in arg[1:]]), wavelet)  # noqa: E731
+    elif bwd and fn == "waverec2":
+        arg = P.wavedec2(x, wavelet, mode=mode, level=level)
+
+        def run(sl):  # forward + backward w.r.t. every coefficient tensor through ATen's autograd
+            leaves = [arg[0][sl].clone().requires_grad_(True)] + [t[sl].clone().requires_grad_(True) for lv in arg[1:] for t in lv]
+            y = port(tuple([leaves[0]] + [tuple(leaves[1 + 3 * k : 4 + 3 * k]) for k in range(len(arg) - 1)]), wavelet)
+            torch.autograd.grad(y, leaves, torch.ones_like(y))
     elif bwd:
         def run(sl):  # forward + backward w.r.t. the data through ATen's autograd, as the reference does it
             xs = x[sl].clone().requires_grad_(True)
@@ -360,7 +369,20 @@ def main():
         return out
 
     is_rec = "rec" in fn_name  # a reconstruction: the inputs are coefficient sets (made by the matching analysis, untimed)
-    if is_rec:
+    if is_rec and is_bwd:
+        ana = getattr(ptwt_amd, fn_name[:-4].replace("rec", "dec"))
+        with torch.no_grad():
+            sets = [ana(make_input(), wavelet, mode=mode, level=level) for _ in range(max(1, args.buffers))]
+        # every coefficient tensor a dense leaf of its own (the analysis returns views of level buffers)
+        bufs = [[t.contiguous().requires_grad_(True) for _, t in _flatten(c)] for c in sets]
+        del sets
+        gout = torch.randn(*shape, dtype=dtype, device=dev)
+
+        def step(i):
+            lv = bufs[i % len(bufs)]
+            y = fn((lv[0], *[tuple(lv[1 + 3 * k : 4 + 3 * k]) for k in range((len(lv) - 1) // 3)]), wavelet)
+            return torch.autograd.grad(y, lv, gout)
+    elif is_rec:
         ana = getattr(ptwt_amd, fn_name.replace("rec", "dec"))
         bufs = [ana(make_input(), wavelet, mode=mode, level=level) for _ in range(max(1, args.buffers))]
 
@@ -456,7 +478,7 @@ def main():
     first_kid = events[0][1] if events else -1
     launch = None
     call_is_launch = False
-    if is_rec and events and len({e[2] for e in events}) == 1:
+    if is_rec and not is_bwd and events and len({e[2] for e in events}) == 1:
         # the whole reconstruction is ONE launch (the streaming / small-plane multi-level kernels): the call is the launch
         first_kid = events[-1][1]
         fused_levels = level

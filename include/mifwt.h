@@ -143,7 +143,11 @@ int mifwt_dwt2_fwd_pyramid(int nlevels, const mifwt_level_desc* const* descs, co
  * L - 2 (+ 1) approximation rows per level that the end of this one lacks (64-bit flags in the workspace, release / acquire at agent
  * scope; a flag is set when it holds `call_id`, which must differ from the ids of earlier calls on the same workspace — nothing is
  * ever cleared).  Identical sums in identical order: bit-identical results.  mifwt_dwt2_fwd_pyramid_workspace() = the bytes it wants
- * (0: the call would not use one); a smaller or NULL workspace selects the prologue form. */
+ * (0: the call would not use one); a smaller or NULL workspace selects the prologue form.
+ * The handover form is an EXPERIMENT (measured slower than the prologues): mifwt_dwt2_fwd_pyramid_workspace answers 0
+ * unless MIFWT_OPT_DEBUG bit 8 is set.  Contract when it is used: `call_id` unique per workspace, the workspace not shared by launches
+ * in flight at the same time, and the whole grid resident at once (one workgroup per CU: batch x segments <= CUs) — a segment that
+ * waits ~1 s for a flag that never comes TRAPS (the launch fails loudly at the next synchronisation) instead of returning wrong rows. */
 size_t mifwt_dwt2_fwd_pyramid_workspace(int nlevels, const mifwt_level_desc* const* descs);
 int mifwt_dwt2_fwd_pyramid_ws(int nlevels, const mifwt_level_desc* const* descs, const void* x, void* const* const* details, void* approx,
                               const double* dec_lo, const double* dec_hi, void* workspace, size_t workspace_bytes, unsigned long long call_id,

@@ -250,6 +250,37 @@ class _SynthesisAdjointLevel(torch.autograd.Function):
         return _SynthesisLevel.apply(rec_lo, rec_hi, out_ext, None, None, bands[0], *bands[1:]), None, None, None
 
 
+class _SynthesisPyramid(torch.autograd.Function):
+    """Several 2-D synthesis levels in ONE launch as a differentiable op w.r.t. the coefficients (C ABI ``mifwt_dwt2_inv_pyramid``: the
+    streaming three-level kernel / the small-plane kernel; src/ptwt/conv_transform_2.py:222-249 per trip): a `waverec2` that asks for
+    gradients runs its forward on the same fused kernels as one that does not.  ``dets`` = three detail bands per level, coarsest level
+    first.  The backward composes the per-level synthesis adjoints (zero-mode analysis kernels) fine to coarse, each a differentiable
+    op in turn."""
+
+    @staticmethod
+    def forward(ctx, rec_lo, rec_hi, out_ext, plan, nlev, approx, *dets):
+        levels = [list(dets[3 * l : 3 * l + 3]) for l in range(nlev)]
+        ctx.meta = (rec_lo, rec_hi, [tuple(lv[0].shape[1:]) for lv in levels])
+        y = _engine.ENGINE.synthesis_pyramid(approx, levels, rec_lo, rec_hi, out_ext, plan=plan)
+        if y is None:  # (bands of a level that do not share their strides: level by level, same op)
+            y = approx
+            for k, lv in enumerate(levels):
+                nxt = levels[k + 1][0].shape[1:] if k + 1 < nlev else out_ext
+                y = _engine.ENGINE.synthesis(y, lv, rec_lo, rec_hi, list(nxt))
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        rec_lo, rec_hi, coef_shapes = ctx.meta
+        grads: list = []
+        g = g_y
+        for shp in reversed(coef_shapes):  # finest level first: its adjoint yields the gradient of its four bands
+            gb = _SynthesisAdjointLevel.apply(g, shp, rec_lo, rec_hi)
+            grads = [gb[:, 1], gb[:, 2], gb[:, 3]] + grads
+            g = gb[:, 0]  # = the gradient of the coarser level's (trimmed) output
+        return (None, None, None, None, None, g, *grads)
+
+
 def _tap_tensors(wavelet):
     """(dec_lo, dec_hi, rec_lo, rec_hi) as the caller's TENSORS when the filter bank is learnable (any of them requires
     grad and grad mode is on), else None.  src/ptwt/_util.py:115-132 keeps such taps in the graph with torch.as_tensor."""
@@ -452,6 +483,8 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
 
 
 # ------------------------------------------------------------------------------------------ synthesis
+# (both memos hold idempotent values and are only touched through single dict operations — get / item assignment / clear — each atomic
+# under the GIL; a thread that loses a race recomputes the same entry)
 _tail_memo: dict = {}  # geometry of a 2-D reconstruction -> (levels the streaming launch takes, final extents, its plan)
 _small_memo: dict = {}  # ... of a small plane -> (final extents, plan of the one-launch reconstruction)
 _engine._routing_caches.append(_tail_memo)
@@ -564,8 +597,11 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
                 cur = fuse(fuse, cur, 0, len(folded))
                 pos = len(folded)
     any_grad = torch.is_grad_enabled() and (tap_t is not None or any(t.requires_grad for t in flat))
+    # (gradients w.r.t. the coefficients only: the multi-level launches as differentiable ops, _SynthesisPyramid; a learnable filter
+    # bank and the separable containers' crops take the per-level ops)
+    fused_grad = any_grad and tap_t is None and not separable
     gkey = None
-    if ndim == 2 and folded and not any_grad:
+    if ndim == 2 and folded and (not any_grad or fused_grad):
         # geometry of the call (every band's shape: the reference's shape checks are part of what is remembered)
         gkey = (cur.dtype, cur.shape, cur.stride(), tuple((lv[0].stride(), *[t.shape for t in lv]) for lv in folded), flen, separable)
     # (the finest level's four coefficient planes alone must fit into LDS: 10 240 samples each at most)
@@ -587,7 +623,10 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
             hit = _small_memo[gkey] = (out_ext, pl)
         out_ext, pl = hit
         if pl is not None and pl[3]:
-            y = _engine.ENGINE.synthesis_pyramid(cur, folded, rec_lo, rec_hi, out_ext, plan=pl)
+            if fused_grad:
+                y = _SynthesisPyramid.apply(rec_lo, rec_hi, tuple(out_ext), pl, len(folded), cur, *[t for lv in folded for t in lv])
+            else:
+                y = _engine.ENGINE.synthesis_pyramid(cur, folded, rec_lo, rec_hi, out_ext, plan=pl)
             if y is not None:
                 return layout.unfold(y)
     # big planes: the FINEST up to three levels (that is where the bytes are) in one streaming launch (mifwt_dwt2_inv_pyramid's
@@ -634,7 +673,11 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
         if tail and pos == len(folded) - tail:
             # (the plan was made for a dense hand-over approximation; a strided one — a separable crop — is looked up afresh)
             same = pos == 0 or cur.is_contiguous()
-            y = _engine.ENGINE.synthesis_pyramid(cur, folded[pos:], rec_lo, rec_hi, tail_ext, plan=tail_plan if same else None)
+            if fused_grad:
+                y = _SynthesisPyramid.apply(rec_lo, rec_hi, tuple(tail_ext), tail_plan if same else None, len(folded) - pos, cur,
+                                            *[t for lv in folded[pos:] for t in lv])
+            else:
+                y = _engine.ENGINE.synthesis_pyramid(cur, folded[pos:], rec_lo, rec_hi, tail_ext, plan=tail_plan if same else None)
             if y is not None:
                 return layout.unfold(y)
             tail = 0  # (bands that do not share their strides: level by level)

@@ -439,6 +439,10 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
               const unsigned long long* f = a.flags + (int64_t)img * a.nseg + seg + 1;
               int spins = 0;
               while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != a.nonce && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(32);
+              // the segment below never raised its flag (its workgroup is not resident, or the workspace / call id is shared with another
+              // launch): abort the launch — the host sees a failed kernel at its next synchronisation — rather than copy rows that were
+              // never deposited
+              if (spins >= (1 << 20)) __builtin_trap();
             }
             asm volatile("" ::: "memory");  // (the requests below are issued after the flag was seen)
             const uint32_t lane16 = 16u * (uint32_t)lane;

@@ -172,6 +172,56 @@ def test_fused_forward_gradients_at_config2_size():
     assert float(err.max()) < 2e-6, float(err.max())
 
 
+@pytest.mark.parametrize("shape,wavelet,level,pmode", [((2, 600, 520), "db4", 3, 0), ((3, 403, 610), "db2", 2, 0), ((6, 96, 80), "db3", 3, 3),
+                                                        ((2, 1024, 1024), "db5", 4, 0)])
+def test_fused_synthesis_of_differentiable_calls(shape, wavelet, level, pmode):
+    """A `waverec2` that asks for gradients w.r.t. the coefficients runs on the multi-level launches (kernel ids 22 / 21:
+    `_fwt._SynthesisPyramid`; src/ptwt/conv_transform_2.py:222-249): same kernel ids and bit-identical output as the plain call,
+    gradients of every coefficient tensor equal to those of the per-level ops within fp32 rounding, a second-order product through it."""
+    torch.manual_seed(12)
+    x = torch.randn(*shape, device=dev())
+    coeffs = ptwt_amd.wavedec2(x, wavelet, mode="symmetric", level=level)
+    leaves = [t.detach().clone().requires_grad_(True) for t in flat(coeffs)]
+    _engine.set_option(_engine.OPT_PYRAMID_MODE, pmode)
+    try:
+        _engine.level_events = []
+        y = ptwt_amd.waverec2(rebuild(coeffs, leaves), wavelet)
+        torch.cuda.synchronize()
+        kids = [e[1] for e in _engine.level_events]
+        _engine.level_events = []
+        with torch.no_grad():
+            y0 = ptwt_amd.waverec2(rebuild(coeffs, leaves), wavelet)
+        torch.cuda.synchronize()
+        kids0 = [e[1] for e in _engine.level_events]
+        _engine.level_events = None
+        assert kids[-1] in (_engine.KID_INV_PYRAMID, _engine.KID_INV_SMALL) and kids[-1] == kids0[-1], (kids, kids0)
+        assert y.requires_grad and torch.equal(y.detach(), y0)
+        v = torch.randn_like(y)
+        gl = torch.autograd.grad((v * y).sum(), leaves, create_graph=True)
+        us = [torch.randn_like(t) for t in leaves]
+        # d/dv of <grad_c <v, R c>, u> = R u: a second backward through the fused op's (differentiable) adjoints
+        vv = v.clone().requires_grad_(True)
+        gl2 = torch.autograd.grad((vv * ptwt_amd.waverec2(rebuild(coeffs, leaves), wavelet)).sum(), leaves, create_graph=True)
+        (ru,) = torch.autograd.grad(sum((a * b).sum() for a, b in zip(gl2, us)), vv)
+        with torch.no_grad():
+            want_ru = ptwt_amd.waverec2(rebuild(coeffs, us), wavelet)
+        assert G.relerr(ru.cpu().numpy(), want_ru.cpu().numpy()) < 2e-6
+    finally:
+        _engine.level_events = None
+        _engine.set_option(_engine.OPT_PYRAMID_MODE, 0)
+    _engine.set_option(_engine.OPT_PYRAMID_MODE, 2)
+    _engine.set_option(_engine.OPT_PAIR_MODE, 2)
+    try:
+        leaves2 = [t.detach().clone().requires_grad_(True) for t in leaves]
+        y2 = ptwt_amd.waverec2(rebuild(coeffs, leaves2), wavelet)
+        gl_ref = torch.autograd.grad((v * y2).sum(), leaves2)
+    finally:
+        _engine.set_option(_engine.OPT_PYRAMID_MODE, 0)
+        _engine.set_option(_engine.OPT_PAIR_MODE, 0)
+    for i, (a, b) in enumerate(zip(gl, gl_ref)):
+        assert G.relerr(a.detach().cpu().numpy(), b.cpu().numpy()) < 2e-6, i
+
+
 def test_backward_routes():
     """Zero-mode analysis adjoints and all synthesis adjoints ride on the fast kernels (kernel ids through the C ABI)."""
     import ctypes
