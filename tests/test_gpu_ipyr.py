@@ -102,6 +102,27 @@ def test_ragged_and_wide_planes():
         check(shape, "db4", "reflect", 3 if shape[1] >= 96 else 2, [K], seed=shape[2])
 
 
+@pytest.mark.parametrize("wavelet", ["db5", "sym5", "bior3.3"])
+def test_ten_taps_on_big_planes(wavelet):
+    """The ten-tap path of the streaming synthesis kernel (one row's windows at a time, 40 accumulator registers) beyond the small
+    planes of `test_three_levels_vs_oracle`: the reference's own 2-D speed-test geometry (32 x 1000^2 db5 level 5 periodic,
+    examples/speed_tests/timeitconv_2d.py:38-57: here 4 images against the numpy oracle), wide and ragged planes, several row segments,
+    random coefficient sets with odd extents (trims between the levels)."""
+    flen = len(O.filter_bank(wavelet)[0])
+    if flen > 10:
+        pytest.skip("more than ten taps: not this kernel's path")
+    check((4, 1000, 1000), wavelet, "periodic", 5, None, seed=3)
+    rng = np.random.default_rng(8)
+    c64 = O.wavedec2(rng.standard_normal((4, 1000, 1000)), wavelet, mode="periodic", level=5)
+    cdev, c32 = to_dev32(c64)
+    got, kids = run_traced(lambda: ptwt_amd.waverec2(cdev, wavelet))
+    assert kids[-1] == K, kids
+    for shape, level in (((2, 700, 1500), 3), ((1, 1031, 1277), 3), ((2, 520, 1024), 2)):
+        check(shape, wavelet, "symmetric", level, None, random_coeffs=True, seed=shape[1])
+    for seg in (40, 104):
+        check((2, 600, 800), wavelet, "reflect", 3, [K], seg_rows=seg, seed=seg)
+
+
 def test_more_levels_than_the_launch_takes():
     """Five levels: the two coarsest go first (one two-level launch or the per-level kernels), the three finest in the streaming launch."""
     rng = np.random.default_rng(5)

@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/pmcw_$WL
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $ROOT/bench.py --workload $WL --steps ${STEPS:-60} --warmup 10 --no-cpu-baseline"
+CMD="python $ROOT/bench.py --workload $WL --steps ${STEPS:-60} --warmup 10 --no-cpu-baseline --no-secondary"
 ( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $CMD ) > $OUT/kt.log 2>&1; echo "kernel-trace rc=$?"
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" \
@@ -21,6 +21,7 @@ cd $ROOT
 python - <<PY
 import collections, csv, glob, json
 out, kern, wl, tag = "$OUT", "$KERNEL", "$WL", "${TAG:-r03}"
+kern2 = "${KERNEL2:-}"  # a second kernel of the same level (composed routes: two launches per level): its traffic is added
 stats = glob.glob(out + "/kt/**/*kernel_stats.csv", recursive=True)
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
@@ -32,10 +33,28 @@ if stats:
 # per grid size: the same kernel name can serve launches of very different sizes
 trace = glob.glob(out + "/kt/**/*kernel_trace.csv", recursive=True)
 bygrid = collections.defaultdict(list)
+allgrid = collections.defaultdict(list)
 if trace:
     for r in csv.DictReader(open(trace[0])):
+        g = r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", "")
+        dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        allgrid[(r["Kernel_Name"][:110], g)].append(dur)
         if kern in r["Kernel_Name"]:
-            bygrid[r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", "")].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            bygrid[g].append(dur)
+if stats and allgrid:
+    # (round 4) the per-name averages above mix launches of every grid size: the same summary split by (kernel, grid size), the first
+    # quarter of each group (idle-clock spin-up launches) left out of the steady-state column
+    top = [r["Name"][:110] for r in rows[:8]]
+    with open(f"gpurun_out/{tag}_kernel_stats_{wl}.csv", "a", newline="") as f:
+        w = csv.writer(f)
+        w.writerow([])
+        w.writerow(["# by grid size", "GridSizeX", "Calls", "AverageNs", "MedianNs", "SteadyAverageNs(last 3/4)", "MinNs", "MaxNs"])
+        for name in top:
+            for (n, g), v in sorted(allgrid.items(), key=lambda kv: -sum(kv[1])):
+                if n != name:
+                    continue
+                sv = v[len(v) // 4:]
+                w.writerow([n, g, len(v), round(sum(v) / len(v), 1), sorted(v)[len(v) // 2], round(sum(sv) / len(sv), 1), min(v), max(v)])
 pmc, meta = {}, {}
 for p in sorted(glob.glob(out + "/p*/**/*_counter_collection.csv", recursive=True)):
     per = collections.defaultdict(list)
@@ -52,6 +71,19 @@ for p in sorted(glob.glob(out + "/p*/**/*_counter_collection.csv", recursive=Tru
         # persistent kernels launch the same grid for every level: the dominant launches are the ones with the big counts
         v = [x for x in v if x >= 0.5 * max(v)] if v and max(v) > 0 else v
         pmc[k] = sum(v) / max(1, len(v))
+pmc2 = {}
+if kern2:
+    for p in sorted(glob.glob(out + "/p*/**/*_counter_collection.csv", recursive=True)):
+        per = collections.defaultdict(list)
+        rows2 = [r for r in csv.DictReader(open(p)) if kern2 in r["Kernel_Name"]]
+        gmax = max((int(r["Grid_Size"]) for r in rows2), default=0)
+        for r in rows2:
+            if int(r["Grid_Size"]) == gmax and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                per[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                meta.setdefault("kernel2", r["Kernel_Name"][:110])
+        for k, v in per.items():
+            v = v[len(v) // 4:]
+            pmc2[k] = sum(v) / max(1, len(v))
 res = dict(meta)
 res["workload"] = wl
 res["counters_per_dispatch"] = {k: round(v, 1) for k, v in sorted(pmc.items())}
@@ -62,6 +94,9 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     res["hbm_read_bytes_corrected"] = int(c["FETCH_SIZE"] * 1024 * 2)
     res["hbm_write_bytes"] = int(c["WRITE_SIZE"] * 1024)
     res["hbm_traffic_bytes"] = res["hbm_read_bytes_corrected"] + res["hbm_write_bytes"]
+    if "FETCH_SIZE" in pmc2 and "WRITE_SIZE" in pmc2:
+        res["kernel2_hbm_traffic_bytes"] = int(pmc2["FETCH_SIZE"] * 1024 * 2) + int(pmc2["WRITE_SIZE"] * 1024)
+        res["hbm_traffic_bytes"] += res["kernel2_hbm_traffic_bytes"]  # (the level = both launches)
 json.dump(res, open(f"gpurun_out/{tag}_pmc_{wl}.json", "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])
 PY
