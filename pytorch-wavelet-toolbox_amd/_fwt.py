@@ -95,11 +95,261 @@ def _synthesis_tap_grads(g_y, approx, details, rec_lo, rec_hi):
     return g_lo, g_hi
 
 
+# ---- learnable filter banks, gradients of any order -----------------------------------------------------------------------------------
+# A level along ONE axis is bilinear in (signal, taps):  c = A(h) x.  Three maps close that under differentiation, each a differentiable
+# op whose backward is made of the other two:
+#     A(h) x            (_Axis1)      d/dx: A(h)^T g              d/dh: C(x, g)
+#     A(h)^T g          (_Axis1Adj)   d/dg: A(h) gg               d/dh: C(gg, g)
+#     C(x, g) = t       (_Axis1Corr)  d/dx: A(w)^T g              d/dg: A(w) x          (w = the gradient that arrives for t: taps!)
+# and likewise for the synthesis  y = S(r) (a, d)  (_Syn1, _Syn1Adj, _Syn1Corr).  An N-D level is a product of such maps, one per axis,
+# so autograd through their composition yields every mixed derivative the reference gets from plain ATen ops (src/ptwt/_util.py:115-132
+# keeps the taps in the graph).  The fused level kernels serve the forward and the first-order backward as before; only a backward
+# that is asked for a graph (create_graph=True) with a learnable filter bank re-runs the level through these ops.  Taps travel to the
+# kernels as host floats (one device-to-host copy per op).
+def _host_taps_of(t: torch.Tensor) -> List[float]:
+    return [float(v) for v in t.detach().double().cpu().reshape(-1).tolist()]
+
+
+class _Axis1(torch.autograd.Function):
+    """rows [R, N] -> [R, 2, M]: one analysis level along the last axis, taps as tensors."""
+
+    @staticmethod
+    def forward(ctx, x, lo_t, hi_t, mode_id):
+        ctx.mode_id = mode_id
+        ctx.save_for_backward(x, lo_t, hi_t)
+        return _engine.ENGINE.analysis(x, _host_taps_of(lo_t), _host_taps_of(hi_t), mode_id)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, lo_t, hi_t = ctx.saved_tensors
+        g_x = _Axis1Adj.apply(g, lo_t, hi_t, ctx.mode_id, x.shape[1]) if ctx.needs_input_grad[0] else None
+        t_lo = t_hi = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            t_lo, t_hi = _Axis1Corr.apply(x, g, lo_t.numel(), ctx.mode_id)
+            t_lo, t_hi = _like(t_lo, lo_t), _like(t_hi, hi_t)
+        return g_x, t_lo, t_hi, None
+
+
+class _Axis1Adj(torch.autograd.Function):
+    """[R, 2, M] -> rows [R, N]: the transpose of :class:`_Axis1`."""
+
+    @staticmethod
+    def forward(ctx, g, lo_t, hi_t, mode_id, n):
+        ctx.mode_id = mode_id
+        ctx.save_for_backward(g, lo_t, hi_t)
+        return _engine.ENGINE.analysis_adjoint(g, (n,), _host_taps_of(lo_t), _host_taps_of(hi_t), mode_id)
+
+    @staticmethod
+    def backward(ctx, gg):
+        g, lo_t, hi_t = ctx.saved_tensors
+        g_g = _Axis1.apply(gg, lo_t, hi_t, ctx.mode_id) if ctx.needs_input_grad[0] else None
+        t_lo = t_hi = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:  # <gg, A(h)^T g> = <A(h) gg, g>
+            t_lo, t_hi = _Axis1Corr.apply(gg, g, lo_t.numel(), ctx.mode_id)
+            t_lo, t_hi = _like(t_lo, lo_t), _like(t_hi, hi_t)
+        return g_g, t_lo, t_hi, None, None
+
+
+class _Axis1Corr(torch.autograd.Function):
+    """(rows x [R, N], g [R, 2, M]) -> (t_lo, t_hi) float64 [L]:  t_b[m] = sum_{row, k} g_b[row, k] x_ext[row, 2 k + 1 - m]."""
+
+    @staticmethod
+    def forward(ctx, x, g, flen, mode_id):
+        ctx.mode_id = mode_id
+        ctx.save_for_backward(x, g)
+        t_lo = torch.zeros(flen, dtype=torch.float64, device=x.device)
+        t_hi = torch.zeros_like(t_lo)
+        _engine.ENGINE.tap_correlate(g[:, 0], x, flen, 1, -1, mode_id, t_lo)
+        _engine.ENGINE.tap_correlate(g[:, 1], x, flen, 1, -1, mode_id, t_hi)
+        return t_lo, t_hi
+
+    @staticmethod
+    def backward(ctx, w_lo, w_hi):
+        x, g = ctx.saved_tensors
+        w_lo, w_hi = w_lo.to(x.dtype), w_hi.to(x.dtype)
+        g_x = _Axis1Adj.apply(g, w_lo, w_hi, ctx.mode_id, x.shape[1]) if ctx.needs_input_grad[0] else None
+        g_g = _Axis1.apply(x, w_lo, w_hi, ctx.mode_id) if ctx.needs_input_grad[1] else None
+        return g_x, g_g, None, None
+
+
+class _Syn1(torch.autograd.Function):
+    """(a, d [R, M]) -> y [R, n_out]: one synthesis level along the last axis (cropped to n_out), taps as tensors."""
+
+    @staticmethod
+    def forward(ctx, a, d, lo_t, hi_t, n_out):
+        ctx.save_for_backward(a, d, lo_t, hi_t)
+        return _engine.ENGINE.synthesis(a, [d], _host_taps_of(lo_t), _host_taps_of(hi_t), [n_out])
+
+    @staticmethod
+    def backward(ctx, g_y):
+        a, d, lo_t, hi_t = ctx.saved_tensors
+        g_a = g_d = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gb = _Syn1Adj.apply(g_y, lo_t, hi_t, a.shape[1])
+            g_a, g_d = gb[:, 0], gb[:, 1]
+        t_lo = t_hi = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            t_lo, t_hi = _Syn1Corr.apply(a, d, g_y, lo_t.numel())
+            t_lo, t_hi = _like(t_lo, lo_t), _like(t_hi, hi_t)
+        return g_a, g_d, t_lo, t_hi, None
+
+
+class _Syn1Adj(torch.autograd.Function):
+    """g_y [R, n_out] -> [R, 2, M]: the transpose of :class:`_Syn1`."""
+
+    @staticmethod
+    def forward(ctx, g_y, lo_t, hi_t, m):
+        ctx.save_for_backward(g_y, lo_t, hi_t)
+        return _engine.ENGINE.synthesis_adjoint(g_y, (m,), _host_taps_of(lo_t), _host_taps_of(hi_t))
+
+    @staticmethod
+    def backward(ctx, gg):
+        g_y, lo_t, hi_t = ctx.saved_tensors
+        g_gy = _Syn1.apply(gg[:, 0], gg[:, 1], lo_t, hi_t, g_y.shape[1]) if ctx.needs_input_grad[0] else None
+        t_lo = t_hi = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:  # <gg, S(r)^T g_y> = <S(r) gg, g_y>
+            t_lo, t_hi = _Syn1Corr.apply(gg[:, 0], gg[:, 1], g_y, lo_t.numel())
+            t_lo, t_hi = _like(t_lo, lo_t), _like(t_hi, hi_t)
+        return g_gy, t_lo, t_hi, None
+
+
+class _Syn1Corr(torch.autograd.Function):
+    """(a, d [R, M], g_y [R, n_out]) -> (t_lo, t_hi) float64 [L]:  t_lo[j] = sum_{row, k} a[row, k] g_y[row, 2 k - (L - 2) + j] (zeros outside)."""
+
+    @staticmethod
+    def forward(ctx, a, d, g_y, flen):
+        ctx.save_for_backward(a, d, g_y)
+        t_lo = torch.zeros(flen, dtype=torch.float64, device=a.device)
+        t_hi = torch.zeros_like(t_lo)
+        _engine.ENGINE.tap_correlate(a, g_y, flen, -(flen - 2), 1, 0, t_lo)
+        _engine.ENGINE.tap_correlate(d, g_y, flen, -(flen - 2), 1, 0, t_hi)
+        return t_lo, t_hi
+
+    @staticmethod
+    def backward(ctx, w_lo, w_hi):
+        a, d, g_y = ctx.saved_tensors
+        w_lo, w_hi = w_lo.to(a.dtype), w_hi.to(a.dtype)
+        g_a = g_d = g_gy = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gb = _Syn1Adj.apply(g_y, w_lo, w_hi, a.shape[1])
+            g_a, g_d = gb[:, 0], gb[:, 1]
+        if ctx.needs_input_grad[2]:
+            g_gy = _Syn1.apply(a, d, w_lo, w_hi, g_y.shape[1])
+        return g_a, g_d, g_gy, None
+
+
+def _analysis_level_closed(x: torch.Tensor, lo_t: torch.Tensor, hi_t: torch.Tensor, mode_id: int) -> torch.Tensor:
+    """One N-D analysis level [B, N..] -> [B, 2^n, M..] as a product of :class:`_Axis1` ops (last axis first): differentiable to any
+    order w.r.t. the data and the taps."""
+    nd = x.dim() - 1
+    bands = {0: x}
+    for a in reversed(range(nd)):
+        bit = 1 << (nd - 1 - a)
+        nxt = {}
+        for s, t in bands.items():
+            tt = t.movedim(1 + a, -1)
+            out = _Axis1.apply(tt.reshape(-1, tt.shape[-1]), lo_t, hi_t, mode_id)  # [rows, 2, M]
+            for sigma in (0, 1):
+                nxt[s | (bit * sigma)] = out[:, sigma].reshape(*tt.shape[:-1], out.shape[-1]).movedim(-1, 1 + a)
+        bands = nxt
+    return torch.stack([bands[s] for s in range(1 << nd)], dim=1)
+
+
+def _synthesis_level_closed(approx: torch.Tensor, details: Sequence[torch.Tensor], lo_t: torch.Tensor, hi_t: torch.Tensor,
+                            out_ext: Sequence[int]) -> torch.Tensor:
+    """One N-D synthesis level (bands [B, M..] in band order -> [B, *out_ext]) as a product of :class:`_Syn1` ops (first axis first)."""
+    nd = approx.dim() - 1
+    bands = {s: t for s, t in enumerate([approx, *details])}
+    for a in range(nd):
+        bit = 1 << (nd - 1 - a)
+        nxt = {}
+        for s, t in bands.items():
+            if s & bit:
+                continue
+            lo, hi = t.movedim(1 + a, -1), bands[s | bit].movedim(1 + a, -1)
+            y = _Syn1.apply(lo.reshape(-1, lo.shape[-1]), hi.reshape(-1, hi.shape[-1]), lo_t, hi_t, int(out_ext[a]))
+            nxt[s] = y.reshape(*lo.shape[:-1], y.shape[-1]).movedim(-1, 1 + a)
+        bands = nxt
+    return bands[0]
+
+
+def _partials_at(values, build, cotangent, weights):
+    """Second-order partial derivatives by automatic differentiation AT DETACHED COPIES: ``values`` are the op's inputs, ``build``
+    maps fresh leaves holding their values to the level's output, ``cotangent`` (one of the leaves' positions, see callers) is the
+    upstream gradient.  Returns d/d(leaf) of  sum_i <weights_i, d <output, cotangent> / d leaf_i>  for every leaf: the derivatives of
+    the first-order gradients (as a vector-Jacobian product with ``weights``) w.r.t. every input of the op, each a PARTIAL derivative —
+    the leaves have no history, so nothing upstream is counted twice."""
+    leaves = [v.detach().clone().requires_grad_(True) for v in values]
+    with torch.enable_grad():
+        out = build(leaves)
+        first = torch.autograd.grad(out, leaves[1:], leaves[0], create_graph=True, allow_unused=True)  # (leaves[0] = the cotangent)
+        s = None
+        for f, w in zip(first, weights):
+            if f is not None and w is not None:
+                term = (f * w.to(f.dtype)).sum()
+                s = term if s is None else s + term
+        if s is None:
+            return [None] * len(leaves)
+        return list(torch.autograd.grad(s, leaves, allow_unused=True))
+
+
+def _third_order_refused(taps) -> None:
+    if torch.is_grad_enabled() and any(t.requires_grad for t in taps):
+        raise RuntimeError("ptwt_amd: derivatives beyond second order through a learnable filter bank are not supported "
+                           "(create_graph=True inside a double backward); first and second order are.")
+
+
+class _AnalysisLevelGrad(torch.autograd.Function):
+    """(g_buf, x, dec taps) -> (g_x, g_lo, g_hi): the first-order gradients of one analysis level, from the fused kernels as in
+    :class:`_AnalysisLevel`, as an op of its own so that a double backward (create_graph=True) with a LEARNABLE filter bank gets the
+    mixed second derivatives: its backward differentiates the level — rebuilt from the per-axis ops that are closed under
+    differentiation (:func:`_analysis_level_closed`) — twice at detached copies of the inputs.  The reference has these terms from
+    ATen's conv / pad backward (src/ptwt/_util.py:115-132 keeps the taps in the graph)."""
+
+    @staticmethod
+    def forward(ctx, g_buf, x, lo_t, hi_t, dec_lo, dec_hi, mode_id):
+        ctx.mode_id = mode_id
+        ctx.save_for_backward(g_buf, x, lo_t, hi_t)
+        g_x = _engine.ENGINE.analysis_adjoint(g_buf, tuple(x.shape[1:]), dec_lo, dec_hi, mode_id)
+        g_lo, g_hi = _analysis_tap_grads(x, g_buf, dec_lo, dec_hi, mode_id)
+        return g_x, _like(g_lo, lo_t), _like(g_hi, hi_t)
+
+    @staticmethod
+    def backward(ctx, w_x, w_lo, w_hi):
+        g_buf, x, lo_t, hi_t = ctx.saved_tensors
+        _third_order_refused((lo_t, hi_t))
+        mode_id = ctx.mode_id
+        d = _partials_at([g_buf, x, lo_t, hi_t], lambda lv: _analysis_level_closed(lv[1], lv[2], lv[3], mode_id), 0, [w_x, w_lo, w_hi])
+        return d[0], d[1], d[2], d[3], None, None, None
+
+
+class _SynthesisLevelGrad(torch.autograd.Function):
+    """(g_y, rec taps, approx, details) -> (g_lo, g_hi, g_approx, g_details...): the first-order gradients of one synthesis level (fused
+    kernels) as an op whose backward has the mixed second derivatives with a learnable filter bank (see :class:`_AnalysisLevelGrad`)."""
+
+    @staticmethod
+    def forward(ctx, g_y, lo_t, hi_t, rec_lo, rec_hi, approx, *details):
+        ctx.save_for_backward(g_y, lo_t, hi_t, approx, *details)
+        g = _engine.ENGINE.synthesis_adjoint(g_y, tuple(approx.shape[1:]), rec_lo, rec_hi)
+        g_lo, g_hi = _synthesis_tap_grads(g_y, approx, details, rec_lo, rec_hi)
+        return (_like(g_lo, lo_t), _like(g_hi, hi_t), *[g[:, s] for s in range(len(details) + 1)])
+
+    @staticmethod
+    def backward(ctx, w_lo, w_hi, *w_bands):
+        g_y, lo_t, hi_t, approx, *details = ctx.saved_tensors
+        _third_order_refused((lo_t, hi_t))
+        out_ext = tuple(g_y.shape[1:])
+        d = _partials_at([g_y, lo_t, hi_t, approx, *details], lambda lv: _synthesis_level_closed(lv[3], lv[4:], lv[1], lv[2], out_ext), 0,
+                         [w_lo, w_hi, *w_bands])
+        return (d[0], d[1], d[2], None, None, *d[3:])
+
+
 def _no_double_backward_through_taps(taps) -> None:
-    """Gradients of any order exist w.r.t. the DATA.  With a learnable filter bank and ``create_graph=True`` (a gradient penalty,
-    say) the mixed terms — d g_x / d taps, and the tap gradients' dependence on the upstream gradient — are not built (the kernels
-    take the taps as host floats); the reference has them from plain ATen ops (src/ptwt/_util.py:115-132).  Refuse instead of
-    silently returning a graph that lacks them."""
+    """STATIONARY levels only (swt / iswt; the ten decimated entry points and the packet trees build every mixed term, see _Axis1).
+    Gradients of any order exist w.r.t. the DATA.  With a learnable filter bank and ``create_graph=True`` (a gradient penalty,
+    say) the mixed terms — d g_x / d taps, and the tap gradients' dependence on the upstream gradient — are not built for the
+    stationary transform (the kernels take the taps as host floats); the reference has them from plain ATen ops
+    (src/ptwt/_util.py:115-132).  Refuse instead of silently returning a graph that lacks them."""
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in taps):
         raise RuntimeError(
             "ptwt_amd: double backward (create_graph=True) through a learnable filter bank is not supported: the mixed "
@@ -131,7 +381,13 @@ class _AnalysisLevel(torch.autograd.Function):
     def backward(ctx, g_buf):
         sig_shape, dec_lo, dec_hi, mode_id = ctx.meta
         (x,) = ctx.saved_tensors
-        _no_double_backward_through_taps(ctx.taps)
+        if x is not None and torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ctx.taps):
+            # a graph of this backward is wanted (create_graph=True) and the filter bank is learnable: the same first-order gradients as
+            # an op whose own backward has the mixed second derivatives (data x taps, taps x taps, upstream gradient x taps)
+            lo_t, hi_t = ctx.taps
+            g_x, g_lo, g_hi = _AnalysisLevelGrad.apply(g_buf, x, lo_t, hi_t, dec_lo, dec_hi, mode_id)
+            return (g_x if ctx.needs_input_grad[0] else None, None, None, None,
+                    g_lo if ctx.needs_input_grad[4] else None, g_hi if ctx.needs_input_grad[5] else None)
         # the adjoint is itself a differentiable level op (its derivative is this level again): gradients of any order w.r.t.
         # the data, as the reference has them from plain F.pad + conv.  (The tap gradients below are first order only.)
         g_x = _AnalysisAdjointLevel.apply(g_buf, sig_shape, dec_lo, dec_hi, mode_id) if ctx.needs_input_grad[0] else None
@@ -221,13 +477,19 @@ class _SynthesisLevel(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_y):
         coef_shape, rec_lo, rec_hi, ndet = ctx.meta
-        _no_double_backward_through_taps(ctx.taps)
+        saved = ctx.saved_tensors
+        if saved and torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ctx.taps):
+            # create_graph=True with a learnable filter bank: first-order gradients as an op that carries the mixed second derivatives
+            lo_t, hi_t = ctx.taps
+            out = _SynthesisLevelGrad.apply(g_y, lo_t, hi_t, rec_lo, rec_hi, *saved)
+            need = ctx.needs_input_grad
+            return (None, None, None, out[0] if need[3] else None, out[1] if need[4] else None,
+                    *[o if need[5 + i] else None for i, o in enumerate(out[2:])])
         g_bands = (None,) * (ndet + 1)
         if any(ctx.needs_input_grad[5:]):
             g = _SynthesisAdjointLevel.apply(g_y, coef_shape, rec_lo, rec_hi)  # differentiable in turn: any order w.r.t. the data
             g_bands = tuple(g[:, s] for s in range(ndet + 1))
         g_lo = g_hi = None
-        saved = ctx.saved_tensors
         if saved and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
             g_lo, g_hi = _synthesis_tap_grads(g_y.detach(), saved[0], saved[1:], rec_lo, rec_hi)
             g_lo, g_hi = _like(g_lo, ctx.taps[0]), _like(g_hi, ctx.taps[1])

@@ -122,3 +122,73 @@ class OracleLevelEngine:
         trims = [2 * approx.shape[1 + a] - flen + 2 - out_extent[a] for a in range(ndim)]
         y = O._idwtn(bands, bank, list(range(1, ndim + 1)), trims)
         return torch.from_numpy(np.ascontiguousarray(y))
+
+    # ---- adjoints and tap correlations (test-only, fp64 numpy: the transposes by explicit index arithmetic) ---------------------------
+    @staticmethod
+    def _pads(n, flen):
+        return flen - 2, flen - 2 + n % 2
+
+    def _axis_adjoint(self, g_lo, g_hi, n, lo, hi, mode, axis):
+        """Transpose of O.dwt_axis along `axis`: u[e] = sum_k g_b[k] h_b[2 k + 1 - e] on the extended index range, folded back through
+        O.ext_index."""
+        flen = len(lo)
+        g_lo, g_hi = np.moveaxis(g_lo, axis, -1), np.moveaxis(g_hi, axis, -1)
+        m = g_lo.shape[-1]
+        pl, pr = self._pads(n, flen)
+        ext = np.arange(-pl, n + pr)
+        u = np.zeros(g_lo.shape[:-1] + (ext.size,), dtype=np.float64)
+        for k in range(m):
+            for t in range(flen):
+                e = 2 * k + 1 - t
+                if -pl <= e < n + pr:
+                    u[..., e + pl] += g_lo[..., k] * lo[t] + g_hi[..., k] * hi[t]
+        src = O.ext_index(ext, n, mode)
+        out = np.zeros(g_lo.shape[:-1] + (n,), dtype=np.float64)
+        for j, s_ in enumerate(src):
+            if s_ >= 0:
+                out[..., s_] += u[..., j]
+        return np.moveaxis(out, -1, axis)
+
+    def analysis_adjoint(self, g_buf, sig_shape, dec_lo, dec_hi, mode_id):
+        nd = g_buf.dim() - 2
+        lo, hi = np.asarray(dec_lo, dtype=np.float64), np.asarray(dec_hi, dtype=np.float64)
+        bands = {s: g_buf[:, s].detach().numpy().astype(np.float64) for s in range(1 << nd)}
+        for a in range(nd):  # undo the axes one by one: pairs that differ in the bit of axis a
+            bit = 1 << (nd - 1 - a)
+            bands = {s: self._axis_adjoint(t, bands[s | bit], int(sig_shape[a]), lo, hi, _MODES[mode_id], 1 + a) for s, t in bands.items() if not s & bit}
+        return torch.from_numpy(np.ascontiguousarray(bands[0])).to(g_buf.dtype)
+
+    def analysis_adjoint_bands(self, g_approx, g_details, sig_shape, dec_lo, dec_hi, mode_id):
+        return self.analysis_adjoint(torch.stack([g_approx, *g_details], dim=1), sig_shape, dec_lo, dec_hi, mode_id)
+
+    def synthesis_adjoint(self, g_y, coef_shape, rec_lo, rec_hi):
+        """Transpose of synthesis(): g_b[k] = sum_n g_y[n] r_b[n + L - 2 - 2 k] per axis (zeros outside the cropped output)."""
+        nd = g_y.dim() - 1
+        lo, hi = np.asarray(rec_lo, dtype=np.float64), np.asarray(rec_hi, dtype=np.float64)
+        flen = len(lo)
+        bands = {0: g_y.detach().numpy().astype(np.float64)}
+        for a in reversed(range(nd)):
+            bit = 1 << (nd - 1 - a)
+            nxt = {}
+            for s, t in bands.items():
+                t = np.moveaxis(t, 1 + a, -1)
+                n, m = t.shape[-1], int(coef_shape[a])
+                ga, gd = np.zeros(t.shape[:-1] + (m,)), np.zeros(t.shape[:-1] + (m,))
+                for k in range(m):
+                    for j in range(flen):
+                        i = 2 * k - (flen - 2) + j
+                        if 0 <= i < n:
+                            ga[..., k] += t[..., i] * lo[j]
+                            gd[..., k] += t[..., i] * hi[j]
+                nxt[s], nxt[s | bit] = np.moveaxis(ga, -1, 1 + a), np.moveaxis(gd, -1, 1 + a)
+            bands = nxt
+        return torch.from_numpy(np.stack([bands[s] for s in range(1 << nd)], axis=1)).to(g_y.dtype)
+
+    def tap_correlate(self, a, b, filt_len, c0, sgn, mode_id, out):
+        """out[t] += sum_{row, k} a[row, k] b_ext[row, 2 k + c0 + sgn t]"""
+        an, bn = a.detach().numpy().astype(np.float64), b.detach().numpy().astype(np.float64)
+        n = bn.shape[1]
+        for t in range(filt_len):
+            idx = O.ext_index(2 * np.arange(an.shape[1]) + c0 + sgn * t, n, _MODES[mode_id])
+            vals = np.where(idx >= 0, bn[:, np.clip(idx, 0, n - 1)], 0.0)
+            out[t] += float((an * vals).sum())

@@ -428,16 +428,77 @@ def test_second_order_gradients_swt():
         assert G.relerr(a.cpu().numpy(), b.cpu().numpy()) < 1e-11
 
 
-def test_double_backward_through_learnable_taps_is_refused():
-    """create_graph=True with a learnable filter bank: the mixed second derivatives w.r.t. the taps are not built, so the backward
-    raises instead of returning a graph that silently lacks them (data-only double backward keeps working: tests above)."""
+def weight2(t, i):
+    return torch.cos(0.53 * torch.arange(t.numel(), dtype=torch.float64, device=t.device) + i).reshape(t.shape).to(t.dtype)
+
+
+def test_second_order_gradients_with_learnable_taps_vs_reference():
+    """create_graph=True through a learnable filter bank (round 4): the mixed second derivatives — data x taps, taps x
+    taps, upstream gradient x taps — against the reference's own double backward through ATen's conv path
+    (tests/golden/ptwt_ref_tapgrads2.npz, tests/golden/make_ptwt_ref_tapgrad2_goldens.py): the ten level transforms, 1-3 axes, five
+    boundary modes; fp64, 1e-9 norm-wise.  (The backward that is asked for a graph re-runs the level as a product of per-axis ops that
+    are closed under differentiation, `_fwt._Axis1` / `_Syn1`.)"""
+    import json
+    import os
+
+    from ptwt_amd import WaveletTensorTuple
+
+    z, idx = G.load("ptwt_ref_tapgrads2.npz")
+    with open(os.path.join(G.GOLDEN, "pywt_filter_banks.json")) as f:
+        banks = json.load(f)
+    for case in idx:
+        k = case["key"]
+        kw = {a: (tuple(v) if isinstance(v, list) else v) for a, v in case["kw"].items()}
+        x = torch.from_numpy(z[k + "_x"]).to(dev()).requires_grad_(True)
+        name = "haar" if case["wavelet"] == "db1" else case["wavelet"]
+        taps = [torch.tensor(banks[name][f], dtype=torch.float64, device=dev(), requires_grad=True) for f in ("dec_lo", "dec_hi", "rec_lo", "rec_hi")]
+        wt = WaveletTensorTuple(*taps)
+        # ---- analysis
+        fl = flat(getattr(ptwt_amd, case["fn"])(x, wt, **kw))
+        f = sum((weight(t, i) * t.square()).sum() for i, t in enumerate(fl)) / 2
+        g_x, t_lo, t_hi = torch.autograd.grad(f, [x, taps[0], taps[1]], create_graph=True)
+        s1 = (g_x * weight2(g_x, 1)).sum() + (t_lo * weight2(t_lo, 2)).sum() + (t_hi * weight2(t_hi, 3)).sum()
+        d = torch.autograd.grad(s1, [x, taps[0], taps[1]])
+        for got, nme in zip(d, ("a_dx", "a_dlo", "a_dhi")):
+            assert G.relerr(got.cpu().numpy(), z["%s_%s" % (k, nme)]) < 1e-9, (case, nme)
+        # ---- synthesis
+        coeffs = getattr(ptwt_amd, case["fn"])(x.detach(), case["wavelet"], **kw)
+        leaves = [t.detach().clone().requires_grad_(True) for t in flat(coeffs)]
+        assert len(leaves) == case["ncoef"]
+        rkw = {a: v for a, v in kw.items() if a in ("axis", "axes")}
+        y = getattr(ptwt_amd, case["rec"])(rebuild(coeffs, leaves), wt, **rkw)
+        f = (weight(y, 7) * y.square()).sum() / 2
+        grads = torch.autograd.grad(f, leaves + [taps[2], taps[3]], create_graph=True)
+        s2 = sum((gc * weight2(gc, 4 + i)).sum() for i, gc in enumerate(grads[:-2]))
+        s2 = s2 + (grads[-2] * weight2(grads[-2], 2)).sum() + (grads[-1] * weight2(grads[-1], 3)).sum()
+        d2 = torch.autograd.grad(s2, leaves + [taps[2], taps[3]])
+        for i, got in enumerate(d2[:-2]):
+            assert G.relerr(got.cpu().numpy(), z["%s_s_dc%d" % (k, i)]) < 1e-9, (case, "s_dc", i)
+        assert G.relerr(d2[-2].cpu().numpy(), z[k + "_s_dlo"]) < 1e-9, (case, "s_dlo")
+        assert G.relerr(d2[-1].cpu().numpy(), z[k + "_s_dhi"]) < 1e-9, (case, "s_dhi")
+
+
+def test_double_backward_through_learnable_taps_decimated_works_stationary_refused():
+    """A gradient penalty with a learnable wavelet (create_graph=True) works for the decimated transforms and packet trees; the
+    stationary transform still refuses instead of returning a graph that lacks the mixed terms."""
     bank = tuple(torch.tensor(v, device=dev(), dtype=torch.float64, requires_grad=True) for v in ptwt_amd._wavelets.host_taps("db2"))
     x = torch.randn(2, 32, 32, device=dev(), dtype=torch.float64, requires_grad=True)
     y = sum(c.square().sum() if isinstance(c, torch.Tensor) else sum(t.square().sum() for t in c) for c in ptwt_amd.wavedec2(x, bank, level=1))
+    (g,) = torch.autograd.grad(y, x, create_graph=True)
+    pen = g.square().sum()
+    gb = torch.autograd.grad(pen, [x, bank[0], bank[1]])
+    assert all(torch.isfinite(t).all() and t.abs().sum() > 0 for t in gb)
+    wp = ptwt_amd.WaveletPacket(x[:, 0], bank, mode="reflect", maxlevel=2)
+    leaf = wp["ad"]
+    (g,) = torch.autograd.grad(leaf.square().sum(), x, create_graph=True)
+    gb = torch.autograd.grad(g.square().sum(), [bank[0], bank[1]])
+    assert all(torch.isfinite(t).all() and t.abs().sum() > 0 for t in gb)
+    xs = torch.randn(2, 64, device=dev(), dtype=torch.float64, requires_grad=True)
+    ys = sum(c.square().sum() for c in ptwt_amd.swt(xs, bank, level=2))
     with pytest.raises(RuntimeError, match="double backward"):
-        torch.autograd.grad(y, x, create_graph=True)
-    (g,) = torch.autograd.grad(y, x)  # first order is fine
-    assert g.shape == x.shape
+        torch.autograd.grad(ys, xs, create_graph=True)
+    (g,) = torch.autograd.grad(ys, xs)  # first order is fine
+    assert g.shape == xs.shape
 
 
 def test_tensor_taps_are_read_live_on_every_call():

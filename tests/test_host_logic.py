@@ -458,3 +458,58 @@ def test_dwt1_inv_long_plan_and_argument_checks():
     rs = (ctypes.c_int64 * 7)(*([0] * 7))
     assert lib.mifwt_dwt1_inv_long(0, 10, 32, 7, arr(m[3:]), null, 0, det, rs, one, 0, taps, taps, null) == -1
     assert lib.mifwt_dwt1_inv_long(0, 10, 32, 8, arr(m[2:]), one, 0, det, rs, one, 0, taps, taps, null) == -2
+
+
+# ------------------------------------------------------------------------------------------ learnable filter banks, second order (no GPU)
+def test_second_order_gradients_with_learnable_taps_host_algebra(oracle_engine):
+    """The autograd algebra of a double backward through a learnable filter bank (`_fwt._AnalysisLevelGrad` / `_SynthesisLevelGrad`:
+    first-order gradients as ops whose backward differentiates the level, rebuilt from per-axis ops that are closed under
+    differentiation, at detached copies of the inputs) against the reference's own double backward
+    (tests/golden/ptwt_ref_tapgrads2.npz), with the level kernels replaced by the oracle stand-in: every mixed term data x taps,
+    taps x taps, upstream gradient x taps, multi-level chains included.  The same cases run on the HIP kernels in
+    tests/test_gpu_autograd.py."""
+    import json
+
+    from ptwt_amd import WaveletTensorTuple
+
+    def weight(t, i, f=0.37):
+        return torch.cos(f * torch.arange(t.numel(), dtype=torch.float64) + i).reshape(t.shape).to(t.dtype)
+
+    def flat(coeffs):
+        return [t for _, t in G.flatten_coeffs(coeffs)]
+
+    def rebuild(coeffs, leaves):
+        it = iter(leaves)
+        out = [next(it)]
+        for c in coeffs[1:]:
+            out.append(next(it) if isinstance(c, torch.Tensor) else ({k: next(it) for k in c} if isinstance(c, dict) else type(c)(*[next(it) for _ in c])))
+        return out if isinstance(coeffs, list) else tuple(out)
+
+    z, idx = G.load("ptwt_ref_tapgrads2.npz")
+    with open(os.path.join(G.GOLDEN, "pywt_filter_banks.json")) as f:
+        banks = json.load(f)
+    for case in idx:
+        if case["fn"] in ("wavedec3", "fswavedec3") and case["shape"][1] > 12:
+            continue  # (the numpy stand-in's adjoints are loops: keep the CPU tier quick)
+        k = case["key"]
+        kw = {a: (tuple(v) if isinstance(v, list) else v) for a, v in case["kw"].items()}
+        x = torch.from_numpy(z[k + "_x"]).requires_grad_(True)
+        taps = [torch.tensor(banks[case["wavelet"]][f], dtype=torch.float64, requires_grad=True) for f in ("dec_lo", "dec_hi", "rec_lo", "rec_hi")]
+        wt = WaveletTensorTuple(*taps)
+        fl = flat(getattr(ptwt_amd, case["fn"])(x, wt, **kw))
+        f = sum((weight(t, i) * t.square()).sum() for i, t in enumerate(fl)) / 2
+        g_x, t_lo, t_hi = torch.autograd.grad(f, [x, taps[0], taps[1]], create_graph=True)
+        s1 = (g_x * weight(g_x, 1, 0.53)).sum() + (t_lo * weight(t_lo, 2, 0.53)).sum() + (t_hi * weight(t_hi, 3, 0.53)).sum()
+        for got, nme in zip(torch.autograd.grad(s1, [x, taps[0], taps[1]]), ("a_dx", "a_dlo", "a_dhi")):
+            assert G.relerr(got.numpy(), z["%s_%s" % (k, nme)]) < 1e-11, (case, nme)
+        coeffs = getattr(ptwt_amd, case["fn"])(x.detach(), case["wavelet"], **kw)
+        leaves = [t.detach().clone().requires_grad_(True) for t in flat(coeffs)]
+        rkw = {a: v for a, v in kw.items() if a in ("axis", "axes")}
+        y = getattr(ptwt_amd, case["rec"])(rebuild(coeffs, leaves), wt, **rkw)
+        grads = torch.autograd.grad((weight(y, 7) * y.square()).sum() / 2, leaves + [taps[2], taps[3]], create_graph=True)
+        s2 = sum((gc * weight(gc, 4 + i, 0.53)).sum() for i, gc in enumerate(grads[:-2]))
+        s2 = s2 + (grads[-2] * weight(grads[-2], 2, 0.53)).sum() + (grads[-1] * weight(grads[-1], 3, 0.53)).sum()
+        d2 = torch.autograd.grad(s2, leaves + [taps[2], taps[3]])
+        for i, got in enumerate(d2[:-2]):
+            assert G.relerr(got.numpy(), z["%s_s_dc%d" % (k, i)]) < 1e-11, (case, "s_dc", i)
+        assert G.relerr(d2[-2].numpy(), z[k + "_s_dlo"]) < 1e-11 and G.relerr(d2[-1].numpy(), z[k + "_s_dhi"]) < 1e-11, case
