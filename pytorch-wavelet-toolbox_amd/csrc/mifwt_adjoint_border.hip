@@ -10,12 +10,13 @@
 // and  (E^T u)[n] = the sum of u over every extended index that maps to n.  For e inside [0, N) u is exactly what the zero-mode adjoint
 // computes — the fused SYNTHESIS kernels with the dec taps reversed (mifwt_api.hip, run_inv) — and an interior sample has no other
 // preimage.  So the adjoint with ANY boundary mode = that fast launch over the whole signal + this kernel, which recomputes, from
-// scratch, the samples within B = L - 1 + N % 2 of a border: one thread per such sample, every preimage of it (itself, mirrored /
+// scratch, the samples within B = L - 1 + N % 2 of a border: 16 lanes per such sample, every preimage of it (itself, mirrored /
 // wrapped / clamped pad positions) times every coefficient in reach.  O(preimages x (L/2)^ndim x 2^ndim) per border sample, a few
 // percent of a level's samples: 64 x 1024^2 db4 reflect: 1.18 ms for the generic per-axis adjoint passes -> the synthesis kernel's
 // 0.12 ms + this.  f32 (f32 sums) and f64, 1-3 axes, L <= 32, single-fold extents (N >= 2 B per axis); everything else stays on the
 // generic passes (launch_axis_adj).
 #include "mifwt_common.h"
+#include "mifwt_stream.h"
 
 namespace mifwt {
 
@@ -31,46 +32,38 @@ struct BorderArgs {
   int64_t as[ND + 1], ds[ND + 1];  // ... of the approximation's / the detail bands' gradients
   int N[ND], M[ND], B[ND], pl[ND], pr[ND];
   int L, mode;
-  int64_t per_image, total;  // border samples per batch element / in all
+  uint32_t per_image;        // border samples per batch element (a launch covers `images` of them: blockIdx.y)
+  int64_t img0;              // first batch element of this launch
+  uint32_t slabs[ND], rest_border[ND];     // decode_border: samples in the border hyperplanes of axis d / border samples of a box of the axes after d
+  FastDiv dv_full[ND], dv_border[ND], dv_n[ND];  // divisions by (full hyperplane of the axes after d), rest_border[d], N[d]
   T lo[kMaxTaps], hi[kMaxTaps];
 };
 
-// the e-th border sample of a box of extents N[d..ND) with border widths B: coordinates n[d..ND).  Samples are enumerated
-// slab by slab: first the 2 B[d] border hyperplanes of axis d (full extent of the other axes), then, for every interior position of
-// axis d, the border samples of the remaining axes.
-template <int ND>
-__device__ __forceinline__ void decode_border(int64_t e, const int* N, const int* B, int* n) {
-  int64_t rest_full = 1;  // samples of a full hyperplane of the axes after d
+// the e-th border sample of a box of extents N with border widths B: coordinates n.  Samples are enumerated slab by slab: first the
+// 2 B[d] border hyperplanes of axis d (full extent of the axes after it), then, for every interior position of axis d, the border
+// samples of the remaining axes.  32-bit indices, divisions by launch-time constants (FastDiv: the 64-bit runtime divisions of the
+// first version cost more than the sums once 16 lanes shared a sample).
+template <typename T, int ND>
+__device__ __forceinline__ void decode_border(uint32_t e, const BorderArgs<T, ND>& a, int* n) {
 #pragma unroll
   for (int d = 0; d < ND; ++d) {
-    rest_full = 1;
-#pragma unroll
-    for (int q = d + 1; q < ND; ++q) rest_full *= N[q];
-    const int64_t slabs = 2 * (int64_t)B[d] * rest_full;
-    if (e < slabs || d == ND - 1) {
-      // inside a border hyperplane of axis d: everything after d is a plain mixed-radix index
-      const int64_t hb = e / rest_full;
-      int64_t r = e - hb * rest_full;
-      n[d] = hb < B[d] ? (int)hb : N[d] - 2 * B[d] + (int)hb;
+    if (e < a.slabs[d] || d == ND - 1) {
+      uint32_t r;
+      const uint32_t hb = a.dv_full[d].divmod(e, r);  // which border hyperplane of axis d, position inside it
+      n[d] = (int)hb < a.B[d] ? (int)hb : a.N[d] - 2 * a.B[d] + (int)hb;
 #pragma unroll
       for (int q = ND - 1; q > d; --q) {
-        n[q] = (int)(r % N[q]);
-        r /= N[q];
+        uint32_t rem;
+        r = a.dv_n[q].divmod(r, rem);
+        n[q] = (int)rem;
       }
       return;
     }
-    e -= slabs;
-    // interior position of axis d, then recurse into the remaining axes
-    int64_t rest_border = 1, rest_inner = 1;
-#pragma unroll
-    for (int q = d + 1; q < ND; ++q) {
-      rest_border *= N[q];
-      rest_inner *= N[q] - 2 * B[q];
-    }
-    rest_border -= rest_inner;  // border samples of a box of the remaining axes
-    const int64_t pos = e / rest_border;
-    n[d] = B[d] + (int)pos;
-    e -= pos * rest_border;
+    e -= a.slabs[d];
+    uint32_t rem;
+    const uint32_t pos = a.dv_border[d].divmod(e, rem);
+    n[d] = a.B[d] + (int)pos;
+    e = rem;
   }
 }
 
@@ -108,6 +101,12 @@ __device__ __forceinline__ void preimages(int n, int N, int pl, int pr, int mode
   }
 }
 
+// 16 lanes per border sample: the lanes split the coefficient positions in reach (per axis: lane part i_d takes k = k_lo + i_d,
+// k_lo + i_d + P_d, ...; P = 16 / 4 x 4 / 2 x 2 x 4 for 1 / 2 / 3 axes), each loops over the preimages and the bands, then the 16
+// partial sums meet in a shuffle tree.  (One thread per sample, the first version, ran ~64 dependent load-then-FMA rounds per thread:
+// 30 us for the smallest level of config 2 whatever its size, 85 us for level 1.)
+constexpr int kLanesPerSample = 16;
+
 template <typename T, int ND>
 __global__ void __launch_bounds__(256) adjoint_border_kernel(const BorderArgs<T, ND> a) {
   // the taps are indexed per lane: from LDS (from the kernel arguments every such read is a memory request)
@@ -117,42 +116,40 @@ __global__ void __launch_bounds__(256) adjoint_border_kernel(const BorderArgs<T,
     s_hi[threadIdx.x] = a.hi[threadIdx.x];
   }
   __syncthreads();
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= a.total) return;
-  const int64_t img = t / a.per_image;
+  const uint32_t e = (blockIdx.x * 256u + threadIdx.x) / kLanesPerSample;
+  const int sub = threadIdx.x & (kLanesPerSample - 1);
+  if (e >= a.per_image) return;  // (whole 16-lane groups leave together)
+  const int64_t img = a.img0 + blockIdx.y;
   int n[ND];
-  decode_border<ND>(t - img * a.per_image, a.N, a.B, n);
+  decode_border<T, ND>(e, a, n);
   int ra[ND][3], rb[ND][3];
 #pragma unroll
   for (int d = 0; d < ND; ++d) preimages(n[d], a.N[d], a.pl[d], a.pr[d], a.mode, ra[d], rb[d]);
   const int L = a.L;
   T acc = 0;
-  // nested loops over (range, extended index, coefficient index) per axis; the innermost axis is ND - 1
   if constexpr (ND == 1) {
     for (int q0 = 0; q0 < 3; ++q0)
       for (int e0 = ra[0][q0]; e0 <= rb[0][q0]; ++e0) {
-        const int k_lo = max(0, (e0 - 1 + 1) >> 1), k_hi = min(a.M[0] - 1, (e0 + L - 2) >> 1);  // (e0 - 1) / 2 rounded up; e0 + L - 2 >= 0
-        for (int k0 = k_lo; k0 <= k_hi; ++k0) {
+        const int k_lo = max(0, e0 >> 1), k_hi = min(a.M[0] - 1, (e0 + L - 2) >> 1);  // 0 <= 2 k + 1 - e0 < L
+        for (int k0 = k_lo + sub; k0 <= k_hi; k0 += 16) {
           const int m0 = 2 * k0 + 1 - e0;
-          if ((unsigned)m0 >= (unsigned)L) continue;
           const int64_t oa = img * a.as[0] + k0 * a.as[1], od = img * a.ds[0] + k0 * a.ds[1];
           acc += a.gband[0][oa] * s_lo[m0] + a.gband[1][od] * s_hi[m0];
         }
       }
   } else if constexpr (ND == 2) {
+    const int i0 = sub >> 2, i1 = sub & 3;
     for (int q0 = 0; q0 < 3; ++q0)
       for (int e0 = ra[0][q0]; e0 <= rb[0][q0]; ++e0) {
         const int k0_lo = max(0, e0 >> 1), k0_hi = min(a.M[0] - 1, (e0 + L - 2) >> 1);
-        for (int k0 = k0_lo; k0 <= k0_hi; ++k0) {
+        for (int k0 = k0_lo + i0; k0 <= k0_hi; k0 += 4) {
           const int m0 = 2 * k0 + 1 - e0;
-          if ((unsigned)m0 >= (unsigned)L) continue;
           const T l0 = s_lo[m0], h0 = s_hi[m0];
           for (int q1 = 0; q1 < 3; ++q1)
             for (int e1 = ra[1][q1]; e1 <= rb[1][q1]; ++e1) {
               const int k1_lo = max(0, e1 >> 1), k1_hi = min(a.M[1] - 1, (e1 + L - 2) >> 1);
-              for (int k1 = k1_lo; k1 <= k1_hi; ++k1) {
+              for (int k1 = k1_lo + i1; k1 <= k1_hi; k1 += 4) {
                 const int m1 = 2 * k1 + 1 - e1;
-                if ((unsigned)m1 >= (unsigned)L) continue;
                 const T l1 = s_lo[m1], h1 = s_hi[m1];
                 const int64_t oa = img * a.as[0] + k0 * a.as[1] + k1 * a.as[2], od = img * a.ds[0] + k0 * a.ds[1] + k1 * a.ds[2];
                 acc += l0 * (a.gband[0][oa] * l1 + a.gband[1][od] * h1) + h0 * (a.gband[2][od] * l1 + a.gband[3][od] * h1);
@@ -161,27 +158,25 @@ __global__ void __launch_bounds__(256) adjoint_border_kernel(const BorderArgs<T,
         }
       }
   } else {
+    const int i0 = sub >> 3, i1 = (sub >> 2) & 1, i2 = sub & 3;
     for (int q0 = 0; q0 < 3; ++q0)
       for (int e0 = ra[0][q0]; e0 <= rb[0][q0]; ++e0) {
         const int k0_lo = max(0, e0 >> 1), k0_hi = min(a.M[0] - 1, (e0 + L - 2) >> 1);
-        for (int k0 = k0_lo; k0 <= k0_hi; ++k0) {
+        for (int k0 = k0_lo + i0; k0 <= k0_hi; k0 += 2) {
           const int m0 = 2 * k0 + 1 - e0;
-          if ((unsigned)m0 >= (unsigned)L) continue;
           const T l0 = s_lo[m0], h0 = s_hi[m0];
           for (int q1 = 0; q1 < 3; ++q1)
             for (int e1 = ra[1][q1]; e1 <= rb[1][q1]; ++e1) {
               const int k1_lo = max(0, e1 >> 1), k1_hi = min(a.M[1] - 1, (e1 + L - 2) >> 1);
-              for (int k1 = k1_lo; k1 <= k1_hi; ++k1) {
+              for (int k1 = k1_lo + i1; k1 <= k1_hi; k1 += 2) {
                 const int m1 = 2 * k1 + 1 - e1;
-                if ((unsigned)m1 >= (unsigned)L) continue;
                 const T l1 = s_lo[m1], h1 = s_hi[m1];
                 const T w00 = l0 * l1, w01 = l0 * h1, w10 = h0 * l1, w11 = h0 * h1;  // (axis 0, axis 1) = (lo, lo), (lo, hi), ...
                 for (int q2 = 0; q2 < 3; ++q2)
                   for (int e2 = ra[2][q2]; e2 <= rb[2][q2]; ++e2) {
                     const int k2_lo = max(0, e2 >> 1), k2_hi = min(a.M[2] - 1, (e2 + L - 2) >> 1);
-                    for (int k2 = k2_lo; k2 <= k2_hi; ++k2) {
+                    for (int k2 = k2_lo + i2; k2 <= k2_hi; k2 += 4) {
                       const int m2 = 2 * k2 + 1 - e2;
-                      if ((unsigned)m2 >= (unsigned)L) continue;
                       const T l2 = s_lo[m2], h2 = s_hi[m2];
                       const int64_t oa = img * a.as[0] + k0 * a.as[1] + k1 * a.as[2] + k2 * a.as[3];
                       const int64_t od = img * a.ds[0] + k0 * a.ds[1] + k1 * a.ds[2] + k2 * a.ds[3];
@@ -194,6 +189,9 @@ __global__ void __launch_bounds__(256) adjoint_border_kernel(const BorderArgs<T,
         }
       }
   }
+#pragma unroll
+  for (int m = kLanesPerSample / 2; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+  if (sub != 0) return;
   int64_t ox = img * a.xs[0];
 #pragma unroll
   for (int d = 0; d < ND; ++d) ox += (int64_t)n[d] * a.xs[1 + d];
@@ -224,16 +222,32 @@ int launch_border(const mifwt_level_desc* d, const void* g_approx, const void* c
   }
   a.L = d->filt_len;
   a.mode = d->mode;
-  a.per_image = box - inner;
-  a.total = a.per_image * d->batch;
+  const int64_t per_image = box - inner;
+  if (per_image * kLanesPerSample >= (int64_t(1) << 31)) return MIFWT_ERR_UNSUPPORTED;
+  a.per_image = (uint32_t)per_image;
+  for (int i = 0; i < ND; ++i) {
+    int64_t rest_full = 1, rest_inner = 1;
+    for (int q = i + 1; q < ND; ++q) {
+      rest_full *= a.N[q];
+      rest_inner *= a.N[q] - 2 * a.B[q];
+    }
+    a.slabs[i] = (uint32_t)(2 * (int64_t)a.B[i] * rest_full);
+    a.rest_border[i] = (uint32_t)(rest_full - rest_inner);
+    a.dv_full[i] = make_fastdiv((uint32_t)rest_full);
+    a.dv_border[i] = make_fastdiv(a.rest_border[i] ? a.rest_border[i] : 1u);
+    a.dv_n[i] = make_fastdiv((uint32_t)a.N[i]);
+  }
   for (int m = 0; m < kMaxTaps; ++m) {
     a.lo[m] = m < a.L ? (T)lo[m] : (T)0;
     a.hi[m] = m < a.L ? (T)hi[m] : (T)0;
   }
-  if (a.total == 0) return MIFWT_OK;
-  const int64_t blocks = (a.total + 255) / 256;
-  if (blocks > INT32_MAX) return MIFWT_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((adjoint_border_kernel<T, ND>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+  if (per_image == 0 || d->batch == 0) return MIFWT_OK;
+  const unsigned gx = (unsigned)((per_image * kLanesPerSample + 255) / 256);
+  for (int64_t b0 = 0; b0 < d->batch; b0 += 32768) {  // (grid.y is 16 bits)
+    a.img0 = b0;
+    const unsigned gy = (unsigned)std::min<int64_t>(32768, d->batch - b0);
+    hipLaunchKernelGGL((adjoint_border_kernel<T, ND>), dim3(gx, gy), dim3(256), 0, stream, a);
+  }
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 
@@ -246,11 +260,15 @@ bool adjoint_border_supported(const mifwt_level_desc* d) {
   if (d->mode == MIFWT_MODE_ZERO || d->ndim < 1 || d->ndim > 3) return false;
   if (d->dtype != MIFWT_F32 && d->dtype != MIFWT_F64) return false;
   if (d->filt_len > kMaxTaps || d->filt_len < 2 || (d->filt_len & 1)) return false;
+  int64_t box = 1, inner = 1;
   for (int i = 0; i < d->ndim; ++i) {
     const int64_t n = d->sig_extent[i];
     if (n < 2 * (d->filt_len + 1) || n > INT32_MAX / 4) return false;
+    box *= n;
+    inner *= n - 2 * (d->filt_len - 1 + (n & 1));
+    if (box >= (int64_t(1) << 40)) return false;
   }
-  return true;
+  return (box - inner) * kLanesPerSample < (int64_t(1) << 31);  // 32-bit sample indices inside one batch element
 }
 
 int adjoint_border(const mifwt_level_desc* d, const void* g_approx, const void* const* g_details, void* g_x, const double* lo,

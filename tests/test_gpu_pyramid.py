@@ -144,7 +144,7 @@ def test_pyramid_small_and_ragged_planes():
                 check(x, wavelet, "symmetric", level)
 
 
-def test_pyramid_config2_full_size_all_images():
+def test_pyramid_config2_full_size_all_64_images_vs_device_f64_and_16_images_vs_numpy_oracle():
     """BASELINE config 2 (64 x 1024^2 db4 level 3): every image of the batch against an on-device fp64 run of the per-level tile
     kernels (already pinned against the oracle and the goldens), 4 images against the numpy oracle itself."""
     g = torch.Generator().manual_seed(17)
