@@ -10,7 +10,7 @@
 // and  (E^T u)[n] = the sum of u over every extended index that maps to n.  For e inside [0, N) u is exactly what the zero-mode adjoint
 // computes — the fused SYNTHESIS kernels with the dec taps reversed (mifwt_api.hip, run_inv) — and an interior sample has no other
 // preimage.  So the adjoint with ANY boundary mode = that fast launch over the whole signal + this kernel, which recomputes, from
-// scratch, the samples within B = L - 1 + N % 2 of a border: 16 lanes per such sample, every preimage of it (itself, mirrored /
+// scratch, the samples within B = L - 1 + N % 2 of a border: one thread per such sample, every preimage of it (itself, mirrored /
 // wrapped / clamped pad positions) times every coefficient in reach.  O(preimages x (L/2)^ndim x 2^ndim) per border sample, a few
 // percent of a level's samples: 64 x 1024^2 db4 reflect: 1.18 ms for the generic per-axis adjoint passes -> the synthesis kernel's
 // 0.12 ms + this.  f32 (f32 sums) and f64, 1-3 axes, L <= 32, single-fold extents (N >= 2 B per axis); everything else stays on the
@@ -101,11 +101,19 @@ __device__ __forceinline__ void preimages(int n, int N, int pl, int pr, int mode
   }
 }
 
-// 16 lanes per border sample: the lanes split the coefficient positions in reach (per axis: lane part i_d takes k = k_lo + i_d,
-// k_lo + i_d + P_d, ...; P = 16 / 4 x 4 / 2 x 2 x 4 for 1 / 2 / 3 axes), each loops over the preimages and the bands, then the 16
-// partial sums meet in a shuffle tree.  (One thread per sample, the first version, ran ~64 dependent load-then-FMA rounds per thread:
-// 30 us for the smallest level of config 2 whatever its size, 85 us for level 1.)
-constexpr int kLanesPerSample = 16;
+// Lanes per border sample (1, 4 or 16): with more than one the lanes split the coefficient positions in reach (per axis: lane part i_d
+// takes k = k_lo + i_d, k_lo + i_d + S_d, ...) and their partial sums meet in a shuffle tree.  MEASURED on config 2 (reflect, level 1 /
+// 2 / 3 of the backward): one lane per sample 85 / 50 / 30 us, sixteen 215 / 105 / 55 us — the kernel is bound by its instruction
+// count (~25 instructions of loop and address arithmetic per 4 loads), not by latency, and sixteen lanes run the loop nests sixteen
+// times.  One lane per sample it is.
+#ifndef MIFWT_BORDER_LANES
+#define MIFWT_BORDER_LANES 1
+#endif
+constexpr int kLanesPerSample = MIFWT_BORDER_LANES;
+static_assert(kLanesPerSample == 1 || kLanesPerSample == 4 || kLanesPerSample == 16, "lanes per border sample");
+constexpr int kS1 = kLanesPerSample;                                                             // 1 axis: all lanes along it
+constexpr int kS2a = kLanesPerSample == 16 ? 4 : (kLanesPerSample == 4 ? 2 : 1), kS2b = kS2a;   // 2 axes
+constexpr int kS3a = kLanesPerSample == 16 ? 2 : 1, kS3b = kLanesPerSample >= 4 ? 2 : 1, kS3c = kLanesPerSample / (kS3a * kS3b);  // 3 axes
 
 template <typename T, int ND>
 __global__ void __launch_bounds__(256) adjoint_border_kernel(const BorderArgs<T, ND> a) {
@@ -131,24 +139,24 @@ __global__ void __launch_bounds__(256) adjoint_border_kernel(const BorderArgs<T,
     for (int q0 = 0; q0 < 3; ++q0)
       for (int e0 = ra[0][q0]; e0 <= rb[0][q0]; ++e0) {
         const int k_lo = max(0, e0 >> 1), k_hi = min(a.M[0] - 1, (e0 + L - 2) >> 1);  // 0 <= 2 k + 1 - e0 < L
-        for (int k0 = k_lo + sub; k0 <= k_hi; k0 += 16) {
+        for (int k0 = k_lo + sub; k0 <= k_hi; k0 += kS1) {
           const int m0 = 2 * k0 + 1 - e0;
           const int64_t oa = img * a.as[0] + k0 * a.as[1], od = img * a.ds[0] + k0 * a.ds[1];
           acc += a.gband[0][oa] * s_lo[m0] + a.gband[1][od] * s_hi[m0];
         }
       }
   } else if constexpr (ND == 2) {
-    const int i0 = sub >> 2, i1 = sub & 3;
+    const int i0 = sub / kS2b, i1 = sub % kS2b;
     for (int q0 = 0; q0 < 3; ++q0)
       for (int e0 = ra[0][q0]; e0 <= rb[0][q0]; ++e0) {
         const int k0_lo = max(0, e0 >> 1), k0_hi = min(a.M[0] - 1, (e0 + L - 2) >> 1);
-        for (int k0 = k0_lo + i0; k0 <= k0_hi; k0 += 4) {
+        for (int k0 = k0_lo + i0; k0 <= k0_hi; k0 += kS2a) {
           const int m0 = 2 * k0 + 1 - e0;
           const T l0 = s_lo[m0], h0 = s_hi[m0];
           for (int q1 = 0; q1 < 3; ++q1)
             for (int e1 = ra[1][q1]; e1 <= rb[1][q1]; ++e1) {
               const int k1_lo = max(0, e1 >> 1), k1_hi = min(a.M[1] - 1, (e1 + L - 2) >> 1);
-              for (int k1 = k1_lo + i1; k1 <= k1_hi; k1 += 4) {
+              for (int k1 = k1_lo + i1; k1 <= k1_hi; k1 += kS2b) {
                 const int m1 = 2 * k1 + 1 - e1;
                 const T l1 = s_lo[m1], h1 = s_hi[m1];
                 const int64_t oa = img * a.as[0] + k0 * a.as[1] + k1 * a.as[2], od = img * a.ds[0] + k0 * a.ds[1] + k1 * a.ds[2];
@@ -158,24 +166,24 @@ __global__ void __launch_bounds__(256) adjoint_border_kernel(const BorderArgs<T,
         }
       }
   } else {
-    const int i0 = sub >> 3, i1 = (sub >> 2) & 1, i2 = sub & 3;
+    const int i0 = sub / (kS3b * kS3c), i1 = (sub / kS3c) % kS3b, i2 = sub % kS3c;
     for (int q0 = 0; q0 < 3; ++q0)
       for (int e0 = ra[0][q0]; e0 <= rb[0][q0]; ++e0) {
         const int k0_lo = max(0, e0 >> 1), k0_hi = min(a.M[0] - 1, (e0 + L - 2) >> 1);
-        for (int k0 = k0_lo + i0; k0 <= k0_hi; k0 += 2) {
+        for (int k0 = k0_lo + i0; k0 <= k0_hi; k0 += kS3a) {
           const int m0 = 2 * k0 + 1 - e0;
           const T l0 = s_lo[m0], h0 = s_hi[m0];
           for (int q1 = 0; q1 < 3; ++q1)
             for (int e1 = ra[1][q1]; e1 <= rb[1][q1]; ++e1) {
               const int k1_lo = max(0, e1 >> 1), k1_hi = min(a.M[1] - 1, (e1 + L - 2) >> 1);
-              for (int k1 = k1_lo + i1; k1 <= k1_hi; k1 += 2) {
+              for (int k1 = k1_lo + i1; k1 <= k1_hi; k1 += kS3b) {
                 const int m1 = 2 * k1 + 1 - e1;
                 const T l1 = s_lo[m1], h1 = s_hi[m1];
                 const T w00 = l0 * l1, w01 = l0 * h1, w10 = h0 * l1, w11 = h0 * h1;  // (axis 0, axis 1) = (lo, lo), (lo, hi), ...
                 for (int q2 = 0; q2 < 3; ++q2)
                   for (int e2 = ra[2][q2]; e2 <= rb[2][q2]; ++e2) {
                     const int k2_lo = max(0, e2 >> 1), k2_hi = min(a.M[2] - 1, (e2 + L - 2) >> 1);
-                    for (int k2 = k2_lo + i2; k2 <= k2_hi; k2 += 4) {
+                    for (int k2 = k2_lo + i2; k2 <= k2_hi; k2 += kS3c) {
                       const int m2 = 2 * k2 + 1 - e2;
                       const T l2 = s_lo[m2], h2 = s_hi[m2];
                       const int64_t oa = img * a.as[0] + k0 * a.as[1] + k1 * a.as[2] + k2 * a.as[3];

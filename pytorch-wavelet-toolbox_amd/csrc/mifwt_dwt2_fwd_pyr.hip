@@ -72,6 +72,7 @@ struct PyrArgs {
   float* xrows;               // [image][segment][(L - 1) rows of W1 floats, (L - 1) rows of W2 floats]
   int xrow_stride;            // floats per (image, segment)
   int xcd_map;
+  int compact;  // 0: 16 waves (6 + 3 + 3 level waves at most, two loaders), one workgroup per CU; 1: 8 waves (3 + 2 + 2, one loader), two per CU
   unsigned long long* prof;
   int dbg;
   f2 tap[L];
@@ -79,22 +80,23 @@ struct PyrArgs {
 
 // a loader's share of one level-0 row: NCH requests of 1 KiB, LDS addresses lds0 + 2048 j (the two loaders take the even / the
 // odd 1-KiB pieces of a row), global offsets voff[j]
-template <int NCH>
+template <int NCH, int STR>
 __device__ __forceinline__ void pyr_dma_row(const uint32_t (&voff)[3], rsrc_t rsrc, uint32_t soff, uint32_t lds0) {
+  // (STR = LDS distance of a loader's consecutive pieces: 2 KiB with two loader waves — they take the even / the odd pieces — 1 KiB with one)
   uint32_t keep;
   if constexpr (NCH == 1) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff[0]), "s"(rsrc), "s"(soff), "s"(lds0) : "memory");
   } else if constexpr (NCH == 2) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen nt lds\n\t"
-                 "s_add_u32 m0, m0, 0x800\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen nt lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "s"(rsrc), "s"(soff), "s"(lds0) : "memory", "scc");
+                 "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen nt lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "s"(rsrc), "s"(soff), "s"(lds0), "n"(STR) : "memory", "scc");
   } else {
     static_assert(NCH == 3, "at most three requests per row and loader");
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %4, %5 offen nt lds\n\t"
-                 "s_add_u32 m0, m0, 0x800\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %5 offen nt lds\n\t"
-                 "s_add_u32 m0, m0, 0x800\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %5 offen nt lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "s"(rsrc), "s"(soff), "s"(lds0) : "memory", "scc");
+                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %5 offen nt lds\n\t"
+                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %5 offen nt lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "s"(rsrc), "s"(soff), "s"(lds0), "n"(STR) : "memory", "scc");
   }
 }
 
@@ -135,9 +137,16 @@ __device__ __forceinline__ void pyr_load_win2(const unsigned char* row, f2 (&w)[
 // 13, level 2 = 5-7, level 3 = 9-11, loaders = 15 and 14; with five level-1 waves the classes hold {L1, L1} {L1, L2, L3}
 // {L1, L2, L3, loader} {L1, L2, L3, loader}.  Waves 0 and 4 share a SIMD: they take interior columns, not the first / last
 // level-1 wave, which also copy the boundary extension of every staged row.
-__device__ __forceinline__ void pyr_role(int wave, int nl1, int nchunks, int& role, int& idx) {
+__device__ __forceinline__ void pyr_role(int wave, int nl1, int nchunks, int compact, int& role, int& idx) {
   role = -1;
   idx = 0;
+  if (compact) {  // eight waves: level 1 = waves 0-2, level 2 = 3-4, level 3 = 5-6, the loader = 7 (two per SIMD)
+    if (wave < 3) role = kRoleL1, idx = wave;
+    else if (wave < 5) role = kRoleL2, idx = wave - 3;
+    else if (wave < 7) role = kRoleL3, idx = wave - 5;
+    else if (wave == 7) role = kRoleLoad;
+    return;
+  }
   if (wave < 5) {
     role = kRoleL1;
     idx = nl1 < 5 ? wave : (wave == 0 ? 1 : (wave == 1 ? 0 : (wave == 2 ? 3 : (wave == 3 ? 4 : 2))));
@@ -166,8 +175,8 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int role, widx;
-  pyr_role(wave, a.nl1, a.nchunks, role, widx);
-  if (wave == 12 && a.handover) role = kRoleXchg;
+  pyr_role(wave, a.nl1, a.nchunks, a.compact, role, widx);
+  if (wave == 12 && a.handover && !a.compact) role = kRoleXchg;
   if (role < 0 || (role == kRoleL1 && widx >= a.nl1) || (role == kRoleL2 && (NLEV < 2 || widx >= a.nl2)) ||
       (role == kRoleL3 && (NLEV < 3 || widx >= a.nl3)))
     return;  // (a wave that has ended does not take part in the barriers of the others)
@@ -266,18 +275,20 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
     const rsrc_t xr = pyr_rsrc(a.x + (int64_t)img * a.xs_b, img_bytes);
     const rsrc_t xr_dead = pyr_rsrc(a.x + (int64_t)img * a.xs_b, 0);  // every lane out of range: a row of zeros lands
     const uint32_t row_bytes = (uint32_t)a.xs_h * 4u;
-    // loader `widx` requests the 1-KiB pieces widx, widx + 2, widx + 4 of every row
-    const int mych = (a.nchunks - widx + 1) / 2;
+    // loader `widx` of `nload` requests the 1-KiB pieces widx, widx + nload, widx + 2 nload of every row
+    const int nload = a.compact ? 1 : 2;
+    const int mych = (a.nchunks - widx + nload - 1) / nload;
     uint32_t voff[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int c = g0 + 256 * (widx + 2 * j) + 4 * lane;
+      const int c = g0 + 256 * (widx + nload * j) + 4 * lane;
       voff[j] = (j < mych && c < a.W[0]) ? 4u * (uint32_t)c : kPyrOob;
     }
     if (!(a.dbg & 16)) __builtin_amdgcn_s_setprio(3);  // the youngest wave of its SIMD, and the one everybody waits for
     __syncthreads();  // the other waves have initialised their LDS
-    auto run = [&](auto nch_tag) {
+    auto run = [&](auto nch_tag, auto str_tag) {
       constexpr int NCH = decltype(nch_tag)::value;
+      constexpr int STR = decltype(str_tag)::value;
       constexpr int PER = kPyrSub * NCH;
       int ib = 0;  // staging sub-buffer of the next sub-step to be requested (sub-steps are requested in order)
       auto issue = [&](int t) {
@@ -289,7 +300,7 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
           const int e = E0 + kPyrSub * t + kk;
           const bool dead = e >= e0_end || (zero_mode && (unsigned)e >= (unsigned)a.H[0]);
           const uint32_t soff = dead ? 0u : (uint32_t)fold(e, a.H[0]) * row_bytes;
-          pyr_dma_row<NCH>(voff, dead ? xr_dead : xr, soff, buf + (uint32_t)(kk * a.pitch0));
+          pyr_dma_row<NCH, STR>(voff, dead ? xr_dead : xr, soff, buf + (uint32_t)(kk * a.pitch0));
         }
       };
       // nbuf - 1 sub-steps are requested ahead; at most 63 requests of a wave can be in flight
@@ -311,7 +322,8 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
         if (t + ahead < nsub1) issue(t + ahead);  // into the buffer sub-step t - 1 was read from
       }
     };
-    pyr_dispatch<3>(mych - 1, [&](auto k) { run(std::integral_constant<int, decltype(k)::value + 1>{}); });
+    if (a.compact) pyr_dispatch<3>(mych - 1, [&](auto k) { run(std::integral_constant<int, decltype(k)::value + 1>{}, std::integral_constant<int, 0x400>{}); });
+    else pyr_dispatch<3>(mych - 1, [&](auto k) { run(std::integral_constant<int, decltype(k)::value + 1>{}, std::integral_constant<int, 0x800>{}); });
     return;
   }
 
@@ -932,6 +944,7 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
 struct PyrPlan {
+  int compact;  // eight-wave workgroups, two per CU (MIFWT_OPT_DEBUG bit 11; see PyrArgs)
   int ngroups, nseg, seg_rows, seg0_rows, cpg0, cpg, nchunks, nbuf, pitch0, pitch1, pitch2, nl1, nl2, nl3, lds;
   int handover, xrow_stride;  // segments hand their first approximation rows over (needs a workspace); floats per (image, segment)
   size_t ws_bytes;
@@ -939,20 +952,21 @@ struct PyrPlan {
 
 // columns of level NLEV a group may own: the level-1 / 2 / 3 lane grids hold 4 x 192 / 3 x 128 / 3 x 64 columns, a staged row
 // at most kPyrMaxChunks x 256 level-0 columns; interior groups recompute (L - 2) halo columns per level on their left
-static int pyr_group_cols(int L, int nlev, bool first) {
+static int pyr_group_cols(int L, int nlev, bool first, bool compact) {
   const int nc1 = 2;
   const int HL = first ? 0 : L - 2;
   int best = 0;
+  const int w1 = compact ? 3 : 6, w2 = compact ? 2 : 3, w3 = compact ? 2 : 3, maxch = compact ? 3 : kPyrMaxChunks;
   for (int n = 1; n <= 4 * 192; ++n) {
     int m = n;  // columns computed at the level below, walking down to level 1
     bool ok = true;
     for (int l = nlev; l >= 1 && ok; --l) {
-      const int cap = l == 1 ? 6 * 128 - nc1 : (l == 2 ? 3 * 128 : 3 * 64);
+      const int cap = l == 1 ? w1 * 128 - nc1 : (l == 2 ? w2 * 128 : w3 * 64);
       ok = m <= cap;
       if (l > 1) m = 2 * m + HL;
     }
     // m = level-1 columns now; level-0 span incl. the 16-byte alignment slack
-    if (ok && 2 * m + HL + 3 <= kPyrMaxChunks * 256) best = n;
+    if (ok && 2 * m + HL + 3 <= maxch * 256) best = n;
   }
   return best;
 }
@@ -963,8 +977,9 @@ static bool pyr_plan(int nlev, const mifwt_level_desc* const* d, PyrPlan* p) {
   const int WN = (int)d[nlev - 1]->coef_extent[1], HN = (int)d[nlev - 1]->coef_extent[0];
   const int min_cols = HL + 2;
   if (WN < min_cols || HN < 2 * (HL + 2)) return false;
-  p->cpg0 = pyr_group_cols(L, nlev, true);
-  p->cpg = pyr_group_cols(L, nlev, false);
+  p->compact = (g_options[MIFWT_OPT_DEBUG] & 2048) ? 1 : 0;
+  p->cpg0 = pyr_group_cols(L, nlev, true, p->compact);
+  p->cpg = pyr_group_cols(L, nlev, false, p->compact);
   if (nlev == 1) {  // level-1 lanes hold column pairs that start on even columns
     p->cpg0 &= ~1;
     p->cpg &= ~1;
@@ -1008,21 +1023,24 @@ static bool pyr_plan(int nlev, const mifwt_level_desc* const* d, PyrPlan* p) {
   p->nl1 = (n[1] + 64 * nc1 - 1) / (64 * nc1);
   p->nl2 = nlev >= 2 ? (n[2] + 127) / 128 : 0;
   p->nl3 = nlev >= 3 ? (n[3] + 63) / 64 : 0;
-  if (p->nl1 > 6 || p->nl2 > 3 || p->nl3 > 3) return false;
+  if (p->nl1 > (p->compact ? 3 : 6) || p->nl2 > (p->compact ? 2 : 3) || p->nl3 > (p->compact ? 2 : 3)) return false;
   p->nchunks = (body + 255) / 256;
-  if (p->nchunks < 1 || p->nchunks > kPyrMaxChunks) return false;
+  if (p->nchunks < 1 || p->nchunks > (p->compact ? 3 : kPyrMaxChunks)) return false;
   p->pitch0 = (kPyrPad + 256 * p->nchunks + 8) * 4;
   p->pitch1 = nlev >= 2 ? ((kPyrPad + n[1] + HL + 8 + 3) & ~3) * 4 : 0;
   p->pitch2 = nlev >= 3 ? ((kPyrPad + n[2] + HL + 8 + 3) & ~3) * 4 : 0;
   const int rings = (kPyrRing + 1) * (p->pitch1 + p->pitch2);
   // as many staging sub-buffers as fit (the loaders run nbuf - 1 sub-steps ahead; a wave holds at most 63 requests in flight)
   p->nbuf = g_options[MIFWT_OPT_PREFETCH_PAIRS] > 1 ? std::min(8, g_options[MIFWT_OPT_PREFETCH_PAIRS]) : 4;  // (3 .. 6 measured alike on config 2)
-  while (p->nbuf > 2 && (kPyrCtl + p->nbuf * kPyrSub * p->pitch0 + rings > 160 * 1024 || (p->nbuf - 1) * kPyrSub * ((p->nchunks + 1) / 2) > 63)) --p->nbuf;
+  const int lds_cap = p->compact ? 80 * 1024 : 160 * 1024, per_loader = p->compact ? p->nchunks : (p->nchunks + 1) / 2;
+  while (p->nbuf > 2 && (kPyrCtl + p->nbuf * kPyrSub * p->pitch0 + rings > lds_cap || (p->nbuf - 1) * kPyrSub * per_loader > 63)) --p->nbuf;
   p->lds = kPyrCtl + p->nbuf * kPyrSub * p->pitch0 + rings;
-  if (p->lds > 160 * 1024) return false;
-  // one workgroup per CU (the segment count below is chosen for that; two small workgroups on one CU leave others idle)
+  if (p->lds > lds_cap) return false;
+  // one workgroup per CU (the segment count below is chosen for that; two small workgroups on one CU leave others idle) — or, compact,
+  // exactly two
   const int lds_used = p->lds;
-  if (p->lds < 82 * 1024) p->lds = 82 * 1024;
+  if (!p->compact && p->lds < 82 * 1024) p->lds = 82 * 1024;
+  if (p->compact && p->lds < 54 * 1024) p->lds = 54 * 1024;  // (never three)
   int dev = 0, ncu = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
     int v = 0;
@@ -1030,7 +1048,7 @@ static bool pyr_plan(int nlev, const mifwt_level_desc* const* d, PyrPlan* p) {
   }
   const int64_t per_seg = d[0]->batch * p->ngroups;
   int nseg = g_options[MIFWT_OPT_PAIR_ROWS] > 0 ? (HN + g_options[MIFWT_OPT_PAIR_ROWS] - 1) / g_options[MIFWT_OPT_PAIR_ROWS]
-                                                  : (int)((ncu + per_seg / 2) / (per_seg > 0 ? per_seg : 1));
+                                                  : (int)(((p->compact ? 2 : 1) * ncu + per_seg / 2) / (per_seg > 0 ? per_seg : 1));
   const int max_seg = HN / 8 > 0 ? HN / 8 : 1;
   nseg = nseg < 1 ? 1 : (nseg > max_seg ? max_seg : nseg);
   p->seg_rows = (HN + nseg - 1) / nseg;
@@ -1046,7 +1064,7 @@ static bool pyr_plan(int nlev, const mifwt_level_desc* const* d, PyrPlan* p) {
   // 4.5 % less traffic and 12 % fewer level-1 rows per workgroup (profiles/r03k_handover.txt).  Without prologues every workgroup is in
   // its full read + write steps at the same time and then all of them drain their deep levels together (7 steps without memory
   // traffic); with prologues the segments are staggered by what they are — 5 read-only steps at the start of three workgroups in four.
-  if (nlev >= 2 && p->nseg > 1 && p->ngroups == 1 && p->nl1 <= 5 && (g_options[MIFWT_OPT_DEBUG] & 256) && g_options[MIFWT_OPT_PAIR_ROWS] <= 0) {
+  if (nlev >= 2 && p->nseg > 1 && p->ngroups == 1 && p->nl1 <= 5 && !p->compact && (g_options[MIFWT_OPT_DEBUG] & 256) && g_options[MIFWT_OPT_PAIR_ROWS] <= 0) {
     const int W1 = (int)d[0]->coef_extent[1], W2 = nlev >= 3 ? (int)d[1]->coef_extent[1] : 0;
     const int XM = HL + 1;
     const int xlds = XM * ((((W1 + 3) & ~3) * 4 + 16) + (nlev >= 3 ? ((W2 + 3) & ~3) * 4 + 16 : 0));
@@ -1110,7 +1128,7 @@ bool dwt2_fwd_pyr_supported(int nlev, const mifwt_level_desc* const* d) {
   // MIFWT_OPT_PYRAMID_MODE 1 overrides): planes of 448 .. ~2560 columns, i.e. one or two column groups.  A workgroup then reads whole
   // rows (or halves of them), one after the other.  Four column groups (4096 columns: 4 KB pieces 16 KB apart) ran at 0.44 of the HBM
   // peak against 0.65 for the per-level tile kernel; narrower planes leave most lanes of the level-2 / 3 waves idle (256^2: 75 against 55 us).
-  if (g_options[MIFWT_OPT_PYRAMID_MODE] != 1 && (p.ngroups > 2 || d0->sig_extent[1] < 448)) return false;
+  if (g_options[MIFWT_OPT_PYRAMID_MODE] != 1 && (p.ngroups > (p.compact ? 4 : 2) || d0->sig_extent[1] < 448)) return false;
   return true;
 }
 
@@ -1154,6 +1172,7 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
   a.cpg0 = p.cpg0;
   a.cpg = p.cpg;
   a.nchunks = p.nchunks;
+  a.compact = p.compact;
   a.nbuf = p.nbuf;
   a.pitch0 = p.pitch0;
   a.pitch1 = p.pitch1;
@@ -1202,13 +1221,13 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
   if (kCanProf && !lds_once_prof.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, false>), 160 * 1024))
     return MIFWT_ERR_LAUNCH;
   if (kCanProf && a.prof)
-    hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, false>), dim3((unsigned)nwg), dim3(64 * kPyrWaves), p.lds, stream, a);
+    hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, false>), dim3((unsigned)nwg), dim3(p.compact ? 512 : 64 * kPyrWaves), p.lds, stream, a);
   else if (st16) {
     count_launch(MIFWT_VARIANT_FWD_PYR_ST16);
-    hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, false, true>), dim3((unsigned)nwg), dim3(64 * kPyrWaves), p.lds, stream, a);
+    hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, false, true>), dim3((unsigned)nwg), dim3(p.compact ? 512 : 64 * kPyrWaves), p.lds, stream, a);
   } else {
     count_launch(MIFWT_VARIANT_FWD_PYR_ST8);
-    hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, false, false>), dim3((unsigned)nwg), dim3(64 * kPyrWaves), p.lds, stream, a);
+    hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, false, false>), dim3((unsigned)nwg), dim3(p.compact ? 512 : 64 * kPyrWaves), p.lds, stream, a);
   }
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }

@@ -262,6 +262,26 @@ def test_pyramid_segment_handover_option(wavelet):
                 assert torch.equal(a, b), (shape, wavelet, mode, n)
 
 
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4"])
+def test_pyramid_compact_layout_option(wavelet):
+    """MIFWT_OPT_DEBUG bit 11: eight-wave workgroups (3 + 2 + 2 level waves, one loader), two per CU, on column groups of about half a
+    1024-column plane (round 4: measured slower than the sixteen-wave form — 124 against 104 us on config 2 — hence off by default; the
+    path stays pinned): the same sums in the same order — bit-identical to the default form, and against the oracle."""
+    g = torch.Generator().manual_seed(41)
+    for shape, level in (((3, 520, 1000), 3), ((1, 1024, 1024), 3), ((2, 333, 517), 2), ((2, 300, 2048), 3), ((4, 257, 771), 1)):
+        x = torch.randn(*shape, generator=g)
+        for mode in ("reflect", "zero", "symmetric"):
+            ref = ptwt_amd.wavedec2(x.to(dev()), wavelet, mode=mode, level=level)
+            _engine.set_option(_engine.OPT_DEBUG, 2048)
+            try:
+                check(x, wavelet, mode, level, [_engine.KID_PYRAMID])
+                got = ptwt_amd.wavedec2(x.to(dev()), wavelet, mode=mode, level=level)
+            finally:
+                _engine.set_option(_engine.OPT_DEBUG, 0)
+            for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(ref)):
+                assert torch.equal(a, b), (shape, wavelet, mode, n)
+
+
 def test_pyramid_randomised_against_per_level_kernels():
     """Random plane shapes (one to four column groups, odd heights, widths that are multiples of 4), batches, filters, modes, level
     counts and row-segment overrides through the multi-level launch against the per-level kernels on the same data (those are
@@ -436,14 +456,17 @@ def test_small_planes_reconstruction_separable_big_batches_and_round_trip():
         _engine.set_option(_engine.OPT_PYRAMID_MODE, 3)
     assert _engine.KID_INV_SMALL not in kids2
     assert float(((rec - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1)).max()) < 2e-6
-    # leading dims and channels folded into the batch; gradients requested: the per-level (differentiable) route instead
+    # leading dims and channels folded into the batch; gradients requested: the same launch as a differentiable op (round 4; it used
+    # to step aside for the per-level ops)
     cs = ptwt_amd.wavedec2(torch.randn(4, 3, 64, 64, device=dev(), generator=g), "db4", level=2)
     rec, kids = run_traced(lambda: ptwt_amd.waverec2(cs, "db4"))
     assert kids == [_engine.KID_INV_SMALL] and rec.shape == (4, 3, 64, 64)
     cs[0].requires_grad_(True)
     rec2, kids = run_traced(lambda: ptwt_amd.waverec2(cs, "db4"))
-    assert _engine.KID_INV_SMALL not in kids and rec2.requires_grad
-    assert float((rec2.detach() - rec).abs().max()) < 1e-5
+    assert kids == [_engine.KID_INV_SMALL] and rec2.requires_grad
+    assert torch.equal(rec2.detach(), rec)
+    (g0,) = torch.autograd.grad(rec2.square().sum(), cs[0])
+    assert g0.shape == cs[0].shape and torch.isfinite(g0).all()
 
 
 def test_small_plane_kernels_randomised_against_per_level_kernels():
