@@ -156,6 +156,8 @@ __global__ void __launch_bounds__(256) adjoint_border_kernel(const BorderArgs<T,
           for (int q1 = 0; q1 < 3; ++q1)
             for (int e1 = ra[1][q1]; e1 <= rb[1][q1]; ++e1) {
               const int k1_lo = max(0, e1 >> 1), k1_hi = min(a.M[1] - 1, (e1 + L - 2) >> 1);
+              // (requesting four columns' sixteen loads before the first use changed nothing: 46 / 85 / 218 us per level of config 2's
+              // backward either way — the kernel is bound by its instruction count, ~43 us per million border samples)
               for (int k1 = k1_lo + i1; k1 <= k1_hi; k1 += kS2b) {
                 const int m1 = 2 * k1 + 1 - e1;
                 const T l1 = s_lo[m1], h1 = s_hi[m1];

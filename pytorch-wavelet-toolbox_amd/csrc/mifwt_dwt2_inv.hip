@@ -228,7 +228,9 @@ int launch(const mifwt_level_desc* d, const void* approx, const void* const* det
     a.thi[j] = (f2){(float)hi[2 * j], (float)hi[2 * j + 1]};
   }
   a.nstrips = (a.W + 2 * C::KQ - 1) / (2 * C::KQ);
-  int rpc = 16;
+  // output rows per task: 16; 32 for long filters on big planes — a task re-reads L/2 - 1 coefficient rows of every band as its halo
+  // (config 4's finest level, 16 taps on 64 x 4096^2: 2.57 ms per waverec2 with 16, 2.45 with 32, 2.53 with 64; profiles/r04j_c4_rpc_sweep.txt)
+  int rpc = (L >= 12 && a.H >= 2048) ? 32 : 16;
   if (g_options[MIFWT_OPT_ROWS_PER_CHUNK] > 0) rpc = (g_options[MIFWT_OPT_ROWS_PER_CHUNK] + 3) & ~3;
   a.rows_per_chunk = rpc;
   a.nchunks = (a.H + rpc - 1) / rpc;
