@@ -9,9 +9,9 @@
 //     u[e] = sum_k sum_bands g_band[k] h_band[2 k + 1 - e]            (per axis; e in [-(L - 2), N + L - 2 + N % 2))
 // and  (E^T u)[n] = the sum of u over every extended index that maps to n.  For e inside [0, N) u is exactly what the zero-mode adjoint
 // computes — the fused SYNTHESIS kernels with the dec taps reversed (mifwt_api.hip, run_inv) — and an interior sample has no other
-// preimage.  So the adjoint with ANY boundary mode = that fast launch over the whole signal + this kernel, which recomputes, from
-// scratch, the samples within B = L - 1 + N % 2 of a border: one thread per such sample, every preimage of it (itself, mirrored /
-// wrapped / clamped pad positions) times every coefficient in reach.  O(preimages x (L/2)^ndim x 2^ndim) per border sample, a few
+// preimage.  So the adjoint with ANY boundary mode = that fast launch over the whole signal + this kernel, which ADDS, to the samples
+// within B = L - 1 + N % 2 of a border, the terms of their other preimages: one thread per such sample, every pad position that maps
+// onto it (mirrored / wrapped / clamped) times every coefficient in reach (the sample's own term is already there).  O(preimages x (L/2)^ndim x 2^ndim) per border sample, a few
 // percent of a level's samples: 64 x 1024^2 db4 reflect: 1.18 ms for the generic per-axis adjoint passes -> the synthesis kernel's
 // 0.12 ms + this.  f32 (f32 sums) and f64, 1-3 axes, L <= 32, single-fold extents (N >= 2 B per axis); everything else stays on the
 // generic passes (launch_axis_adj).
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) adjoint_border_kernel(const BorderArgs<T,
   const int L = a.L;
   T acc = 0;
   if constexpr (ND == 1) {
-    for (int q0 = 0; q0 < 3; ++q0)
+    for (int q0 = 1; q0 < 3; ++q0)  // (q0 = 0 is the sample itself: that term is what the zero-mode adjoint has written)
       for (int e0 = ra[0][q0]; e0 <= rb[0][q0]; ++e0) {
         const int k_lo = max(0, e0 >> 1), k_hi = min(a.M[0] - 1, (e0 + L - 2) >> 1);  // 0 <= 2 k + 1 - e0 < L
         for (int k0 = k_lo + sub; k0 <= k_hi; k0 += kS1) {
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) adjoint_border_kernel(const BorderArgs<T,
         for (int k0 = k0_lo + i0; k0 <= k0_hi; k0 += kS2a) {
           const int m0 = 2 * k0 + 1 - e0;
           const T l0 = s_lo[m0], h0 = s_hi[m0];
-          for (int q1 = 0; q1 < 3; ++q1)
+          for (int q1 = (q0 == 0 ? 1 : 0); q1 < 3; ++q1)  // (q0 = q1 = 0: the sample itself, already in g_x)
             for (int e1 = ra[1][q1]; e1 <= rb[1][q1]; ++e1) {
               const int k1_lo = max(0, e1 >> 1), k1_hi = min(a.M[1] - 1, (e1 + L - 2) >> 1);
               // (requesting four columns' sixteen loads before the first use changed nothing: 46 / 85 / 218 us per level of config 2's
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) adjoint_border_kernel(const BorderArgs<T,
                 const int m1 = 2 * k1 + 1 - e1;
                 const T l1 = s_lo[m1], h1 = s_hi[m1];
                 const T w00 = l0 * l1, w01 = l0 * h1, w10 = h0 * l1, w11 = h0 * h1;  // (axis 0, axis 1) = (lo, lo), (lo, hi), ...
-                for (int q2 = 0; q2 < 3; ++q2)
+                for (int q2 = (q0 == 0 && q1 == 0 ? 1 : 0); q2 < 3; ++q2)  // (all three zero: the sample itself, already in g_x)
                   for (int e2 = ra[2][q2]; e2 <= rb[2][q2]; ++e2) {
                     const int k2_lo = max(0, e2 >> 1), k2_hi = min(a.M[2] - 1, (e2 + L - 2) >> 1);
                     for (int k2 = k2_lo + i2; k2 <= k2_hi; k2 += kS3c) {
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256) adjoint_border_kernel(const BorderArgs<T,
   int64_t ox = img * a.xs[0];
 #pragma unroll
   for (int d = 0; d < ND; ++d) ox += (int64_t)n[d] * a.xs[1 + d];
-  a.gx[ox] = acc;
+  a.gx[ox] += acc;  // (on top of the sample's own term, which the zero-mode adjoint launch has written)
 }
 
 template <typename T, int ND>
