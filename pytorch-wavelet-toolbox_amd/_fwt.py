@@ -458,6 +458,59 @@ class _AnalysisPyramid(torch.autograd.Function):
         return g, None, None, None, None
 
 
+class _FusedRouteUnavailable(Exception):
+    """Raised inside the forward of a multi-level autograd op when the library turns the launch down after all; the caller goes level
+    by level."""
+
+
+class _AnalysisTail(torch.autograd.Function):
+    """Several 1-D analysis levels in one launch (C ABI ``mifwt_dwt1_fwd_long`` / ``mifwt_dwt1_fwd_tail``; src/ptwt/conv_transform.py:133-140
+    per trip) as a differentiable op w.r.t. the data: outputs = the last level's approximation, then the detail rows, finest first; the
+    backward composes the per-level adjoints coarse to fine."""
+
+    @staticmethod
+    def forward(ctx, x, dec_lo, dec_hi, mode_id, want):
+        bufs = _engine.ENGINE.analysis_tail(x, dec_lo, dec_hi, mode_id, want)
+        if bufs is None:
+            raise _FusedRouteUnavailable()
+        shapes, n = [], int(x.shape[1])
+        for b in bufs:
+            shapes.append((n,))
+            n = int(b.shape[2])
+        ctx.meta = (shapes, dec_lo, dec_hi, mode_id)
+        return (bufs[-1][:, 0], *[b[:, -1] for b in bufs])
+
+    @staticmethod
+    def backward(ctx, g_approx, *g_details):
+        shapes, dec_lo, dec_hi, mode_id = ctx.meta
+        g = g_approx
+        for lvl in range(len(shapes) - 1, -1, -1):
+            g = _AnalysisAdjointBands.apply(shapes[lvl], dec_lo, dec_hi, mode_id, g, g_details[lvl])
+        return g, None, None, None, None
+
+
+class _SynthesisChain1d(torch.autograd.Function):
+    """A whole 1-D reconstruction on the multi-level launches (``mifwt_dwt1_inv_tail`` for the coarse levels, ``mifwt_dwt1_inv_long`` for
+    the fine ones; src/ptwt/conv_transform.py:184-199 per trip) as a differentiable op w.r.t. the coefficients; ``run`` does the launches
+    (the caller's recursion over the two kernels), the backward composes the per-level synthesis adjoints fine to coarse."""
+
+    @staticmethod
+    def forward(ctx, run, rec_lo, rec_hi, approx, *dets):
+        ctx.meta = (rec_lo, rec_hi, [tuple(d.shape[1:]) for d in dets])
+        return run(approx, list(dets))
+
+    @staticmethod
+    def backward(ctx, g_y):
+        rec_lo, rec_hi, coef_shapes = ctx.meta
+        grads: list = []
+        g = g_y
+        for shp in reversed(coef_shapes):
+            gb = _SynthesisAdjointLevel.apply(g, shp, rec_lo, rec_hi)
+            grads.insert(0, gb[:, 1])
+            g = gb[:, 0]
+        return (None, None, None, g, *grads)
+
+
 class _SynthesisLevel(torch.autograd.Function):
     """One synthesis level, differentiable w.r.t. the approximation, every detail band and (optionally) the rec taps
     (backward: ``mifwt_dwt_inv_adjoint`` + ``mifwt_tap_correlate``; reference: autograd through torch.stack +
@@ -719,7 +772,7 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
                 cur = pair[1][:, 0]
                 done += 2
                 continue
-        if ndim == 1 and level - done >= 2 and not differentiable:
+        if ndim == 1 and level - done >= 2 and (not differentiable or tap_t is None):
             # the deep levels of a 1-D pyramid in one launch (mifwt_dwt1_fwd_tail) once a row fits into LDS, several levels of
             # longer rows per launch before that (mifwt_dwt1_fwd_long); the pad checks of the fused trips are the reference's
             # own and run before anything is launched
@@ -727,12 +780,23 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
             for _l in range(level - done):
                 _check_pad([n], flen, "reflect" if mode is None else mode)
                 n = (n + flen - 1) // 2
-            tail = _engine.ENGINE.analysis_tail(cur, dec_lo, dec_hi, mode_id, level - done)
-            if tail is not None:
-                bufs.extend(tail)
-                cur = tail[-1][:, 0]
-                done += len(tail)
-                continue
+            if differentiable:  # (gradients w.r.t. the data only: the same launches as a differentiable op)
+                try:
+                    bands = _AnalysisTail.apply(cur, dec_lo, dec_hi, mode_id, level - done)
+                except _FusedRouteUnavailable:
+                    bands = None
+                if bands is not None:
+                    cur = bands[0]
+                    bufs.extend((d,) for d in bands[1:])  # (a level as its detail row: pack_1d takes either form)
+                    done += len(bands) - 1
+                    continue
+            else:
+                tail = _engine.ENGINE.analysis_tail(cur, dec_lo, dec_hi, mode_id, level - done)
+                if tail is not None:
+                    bufs.extend(tail)
+                    cur = tail[-1][:, 0]
+                    done += len(tail)
+                    continue
         done += 1
         if differentiable:
             buf = _AnalysisLevel.apply(cur, dec_lo, dec_hi, mode_id, *((tap_t[0], tap_t[1]) if tap_t else (None, None)))
@@ -816,7 +880,7 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
         # the coarse levels of a 1-D reconstruction in one launch (mifwt_dwt1_inv_tail) while a level's output still fits into
         # LDS; every fused trip passes the reference's own checks first
         differentiable = torch.is_grad_enabled() and (tap_t is not None or any(t.requires_grad for t in flat))
-        if not differentiable:
+        if not differentiable or tap_t is None:
             try:
                 outs, shape = [], tuple(cur.shape)
                 for lv in range(len(folded)):
@@ -856,12 +920,16 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
                 return cur
 
             if len(outs) == len(folded):
-                cur = fuse(fuse, cur, 0, len(folded))
+                if differentiable:  # (gradients w.r.t. the coefficients only: the same launches as ONE differentiable op)
+                    cur = _SynthesisChain1d.apply(lambda a0, dd: fuse(fuse, a0, 0, len(dd)), rec_lo, rec_hi, cur, *dets)  # (fuse reads `dets`: the same tensors)
+                else:
+                    cur = fuse(fuse, cur, 0, len(folded))
                 pos = len(folded)
     any_grad = torch.is_grad_enabled() and (tap_t is not None or any(t.requires_grad for t in flat))
     # (gradients w.r.t. the coefficients only: the multi-level launches as differentiable ops, _SynthesisPyramid; a learnable filter
-    # bank and the separable containers' crops take the per-level ops)
-    fused_grad = any_grad and tap_t is None and not separable
+    # bank takes the per-level ops.  The separable containers' crops of the running approximation take its LEADING samples, like the
+    # reference's trims: the adjoint of a level sees a gradient of the cropped extents and treats the rest as zeros — same backward)
+    fused_grad = any_grad and tap_t is None
     gkey = None
     if ndim == 2 and folded and (not any_grad or fused_grad):
         # geometry of the call (every band's shape: the reference's shape checks are part of what is remembered)
@@ -968,7 +1036,8 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
 
 # ------------------------------------------------------------------------------------------ containers
 def pack_1d(layout: _Layout, approx, bufs) -> List[torch.Tensor]:
-    return [layout.unfold(approx)] + [layout.unfold(b[:, -1]) for b in bufs]  # (the detail row is the last plane: [B, 2, M] or [B, 1, M])
+    # (the detail row is the last plane of a level buffer — [B, 2, M] or [B, 1, M] — or the one band of a differentiable multi-level launch)
+    return [layout.unfold(approx)] + [layout.unfold(b[-1] if isinstance(b, tuple) else b[:, -1]) for b in bufs]
 
 
 def pack_2d(layout: _Layout, approx, bufs):

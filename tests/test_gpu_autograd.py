@@ -172,25 +172,26 @@ def test_fused_forward_gradients_at_config2_size():
     assert float(err.max()) < 2e-6, float(err.max())
 
 
-@pytest.mark.parametrize("shape,wavelet,level,pmode", [((2, 600, 520), "db4", 3, 0), ((3, 403, 610), "db2", 2, 0), ((6, 96, 80), "db3", 3, 3),
+@pytest.mark.parametrize("fn,rec", [("wavedec2", "waverec2"), ("fswavedec2", "fswaverec2")])
+@pytest.mark.parametrize("shape,wavelet,level,pmode", [((2, 600, 520), "db4", 3, 0), ((3, 403, 611), "db2", 2, 0), ((6, 95, 81), "db3", 3, 3),
                                                         ((2, 1024, 1024), "db5", 4, 0)])
-def test_fused_synthesis_of_differentiable_calls(shape, wavelet, level, pmode):
+def test_fused_synthesis_of_differentiable_calls(shape, wavelet, level, pmode, fn, rec):
     """A `waverec2` that asks for gradients w.r.t. the coefficients runs on the multi-level launches (kernel ids 22 / 21:
     `_fwt._SynthesisPyramid`; src/ptwt/conv_transform_2.py:222-249): same kernel ids and bit-identical output as the plain call,
     gradients of every coefficient tensor equal to those of the per-level ops within fp32 rounding, a second-order product through it."""
     torch.manual_seed(12)
     x = torch.randn(*shape, device=dev())
-    coeffs = ptwt_amd.wavedec2(x, wavelet, mode="symmetric", level=level)
+    coeffs = getattr(ptwt_amd, fn)(x, wavelet, mode="symmetric", level=level)
     leaves = [t.detach().clone().requires_grad_(True) for t in flat(coeffs)]
     _engine.set_option(_engine.OPT_PYRAMID_MODE, pmode)
     try:
         _engine.level_events = []
-        y = ptwt_amd.waverec2(rebuild(coeffs, leaves), wavelet)
+        y = getattr(ptwt_amd, rec)(rebuild(coeffs, leaves), wavelet)
         torch.cuda.synchronize()
         kids = [e[1] for e in _engine.level_events]
         _engine.level_events = []
         with torch.no_grad():
-            y0 = ptwt_amd.waverec2(rebuild(coeffs, leaves), wavelet)
+            y0 = getattr(ptwt_amd, rec)(rebuild(coeffs, leaves), wavelet)
         torch.cuda.synchronize()
         kids0 = [e[1] for e in _engine.level_events]
         _engine.level_events = None
@@ -201,10 +202,10 @@ def test_fused_synthesis_of_differentiable_calls(shape, wavelet, level, pmode):
         us = [torch.randn_like(t) for t in leaves]
         # d/dv of <grad_c <v, R c>, u> = R u: a second backward through the fused op's (differentiable) adjoints
         vv = v.clone().requires_grad_(True)
-        gl2 = torch.autograd.grad((vv * ptwt_amd.waverec2(rebuild(coeffs, leaves), wavelet)).sum(), leaves, create_graph=True)
+        gl2 = torch.autograd.grad((vv * getattr(ptwt_amd, rec)(rebuild(coeffs, leaves), wavelet)).sum(), leaves, create_graph=True)
         (ru,) = torch.autograd.grad(sum((a * b).sum() for a, b in zip(gl2, us)), vv)
         with torch.no_grad():
-            want_ru = ptwt_amd.waverec2(rebuild(coeffs, us), wavelet)
+            want_ru = getattr(ptwt_amd, rec)(rebuild(coeffs, us), wavelet)
         assert G.relerr(ru.cpu().numpy(), want_ru.cpu().numpy()) < 2e-6
     finally:
         _engine.level_events = None
@@ -213,13 +214,61 @@ def test_fused_synthesis_of_differentiable_calls(shape, wavelet, level, pmode):
     _engine.set_option(_engine.OPT_PAIR_MODE, 2)
     try:
         leaves2 = [t.detach().clone().requires_grad_(True) for t in leaves]
-        y2 = ptwt_amd.waverec2(rebuild(coeffs, leaves2), wavelet)
+        y2 = getattr(ptwt_amd, rec)(rebuild(coeffs, leaves2), wavelet)
         gl_ref = torch.autograd.grad((v * y2).sum(), leaves2)
     finally:
         _engine.set_option(_engine.OPT_PYRAMID_MODE, 0)
         _engine.set_option(_engine.OPT_PAIR_MODE, 0)
     for i, (a, b) in enumerate(zip(gl, gl_ref)):
         assert G.relerr(a.detach().cpu().numpy(), b.cpu().numpy()) < 2e-6, i
+
+
+@pytest.mark.parametrize("mode", ["zero", "reflect", "periodic", "symmetric"])
+@pytest.mark.parametrize("shape,wavelet,level", [((3, 5001), "db4", 5), ((2, 40000), "db5", 8), ((40, 1000), "db2", 4), ((1, 300000), "haar", 10)])
+def test_fused_1d_launches_of_differentiable_calls(mode, shape, wavelet, level):
+    """`wavedec` / `waverec` with gradients w.r.t. the data run on the multi-level 1-D launches (kernel ids 17 / 14 and 18 / 15:
+    `_fwt._AnalysisTail`, `_SynthesisChain1d`; src/ptwt/conv_transform.py:133-140, :184-199): same kernel ids and bit-identical values as
+    the plain calls, gradients equal to those of the per-level ops (multi-level launches off) within fp32 rounding."""
+    torch.manual_seed(14)
+    x = torch.randn(*shape, device=dev(), requires_grad=True)
+    _engine.level_events = []
+    coeffs = ptwt_amd.wavedec(x, wavelet, mode=mode, level=level)
+    torch.cuda.synchronize()
+    kids = [e[1] for e in _engine.level_events]
+    _engine.level_events = []
+    with torch.no_grad():
+        plain = ptwt_amd.wavedec(x, wavelet, mode=mode, level=level)
+    torch.cuda.synchronize()
+    kids0 = [e[1] for e in _engine.level_events]
+    _engine.level_events = None
+    assert kids == kids0 and any(k in (14, 17) for k in kids), (kids, kids0)
+    for a, b in zip(coeffs, plain):
+        assert a.requires_grad and torch.equal(a.detach(), b)
+    ws = [torch.randn_like(t) for t in coeffs]
+    (gx,) = torch.autograd.grad(sum((w * t).sum() for w, t in zip(ws, coeffs)), x)
+    leaves = [t.detach().clone().requires_grad_(True) for t in coeffs]
+    _engine.level_events = []
+    y = ptwt_amd.waverec(leaves, wavelet)
+    torch.cuda.synchronize()
+    rkids = [e[1] for e in _engine.level_events]
+    _engine.level_events = None
+    assert any(k in (15, 18) for k in rkids), rkids
+    v = torch.randn_like(y)
+    gl = torch.autograd.grad((v * y).sum(), leaves)
+    _engine.set_option(_engine.OPT_PAIR_MODE, 2)  # every multi-level launch off
+    try:
+        x2 = x.detach().clone().requires_grad_(True)
+        c2 = ptwt_amd.wavedec(x2, wavelet, mode=mode, level=level)
+        (gx2,) = torch.autograd.grad(sum((w * t).sum() for w, t in zip(ws, c2)), x2)
+        leaves2 = [t.detach().clone().requires_grad_(True) for t in leaves]
+        y2 = ptwt_amd.waverec(leaves2, wavelet)
+        gl2 = torch.autograd.grad((v * y2).sum(), leaves2)
+    finally:
+        _engine.set_option(_engine.OPT_PAIR_MODE, 0)
+    assert G.relerr(gx.cpu().numpy(), gx2.cpu().numpy()) < 2e-6
+    assert G.relerr(y.detach().cpu().numpy(), y2.detach().cpu().numpy()) < 2e-6
+    for a, b in zip(gl, gl2):
+        assert G.relerr(a.cpu().numpy(), b.cpu().numpy()) < 2e-6
 
 
 def test_backward_routes():

@@ -1,0 +1,3 @@
+#!/bin/bash
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_autograd.py -q -m gpu -k "fused_synthesis" 2>&1 | tail -12
