@@ -344,20 +344,6 @@ class _SynthesisLevelGrad(torch.autograd.Function):
         return (d[0], d[1], d[2], None, None, *d[3:])
 
 
-def _no_double_backward_through_taps(taps) -> None:
-    """STATIONARY levels only (swt / iswt; the ten decimated entry points and the packet trees build every mixed term, see _Axis1).
-    Gradients of any order exist w.r.t. the DATA.  With a learnable filter bank and ``create_graph=True`` (a gradient penalty,
-    say) the mixed terms — d g_x / d taps, and the tap gradients' dependence on the upstream gradient — are not built for the
-    stationary transform (the kernels take the taps as host floats); the reference has them from plain ATen ops
-    (src/ptwt/_util.py:115-132).  Refuse instead of silently returning a graph that lacks them."""
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in taps):
-        raise RuntimeError(
-            "ptwt_amd: double backward (create_graph=True) through a learnable filter bank is not supported: the mixed "
-            "second derivatives w.r.t. the filter taps are not built. Detach the filter bank for this term, or use first-order "
-            "gradients."
-        )
-
-
 def _like(grad64: torch.Tensor, ref: Optional[torch.Tensor]):
     return None if ref is None else grad64.to(device=ref.device, dtype=ref.dtype).reshape(ref.shape)
 

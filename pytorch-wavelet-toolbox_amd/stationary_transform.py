@@ -78,6 +78,153 @@ def _level_inv(a: torch.Tensor, d: torch.Tensor, lo: Sequence[float], hi: Sequen
     return y
 
 
+# ---- learnable filter banks, second order (the per-level maps closed under differentiation, as _fwt._Axis1 … for the decimated levels) ----
+# A stationary level is bilinear in (signal, taps):  lo[n] = s sum_m h[m] x[(n + D (L/2 - m)) mod N].  Analysis A(h) x, its transpose
+# A(h)^T g (= the synthesis kernel with reversed taps) and the tap correlation C(x, g) form a set closed under differentiation; the
+# synthesis y = S(r)(a, d), S(r)^T g_y (= the analysis kernel with reversed taps) and C'(a, d, g_y) likewise.
+def _rev(t: torch.Tensor) -> torch.Tensor:
+    return t.flip(0)
+
+
+class _Swt1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lo_t, hi_t, dilation, scale):
+        ctx.meta = (dilation, scale)
+        ctx.save_for_backward(x, lo_t, hi_t)
+        return _level_fwd(x, _fwt._host_taps_of(lo_t), _fwt._host_taps_of(hi_t), dilation, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, lo_t, hi_t = ctx.saved_tensors
+        dilation, scale = ctx.meta
+        g_x = _Iswt1.apply(g[:, 0], g[:, 1], _rev(lo_t), _rev(hi_t), dilation, scale) if ctx.needs_input_grad[0] else None
+        t_lo = t_hi = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            t_lo, t_hi = _Swt1Corr.apply(x, g, lo_t.numel(), dilation, scale)
+            t_lo, t_hi = _fwt._like(t_lo, lo_t), _fwt._like(t_hi, hi_t)
+        return g_x, t_lo, t_hi, None, None
+
+
+class _Iswt1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, d, lo_t, hi_t, dilation, scale):
+        ctx.meta = (dilation, scale)
+        ctx.save_for_backward(a, d, lo_t, hi_t)
+        return _level_inv(a, d, _fwt._host_taps_of(lo_t), _fwt._host_taps_of(hi_t), dilation, scale)
+
+    @staticmethod
+    def backward(ctx, g_y):
+        a, d, lo_t, hi_t = ctx.saved_tensors
+        dilation, scale = ctx.meta
+        g_a = g_d = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gb = _Swt1.apply(g_y, _rev(lo_t), _rev(hi_t), dilation, scale)
+            g_a, g_d = gb[:, 0], gb[:, 1]
+        t_lo = t_hi = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            t_lo, t_hi = _Iswt1Corr.apply(a, d, g_y, lo_t.numel(), dilation, scale)
+            t_lo, t_hi = _fwt._like(t_lo, lo_t), _fwt._like(t_hi, hi_t)
+        return g_a, g_d, t_lo, t_hi, None, None
+
+
+class _Swt1Corr(torch.autograd.Function):
+    """(x [B, N], g [B, 2, N]) -> (t_lo, t_hi):  t_b[m] = s sum_n g_b[n] x[(n + D L/2 - D m) mod N]."""
+
+    @staticmethod
+    def forward(ctx, x, g, flen, dilation, scale):
+        ctx.meta = (dilation, scale)
+        ctx.save_for_backward(x, g)
+        t_lo = torch.zeros(flen, dtype=torch.float64, device=x.device)
+        t_hi = torch.zeros_like(t_lo)
+        _engine.ENGINE.tap_correlate_dilated(g[:, 0], x, flen, dilation * (flen // 2), -dilation, t_lo)
+        _engine.ENGINE.tap_correlate_dilated(g[:, 1], x, flen, dilation * (flen // 2), -dilation, t_hi)
+        return t_lo * scale, t_hi * scale
+
+    @staticmethod
+    def backward(ctx, w_lo, w_hi):
+        x, g = ctx.saved_tensors
+        dilation, scale = ctx.meta
+        w_lo, w_hi = w_lo.to(x.dtype), w_hi.to(x.dtype)
+        g_x = _Iswt1.apply(g[:, 0], g[:, 1], _rev(w_lo), _rev(w_hi), dilation, scale) if ctx.needs_input_grad[0] else None
+        g_g = _Swt1.apply(x, w_lo, w_hi, dilation, scale) if ctx.needs_input_grad[1] else None
+        return g_x, g_g, None, None, None
+
+
+class _Iswt1Corr(torch.autograd.Function):
+    """(a, d, g_y [B, N]) -> (t_lo, t_hi):  t_lo[j] = s sum_n g_y[n] a[(n + D (L/2 - 1) - D j) mod N]."""
+
+    @staticmethod
+    def forward(ctx, a, d, g_y, flen, dilation, scale):
+        ctx.meta = (dilation, scale)
+        ctx.save_for_backward(a, d, g_y)
+        t_lo = torch.zeros(flen, dtype=torch.float64, device=a.device)
+        t_hi = torch.zeros_like(t_lo)
+        _engine.ENGINE.tap_correlate_dilated(g_y, a, flen, dilation * (flen // 2 - 1), -dilation, t_lo)
+        _engine.ENGINE.tap_correlate_dilated(g_y, d, flen, dilation * (flen // 2 - 1), -dilation, t_hi)
+        return t_lo * scale, t_hi * scale
+
+    @staticmethod
+    def backward(ctx, w_lo, w_hi):
+        a, d, g_y = ctx.saved_tensors
+        dilation, scale = ctx.meta
+        w_lo, w_hi = w_lo.to(a.dtype), w_hi.to(a.dtype)
+        g_a = g_d = g_gy = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gb = _Swt1.apply(g_y, _rev(w_lo), _rev(w_hi), dilation, scale)
+            g_a, g_d = gb[:, 0], gb[:, 1]
+        if ctx.needs_input_grad[2]:
+            g_gy = _Iswt1.apply(a, d, w_lo, w_hi, dilation, scale)
+        return g_a, g_d, g_gy, None, None, None
+
+
+class _SwtLevelGrad(torch.autograd.Function):
+    """First-order gradients of a stationary analysis level as an op whose backward has the mixed second derivatives with a learnable
+    filter bank (see _fwt._AnalysisLevelGrad)."""
+
+    @staticmethod
+    def forward(ctx, g_buf, x, lo_t, hi_t, lo, hi, dilation, scale):
+        ctx.meta = (dilation, scale)
+        ctx.save_for_backward(g_buf, x, lo_t, hi_t)
+        g_x = _level_inv(g_buf[:, 0], g_buf[:, 1], lo[::-1], hi[::-1], dilation, scale)
+        L = len(lo)
+        t_lo = torch.zeros(L, dtype=torch.float64, device=x.device)
+        t_hi = torch.zeros_like(t_lo)
+        _engine.ENGINE.tap_correlate_dilated(g_buf[:, 0], x, L, dilation * (L // 2), -dilation, t_lo)
+        _engine.ENGINE.tap_correlate_dilated(g_buf[:, 1], x, L, dilation * (L // 2), -dilation, t_hi)
+        return g_x, _fwt._like(t_lo * scale, lo_t), _fwt._like(t_hi * scale, hi_t)
+
+    @staticmethod
+    def backward(ctx, w_x, w_lo, w_hi):
+        g_buf, x, lo_t, hi_t = ctx.saved_tensors
+        _fwt._third_order_refused((lo_t, hi_t))
+        dilation, scale = ctx.meta
+        d = _fwt._partials_at([g_buf, x, lo_t, hi_t], lambda lv: _Swt1.apply(lv[1], lv[2], lv[3], dilation, scale), 0, [w_x, w_lo, w_hi])
+        return d[0], d[1], d[2], d[3], None, None, None, None
+
+
+class _IswtLevelGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g_y, a, d, lo_t, hi_t, lo, hi, dilation, scale):
+        ctx.meta = (dilation, scale)
+        ctx.save_for_backward(g_y, a, d, lo_t, hi_t)
+        g = _level_fwd(g_y, lo[::-1], hi[::-1], dilation, scale)
+        L = len(lo)
+        t_lo = torch.zeros(L, dtype=torch.float64, device=g_y.device)
+        t_hi = torch.zeros_like(t_lo)
+        _engine.ENGINE.tap_correlate_dilated(g_y, a, L, dilation * (L // 2 - 1), -dilation, t_lo)
+        _engine.ENGINE.tap_correlate_dilated(g_y, d, L, dilation * (L // 2 - 1), -dilation, t_hi)
+        return g[:, 0], g[:, 1], _fwt._like(t_lo * scale, lo_t), _fwt._like(t_hi * scale, hi_t)
+
+    @staticmethod
+    def backward(ctx, w_a, w_d, w_lo, w_hi):
+        g_y, a, d, lo_t, hi_t = ctx.saved_tensors
+        _fwt._third_order_refused((lo_t, hi_t))
+        dilation, scale = ctx.meta
+        out = _fwt._partials_at([g_y, a, d, lo_t, hi_t], lambda lv: _Iswt1.apply(lv[1], lv[2], lv[3], lv[4], dilation, scale), 0,
+                                [w_a, w_d, w_lo, w_hi])
+        return out[0], out[1], out[2], out[3], out[4], None, None, None, None
+
+
 class _SwtLevel(torch.autograd.Function):
     """One stationary analysis level (free output scale), differentiable w.r.t. its input and (optionally) the dec taps.  With
     reversed taps the synthesis kernel is its transpose and vice versa, so each Function's backward is the other Function:
@@ -97,7 +244,11 @@ class _SwtLevel(torch.autograd.Function):
     def backward(ctx, g_buf):
         lo, hi, dilation, scale = ctx.meta
         (x,) = ctx.saved_tensors
-        _fwt._no_double_backward_through_taps(ctx.taps)
+        if x is not None and torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ctx.taps):
+            # create_graph=True with a learnable filter bank: the same gradients as an op that carries the mixed second derivatives
+            g_x, g_lo, g_hi = _SwtLevelGrad.apply(g_buf, x, ctx.taps[0], ctx.taps[1], lo, hi, dilation, scale)
+            need = ctx.needs_input_grad
+            return g_x if need[0] else None, None, None, None, None, g_lo if need[5] else None, g_hi if need[6] else None
         g_x = _IswtLevel.apply(g_buf[:, 0], g_buf[:, 1], lo[::-1], hi[::-1], dilation, scale) if ctx.needs_input_grad[0] else None
         g_lo = g_hi = None
         if x is not None and (ctx.needs_input_grad[5] or ctx.needs_input_grad[6]):
@@ -127,7 +278,12 @@ class _IswtLevel(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_y):
         lo, hi, dilation, scale = ctx.meta
-        _fwt._no_double_backward_through_taps(ctx.taps)
+        if ctx.saved_tensors and torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ctx.taps):
+            a, d = ctx.saved_tensors
+            g_a, g_d, g_lo, g_hi = _IswtLevelGrad.apply(g_y, a, d, ctx.taps[0], ctx.taps[1], lo, hi, dilation, scale)
+            need = ctx.needs_input_grad
+            return (g_a if need[0] else None, g_d if need[1] else None, None, None, None, None, g_lo if need[6] else None,
+                    g_hi if need[7] else None)
         g_a = g_d = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             g = _SwtLevel.apply(g_y, lo[::-1], hi[::-1], dilation, scale)

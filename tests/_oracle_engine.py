@@ -192,3 +192,33 @@ class OracleLevelEngine:
             idx = O.ext_index(2 * np.arange(an.shape[1]) + c0 + sgn * t, n, _MODES[mode_id])
             vals = np.where(idx >= 0, bn[:, np.clip(idx, 0, n - 1)], 0.0)
             out[t] += float((an * vals).sum())
+
+    def tap_correlate_dilated(self, a, b, filt_len, c0, tstep, out):
+        """out[t] += sum_{row, k} a[row, k] b[row, (k + c0 + tstep t) mod N]"""
+        an, bn = a.detach().numpy().astype(np.float64), b.detach().numpy().astype(np.float64)
+        n = bn.shape[1]
+        for t in range(filt_len):
+            out[t] += float((an * bn[:, (np.arange(n) + c0 + tstep * t) % n]).sum())
+
+
+def swt_level_fwd(x, lo, hi, dilation, scale):
+    """TEST-ONLY stand-in for stationary_transform._level_fwd: buf[:, 0 / 1][n] = s sum_m lo / hi[m] x[(n + D (L/2 - m)) mod N]."""
+    xn = x.detach().numpy().astype(np.float64)
+    n, flen = xn.shape[1], len(lo)
+    out = np.zeros((xn.shape[0], 2, n))
+    for m in range(flen):
+        sh = xn[:, (np.arange(n) + dilation * (flen // 2 - m)) % n]
+        out[:, 0] += scale * lo[m] * sh
+        out[:, 1] += scale * hi[m] * sh
+    return torch.from_numpy(out).to(x.dtype)
+
+
+def swt_level_inv(a, d, lo, hi, dilation, scale):
+    """TEST-ONLY stand-in for stationary_transform._level_inv: y[n] = s sum_j lo[j] a[(n + D (L/2 - 1 - j)) mod N] + hi[j] d[...]."""
+    an, dn = a.detach().numpy().astype(np.float64), d.detach().numpy().astype(np.float64)
+    n, flen = an.shape[1], len(lo)
+    y = np.zeros_like(an)
+    for j in range(flen):
+        idx = (np.arange(n) + dilation * (flen // 2 - 1 - j)) % n
+        y += scale * (lo[j] * an[:, idx] + hi[j] * dn[:, idx])
+    return torch.from_numpy(y).to(a.dtype)

@@ -100,6 +100,10 @@ case("fswavedec2", "fswaverec2", (2, 22, 19), "db2", 13, mode="symmetric", level
 case("fswavedec3", "fswaverec3", (1, 12, 11, 13), "db2", 14, mode="reflect", level=1)
 case("wavedec2", "waverec2", (2, 40, 44), "bior2.2", 15, mode="symmetric", level=2)
 case("wavedec", "waverec", (3, 5, 64), "sym4", 16, mode="reflect", level=3, axis=-1)
+# stationary transform (a list of tensors in, one tensor out)
+case("swt", "iswt", (2, 64), "db2", 17, level=3)
+case("swt", "iswt", (3, 48), "haar", 18, level=2)
+case("swt", "iswt", (1, 96), "sym4", 19, level=None)
 
 out = os.path.join(HERE, "ptwt_ref_tapgrads2.npz")
 np.savez_compressed(out, index=json.dumps(index), **store)

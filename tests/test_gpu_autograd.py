@@ -485,7 +485,7 @@ def test_second_order_gradients_with_learnable_taps_vs_reference():
     """create_graph=True through a learnable filter bank (round 4): the mixed second derivatives — data x taps, taps x
     taps, upstream gradient x taps — against the reference's own double backward through ATen's conv path
     (tests/golden/ptwt_ref_tapgrads2.npz, tests/golden/make_ptwt_ref_tapgrad2_goldens.py): the ten level transforms, 1-3 axes, five
-    boundary modes; fp64, 1e-9 norm-wise.  (The backward that is asked for a graph re-runs the level as a product of per-axis ops that
+    boundary modes, and swt / iswt; fp64, 1e-9 norm-wise.  (The backward that is asked for a graph re-runs the level as a product of per-axis ops that
     are closed under differentiation, `_fwt._Axis1` / `_Syn1`.)"""
     import json
     import os
@@ -527,16 +527,19 @@ def test_second_order_gradients_with_learnable_taps_vs_reference():
         assert G.relerr(d2[-1].cpu().numpy(), z[k + "_s_dhi"]) < 1e-9, (case, "s_dhi")
 
 
-def test_double_backward_through_learnable_taps_decimated_works_stationary_refused():
-    """A gradient penalty with a learnable wavelet (create_graph=True) works for the decimated transforms and packet trees; the
-    stationary transform still refuses instead of returning a graph that lacks the mixed terms."""
+def test_double_backward_through_learnable_taps_works_third_order_refused():
+    """A gradient penalty with a learnable wavelet (create_graph=True) works for the decimated transforms, the packet trees and the
+    stationary transform (round 3 refused all of them); a THIRD-order derivative through learnable taps raises instead of returning a
+    graph that lacks terms."""
     bank = tuple(torch.tensor(v, device=dev(), dtype=torch.float64, requires_grad=True) for v in ptwt_amd._wavelets.host_taps("db2"))
     x = torch.randn(2, 32, 32, device=dev(), dtype=torch.float64, requires_grad=True)
     y = sum(c.square().sum() if isinstance(c, torch.Tensor) else sum(t.square().sum() for t in c) for c in ptwt_amd.wavedec2(x, bank, level=1))
     (g,) = torch.autograd.grad(y, x, create_graph=True)
     pen = g.square().sum()
-    gb = torch.autograd.grad(pen, [x, bank[0], bank[1]])
+    gb = torch.autograd.grad(pen, [x, bank[0], bank[1]], retain_graph=True)
     assert all(torch.isfinite(t).all() and t.abs().sum() > 0 for t in gb)
+    with pytest.raises(RuntimeError, match="beyond second order"):  # a graph of the second derivatives = third order
+        torch.autograd.grad(pen, [x, bank[0], bank[1]], create_graph=True)
     wp = ptwt_amd.WaveletPacket(x[:, 0], bank, mode="reflect", maxlevel=2)
     leaf = wp["ad"]
     (g,) = torch.autograd.grad(leaf.square().sum(), x, create_graph=True)
@@ -544,10 +547,9 @@ def test_double_backward_through_learnable_taps_decimated_works_stationary_refus
     assert all(torch.isfinite(t).all() and t.abs().sum() > 0 for t in gb)
     xs = torch.randn(2, 64, device=dev(), dtype=torch.float64, requires_grad=True)
     ys = sum(c.square().sum() for c in ptwt_amd.swt(xs, bank, level=2))
-    with pytest.raises(RuntimeError, match="double backward"):
-        torch.autograd.grad(ys, xs, create_graph=True)
-    (g,) = torch.autograd.grad(ys, xs)  # first order is fine
-    assert g.shape == xs.shape
+    (g,) = torch.autograd.grad(ys, xs, create_graph=True)
+    gb = torch.autograd.grad(g.square().sum(), [xs, bank[0], bank[1]])
+    assert all(torch.isfinite(t).all() and t.abs().sum() > 0 for t in gb)
 
 
 def test_tensor_taps_are_read_live_on_every_call():

@@ -22,7 +22,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture()
 def oracle_engine(monkeypatch):
+    from ptwt_amd import stationary_transform as st
+    from tests import _oracle_engine as oe
+
     monkeypatch.setattr(_engine, "ENGINE", OracleLevelEngine())
+    monkeypatch.setattr(st, "_level_fwd", oe.swt_level_fwd)
+    monkeypatch.setattr(st, "_level_inv", oe.swt_level_inv)
 
 
 def test_public_surface_matches_reference():
@@ -491,6 +496,8 @@ def test_second_order_gradients_with_learnable_taps_host_algebra(oracle_engine):
     for case in idx:
         if case["fn"] in ("wavedec3", "fswavedec3") and case["shape"][1] > 12:
             continue  # (the numpy stand-in's adjoints are loops: keep the CPU tier quick)
+        if case["fn"] == "swt":
+            kw = {a: v for a, v in case["kw"].items()}
         k = case["key"]
         kw = {a: (tuple(v) if isinstance(v, list) else v) for a, v in case["kw"].items()}
         x = torch.from_numpy(z[k + "_x"]).requires_grad_(True)
