@@ -303,6 +303,32 @@ def secondary_lines(dev, steps=20, warmup=5, buffers=3):
             out.append({"workload": name, "error": repr(exc)[:200]})
         if DEVICE_KIND == "cuda":
             torch.cuda.empty_cache()
+    # launch-bound calls: the same call sequence eager and replayed from a HIP graph (ptwt_amd.capture) — host time is what the
+    # eager call costs on a small batch, the replay runs at the kernels' own time
+    if DEVICE_KIND == "cuda":
+        for shape, wavelet, level, mode in (((16, 64, 64), "db2", 3, "reflect"), ((32, 1000, 1000), "db5", 5, "periodic")):
+            name = f"waverec2_of_wavedec2_{wavelet}_L{level}_{'x'.join(map(str, shape))}_f32_{mode}"
+            try:
+                x = torch.randn(*shape, device=dev)
+                fn = lambda t: ptwt_amd.waverec2(ptwt_amd.wavedec2(t, wavelet, mode=mode, level=level), wavelet)  # noqa: E731
+                cap = ptwt_amd.capture(fn, x)
+
+                def per_call(f, n=200):
+                    for _ in range(20):
+                        f()
+                    sync()
+                    t0 = time.perf_counter()
+                    for _ in range(n):
+                        f()
+                    sync()
+                    return (time.perf_counter() - t0) / n * 1e3
+
+                out.append({"workload": name, "eager_ms_per_step": round(per_call(lambda: fn(x)), 4),
+                            "graph_replay_ms_per_step": round(per_call(cap.replay), 4),
+                            "note": "wavedec2 + waverec2 per step; replay = one HIP graph launch of the same kernels (bit-identical)"})
+                del cap
+            except Exception as exc:
+                out.append({"workload": name, "error": repr(exc)[:200]})
     return out
 
 

@@ -25,6 +25,7 @@ from .conv_transform_3 import wavedec3, waverec3
 from .packets import WaveletPacket, WaveletPacket2D
 from .stationary_transform import iswt, swt
 from .separable_conv_transform import fswavedec2, fswavedec3, fswaverec2, fswaverec3
+from .graphs import CapturedCall, capture
 
 __version__ = "0.1.0"
 
@@ -51,4 +52,6 @@ __all__ = [
     "swt",
     "iswt",
     "WaveletPacket2D",
+    "capture",
+    "CapturedCall",
 ]
