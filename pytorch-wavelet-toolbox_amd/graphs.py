@@ -8,9 +8,9 @@ wavelets), so a whole call — or any function made of such calls — can be rec
     fwd = ptwt_amd.capture(lambda t: ptwt_amd.wavedec2(t, "db4", level=3), x)      # records the launches for x's geometry
     coeffs = fwd(x_new)                                                              # one graph launch; same containers
 
-Measured (MI355X, `tools/graph_probe.py`, ``waverec2(wavedec2(x))`` per iteration): 16 x 64^2 db2 level 3 47.6 -> 22.0 us, 8 x 256^2 db4
-level 4 87.5 -> 39.2 us, the reference's 2-D speed-test shape (32 x 1000^2 db5 level 5 periodic) 294 -> 162 us — the replay runs at
-the kernels' own time.  Bit-identical to the eager call (the same kernels on the same data).
+Measured (MI355X, `tools/graph_probe.py`, ``waverec2(wavedec2(x))`` per iteration): 16 x 64^2 db2 level 3 47.3 -> 22.6 us, 8 x 256^2 db4
+level 4 86.0 -> 39.6 us (the replay runs at the kernels' own time); calls that are GPU-bound anyway gain nothing (the reference's 2-D
+speed-test shape, 32 x 1000^2 db5 level 5 periodic: 156 against 160 us).  Bit-identical to the eager call (the same kernels on the same data).
 """
 from __future__ import annotations
 
