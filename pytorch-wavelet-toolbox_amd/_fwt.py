@@ -438,6 +438,14 @@ class _AnalysisPyramid(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_approx, *g_bands):
         shapes, dec_lo, dec_hi, mode_id = ctx.meta
+        if mode_id == _engine.MODE_IDS["zero"] and not torch.is_grad_enabled():
+            # zero mode, no graph of the backward wanted: the adjoint of every level is a synthesis level with the dec taps reversed,
+            # so the adjoint of the whole launch is ONE multi-level synthesis launch (kernels 22 / 21) where the library serves it
+            levels = [list(g_bands[3 * lvl : 3 * lvl + 3]) for lvl in range(len(shapes) - 1, -1, -1)]  # coarsest first
+            g = _engine.ENGINE.synthesis_pyramid(g_approx if g_approx.stride(-1) == 1 else g_approx.contiguous(), levels, dec_lo[::-1], dec_hi[::-1],
+                                                 list(shapes[0]))
+            if g is not None:
+                return g, None, None, None, None
         g = g_approx
         for lvl in range(len(shapes) - 1, -1, -1):
             g = _AnalysisAdjointBands.apply(shapes[lvl], dec_lo, dec_hi, mode_id, g, *g_bands[3 * lvl : 3 * lvl + 3])

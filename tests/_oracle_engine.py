@@ -60,6 +60,14 @@ class OracleLevelEngine:
             cur = buf[:, 0].clone()
         return ([b[:, 1:].contiguous() for b in bufs[:-1]] + [bufs[-1]]) or None
 
+    def pyramid_levels(self, x, flen, mode_id, nlevels):
+        """Same contract as HipLevelEngine.pyramid_levels (how many levels analysis_pyramid would fuse; nothing launched): asks the
+        stand-in itself on a detached copy."""
+        if x.dim() != 3 or x.dtype != torch.float32:
+            return 0
+        got = self.analysis_pyramid(x.detach(), [0.0] * flen, [0.0] * flen, mode_id, nlevels)
+        return 0 if got is None else len(got)
+
     def synthesis_pyramid_plan(self, approx, levels, flen, out_extent):
         """Same contract as HipLevelEngine.synthesis_pyramid_plan: (plan, descriptors, references, route) — route 1 = the
         whole-reconstruction launch of a small plane (what the stand-in below takes), 0 = no multi-level launch."""

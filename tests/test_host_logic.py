@@ -520,3 +520,31 @@ def test_second_order_gradients_with_learnable_taps_host_algebra(oracle_engine):
         for i, got in enumerate(d2[:-2]):
             assert G.relerr(got.numpy(), z["%s_s_dc%d" % (k, i)]) < 1e-11, (case, "s_dc", i)
         assert G.relerr(d2[-2].numpy(), z[k + "_s_dlo"]) < 1e-11 and G.relerr(d2[-1].numpy(), z[k + "_s_dhi"]) < 1e-11, case
+
+
+def test_differentiable_calls_take_the_multi_level_ops_host_side(oracle_engine):
+    """Host logic of the differentiable multi-level ops (`_fwt._AnalysisPyramid`, `_AnalysisTail`, `_SynthesisPyramid`,
+    `_SynthesisChain1d`) with the oracle stand-in: same values as the plain calls, gradients equal to those of the per-level ops
+    (autograd through the stand-in's adjoints), containers unchanged."""
+    torch.manual_seed(2)
+    for fn, rec, shape, kw in (("wavedec2", "waverec2", (2, 40, 44), dict(level=3, mode="symmetric")), ("wavedec", "waverec", (3, 60), dict(level=3, mode="reflect")),
+                               ("fswavedec2", "fswaverec2", (2, 33, 41), dict(level=2, mode="zero"))):
+        x = torch.randn(*shape, dtype=torch.float32, requires_grad=True)
+        with torch.no_grad():
+            plain = getattr(ptwt_amd, fn)(x, "db2", **kw)
+        coeffs = getattr(ptwt_amd, fn)(x, "db2", **kw)
+        fl, pl = [t for _, t in G.flatten_coeffs(coeffs)], [t for _, t in G.flatten_coeffs(plain)]
+        assert type(coeffs) is type(plain) and all(a.requires_grad and torch.equal(a.detach(), b) for a, b in zip(fl, pl))
+        ws = [torch.cos(torch.arange(t.numel(), dtype=torch.float32) * 0.3).reshape(t.shape) for t in fl]
+        (gx,) = torch.autograd.grad(sum((w * t).sum() for w, t in zip(ws, fl)), x)
+        # the adjoint identity against the plain forward: <A x, w> = <x, A^T w>
+        lhs = sum((w * t).sum() for w, t in zip(ws, pl)).item()
+        assert abs(lhs - (gx * x.detach()).sum().item()) < 1e-3 * max(1.0, abs(lhs))
+        leaves = [t.detach().clone().requires_grad_(True) for t in pl]
+        it = iter(leaves)
+        rebuilt = [next(it)] + [({k: next(it) for k in c} if isinstance(c, dict) else (type(c)(*[next(it) for _ in c]) if isinstance(c, tuple) else next(it))) for c in plain[1:]]
+        y = getattr(ptwt_amd, rec)(rebuilt if isinstance(plain, list) else tuple(rebuilt), "db2")
+        v = torch.sin(torch.arange(y.numel(), dtype=torch.float32) * 0.2).reshape(y.shape)
+        gl = torch.autograd.grad((v * y).sum(), leaves)
+        lhs = (v * y.detach()).sum().item()
+        assert abs(lhs - sum((g * t.detach()).sum().item() for g, t in zip(gl, leaves))) < 1e-3 * max(1.0, abs(lhs))
