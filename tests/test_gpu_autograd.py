@@ -143,6 +143,35 @@ def test_fused_forward_of_differentiable_calls(mode, shape, wavelet, level, pmod
     assert G.relerr(gx.cpu().numpy(), gx2.cpu().numpy()) < 2e-6
 
 
+def test_zero_mode_backward_is_one_multi_level_synthesis_launch():
+    """Zero mode: the adjoint of a multi-level analysis launch is ONE multi-level synthesis launch with the dec taps reversed (kernels 22 /
+    21) when no graph of the backward is asked for; with create_graph=True the per-level (differentiable) adjoints run instead.  Same
+    gradient either way (fp32 rounding)."""
+    torch.manual_seed(16)
+    for shape, pmode, want in (((4, 600, 520), 0, _engine.KID_INV_PYRAMID), ((8, 96, 80), 3, _engine.KID_INV_SMALL)):
+        _engine.set_option(_engine.OPT_PYRAMID_MODE, pmode)
+        try:
+            x = torch.randn(*shape, device=dev(), requires_grad=True)
+            fl = flat(ptwt_amd.wavedec2(x, "db4", mode="zero", level=3))
+            ws = [torch.randn_like(t) for t in fl]
+            loss = sum((w * t).sum() for w, t in zip(ws, fl))
+            _engine.level_events = []
+            (g1,) = torch.autograd.grad(loss, x, retain_graph=True)
+            torch.cuda.synchronize()
+            kids1 = [e[1] for e in _engine.level_events]
+            _engine.level_events = []
+            (g2,) = torch.autograd.grad(loss, x, create_graph=True)
+            torch.cuda.synchronize()
+            kids2 = [e[1] for e in _engine.level_events]
+            _engine.level_events = None
+        finally:
+            _engine.level_events = None
+            _engine.set_option(_engine.OPT_PYRAMID_MODE, 0)
+        assert kids1 == [want], (shape, kids1)
+        assert len(kids2) == 3 and want not in kids2, (shape, kids2)
+        assert G.relerr(g1.cpu().numpy(), g2.detach().cpu().numpy()) < 2e-6
+
+
 def test_fused_forward_gradients_at_config2_size():
     """Forward + backward of `wavedec2` db4 level 3 on 64 x 1024^2 (BASELINE config 2 with gradients; the benchmark workload
     `wavedec2_bwd_...`): one forward launch (kernel 16), gradient against the per-level ops on every image, adjoint identity."""
