@@ -221,6 +221,7 @@ size_t route_ws(const mifwt_level_desc* d, int direction, int kid) {
     case kDwt2InvMfma:
     case kDwt3FwdTile:
     case kDwt3InvTile:
+    case kDwt2InvPyr:
     case kDwt2InvStream: return 0;
     case kDwt3FwdStream:
     case kDwt3InvStream: return plane3_ws_bytes(d, direction);
@@ -376,6 +377,7 @@ static int run_inv(const mifwt_level_desc* desc, const void* approx, const void*
     case kDwt2InvStream: return dwt2_inv_stream(desc, approx, details, y, rec_lo, rec_hi, st);
     case kDwt2InvTile: return dwt2_inv_tile(desc, approx, details, y, rec_lo, rec_hi, st);
     case kDwt2InvMfma: return dwt2_inv_mfma(desc, approx, details, y, rec_lo, rec_hi, st);
+    case kDwt2InvPyr: return dwt2_inv_fused(desc, approx, details, y, rec_lo, rec_hi, st);  // (one level through the streaming kernel)
     case kDwt3InvTile: return dwt3_inv_tile(desc, approx, details, y, rec_lo, rec_hi, st);
     case kDwt3InvStream: return plane3_inv(desc, approx, details, y, rec_lo, rec_hi, workspace, st);
     case kDwt1InvRow: return rows_inv(desc, approx, details, y, rec_lo, rec_hi, workspace, st);

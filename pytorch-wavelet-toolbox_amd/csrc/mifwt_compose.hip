@@ -186,6 +186,14 @@ int dwt2_inv_tile(const mifwt_level_desc* d, const void* approx, const void* con
 int dwt2_inv_choice(const mifwt_level_desc* d) {
   const int tm = g_options[MIFWT_OPT_TILE_MODE];  // 0 auto, 1 always tile, 2 never tile
   if (dwt2_inv_mfma_supported(d)) return kDwt2InvMfma;
+  if (tm == 0 && g_options[MIFWT_OPT_PYRAMID_MODE] != 2 && d->sig_extent[1] >= 700 && d->sig_extent[1] <= 1536 && d->sig_extent[0] >= 256) {
+    // ONE level through the streaming multi-level kernel (id 22): measured ahead of both per-level kernels on planes of about a
+    // thousand columns (64 x 1024^2 db4: 80 against 115 us; db2: 81 against 98; 32 x 1000^2 db5: 43 against 53; 16 x 1400^2 db3: 42
+    // against 50; equal at 515^2, behind at 2055^2: tools/inv1_probe.py, profiles/r04q_inv1_probe.txt) — what a single-level
+    // mifwt_dwt_inv call and the zero-mode part of every analysis adjoint of such planes now take
+    const mifwt_level_desc* dd[1] = {d};
+    if (dwt2_inv_pyr_supported(1, dd)) return kDwt2InvPyr;
+  }
   const bool stream_ok = dwt2_inv_stream_supported(d), tile_ok = dwt2_inv_tile_supported(d);
   if (stream_ok && (tm == 2 || !tile_ok)) return kDwt2InvStream;
   if (tile_ok && tm != 2) {
@@ -204,6 +212,11 @@ int dwt2_inv_fused(const mifwt_level_desc* d, const void* approx, const void* co
     case kDwt2InvTile: return dwt2_inv_tile(d, approx, details, y, lo, hi, stream);
     case kDwt2InvStream: return dwt2_inv_stream(d, approx, details, y, lo, hi, stream);
     case kDwt2InvMfma: return dwt2_inv_mfma(d, approx, details, y, lo, hi, stream);
+    case kDwt2InvPyr: {
+      const mifwt_level_desc* dd[1] = {d};
+      const void* const* dp[1] = {details};
+      return dwt2_inv_pyr(1, dd, approx, dp, y, lo, hi, stream);
+    }
     default: return MIFWT_ERR_UNSUPPORTED;
   }
 }

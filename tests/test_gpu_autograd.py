@@ -312,10 +312,10 @@ def test_backward_routes():
     d.sig_stride[0], d.sig_stride[1], d.sig_stride[2] = 1024 * 1024, 1024, 1
     for s in (d.approx_stride, d.detail_stride):
         s[0], s[1], s[2] = 4 * 515 * 515, 515, 1
-    assert lib.mifwt_kernel_id(ctypes.byref(d), 2) == 2  # adjoint of a zero-mode analysis = fused synthesis kernel
+    assert lib.mifwt_kernel_id(ctypes.byref(d), 2) == 22  # adjoint of a zero-mode analysis = a synthesis level: the streaming kernel with one level (round 4; was: id 2)
     assert lib.mifwt_kernel_id(ctypes.byref(d), 3) == 7  # adjoint of a synthesis = fused zero-mode analysis kernel
     d.mode = 2
-    assert lib.mifwt_kernel_id(ctypes.byref(d), 2) == 2  # reflect: the same launch + the border kernel (round 4; was: generic passes)
+    assert lib.mifwt_kernel_id(ctypes.byref(d), 2) == 22  # reflect: the same launch + the border kernel (round 4; was: generic passes)
     assert lib.mifwt_kernel_id(ctypes.byref(d), 3) == 7
     _engine.set_option(_engine.OPT_DEBUG, 1024)
     try:

@@ -218,7 +218,8 @@ def test_cabi_descriptor_validation_and_dispatch():
     assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (1024, 1024)) == 7  # fused 2-D analysis, LDS tiles
     assert _engine.kernel_id(2, torch.float32, "reflect", 16, 64, (4096, 4096)) == 1  # fused 2-D analysis, streaming
     assert _engine.kernel_id(2, torch.float32, "reflect", 16, 64, (1035, 1035)) == 7
-    assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (1024, 1024), direction=1) == 2  # fused 2-D synthesis
+    assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (1024, 1024), direction=1) == 22  # one level through the streaming multi-level kernel (round 4)
+    assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (2048, 2048), direction=1) == 2  # fused 2-D synthesis, streaming wave strips
     assert _engine.kernel_id(2, torch.float64, "reflect", 8, 64, (1024, 1024)) == 7  # f64, L <= 16: LDS tiles in double
     assert _engine.kernel_id(2, torch.float64, "reflect", 8, 64, (1024, 1024), direction=1) == 8
     assert _engine.kernel_id(2, torch.float64, "reflect", 20, 4, (512, 512)) == 3    # f64, long filter: streaming axis passes
