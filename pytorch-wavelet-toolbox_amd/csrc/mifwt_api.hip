@@ -214,6 +214,7 @@ size_t generic_ws(const mifwt_level_desc* d, int direction) {
 
 size_t route_ws(const mifwt_level_desc* d, int direction, int kid) {
   switch (kid) {
+    case kDwt2FwdPyr:
     case kDwt2FwdStream:
     case kDwt2FwdTile:
     case kDwt2FwdMfma:
@@ -352,6 +353,7 @@ static int run_fwd(const mifwt_level_desc* desc, const void* x, void* approx, vo
     case kDwt2FwdStream: return dwt2_fwd_stream(desc, x, approx, details, dec_lo, dec_hi, st);
     case kDwt2FwdTile: return dwt2_fwd_tile(desc, x, approx, details, dec_lo, dec_hi, st);
     case kDwt2FwdMfma: return dwt2_fwd_mfma(desc, x, approx, details, dec_lo, dec_hi, st);
+    case kDwt2FwdPyr: return dwt2_fwd_fused(desc, x, approx, details, dec_lo, dec_hi, st);  // (one level through the streaming kernel)
     case kDwt3FwdTile: return dwt3_fwd_tile(desc, x, approx, details, dec_lo, dec_hi, st);
     case kDwt3FwdStream: return plane3_fwd(desc, x, approx, details, dec_lo, dec_hi, workspace, st);
     case kDwt1FwdRow: return rows_fwd(desc, x, approx, details, dec_lo, dec_hi, workspace, st);

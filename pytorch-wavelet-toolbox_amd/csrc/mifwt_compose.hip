@@ -135,6 +135,13 @@ int dwt2_fwd_tile(const mifwt_level_desc* d, const void* x, void* approx, void* 
 int dwt2_fwd_choice(const mifwt_level_desc* d) {
   const int tm = g_options[MIFWT_OPT_TILE_MODE];  // 0 auto, 1 always tile, 2 never tile
   if (g_options[MIFWT_OPT_MFMA_MODE] != 2 && dwt2_fwd_mfma_supported(d)) return kDwt2FwdMfma;
+  if (tm == 0 && g_options[MIFWT_OPT_PYRAMID_MODE] != 2 && d->sig_extent[1] >= 896 && d->sig_extent[1] <= 1280 && d->sig_extent[0] >= 256) {
+    // ONE level through the streaming multi-level kernel (id 16): 64 x 1024^2 db4 83.6 against 105.3 us for the tile kernel (db2: 83.6
+    // against 98.5; equal at 515^2, behind at 1400^2 and 2048^2: tools/fwd1_probe.py, profiles/r04r_fwd1_probe.txt) — what a
+    // single-level mifwt_dwt_fwd call and every synthesis adjoint of such planes now take
+    const mifwt_level_desc* dd[1] = {d};
+    if (dwt2_fwd_pyr_supported(1, dd)) return kDwt2FwdPyr;
+  }
   const bool stream_ok = dwt2_fwd_stream_supported(d), tile_ok = dwt2_fwd_tile_supported(d);
   if (stream_ok && (tm == 2 || !tile_ok)) return kDwt2FwdStream;
   if (tile_ok && tm != 2) {
@@ -149,6 +156,11 @@ int dwt2_fwd_fused(const mifwt_level_desc* d, const void* x, void* approx, void*
   switch (dwt2_fwd_choice(d)) {
     case kDwt2FwdTile: return dwt2_fwd_tile(d, x, approx, details, lo, hi, stream);
     case kDwt2FwdStream: return dwt2_fwd_stream(d, x, approx, details, lo, hi, stream);
+    case kDwt2FwdPyr: {
+      const mifwt_level_desc* dd[1] = {d};
+      void* const* dp[1] = {details};
+      return dwt2_fwd_pyr(1, dd, x, dp, approx, lo, hi, nullptr, 0, 0ull, stream);
+    }
     default: return MIFWT_ERR_UNSUPPORTED;
   }
 }

@@ -1055,6 +1055,9 @@ static bool pyr_plan(int nlev, const mifwt_level_desc* const* d, PyrPlan* p) {
   p->nseg = (HN + p->seg_rows - 1) / p->seg_rows;
   if (p->nseg > 1 && HN - (p->nseg - 1) * p->seg_rows < 8) --p->nseg;
   p->seg0_rows = p->seg_rows;
+  // (Round 4: a first segment SHORTER by the two level-3 rows its longer top-of-plane lags cost — 42 / 42 / 42 / 42 steps of 8 rows per
+  // workgroup instead of 44 / 42 / 42 / 40 — measured the same, 104.4-106.5 against 104.4-105.1 us in three alternating runs,
+  // profiles/r04t_segment_balance.txt: as with round 3's longer first segment, the launch does not wait for its longest workgroup.)
   // handover between the row segments of an image instead of prologues (kernel: exchange wave): two levels at least, more than one
   // segment, one column group, a spare wave (at most five level-1 waves), room in LDS for the rows taken over
   p->handover = 0;

@@ -313,10 +313,10 @@ def test_backward_routes():
     for s in (d.approx_stride, d.detail_stride):
         s[0], s[1], s[2] = 4 * 515 * 515, 515, 1
     assert lib.mifwt_kernel_id(ctypes.byref(d), 2) == 22  # adjoint of a zero-mode analysis = a synthesis level: the streaming kernel with one level (round 4; was: id 2)
-    assert lib.mifwt_kernel_id(ctypes.byref(d), 3) == 7  # adjoint of a synthesis = fused zero-mode analysis kernel
+    assert lib.mifwt_kernel_id(ctypes.byref(d), 3) == 16  # adjoint of a synthesis = a zero-mode analysis level: the streaming kernel with one level (round 4; was: id 7)
     d.mode = 2
     assert lib.mifwt_kernel_id(ctypes.byref(d), 2) == 22  # reflect: the same launch + the border kernel (round 4; was: generic passes)
-    assert lib.mifwt_kernel_id(ctypes.byref(d), 3) == 7
+    assert lib.mifwt_kernel_id(ctypes.byref(d), 3) == 16
     _engine.set_option(_engine.OPT_DEBUG, 1024)
     try:
         assert lib.mifwt_kernel_id(ctypes.byref(d), 2) == 0  # the generic adjoint passes (halo fold-back), kept for short axes / long filters

@@ -215,7 +215,8 @@ def test_cabi_descriptor_validation_and_dispatch():
     lib = _engine.load_library()
     d = _engine.LevelDesc()
     assert lib.mifwt_kernel_id(ctypes.byref(d), 0) == -1  # ndim = 0
-    assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (1024, 1024)) == 7  # fused 2-D analysis, LDS tiles
+    assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (1024, 1024)) == 16  # one level through the streaming multi-level kernel (round 4)
+    assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (640, 640)) == 7  # fused 2-D analysis, LDS tiles
     assert _engine.kernel_id(2, torch.float32, "reflect", 16, 64, (4096, 4096)) == 1  # fused 2-D analysis, streaming
     assert _engine.kernel_id(2, torch.float32, "reflect", 16, 64, (1035, 1035)) == 7
     assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (1024, 1024), direction=1) == 22  # one level through the streaming multi-level kernel (round 4)
