@@ -469,29 +469,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
 
-    # The K timed steps drop every result, so the caching allocator hands each step the SAME output block and part of the rewritten
-    # output lives in the 256 MiB Infinity Cache.  Second figure, reported next to the headline: the same K steps with the last
-    # `--buffers` results kept alive, i.e. rotating output sets as well as rotating inputs (config 2: ~8 % slower).
-    held = [None] * max(1, args.buffers)
-    for i in range(max(len(held), min(args.warmup, 10))):
-        held[i % len(held)] = step(i)
-    sync()
-    t1 = time.perf_counter()
-    for i in range(args.steps):
-        held[i % len(held)] = step(i)
-    sync()
-    rotating_ms = (time.perf_counter() - t1) / args.steps * 1e3
-    del held
     gc.enable()
-    # ... and with the interpreter's cyclic collector left on (how BENCH_r01 / r02 were timed)
-    for i in range(3):
-        step(i)
-    sync()
-    t1 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    sync()
-    gc_on_ms = (time.perf_counter() - t1) / args.steps * 1e3
 
     # Roofline leg: the same K steps once more with a HIP event pair around every level launch, recorded on
     # the launch stream.  It is a separate pass because hipEventRecord inserts a barrier packet into the
@@ -547,6 +525,36 @@ def main():
             sync()
             batches.append(e0.elapsed_time(e1) / 20)
         lvl1_b2b_ms, lvl1_b2b_min = statistics.median(batches), min(batches)
+
+    # The K timed steps drop every result, so the caching allocator hands each step the SAME output block and part of the rewritten
+    # output lives in the 256 MiB Infinity Cache.  Second figure, reported next to the headline: the same K steps with the last
+    # `--buffers` results kept alive, i.e. rotating output sets as well as rotating inputs (config 2: ~8 % slower).
+    # (these two loops run AFTER the roofline legs: the rotating loop leaves three freed output sets in the caching allocator, and the
+    # launches that follow would cycle through them — the dominant-kernel leg then measured 0.1076 ms against 0.1048 ms per whole call
+    # and failed its own consistency check)
+    if os.environ.get("MIFWT_BENCH_GC") != "1":
+        gc.disable()
+    held = [None] * max(1, args.buffers)
+    for i in range(max(len(held), min(args.warmup, 10))):
+        held[i % len(held)] = step(i)
+    sync()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        held[i % len(held)] = step(i)
+    sync()
+    rotating_ms = (time.perf_counter() - t1) / args.steps * 1e3
+    del held
+    gc.enable()
+    # ... and with the interpreter's cyclic collector left on (how BENCH_r01 / r02 were timed)
+    for i in range(3):
+        step(i)
+    sync()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync()
+    gc_on_ms = (time.perf_counter() - t1) / args.steps * 1e3
+
 
     # Optional, outside the timed region (N > 1): what replicating the coefficients on every rank would cost — one
     # all_gather_into_tensor per level buffer over RCCL / xGMI (ptwt_amd.distributed.gather_coeffs).  Reported, never part
