@@ -610,7 +610,7 @@ def main():
             # read and written the other way round)
             lvl1_b = algorithmic_bytes(shape[0], shape[1:], flen, fused_levels, esize)[0]
         klabel = {1: "dwt2_fwd_stream_kernel (level 1)", 7: "dwt2_fwd_tile_kernel (level 1)", 0: "generic axis kernels (level 1)",
-                  3: "streaming axis kernels (level 1)", 5: "composed 3-D level 1: fused 2-D kernel over all depth slices + depth pass (two launches; traffic = both)", 9: "dwt3_fwd_tile_kernel (level 1)",
+                  3: "streaming axis kernels (level 1)", 5: "composed 3-D level 1: fused 2-D kernel over all depth slices + depth pass (two launches; traffic = both)", 9: "dwt3_fwd_tile_kernel (level 1)", 24: "dwt3_fwd_walk_kernel (level 1)", 25: "idwt3_walk_kernel (finest level)",
                   11: "dwt2_fwd_mfma_walk_kernel (level 1)", 23: "idwt2_mfma_walk_kernel (finest level)",
                   12: ("dwt2_fwd_roll_kernel" if flen >= 8 else "dwt2_fwd_pair_kernel") + " (levels 1+2 in one launch)",
                   16: f"dwt2_fwd_pyr_kernel (levels 1-{fused_levels} in one launch)",

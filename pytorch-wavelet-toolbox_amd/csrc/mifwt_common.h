@@ -144,7 +144,7 @@ int stream_call(int dtype, int kind, const StreamCall& c);  // dispatches on dty
 // Each returns MIFWT_ERR_UNSUPPORTED when the descriptor is outside its envelope (the dispatcher then
 // falls back to the generic passes) and never touches the workspace.
 enum KernelId { kGeneric = 0, kDwt2FwdStream = 1, kDwt2InvStream = 2, kDwt1FwdRow = 3, kDwt1InvRow = 4, kDwt3FwdStream = 5, kDwt3InvStream = 6, kDwt2FwdTile = 7, kDwt2InvTile = 8, kDwt3FwdTile = 9, kDwt3InvTile = 10, kDwt2FwdMfma = 11, kDwt2FwdPair = 12, kDwt2InvPair = 13, kDwt1FwdTail = 14, kDwt1InvTail = 15, kDwt2FwdPyr = 16,
-  kDwt1FwdLong = 17, kDwt1InvLong = 18, kDwt2FwdSmall = 20, kDwt2InvSmall = 21, kDwt2InvPyr = 22, kDwt2InvMfma = 23 };
+  kDwt1FwdLong = 17, kDwt1InvLong = 18, kDwt2FwdSmall = 20, kDwt2InvSmall = 21, kDwt2InvPyr = 22, kDwt2InvMfma = 23, kDwt3FwdWalk = 24, kDwt3InvWalk = 25 };
 
 bool dwt2_fwd_stream_supported(const mifwt_level_desc* d);
 int dwt2_fwd_stream(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
@@ -254,6 +254,14 @@ int dwt2_inv_stream(const mifwt_level_desc* d, const void* approx, const void* c
 bool dwt3_fwd_tile_supported(const mifwt_level_desc* d);
 int dwt3_fwd_tile(const mifwt_level_desc* d, const void* x, void* approx, void* const* details,
                   const double* dec_lo, const double* dec_hi, hipStream_t stream);
+// fully fused 3-D analysis level, workgroups walking along the depth axis (mifwt_dwt3_fwd_walk.hip): f32, even L <= 10, every mode
+bool dwt3_fwd_walk_supported(const mifwt_level_desc* d);
+int dwt3_fwd_walk(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo, const double* hi,
+                  hipStream_t stream);
+// ... and its synthesis mirror (mifwt_dwt3_inv_walk.hip): f32, even L <= 8, dense coefficient rows
+bool dwt3_inv_walk_supported(const mifwt_level_desc* d);
+int dwt3_inv_walk(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y, const double* lo, const double* hi,
+                  hipStream_t stream);
 // fully fused LDS-brick 3-D synthesis level (mifwt_dwt3_inv_tile.hip): f32, L in {2, 4, 6}
 bool dwt3_inv_tile_supported(const mifwt_level_desc* d);
 int dwt3_inv_tile(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y, const double* lo,

@@ -322,8 +322,8 @@ def test_stream_routes_selected():
     kid = _engine.kernel_id
     assert kid(1, torch.float32, "reflect", 8, 4, (1000,)) == 3 and kid(1, torch.float32, "zero", 8, 4, (1000,), direction=1) == 4
     assert kid(1, torch.float64, "reflect", 2, 1, (4096,)) == 3
-    assert kid(3, torch.float32, "zero", 4, 8, (256, 256, 256)) == 9  # fully fused LDS-brick 3-D analysis
-    assert kid(3, torch.float32, "zero", 8, 8, (256, 256, 256)) == 5 and kid(3, torch.float32, "zero", 4, 8, (256, 256, 256), direction=1) == 10 and kid(3, torch.float32, "zero", 10, 8, (256, 256, 256), direction=1) == 6
+    assert kid(3, torch.float32, "zero", 4, 8, (256, 256, 256)) == 24 and kid(3, torch.float32, "zero", 4, 8, (129, 129, 129)) == 9  # 3-D analysis: depth-walking kernel on big volumes (round 4), LDS bricks below
+    assert kid(3, torch.float32, "zero", 8, 8, (256, 256, 256)) == 24 and kid(3, torch.float32, "zero", 12, 8, (256, 256, 256)) == 5 and kid(3, torch.float32, "zero", 4, 8, (256, 256, 256), direction=1) == 25 and kid(3, torch.float32, "zero", 4, 8, (64, 64, 64), direction=1) == 10 and kid(3, torch.float32, "zero", 10, 8, (256, 256, 256), direction=1) == 6
     assert kid(3, torch.float64, "zero", 4, 2, (33, 34, 35)) == 3  # f64: inner pass + two outer passes
     assert kid(2, torch.float64, "reflect", 8, 2, (64, 64)) == 7 and kid(2, torch.float64, "reflect", 8, 2, (64, 64), direction=1) == 8  # f64 tiles
     assert kid(2, torch.float64, "reflect", 24, 2, (64, 64)) == 3  # f64, long filter: inner + outer pass

@@ -1,0 +1,154 @@
+"""The depth-walking fused 3-D analysis kernel (kernel id 24, mifwt_dwt3_fwd_walk.hip) against the fp64 oracle and against the
+other 3-D routes (LDS bricks, id 9; composed 2-D planes + depth pass, id 5): every boundary mode — periodic included —, filters
+of 2 .. 10 taps, one to three column strips, ragged row groups, odd extents, rows longer than one 1-KiB request, several depth
+segments, strided (sliced) inputs.  Reference seam: src/ptwt/conv_transform_3.py:121-141."""
+import numpy as np
+import pytest
+import torch
+
+import ptwt_amd
+from ptwt_amd import _engine
+from oracle import fwt_oracle as O
+from tests import _golden as G
+from tests.test_gpu_parity import MODES, TOL32, check_tree, dev, to_np
+
+pytestmark = pytest.mark.gpu
+
+WALK = 4  # MIFWT_OPT_TILE_MODE value that routes 3-D analysis levels to the walk kernel wherever it can run
+
+
+def _walk(fn):
+    _engine.set_option(_engine.OPT_TILE_MODE, WALK)
+    try:
+        _engine.level_events = []
+        out = fn()
+        kids = [e[1] for e in _engine.level_events]
+    finally:
+        _engine.level_events = None
+        _engine.set_option(_engine.OPT_TILE_MODE, 0)
+    return out, kids
+
+
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4", "db5"])
+def test_walk3_vs_oracle(wavelet):
+    rng = np.random.default_rng(len(wavelet) + 40)
+    flen = len(O.filter_bank(wavelet)[0])
+    shapes = [(2, 21, 37, 141), (1, 2 * flen + 1, 2 * flen, 2 * flen + 3), (3, 9, 70, 66), (2, 12, 21, 130), (1, 40, 20, 258),
+              (1, 11, 13, 300), (1, 33, 9, 129)]
+    for shape in shapes:
+        if min(shape[1:]) < flen:  # (the kernel's single-fold boundary map wants every extent >= the filter length)
+            continue
+        x = rng.standard_normal(shape)
+        xg = torch.from_numpy(x).float().to(dev())
+        for mode in MODES:
+            level = 2 if min(shape[1:]) >= 3 * flen else 1
+            try:
+                want = O.wavedec3(x, wavelet, mode=mode, level=level)
+            except RuntimeError:
+                continue
+            got, kids = _walk(lambda: ptwt_amd.wavedec3(xg, wavelet, mode=mode, level=level))
+            assert kids and kids[0] == 24, (kids, shape, mode)
+            check_tree(got, want, TOL32, f"dwt3 walk {wavelet} {mode} {shape}")
+
+
+def test_walk3_many_segments_and_strided_input():
+    """Depth segments forced short (8 output slices each), the input a slice of a bigger tensor (strides larger than the extents)."""
+    rng = np.random.default_rng(77)
+    big = torch.from_numpy(rng.standard_normal((2, 70, 45, 140))).float().to(dev())
+    xg = big[:, 3:69, 2:43, 5:137]
+    x = to_np(xg).astype(np.float64)
+    for wavelet, mode in [("db2", "reflect"), ("db3", "periodic"), ("db2", "zero"), ("db4", "symmetric"), ("haar", "constant")]:
+        want = O.wavedec3(x, wavelet, mode=mode, level=1)
+        _engine.set_option(_engine.OPT_ROWS_PER_CHUNK, 8)
+        try:
+            got, kids = _walk(lambda: ptwt_amd.wavedec3(xg, wavelet, mode=mode, level=1))
+        finally:
+            _engine.set_option(_engine.OPT_ROWS_PER_CHUNK, 0)
+        assert kids == [24], kids
+        check_tree(got, want, TOL32, f"dwt3 walk segments {wavelet} {mode}")
+
+
+def test_walk3_agrees_with_bricks_on_config3_shape():
+    """One volume of BASELINE configs[2] (256^3, db2, level 3, zero mode): walk kernel vs the brick kernel, band by band."""
+    x = torch.randn(1, 256, 256, 256, device=dev())
+    _engine.set_option(_engine.OPT_TILE_MODE, 1)
+    try:
+        ref = ptwt_amd.wavedec3(x, "db2", mode="zero", level=3)
+    finally:
+        _engine.set_option(_engine.OPT_TILE_MODE, 0)
+    got, kids = _walk(lambda: ptwt_amd.wavedec3(x, "db2", mode="zero", level=3))
+    assert kids == [24, 24, 24], kids
+    for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(ref)):
+        assert G.relerr(to_np(a), to_np(b)) < 5e-7, n
+    # auto routing: the walk kernel on the 256^3 level, the bricks on the 129^3 / 66^3 levels
+    _engine.level_events = []
+    try:
+        auto = ptwt_amd.wavedec3(x, "db2", mode="zero", level=3)
+        kids = [e[1] for e in _engine.level_events]
+    finally:
+        _engine.level_events = None
+    assert kids == [24, 9, 9], kids
+    for (n, a), (_, b) in zip(G.flatten_coeffs(auto), G.flatten_coeffs(ref)):
+        assert G.relerr(to_np(a), to_np(b)) < 5e-7, n
+
+
+# ------------------------------------------------------------------ synthesis mirror (kernel id 25, mifwt_dwt3_inv_walk.hip)
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4"])
+def test_iwalk3_vs_oracle(wavelet):
+    """The depth-walking synthesis kernel against the fp64 oracle fed the same f32 coefficients (coefficients of every boundary mode:
+    odd extents, i.e. trimmed outputs; one to three column strips; ragged row groups; pieces of 1 .. 5 KiB) and against the bricks.
+    Reference seam: src/ptwt/conv_transform_3.py:205-249."""
+    rng = np.random.default_rng(len(wavelet) + 51)
+    flen = len(O.filter_bank(wavelet)[0])
+    for shape in [(2, 21, 37, 141), (1, 2 * flen + 1, 2 * flen, 2 * flen + 3), (3, 9, 70, 66), (1, 12, 21, 260), (2, 40, 33, 128), (1, 20, 9, 300)]:
+        x = rng.standard_normal(shape)
+        for mode in MODES:
+            level = 2 if min(shape[1:]) >= 3 * flen else 1
+            try:
+                coeffs = O.wavedec3(x, wavelet, mode=mode, level=level)
+            except RuntimeError:
+                continue
+            cdev = [torch.from_numpy(coeffs[0]).float().to(dev())] + [{k: torch.from_numpy(v).float().to(dev()) for k, v in c.items()} for c in coeffs[1:]]
+            c32 = [cdev[0].cpu().double().numpy()] + [{k: v.cpu().double().numpy() for k, v in c.items()} for c in cdev[1:]]
+            want = O.waverec3(c32, wavelet)
+            _engine.set_option(_engine.OPT_TILE_MODE, 1)
+            try:
+                ref = ptwt_amd.waverec3(cdev, wavelet)
+            finally:
+                _engine.set_option(_engine.OPT_TILE_MODE, 0)
+            got, kids = _walk(lambda: ptwt_amd.waverec3(cdev, wavelet))
+            assert kids == [25] * level, (wavelet, mode, shape, kids)
+            assert tuple(got.shape) == tuple(want.shape)
+            assert G.relerr(to_np(got), want) < TOL32, (wavelet, mode, shape)
+            assert G.relerr(to_np(got), to_np(ref)) < 5e-7, (wavelet, mode, shape)
+
+
+def test_iwalk3_many_segments_round_trip_config3_shape():
+    """One volume of BASELINE configs[2] (256^3, db2, level 3, zero mode) through both walk kernels: round trip, and the synthesis
+    against the bricks; then short depth segments (8 output slice pairs each)."""
+    x = torch.randn(1, 256, 256, 256, device=dev())
+    c = ptwt_amd.wavedec3(x, "db2", mode="zero", level=3)
+    _engine.set_option(_engine.OPT_TILE_MODE, 1)
+    try:
+        ref = ptwt_amd.waverec3(c, "db2")
+    finally:
+        _engine.set_option(_engine.OPT_TILE_MODE, 0)
+    got, kids = _walk(lambda: ptwt_amd.waverec3(c, "db2"))
+    assert kids == [25, 25, 25], kids
+    assert (got - x).abs().max().item() < 5e-6
+    assert G.relerr(to_np(got), to_np(ref)) < 5e-7
+    _engine.set_option(_engine.OPT_ROWS_PER_CHUNK, 8)
+    try:
+        seg, kids = _walk(lambda: ptwt_amd.waverec3(c, "db2"))
+    finally:
+        _engine.set_option(_engine.OPT_ROWS_PER_CHUNK, 0)
+    assert kids == [25, 25, 25] and torch.equal(seg, got)
+    # auto routing: bricks for the 66^3 level, the walk kernel from the 129^3 level on
+    _engine.level_events = []
+    try:
+        auto = ptwt_amd.waverec3(c, "db2")
+        kids = [e[1] for e in _engine.level_events]
+    finally:
+        _engine.level_events = None
+    assert kids == [10, 25, 25], kids
+    assert G.relerr(to_np(auto), to_np(ref)) < 5e-7

@@ -231,10 +231,12 @@ def test_cabi_descriptor_validation_and_dispatch():
     assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (515, 515), direction=1) == 8   # small plane: tiles
     assert _engine.kernel_id(1, torch.float64, "zero", 2, 1, (4096,)) == 3
     assert _engine.kernel_id(1, torch.float32, "zero", 8, 1, (4096,), direction=1) == 4
-    assert _engine.kernel_id(3, torch.float32, "zero", 4, 8, (256, 256, 256)) == 9   # fully fused LDS-brick kernel
-    assert _engine.kernel_id(3, torch.float32, "zero", 8, 8, (256, 256, 256)) == 5   # fused planes + depth pass
-    assert _engine.kernel_id(3, torch.float32, "zero", 4, 8, (256, 256, 256), direction=1) == 10  # fully fused LDS-brick synthesis
-    assert _engine.kernel_id(3, torch.float32, "zero", 8, 8, (256, 256, 256), direction=1) == 10 and _engine.kernel_id(3, torch.float32, "zero", 10, 8, (256, 256, 256), direction=1) == 6   # ten taps: fused planes + depth pass
+    assert _engine.kernel_id(3, torch.float32, "zero", 4, 8, (256, 256, 256)) == 24  # depth-walking fused kernel (big volumes)
+    assert _engine.kernel_id(3, torch.float32, "zero", 4, 8, (128, 128, 128)) == 9   # fully fused LDS-brick kernel
+    assert _engine.kernel_id(3, torch.float32, "zero", 12, 8, (256, 256, 256)) == 5  # fused planes + depth pass
+    assert _engine.kernel_id(3, torch.float32, "zero", 4, 8, (256, 256, 256), direction=1) == 25  # depth-walking fused synthesis (from ~1 M outputs)
+    assert _engine.kernel_id(3, torch.float32, "zero", 4, 8, (64, 64, 64), direction=1) == 10  # fully fused LDS-brick synthesis
+    assert _engine.kernel_id(3, torch.float32, "zero", 8, 8, (256, 256, 256), direction=1) == 25 and _engine.kernel_id(3, torch.float32, "zero", 8, 8, (64, 64, 64), direction=1) == 10 and _engine.kernel_id(3, torch.float32, "zero", 10, 8, (256, 256, 256), direction=1) == 6   # ten taps: fused planes + depth pass
     assert _engine.kernel_id(3, torch.float64, "zero", 4, 8, (256, 256, 256), direction=1) != 10
     assert _engine.kernel_id(2, torch.float32, "reflect", 102, 4, (512, 512)) == 0   # coif17 -> generic passes
     assert _engine.kernel_id(2, torch.float32, "reflect", 22, 4, (512, 512)) == 0    # L not in the streaming set
