@@ -310,7 +310,10 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  *          axis); unit innermost stride, f32 / f64 / f16, L in {2..20 even, 24, 32}
  *   5 / 6  3-D analysis / synthesis (f32, even L <= 16; what the brick kernels 9 / 10 do not take): fused 2-D kernel over every
  *          depth slice + one streaming pass along depth
- *   9 / 10 fully fused 3-D analysis / synthesis level, LDS bricks (f32, L in {2, 4, 6}; synthesis also 8)
+ *   9 / 10 fully fused 3-D analysis / synthesis level, LDS bricks (f32, L in {2, 4, 6}; synthesis also 8): the small volumes
+ *   24 / 25  fully fused 3-D analysis / synthesis level, workgroups walking along the depth axis (f32; analysis: even L <= 10, every
+ *          mode, rows <= 512 samples, picked from 2^22 samples per volume on and for 8 taps; synthesis: even L <= 8, dense coefficient
+ *          rows, picked from 2^20 output samples on)
  *   11 / 23  fused 2-D analysis / synthesis level on the matrix cores (banded-Toeplitz MFMA; f16 storage, even L in [18, 32]; both walk down
  *          column panels; the synthesis kernel from 16 tiles of 32 x 128 samples per call on, the vector tile kernel 8 below that)
  *   12 / 13  two fused 2-D analysis / synthesis levels per launch (mifwt_dwt2_fwd_pair / mifwt_dwt2_inv_pair; never
@@ -334,7 +337,7 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 #define MIFWT_OPT_PREFETCH_PAIRS 2 /* >0 overrides the fused kernels' prefetch depth (row pairs in flight) */
 #define MIFWT_OPT_RESERVED3 3      /* unused (was: cooperative full-line writer, removed after measurement) */
 #define MIFWT_OPT_NT_STORE 4       /* non-zero: nontemporal stores for the sub-band planes */
-#define MIFWT_OPT_TILE_MODE 5      /* 2-D analysis: 0 = auto (LDS-tile kernel on small planes), 1 = always tile, 2 = never */
+#define MIFWT_OPT_TILE_MODE 5      /* 2-D analysis: 0 = auto (LDS-tile kernel on small planes), 1 = always tile, 2 = never.  3-D: 0 = auto (depth-walking kernels 24 / 25 on big volumes, bricks 9 / 10 on small ones), 1 = bricks wherever they can run, 2 = composed route, 4 = walking kernels wherever they can run */
 #define MIFWT_OPT_TILE_ROWS 6      /* >0 overrides the tile kernels' output rows per tile */
 #define MIFWT_OPT_MFMA_MODE 7      /* 2-D analysis, f16 storage, 18..32 taps: 0 = matrix-core kernels (walking down column panels), 2 = vector tile
                                       kernels, 3 = the tile-at-a-time analysis kernel of round 2 (comparisons), 4 = the synthesis kernel for every size */

@@ -75,18 +75,28 @@ __device__ __forceinline__ void walk3_dma_row(const uint32_t (&voff)[3], rsrc_t 
   }
 }
 
-template <int L, int TR, int NCH>
-__global__ void __launch_bounds__(64 * (kW3MaxStrips + 1)) dwt3_fwd_walk_kernel(const Walk3Args<L> a) {
+// bytes per staged row: NCH requests of 1 KiB, NCH = 0: one request of 512 bytes (32 lanes)
+constexpr int walk3_pitch(int NCH) { return (kW3Pad + (NCH == 0 ? 128 : 256 * NCH) + kW3Pad) * 4; }
+// loader waves: the requests of four slices ahead must fit a wave's vmcnt counter (63)
+constexpr int walk3_nload(int IRW, int NCH) { return IRW * (NCH == 0 ? 1 : NCH) * 4 > 63 ? 2 : 1; }
+constexpr int kW3MaxWaves = 10;  // compute waves (column strips x row sub-groups, at most 8) + loaders
+
+template <int L, int TR, int NCH, int NRG>
+__global__ void __launch_bounds__(64 * kW3MaxWaves) dwt3_fwd_walk_kernel(const Walk3Args<L> a) {
+  // a workgroup owns NRG row sub-groups of TR output rows: compute wave w filters strip w % nstrips of sub-group w / nstrips
   constexpr int HL = L - 2, HP = L / 2, IR = 2 * TR + HL, NC = 2 * TR;
-  constexpr int PITCH = (kW3Pad + 256 * NCH + kW3Pad) * 4;  // bytes per staged row
-  constexpr int SLAB = IR * PITCH;
+  constexpr int IRW = 2 * TR * NRG + HL;  // staged rows of a slice
+  constexpr int PITCH = walk3_pitch(NCH);
+  constexpr int SLAB = IRW * PITCH;
+  constexpr int NLOAD = walk3_nload(IRW, NCH), NCHE = NCH == 0 ? 1 : NCH;
+  static_assert(IRW % NLOAD == 0, "the loaders take every NLOAD-th row: equal shares");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t ug, us;
   const int img = __builtin_amdgcn_readfirstlane((int)a.div_s.divmod(a.div_g.divmod((uint32_t)xcd_remap(blockIdx.x, gridDim.x), ug), us));
-  const int j0 = __builtin_amdgcn_readfirstlane((int)ug * TR);
+  const int j0 = __builtin_amdgcn_readfirstlane((int)ug * (TR * NRG));
   const int zA = __builtin_amdgcn_readfirstlane((int)us * a.seg_out), zB = min(a.Do, zA + a.seg_out);
   const int E0 = 2 * zA - HL;            // first input slice (extended index) of the walk
   const int nsl = 2 * (zB - zA) + HL;    // slices = steps (even)
@@ -95,20 +105,23 @@ __global__ void __launch_bounds__(64 * (kW3MaxStrips + 1)) dwt3_fwd_walk_kernel(
   fold.set(a.mode);
 
   // =====================================================================================================================
-  // loader wave
-  if (wave == a.nstrips) {
+  // loader waves: loader l requests the staged rows l, l + NLOAD, ...
+  const int ncomp = a.nstrips * NRG;
+  if (wave >= ncomp) {
+    const int l = wave - ncomp;
+    constexpr int NR = IRW / NLOAD;
     const uint32_t vol_bytes = (uint32_t)(((int64_t)(a.D - 1) * a.xs_d + (int64_t)(a.H - 1) * a.xs_h + a.W) * 4);
     const rsrc_t xr = pyr_rsrc(a.x + (int64_t)img * a.xs_b, vol_bytes);
     const rsrc_t xr_dead = pyr_rsrc(a.x + (int64_t)img * a.xs_b, 0);  // every lane out of range: zeros land
     const uint32_t row_bytes = a.xs_h * 4u, slice_bytes = a.xs_d * 4u;
     const int r_first = 2 * j0 - HL;
-    const int nr_need = 2 * (min(j0 + TR, a.Ho) - j0) + HL;
-    uint32_t roff[IR];
+    const int nr_need = 2 * (min(j0 + TR * NRG, a.Ho) - j0) + HL;
+    uint32_t roff[NR];
     uint32_t rdead = 0;
 #pragma unroll
-    for (int i = 0; i < IR; ++i) {
-      const int ri = r_first + i;
-      const bool dead = i >= nr_need || (zero_mode && (unsigned)ri >= (unsigned)a.H);
+    for (int i = 0; i < NR; ++i) {
+      const int ri = r_first + l + NLOAD * i;
+      const bool dead = l + NLOAD * i >= nr_need || (zero_mode && (unsigned)ri >= (unsigned)a.H);
       roff[i] = __builtin_amdgcn_readfirstlane(dead ? 0u : (uint32_t)fold(ri, a.H) * row_bytes);
       rdead |= dead ? 1u << i : 0u;
     }
@@ -116,10 +129,10 @@ __global__ void __launch_bounds__(64 * (kW3MaxStrips + 1)) dwt3_fwd_walk_kernel(
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int c = 256 * j + 4 * lane;
-      voff[j] = (j < NCH && c < a.W) ? 4u * (uint32_t)c : kPyrOob;
+      voff[j] = (j < NCHE && c < a.W) ? 4u * (uint32_t)c : kPyrOob;
     }
     __builtin_amdgcn_s_setprio(3);
-    constexpr int PER = IR * NCH;
+    constexpr int PER = NR * NCHE;
     int ib = 0;  // slot of the next slice to be requested
     auto issue = [&](int t) {
       const uint32_t buf = (uint32_t)ib * (uint32_t)SLAB + kW3Pad * 4u;
@@ -129,13 +142,17 @@ __global__ void __launch_bounds__(64 * (kW3MaxStrips + 1)) dwt3_fwd_walk_kernel(
       const bool sdead = zero_mode && (unsigned)e >= (unsigned)a.D;
       const uint32_t sbase = sdead ? 0u : (uint32_t)fold(e, a.D) * slice_bytes;
 #pragma unroll
-      for (int i = 0; i < IR; ++i) {
+      for (int i = 0; i < NR; ++i) {
         const bool dead = __builtin_amdgcn_readfirstlane((int)(sdead || ((rdead >> i) & 1u))) != 0;
-        const uint32_t so = __builtin_amdgcn_readfirstlane(sbase + roff[i]), la = __builtin_amdgcn_readfirstlane(buf + (uint32_t)(i * PITCH));
+        const uint32_t so = __builtin_amdgcn_readfirstlane(sbase + roff[i]), la = __builtin_amdgcn_readfirstlane(buf + (uint32_t)((l + NLOAD * i) * PITCH));
         // default cache policy: the first and last L - 2 rows are staged by the row groups next door as well, about now, and a non-temporal
         // request does not leave them in L2 for the neighbour (config 3, level 1: HBM reads 1.23 x the volume and 261 us, against 227 us)
-        if (a.dbg & 16) walk3_dma_row<NCH, true>(voff, dead ? xr_dead : xr, so, la);
-        else walk3_dma_row<NCH, false>(voff, dead ? xr_dead : xr, so, la);
+        if constexpr (NCH == 0) {
+          if (lane < 32) walk3_dma_row<1, false>(voff, dead ? xr_dead : xr, so, la);  // masked lanes write nothing: 512 bytes land
+        } else {
+          if (a.dbg & 16) walk3_dma_row<NCH, true>(voff, dead ? xr_dead : xr, so, la);
+          else walk3_dma_row<NCH, false>(voff, dead ? xr_dead : xr, so, la);
+        }
       }
     };
     const int ahead = a.nslots - 1;  // slices requested ahead (<= 4)
@@ -152,11 +169,13 @@ __global__ void __launch_bounds__(64 * (kW3MaxStrips + 1)) dwt3_fwd_walk_kernel(
 
   // =====================================================================================================================
   // compute wave: output columns [k0, k1)
-  const int k0 = wave * a.nq, k1 = min(a.Wo, k0 + a.nq);
+  const int sub = __builtin_amdgcn_readfirstlane(wave / a.nstrips), strip = wave - sub * a.nstrips;
+  const int jw = j0 + sub * TR;  // first output row of this wave
+  const int k0 = strip * a.nq, k1 = min(a.Wo, k0 + a.nq);
   const int k = k0 + lane;
   const bool active = k < k1;
   const int kk = min(k, a.Wo - 1);  // idle lanes filter the plane's last column (their windows stay inside the row)
-  const bool first = wave == 0, last = wave == a.nstrips - 1;
+  const bool first = strip == 0, last = strip == a.nstrips - 1;
   const int nrp = 2 * a.Wo - a.W;  // pad samples behind a row (0 .. L - 1)
 
   float* obase[8];
@@ -169,7 +188,7 @@ __global__ void __launch_bounds__(64 * (kW3MaxStrips + 1)) dwt3_fwd_walk_kernel(
 
   // one slice: pads, W pass, H pass -> hv[2 j] = (Ha Wa, Hd Wa), hv[2 j + 1] = (Ha Wd, Hd Wd) of row j
   auto filter_slice = [&](f2 (&hv)[NC]) {
-    unsigned char* const sl = smem + slot * SLAB;
+    unsigned char* const sl = smem + slot * SLAB + sub * (2 * TR * PITCH);  // the wave's 2 TR + L - 2 rows
     slot = slot + 1 == a.nslots ? 0 : slot + 1;
     if constexpr (HL > 0) {
       if (first)
@@ -228,7 +247,7 @@ __global__ void __launch_bounds__(64 * (kW3MaxStrips + 1)) dwt3_fwd_walk_kernel(
     const uint32_t za = (uint32_t)z * a.os_d[0] + (uint32_t)k, zd = (uint32_t)z * a.os_d[1] + (uint32_t)k;
 #pragma unroll
     for (int j = 0; j < TR; ++j) {
-      const int y = j0 + j;
+      const int y = jw + j;
       if (y < a.Ho && active) {
         uint32_t oa = za + (uint32_t)y * a.os_h[0], od = zd + (uint32_t)y * a.os_h[1];
         if (a.dbg & 8) {  // A/B (wrong results): rows on a 128-sample pitch, i.e. line-aligned 256-byte stores
@@ -282,11 +301,12 @@ __global__ void __launch_bounds__(64 * (kW3MaxStrips + 1)) dwt3_fwd_walk_kernel(
   }
 }
 
-template <int L, int TR, int NCH>
+template <int L, int TR, int NCH, int NRG>
 int launch_walk3(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo, const double* hi,
                  hipStream_t stream) {
-  constexpr int HL = L - 2, IR = 2 * TR + HL;
-  constexpr int PITCH = (kW3Pad + 256 * NCH + kW3Pad) * 4, SLAB = IR * PITCH;
+  constexpr int HL = L - 2, IRW = 2 * TR * NRG + HL;
+  constexpr int PITCH = walk3_pitch(NCH), SLAB = IRW * PITCH;
+  constexpr int NLOAD = walk3_nload(IRW, NCH), PER = IRW / NLOAD * (NCH == 0 ? 1 : NCH);
   Walk3Args<L> a;
   a.x = static_cast<const float*>(x);
   for (int s = 0; s < 8; ++s) a.out[s] = static_cast<float*>(s == 0 ? approx : details[s - 1]);
@@ -311,13 +331,13 @@ int launch_walk3(const mifwt_level_desc* d, const void* x, void* approx, void* c
   for (int m = 0; m < L; ++m) a.tap[m] = (f2){(float)lo[m], (float)hi[m]};
   a.nstrips = (a.Wo + 63) / 64;
   a.nq = (g_options[MIFWT_OPT_DEBUG] & 64) ? 64 : (a.Wo + a.nstrips - 1) / a.nstrips;
-  a.ngroups = (a.Ho + TR - 1) / TR;
+  a.ngroups = (a.Ho + TR * NRG - 1) / (TR * NRG);
   // staged slices: four ahead of the one being filtered (config 3 level 1: 2 / 3 / 4 / 5 / 6 ahead = 271 / 259 / 241 / 252 / 256 us)
-  int nslots = 5;
+  int nslots = L == 10 ? 3 : 5;
   if (g_options[MIFWT_OPT_PREFETCH_PAIRS] > 0) nslots = g_options[MIFWT_OPT_PREFETCH_PAIRS] + 1;
   if (nslots < 2) nslots = 2;
   if (nslots > 7) nslots = 7;
-  while (nslots > 2 && (IR * NCH * (nslots - 1) > 63 || nslots * SLAB > 150 * 1024)) --nslots;
+  while (nslots > 2 && (PER * (nslots - 1) > 63 || nslots * SLAB > 150 * 1024)) --nslots;
   a.nslots = nslots;
   const size_t lds_bytes = (size_t)nslots * SLAB;
   // depth segments: enough workgroups for ~3 per slot (workgroups per CU: by LDS), at least 8 output slices each
@@ -343,9 +363,9 @@ int launch_walk3(const mifwt_level_desc* d, const void* x, void* approx, void* c
   const int64_t nblk = base * a.nseg;
   if (nblk > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
   static DynLdsOnce lds_once;
-  if (!lds_once.ensure(reinterpret_cast<const void*>(&dwt3_fwd_walk_kernel<L, TR, NCH>), 7 * SLAB > 160 * 1024 ? 160 * 1024 : 7 * SLAB))
+  if (!lds_once.ensure(reinterpret_cast<const void*>(&dwt3_fwd_walk_kernel<L, TR, NCH, NRG>), 7 * SLAB > 160 * 1024 ? 160 * 1024 : 7 * SLAB))
     return MIFWT_ERR_LAUNCH;
-  hipLaunchKernelGGL((dwt3_fwd_walk_kernel<L, TR, NCH>), dim3((unsigned)nblk), dim3(64 * (a.nstrips + 1)), lds_bytes, stream, a);
+  hipLaunchKernelGGL((dwt3_fwd_walk_kernel<L, TR, NCH, NRG>), dim3((unsigned)nblk), dim3(64 * (a.nstrips * NRG + NLOAD)), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 
@@ -353,8 +373,22 @@ template <int L>
 int launch_walk3_l(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo, const double* hi,
                    hipStream_t stream) {
   constexpr int TR = L <= 6 ? 4 : 2;
-  if (d->sig_extent[2] <= 256) return launch_walk3<L, TR, 1>(d, x, approx, details, lo, hi, stream);
-  return launch_walk3<L, TR, 2>(d, x, approx, details, lo, hi, stream);
+  const int W = (int)d->sig_extent[2], nstrips = ((int)d->coef_extent[2] + 63) / 64;
+  // row sub-groups per workgroup (several sub-groups share a staged slice: fewer halo rows, more compute waves per loader): pays for ten
+  // taps only, where a lone sub-group stages 12 rows per 2 it completes (32 x 100^3 db5, 1 / 2 / 4 sub-groups: 174 / 164 / 187 us;
+  // 16 x 128^3 db4: 129 / 147 / 146; 8 x 256^3 db2: 228 / 234; 8 x 66^3 db2: 20.7 / 21.4 / 25.3); MIFWT_OPT_PAIR_ROWS overrides (1, 2, 4)
+  int nrg = (L == 10 && nstrips <= 2) ? 2 : 1;
+  if (g_options[MIFWT_OPT_PAIR_ROWS] > 0) nrg = g_options[MIFWT_OPT_PAIR_ROWS];
+  if (W <= 128) {
+    if (nrg >= 4 && nstrips <= 2) return launch_walk3<L, TR, 0, 4>(d, x, approx, details, lo, hi, stream);
+    if (nrg >= 2) return launch_walk3<L, TR, 0, 2>(d, x, approx, details, lo, hi, stream);
+    return launch_walk3<L, TR, 0, 1>(d, x, approx, details, lo, hi, stream);
+  }
+  if (W <= 256) {
+    if (nrg >= 2 && nstrips <= 4) return launch_walk3<L, TR, 1, 2>(d, x, approx, details, lo, hi, stream);
+    return launch_walk3<L, TR, 1, 1>(d, x, approx, details, lo, hi, stream);
+  }
+  return launch_walk3<L, TR, 2, 1>(d, x, approx, details, lo, hi, stream);
 }
 
 }  // namespace
