@@ -75,20 +75,21 @@ __device__ __forceinline__ void walk3_dma_row(const uint32_t (&voff)[3], rsrc_t 
   }
 }
 
-// bytes per staged row: NCH requests of 1 KiB, NCH = 0: one request of 512 bytes (32 lanes)
-constexpr int walk3_pitch(int NCH) { return (kW3Pad + (NCH == 0 ? 128 : 256 * NCH) + kW3Pad) * 4; }
+// a staged row: BODY samples (128, 160, 256 or 512: one request of BODY / 4 lanes, or two of 1 KiB) between two pads
+constexpr int walk3_pitch(int BODY) { return (kW3Pad + BODY + kW3Pad) * 4; }
+constexpr int walk3_nreq(int BODY) { return BODY > 256 ? 2 : 1; }
 // loader waves: the requests of four slices ahead must fit a wave's vmcnt counter (63)
-constexpr int walk3_nload(int IRW, int NCH) { return IRW * (NCH == 0 ? 1 : NCH) * 4 > 63 ? 2 : 1; }
+constexpr int walk3_nload(int IRW, int BODY) { return IRW * walk3_nreq(BODY) * 4 > 63 ? 2 : 1; }
 constexpr int kW3MaxWaves = 10;  // compute waves (column strips x row sub-groups, at most 8) + loaders
 
-template <int L, int TR, int NCH, int NRG>
+template <int L, int TR, int BODY, int NRG>
 __global__ void __launch_bounds__(64 * kW3MaxWaves) dwt3_fwd_walk_kernel(const Walk3Args<L> a) {
   // a workgroup owns NRG row sub-groups of TR output rows: compute wave w filters strip w % nstrips of sub-group w / nstrips
   constexpr int HL = L - 2, HP = L / 2, IR = 2 * TR + HL, NC = 2 * TR;
   constexpr int IRW = 2 * TR * NRG + HL;  // staged rows of a slice
-  constexpr int PITCH = walk3_pitch(NCH);
+  constexpr int PITCH = walk3_pitch(BODY);
   constexpr int SLAB = IRW * PITCH;
-  constexpr int NLOAD = walk3_nload(IRW, NCH), NCHE = NCH == 0 ? 1 : NCH;
+  constexpr int NLOAD = walk3_nload(IRW, BODY), NCHE = walk3_nreq(BODY);
   static_assert(IRW % NLOAD == 0, "the loaders take every NLOAD-th row: equal shares");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -147,11 +148,11 @@ __global__ void __launch_bounds__(64 * kW3MaxWaves) dwt3_fwd_walk_kernel(const W
         const uint32_t so = __builtin_amdgcn_readfirstlane(sbase + roff[i]), la = __builtin_amdgcn_readfirstlane(buf + (uint32_t)((l + NLOAD * i) * PITCH));
         // default cache policy: the first and last L - 2 rows are staged by the row groups next door as well, about now, and a non-temporal
         // request does not leave them in L2 for the neighbour (config 3, level 1: HBM reads 1.23 x the volume and 261 us, against 227 us)
-        if constexpr (NCH == 0) {
-          if (lane < 32) walk3_dma_row<1, false>(voff, dead ? xr_dead : xr, so, la);  // masked lanes write nothing: 512 bytes land
+        if constexpr (BODY < 256) {
+          if (lane < BODY / 4) walk3_dma_row<1, false>(voff, dead ? xr_dead : xr, so, la);  // masked lanes write nothing: 4 BODY bytes land
         } else {
-          if (a.dbg & 16) walk3_dma_row<NCH, true>(voff, dead ? xr_dead : xr, so, la);
-          else walk3_dma_row<NCH, false>(voff, dead ? xr_dead : xr, so, la);
+          if (a.dbg & 16) walk3_dma_row<NCHE, true>(voff, dead ? xr_dead : xr, so, la);
+          else walk3_dma_row<NCHE, false>(voff, dead ? xr_dead : xr, so, la);
         }
       }
     };
@@ -301,12 +302,12 @@ __global__ void __launch_bounds__(64 * kW3MaxWaves) dwt3_fwd_walk_kernel(const W
   }
 }
 
-template <int L, int TR, int NCH, int NRG>
+template <int L, int TR, int BODY, int NRG>
 int launch_walk3(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo, const double* hi,
                  hipStream_t stream) {
   constexpr int HL = L - 2, IRW = 2 * TR * NRG + HL;
-  constexpr int PITCH = walk3_pitch(NCH), SLAB = IRW * PITCH;
-  constexpr int NLOAD = walk3_nload(IRW, NCH), PER = IRW / NLOAD * (NCH == 0 ? 1 : NCH);
+  constexpr int PITCH = walk3_pitch(BODY), SLAB = IRW * PITCH;
+  constexpr int NLOAD = walk3_nload(IRW, BODY), PER = IRW / NLOAD * walk3_nreq(BODY);
   Walk3Args<L> a;
   a.x = static_cast<const float*>(x);
   for (int s = 0; s < 8; ++s) a.out[s] = static_cast<float*>(s == 0 ? approx : details[s - 1]);
@@ -333,14 +334,16 @@ int launch_walk3(const mifwt_level_desc* d, const void* x, void* approx, void* c
   a.nq = (g_options[MIFWT_OPT_DEBUG] & 64) ? 64 : (a.Wo + a.nstrips - 1) / a.nstrips;
   a.ngroups = (a.Ho + TR * NRG - 1) / (TR * NRG);
   // staged slices: four ahead of the one being filtered (config 3 level 1: 2 / 3 / 4 / 5 / 6 ahead = 271 / 259 / 241 / 252 / 256 us)
-  int nslots = L == 10 ? 3 : 5;
+  // (volumes below ~4 M samples are latency-bound: workgroups per CU beat depth — 8 x 129^3, 1 / 2 / 3 / 4 ahead: 37 / 34 / 50 / 46 us)
+  const int64_t in_vol = d->sig_extent[0] * d->sig_extent[1] * d->sig_extent[2];
+  int nslots = (L == 10 || in_vol < (int64_t(1) << 22)) ? 3 : 5;
   if (g_options[MIFWT_OPT_PREFETCH_PAIRS] > 0) nslots = g_options[MIFWT_OPT_PREFETCH_PAIRS] + 1;
   if (nslots < 2) nslots = 2;
   if (nslots > 7) nslots = 7;
   while (nslots > 2 && (PER * (nslots - 1) > 63 || nslots * SLAB > 150 * 1024)) --nslots;
   a.nslots = nslots;
   const size_t lds_bytes = (size_t)nslots * SLAB;
-  // depth segments: enough workgroups for ~3 per slot (workgroups per CU: by LDS), at least 8 output slices each
+  // depth segments: enough workgroups for ~3 per slot (workgroups per CU: by LDS), at least 6 output slices each
   int ncu = 256;
   {
     int dev = 0;
@@ -354,7 +357,7 @@ int launch_walk3(const mifwt_level_desc* d, const void* x, void* approx, void* c
   const int64_t base = (int64_t)d->batch * a.ngroups;
   int nseg = (int)((3 * (int64_t)ncu * wpc + base - 1) / base);
   if (g_options[MIFWT_OPT_ROWS_PER_CHUNK] > 0) nseg = (a.Do + g_options[MIFWT_OPT_ROWS_PER_CHUNK] - 1) / g_options[MIFWT_OPT_ROWS_PER_CHUNK];
-  if (nseg > a.Do / 8 && g_options[MIFWT_OPT_ROWS_PER_CHUNK] <= 0) nseg = a.Do / 8;
+  if (nseg > a.Do / 6 && g_options[MIFWT_OPT_ROWS_PER_CHUNK] <= 0) nseg = a.Do / 6;
   if (nseg < 1) nseg = 1;
   a.seg_out = (a.Do + nseg - 1) / nseg;
   a.nseg = (a.Do + a.seg_out - 1) / a.seg_out;
@@ -363,9 +366,9 @@ int launch_walk3(const mifwt_level_desc* d, const void* x, void* approx, void* c
   const int64_t nblk = base * a.nseg;
   if (nblk > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
   static DynLdsOnce lds_once;
-  if (!lds_once.ensure(reinterpret_cast<const void*>(&dwt3_fwd_walk_kernel<L, TR, NCH, NRG>), 7 * SLAB > 160 * 1024 ? 160 * 1024 : 7 * SLAB))
+  if (!lds_once.ensure(reinterpret_cast<const void*>(&dwt3_fwd_walk_kernel<L, TR, BODY, NRG>), 7 * SLAB > 160 * 1024 ? 160 * 1024 : 7 * SLAB))
     return MIFWT_ERR_LAUNCH;
-  hipLaunchKernelGGL((dwt3_fwd_walk_kernel<L, TR, NCH, NRG>), dim3((unsigned)nblk), dim3(64 * (a.nstrips * NRG + NLOAD)), lds_bytes, stream, a);
+  hipLaunchKernelGGL((dwt3_fwd_walk_kernel<L, TR, BODY, NRG>), dim3((unsigned)nblk), dim3(64 * (a.nstrips * NRG + NLOAD)), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 
@@ -376,19 +379,14 @@ int launch_walk3_l(const mifwt_level_desc* d, const void* x, void* approx, void*
   const int W = (int)d->sig_extent[2], nstrips = ((int)d->coef_extent[2] + 63) / 64;
   // row sub-groups per workgroup (several sub-groups share a staged slice: fewer halo rows, more compute waves per loader): pays for ten
   // taps only, where a lone sub-group stages 12 rows per 2 it completes (32 x 100^3 db5, 1 / 2 / 4 sub-groups: 174 / 164 / 187 us;
-  // 16 x 128^3 db4: 129 / 147 / 146; 8 x 256^3 db2: 228 / 234; 8 x 66^3 db2: 20.7 / 21.4 / 25.3); MIFWT_OPT_PAIR_ROWS overrides (1, 2, 4)
+  // 16 x 128^3 db4: 129 / 147 / 146; 8 x 256^3 db2: 228 / 234; 8 x 66^3 db2: 20.7 / 21.4 / 25.3); MIFWT_OPT_PAIR_ROWS overrides (1, 2)
   int nrg = (L == 10 && nstrips <= 2) ? 2 : 1;
   if (g_options[MIFWT_OPT_PAIR_ROWS] > 0) nrg = g_options[MIFWT_OPT_PAIR_ROWS];
-  if (W <= 128) {
-    if (nrg >= 4 && nstrips <= 2) return launch_walk3<L, TR, 0, 4>(d, x, approx, details, lo, hi, stream);
-    if (nrg >= 2) return launch_walk3<L, TR, 0, 2>(d, x, approx, details, lo, hi, stream);
-    return launch_walk3<L, TR, 0, 1>(d, x, approx, details, lo, hi, stream);
-  }
-  if (W <= 256) {
-    if (nrg >= 2 && nstrips <= 4) return launch_walk3<L, TR, 1, 2>(d, x, approx, details, lo, hi, stream);
-    return launch_walk3<L, TR, 1, 1>(d, x, approx, details, lo, hi, stream);
-  }
-  return launch_walk3<L, TR, 2, 1>(d, x, approx, details, lo, hi, stream);
+  const bool two = nrg >= 2 && L == 10 && nstrips <= 4;  // (instantiated for ten taps only)
+  if (W <= 128) return two ? launch_walk3<L, TR, 128, (L == 10 ? 2 : 1)>(d, x, approx, details, lo, hi, stream) : launch_walk3<L, TR, 128, 1>(d, x, approx, details, lo, hi, stream);
+  if (W <= 160) return two ? launch_walk3<L, TR, 160, (L == 10 ? 2 : 1)>(d, x, approx, details, lo, hi, stream) : launch_walk3<L, TR, 160, 1>(d, x, approx, details, lo, hi, stream);
+  if (W <= 256) return two ? launch_walk3<L, TR, 256, (L == 10 ? 2 : 1)>(d, x, approx, details, lo, hi, stream) : launch_walk3<L, TR, 256, 1>(d, x, approx, details, lo, hi, stream);
+  return launch_walk3<L, TR, 512, 1>(d, x, approx, details, lo, hi, stream);
 }
 
 }  // namespace
