@@ -241,7 +241,8 @@ __global__ void __launch_bounds__(64 * kW3MaxWaves) dwt3_fwd_walk_kernel(const W
     }
   };
 
-  // output slice z from accumulator slot SL
+  // output slice z from accumulator slot SL.  (Measured and dropped: lanes l / l + 32 owning neighbouring columns and exchanging the rows of
+  // a row pair for 8-byte stores — on 129-sample rows they are only 4-byte aligned: 235 against 229 us, profiles/r04w16_walk3_st8.txt)
   auto emit = [&](auto sl_tag, int z) {
     constexpr int SL = decltype(sl_tag)::value;
     if (a.dbg & 1) return;

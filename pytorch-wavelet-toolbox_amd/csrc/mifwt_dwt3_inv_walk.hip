@@ -39,6 +39,7 @@ struct IWalk3Args {
   int nseg, seg_out;  // depth segments, output slice PAIRS per segment
   int nslots;         // staged coefficient slices
   int yvec, nt, dbg;
+  int st16;  // 16-byte output stores: lanes l and l + 32 own neighbouring column pairs and exchange rows (W, strides, base: multiples of 4)
   FastDiv div_g, div_s;
   f2 tlo[L / 2], thi[L / 2];  // (rec_lo[2j], rec_lo[2j+1]), (rec_hi[2j], rec_hi[2j+1])
 };
@@ -125,7 +126,9 @@ __global__ void __launch_bounds__(64 * (kIW3MaxStrips + 2)) idwt3_walk_kernel(co
 
   // =====================================================================================================================
   // compute wave: output column pairs 64 wave .. 64 wave + 63
-  const int p = 64 * wave + lane;
+  // (16-byte stores: lane l < 32 owns pair 2 l of the wave's 64, lane l + 32 pair 2 l + 1 — after the exchange each lane holds four
+  // columns of one row)
+  const int p = 64 * wave + (a.st16 ? 2 * (lane & 31) + (lane >> 5) : lane);
   const int xo = 2 * p;
   const bool active = xo < a.W, both = xo + 1 < a.W;
   const int pc = min(p, a.Mw - HL);  // idle lanes read the row's last window
@@ -133,6 +136,8 @@ __global__ void __launch_bounds__(64 * (kIW3MaxStrips + 2)) idwt3_walk_kernel(co
 #pragma unroll
   for (int yy = 0; yy < IY; ++yy) rowaddr[yy] = (uint32_t)(yy * a.Mw + pc) * 4u;
   float* const yb = a.y + (int64_t)img * a.ys_b;
+  const rsrc_t yr = pyr_rsrc(yb, a.st16 ? (uint32_t)(((int64_t)(a.D - 1) * a.ys_d + (int64_t)(a.H - 1) * a.ys_h + a.W) * 4) : 0u);
+  const uint32_t c16 = 4u * (uint32_t)(128 * wave + 4 * (lane & 31));  // byte offset of the lane's four columns (16-byte path)
 
   f2 acc[HL][CY][2][2];  // [slot of the output slice pair][row pair q][column c][row r of the pair]: (slice 2P, slice 2P + 1)
 #pragma unroll
@@ -224,7 +229,24 @@ __global__ void __launch_bounds__(64 * (kIW3MaxStrips + 2)) idwt3_walk_kernel(co
   // output slice pair P from accumulator slot S
   auto emit = [&](auto s_tag, int P) {
     constexpr int S = decltype(s_tag)::value;
-    if ((a.dbg & 1) || !active) return;
+    if (a.dbg & 1) return;
+    if (a.st16) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int z = 2 * P + r;
+        if (z >= a.D) continue;
+        const uint32_t so = (uint32_t)z * a.ys_d * 4u;
+#pragma unroll
+        for (int q = 0; q < CY; ++q) {
+          const int n = 2 * (py0 + q) + (lane >> 5);  // lanes 0-31 store row 2 q of the group, lanes 32-63 row 2 q + 1
+          const f4 t = r ? pyr_swap_rows(acc[S][q][0][0].y, acc[S][q][1][0].y, acc[S][q][0][1].y, acc[S][q][1][1].y)
+                         : pyr_swap_rows(acc[S][q][0][0].x, acc[S][q][1][0].x, acc[S][q][0][1].x, acc[S][q][1][1].x);
+          pyr_store4(t, yr, (n < a.H && c16 < 4u * (uint32_t)a.W) ? (uint32_t)n * a.ys_h * 4u + c16 : kPyrOob, so);
+        }
+      }
+      return;
+    }
+    if (!active) return;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int z = 2 * P + r;
@@ -290,6 +312,12 @@ int launch_iwalk3(const mifwt_level_desc* d, const void* approx, const void* con
   a.nt = g_options[MIFWT_OPT_NT_STORE];
   a.dbg = g_options[MIFWT_OPT_DEBUG] & 7;
   a.yvec = (a.ys_h % 2 == 0 && a.ys_d % 2 == 0 && a.ys_b % 2 == 0 && reinterpret_cast<uintptr_t>(y) % 8 == 0) ? 1 : 0;
+  // 16-byte stores where every row piece of four columns is aligned and inside the row (MIFWT_OPT_DEBUG 512: never, as for kernel 16)
+  {
+    const int64_t span = (int64_t)(a.D - 1) * a.ys_d + (int64_t)(a.H - 1) * a.ys_h + a.W;
+    a.st16 = (a.W % 4 == 0 && a.ys_h % 4 == 0 && a.ys_d % 4 == 0 && a.ys_b % 4 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
+              span < (int64_t(1) << 30) && !(g_options[MIFWT_OPT_DEBUG] & 512)) ? 1 : 0;
+  }
   for (int j = 0; j < HL; ++j) {
     a.tlo[j] = (f2){(float)lo[2 * j], (float)lo[2 * j + 1]};
     a.thi[j] = (f2){(float)hi[2 * j], (float)hi[2 * j + 1]};
