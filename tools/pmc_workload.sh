@@ -59,8 +59,16 @@ pmc, meta = {}, {}
 for p in sorted(glob.glob(out + "/p*/**/*_counter_collection.csv", recursive=True)):
     per = collections.defaultdict(list)
     rows = [r for r in csv.DictReader(open(p)) if kern in r["Kernel_Name"]]
-    # the dominant launch = the biggest grid of that kernel (the same kernel serves the deeper levels with smaller grids)
+    # the dominant launch = the grid of that kernel with the longest launches in the kernel trace (the same kernel serves the other
+    # levels; round 4: the 129^3 level of the 3-D synthesis walk has MORE workgroups than the 256^3 level — shorter depth segments —
+    # so "the biggest grid" picked the wrong one); without a trace: the biggest grid
     gmax = max((int(r["Grid_Size"]) for r in rows), default=0)
+    if bygrid:
+        gdom = max(bygrid.items(), key=lambda kv: sorted(kv[1])[len(kv[1]) // 2])[0]
+        cand = [int(r["Grid_Size"]) for r in rows]
+        # (kernel-trace grid = Grid_Size_X, counter-collection grid = total work-items: same number for 1-D launches)
+        if int(gdom) in cand:
+            gmax = int(gdom)
     for r in rows:
         if int(r["Grid_Size"]) != gmax:
             continue

@@ -1,4 +1,3 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_walk2.py -x -q 2>&1 | tail -15 | tee gpurun_out/r04x1_walk2_tests.txt
-timeout 300 python tools/iwalk2_time.py 2>&1 | tee gpurun_out/r04x1_iwalk2_time.txt
+TAG=r04z2 WL=waverec3_db2_L3_8x256x256x256_f32 KERNEL=idwt3_walk_kernel STEPS=30 bash tools/pmc_workload.sh 2>&1 | tail -32
