@@ -225,7 +225,7 @@ __device__ __forceinline__ void ipyr_store4(const f4 data, rsrc_t rsrc, uint32_t
 __device__ __forceinline__ void ipyr_dma(uint32_t voff, uint32_t limit, rsrc_t rsrc, uint32_t soff, uint32_t lds) {
   if (voff < limit) {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen " MIFWT_PYR_DMA_POLICY " lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds) : "memory");
   }
 }

@@ -99,6 +99,10 @@ struct PyrSt16 {
   }
 };
 
+// cache policy of the streamed input requests (build-time switch for A/B runs: tools/pyr_ab.py)
+#ifndef MIFWT_PYR_DMA_POLICY
+#define MIFWT_PYR_DMA_POLICY "nt"
+#endif
 // (LDS-DMA) a loader's share of one staged row: NCH requests of 1 KiB, LDS addresses lds0 + 2048 j (the two loaders take the even / the
 // odd 1-KiB pieces of a row), global offsets voff[j]
 template <int NCH, int STR>
@@ -106,17 +110,17 @@ __device__ __forceinline__ void pyr_dma_row(const uint32_t (&voff)[3], rsrc_t rs
   // (STR = LDS distance of a loader's consecutive pieces: 2 KiB with two loader waves — they take the even / the odd pieces — 1 KiB with one)
   uint32_t keep;
   if constexpr (NCH == 1) {
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen " MIFWT_PYR_DMA_POLICY " lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff[0]), "s"(rsrc), "s"(soff), "s"(lds0) : "memory");
   } else if constexpr (NCH == 2) {
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen nt lds\n\t"
-                 "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen nt lds\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen " MIFWT_PYR_DMA_POLICY " lds\n\t"
+                 "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen " MIFWT_PYR_DMA_POLICY " lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "s"(rsrc), "s"(soff), "s"(lds0), "n"(STR) : "memory", "scc");
   } else {
     static_assert(NCH == 3, "at most three requests per row and loader");
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %4, %5 offen nt lds\n\t"
-                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %5 offen nt lds\n\t"
-                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %5 offen nt lds\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %4, %5 offen " MIFWT_PYR_DMA_POLICY " lds\n\t"
+                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, %5 offen " MIFWT_PYR_DMA_POLICY " lds\n\t"
+                 "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, %5 offen " MIFWT_PYR_DMA_POLICY " lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "s"(rsrc), "s"(soff), "s"(lds0), "n"(STR) : "memory", "scc");
   }
 }
