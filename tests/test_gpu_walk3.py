@@ -100,7 +100,10 @@ def test_iwalk3_vs_oracle(wavelet):
     Reference seam: src/ptwt/conv_transform_3.py:205-249."""
     rng = np.random.default_rng(len(wavelet) + 51)
     flen = len(O.filter_bank(wavelet)[0])
-    for shape in [(2, 21, 37, 141), (1, 2 * flen + 1, 2 * flen, 2 * flen + 3), (3, 9, 70, 66), (1, 12, 21, 260), (2, 40, 33, 128), (1, 20, 9, 300)]:
+    for shape in [(2, 21, 37, 141), (1, 2 * flen + 1, 2 * flen, 2 * flen + 3), (3, 9, 70, 66), (1, 12, 21, 260), (2, 40, 33, 128), (1, 20, 9, 300),
+                  (1, 9, 10, 400), (2, 10, 12, 180), (2, 9, 9, 40)]:  # (the last three: row pieces of 5 / 2 / 1 KiB)
+        if min(shape[1:]) < flen:
+            continue
         x = rng.standard_normal(shape)
         for mode in MODES:
             level = 2 if min(shape[1:]) >= 3 * flen else 1
@@ -152,3 +155,33 @@ def test_iwalk3_many_segments_round_trip_config3_shape():
         _engine.level_events = None
     assert kids == [10, 25, 25], kids
     assert G.relerr(to_np(auto), to_np(ref)) < 5e-7
+
+
+def test_walk3_gradients_agree_with_the_brick_route():
+    """A differentiable wavedec3 / waverec3 of a volume big enough for both walk kernels (168 x 160 x 164 > 2^22 samples): the forward runs on kernel 24, the
+    analysis adjoint on kernel 25 (zero-mode synthesis launch + border kernel) and vice versa — gradients against the brick route."""
+    x = torch.randn(1, 168, 160, 164, device=dev())
+    def grads(tile_mode):
+        _engine.set_option(_engine.OPT_TILE_MODE, tile_mode)
+        try:
+            xx = x.clone().requires_grad_(True)
+            c = ptwt_amd.wavedec3(xx, "db2", mode="reflect", level=1)
+            loss = (c[0] ** 2).sum() + sum((v ** 2).sum() * (i + 2) for i, v in enumerate(c[1].values()))
+            gx, = torch.autograd.grad(loss, xx)
+            cc = [c[0].detach().clone().requires_grad_(True), {k: v.detach().clone().requires_grad_(True) for k, v in c[1].items()}]
+            y = ptwt_amd.waverec3(cc, "db2")
+            gc = torch.autograd.grad((y ** 3).sum(), [cc[0], *cc[1].values()])
+        finally:
+            _engine.set_option(_engine.OPT_TILE_MODE, 0)
+        return gx, gc
+    _engine.level_events = []
+    try:
+        gx_w, gc_w = grads(0)
+        kids = {(e[0], e[1]) for e in _engine.level_events}
+    finally:
+        _engine.level_events = None
+    assert kids == {("fwd", 24), ("fwd_adj", 25), ("inv", 25), ("inv_adj", 24)}, kids
+    gx_b, gc_b = grads(1)
+    assert G.relerr(to_np(gx_w), to_np(gx_b)) < 1e-6
+    for a, b in zip(gc_w, gc_b):
+        assert G.relerr(to_np(a), to_np(b)) < 1e-6
