@@ -24,7 +24,10 @@ namespace mifwt {
 
 namespace {
 
-constexpr int kW3Pad = 8;        // floats in front of a staged row's body (the left pad samples live there) and behind it
+constexpr int kW3Pad = 8;        // floats behind a staged row's body (the right pad samples: at most L - 1)
+// floats in front of it (the L - 2 left pad samples; the body stays 16-byte aligned).  Four for filters up to six taps: five staged slices
+// of ten 256-sample rows are then 53 600 bytes, and THREE workgroups fit a CU's 160 KB (with eight: 54 400, two)
+constexpr int walk3_lpad(int L) { return L <= 6 ? 4 : 8; }
 constexpr int kW3MaxStrips = 4;  // compute waves per workgroup
 
 template <int L>
@@ -76,7 +79,7 @@ __device__ __forceinline__ void walk3_dma_row(const uint32_t (&voff)[3], rsrc_t 
 }
 
 // a staged row: BODY samples (128, 160, 256 or 512: one request of BODY / 4 lanes, or two of 1 KiB) between two pads
-constexpr int walk3_pitch(int BODY) { return (kW3Pad + BODY + kW3Pad) * 4; }
+constexpr int walk3_pitch(int L, int BODY) { return (walk3_lpad(L) + BODY + kW3Pad) * 4; }
 constexpr int walk3_nreq(int BODY) { return BODY > 256 ? 2 : 1; }
 // loader waves: the requests of four slices ahead must fit a wave's vmcnt counter (63)
 constexpr int walk3_nload(int IRW, int BODY) { return IRW * walk3_nreq(BODY) * 4 > 63 ? 2 : 1; }
@@ -87,7 +90,7 @@ __global__ void __launch_bounds__(64 * kW3MaxWaves) dwt3_fwd_walk_kernel(const W
   // a workgroup owns NRG row sub-groups of TR output rows: compute wave w filters strip w % nstrips of sub-group w / nstrips
   constexpr int HL = L - 2, HP = L / 2, IR = 2 * TR + HL, NC = 2 * TR;
   constexpr int IRW = 2 * TR * NRG + HL;  // staged rows of a slice
-  constexpr int PITCH = walk3_pitch(BODY);
+  constexpr int PITCH = walk3_pitch(L, BODY);
   constexpr int SLAB = IRW * PITCH;
   constexpr int NLOAD = walk3_nload(IRW, BODY), NCHE = walk3_nreq(BODY);
   static_assert(IRW % NLOAD == 0, "the loaders take every NLOAD-th row: equal shares");
@@ -136,7 +139,7 @@ __global__ void __launch_bounds__(64 * kW3MaxWaves) dwt3_fwd_walk_kernel(const W
     constexpr int PER = NR * NCHE;
     int ib = 0;  // slot of the next slice to be requested
     auto issue = [&](int t) {
-      const uint32_t buf = (uint32_t)ib * (uint32_t)SLAB + kW3Pad * 4u;
+      const uint32_t buf = (uint32_t)ib * (uint32_t)SLAB + walk3_lpad(L) * 4u;
       ib = ib + 1 == a.nslots ? 0 : ib + 1;
       if (a.dbg & 2) return;
       const int e = E0 + t;
@@ -195,14 +198,14 @@ __global__ void __launch_bounds__(64 * kW3MaxWaves) dwt3_fwd_walk_kernel(const W
       if (first)
       for (int it = lane; it < IR * HL; it += 64) {
         const int r = it / HL, i = it - r * HL;
-        float* row = reinterpret_cast<float*>(sl + r * PITCH) + kW3Pad;
+        float* row = reinterpret_cast<float*>(sl + r * PITCH) + walk3_lpad(L);
         row[i - HL] = zero_mode ? 0.f : row[fold(i - HL, a.W)];
       }
     }
     if (last && nrp > 0) {
       for (int it = lane; it < IR * nrp; it += 64) {
         const int r = it / nrp, i = it - r * nrp;
-        float* row = reinterpret_cast<float*>(sl + r * PITCH) + kW3Pad;
+        float* row = reinterpret_cast<float*>(sl + r * PITCH) + walk3_lpad(L);
         row[a.W + i] = zero_mode ? 0.f : row[fold(a.W + i, a.W)];
       }
     }
@@ -213,7 +216,7 @@ __global__ void __launch_bounds__(64 * kW3MaxWaves) dwt3_fwd_walk_kernel(const W
       return;
     }
     f2 rowv[IR];  // (W-low, W-high) of column k, row i
-    const unsigned char* wb = sl + (kW3Pad + 2 * kk - HL) * 4;
+    const unsigned char* wb = sl + (walk3_lpad(L) + 2 * kk - HL) * 4;
 #pragma unroll
     for (int i = 0; i < IR; ++i) {
       const f2* row = reinterpret_cast<const f2*>(wb + i * PITCH);
@@ -307,7 +310,7 @@ template <int L, int TR, int BODY, int NRG>
 int launch_walk3(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo, const double* hi,
                  hipStream_t stream) {
   constexpr int HL = L - 2, IRW = 2 * TR * NRG + HL;
-  constexpr int PITCH = walk3_pitch(BODY), SLAB = IRW * PITCH;
+  constexpr int PITCH = walk3_pitch(L, BODY), SLAB = IRW * PITCH;
   constexpr int NLOAD = walk3_nload(IRW, BODY), PER = IRW / NLOAD * walk3_nreq(BODY);
   Walk3Args<L> a;
   a.x = static_cast<const float*>(x);
