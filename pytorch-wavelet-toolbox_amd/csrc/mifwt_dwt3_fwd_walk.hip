@@ -350,10 +350,8 @@ int launch_walk3(const mifwt_level_desc* d, const void* x, void* approx, void* c
   // depth segments: enough workgroups for ~3 per slot (workgroups per CU: by LDS), at least 6 output slices each
   int ncu = 256;
   {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      ncu = prop.multiProcessorCount;
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
   }
   int wpc = (int)((size_t)(160 * 1024) / lds_bytes);
   if (wpc > 8) wpc = 8;

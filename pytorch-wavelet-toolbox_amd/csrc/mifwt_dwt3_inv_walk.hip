@@ -336,10 +336,8 @@ int launch_iwalk3(const mifwt_level_desc* d, const void* approx, const void* con
   const size_t lds_bytes = (size_t)nslots * SLOTB;
   int ncu = 256;
   {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      ncu = prop.multiProcessorCount;
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
   }
   int wpc = (int)((size_t)(160 * 1024) / lds_bytes);
   if (wpc > 8) wpc = 8;
