@@ -1,4 +1,4 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_walk3.py -x -q 2>&1 | tail -8 | tee gpurun_out/r04x7_tests.txt
-timeout 300 python tools/walk3_run16.py 2>&1 | grep -v amdgpu | tee gpurun_out/r04x7_walk3_run16.txt
+( time timeout 1200 python -m pytest tests -q -m gpu -x 2>&1 | tail -4 ) 2>&1 | tee gpurun_out/r04_final_gpu_suite.txt
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a gpurun_out/r04_final_gpu_suite.txt
