@@ -630,8 +630,11 @@ def main():
         # ms_per_step for those, which biased the fraction towards the optimistic figure; both are in the line)
         achieved = lvl1_b / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic, traffic_src = profiled_traffic(args.workload, klabel)
-        # the dominant kernel is one launch of a step: its steady-state duration cannot exceed the step's (2 % timer slack)
-        consistent = avg_ms <= ms_per_step * 1.02
+        # the dominant kernel is one launch of a step: its steady-state duration cannot exceed the step's
+        # (two separately timed loops of the same launches differ by 2-3 % from run to run — 0.1060 against 0.1037 ms in one round-4 run —
+        # so the flag allows 5 %, and the fraction is reported either way: it is the fixed definition above, and when the two disagree it is
+        # the conservative one of the two)
+        consistent = avg_ms <= ms_per_step * 1.05
         result = {
             "metric": "Msamples/s",
             "value": round(samples_per_step / (elapsed / args.steps) / 1e6, 1),
@@ -672,7 +675,7 @@ def main():
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4) if consistent else None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "consistent": consistent,
                 "algorithmic_bytes_per_launch": lvl1_b,
                 "avg_launch_ms": round(avg_ms, 4),
