@@ -310,7 +310,7 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  *          axis); unit innermost stride, f32 / f64 / f16, L in {2..20 even, 24, 32}
  *   5 / 6  3-D analysis / synthesis (f32, even L <= 16; what the brick kernels 9 / 10 do not take): fused 2-D kernel over every
  *          depth slice + one streaming pass along depth
- *   9 / 10 fully fused 3-D analysis / synthesis level, LDS bricks (f32, L in {2, 4, 6}; synthesis also 8): the small volumes
+ *   9 / 10  fully fused 3-D analysis / synthesis level, LDS bricks (f32, L in {2, 4, 6}; synthesis also 8): the small volumes
  *   24 / 25  fully fused 3-D analysis / synthesis level, workgroups walking along the depth axis (f32; analysis: even L <= 10, every
  *          mode, rows <= 512 samples, picked from 2^22 samples per volume on and for 8 taps; synthesis: even L <= 8, dense coefficient
  *          rows, picked from 2^20 output samples on)

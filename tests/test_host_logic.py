@@ -552,3 +552,21 @@ def test_differentiable_calls_take_the_multi_level_ops_host_side(oracle_engine):
         gl = torch.autograd.grad((v * y).sum(), leaves)
         lhs = (v * y.detach()).sum().item()
         assert abs(lhs - sum((g * t.detach()).sum().item() for g, t in zip(gl, leaves))) < 1e-3 * max(1.0, abs(lhs))
+
+
+def test_every_kernel_id_is_documented_in_the_header():
+    """`enum KernelId` (csrc/mifwt_common.h) against the kernel-id list in the comment of `mifwt_kernel_id` (include/mifwt.h): a new
+    kernel family must appear in the public header."""
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "pytorch-wavelet-toolbox_amd", "csrc", "mifwt_common.h")).read()
+    body = re.search(r"enum KernelId \{(.*?)\};", src, flags=re.S).group(1)
+    ids = sorted({int(v) for v in re.findall(r"=\s*(\d+)", body)})
+    assert ids[0] == 0 and 24 in ids and 25 in ids
+    hdr = open(os.path.join(root, "include", "mifwt.h")).read()
+    block = hdr[hdr.index("generic per-axis passes (any strides"):hdr.index("int mifwt_kernel_id(")]
+    documented = {int(v) for head in re.findall(r"^ \*\s{3}((?:\d+ / )?\d+)\s+\S", block, flags=re.M) for v in head.split(" / ")}
+    documented.add(0)
+    assert set(ids) <= documented, sorted(set(ids) - documented)
