@@ -72,6 +72,8 @@ struct PyrArgs {
   float* xrows;               // [image][segment][(L - 1) rows of W1 floats, (L - 1) rows of W2 floats]
   int xrow_stride;            // floats per (image, segment)
   int xcd_map;
+  int exp;      // MIFWT_OPT_EXP: experiment word of the current A/B run (0 in the product)
+  int l2split;  // the level-2 waves take one row pair in each half of a step (else both behind the step's second barrier)
   int compact;  // 0: 16 waves (6 + 3 + 3 level waves at most, two loaders), one workgroup per CU; 1: 8 waves (3 + 2 + 2, one loader), two per CU
   unsigned long long* prof;
   int dbg;
@@ -307,11 +309,21 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
 
   unsigned long long waited = 0;
   const unsigned long long t_start = PROF ? __builtin_readcyclecounter() : 0;
+  // (profiling build: wave 0 also leaves the workgroup's start / end on the 100 MHz wall clock and where it ran — HW_ID, XCC_ID — in
+  // the slots of the unused waves 8 and 12: ramp, tail and the gap between launches, tools/pyr_prof.py)
+  const unsigned long long w_start = PROF ? __builtin_amdgcn_s_memrealtime() : 0;
   auto prof_out = [&]() {
     if (PROF && lane == 0) {
       unsigned long long* o = a.prof + ((size_t)blockIdx.x * kPyrWaves + wave) * 2;
       o[0] = __builtin_readcyclecounter() - t_start;
       o[1] = waited;
+      if (wave == 0) {
+        unsigned long long* w = a.prof + ((size_t)blockIdx.x * kPyrWaves + 8) * 2;
+        w[0] = w_start;
+        w[1] = __builtin_amdgcn_s_memrealtime();
+        w[8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        w[9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+      }
     }
   };
   f2 tap[L];
@@ -520,7 +532,7 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
         f_dst = (uint32_t)(kk * a.pitch0) + 4u * (uint32_t)(kPyrPad + e - g0);
       }
     }
-    const bool f_any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(f_on) != 0);
+    const bool f_any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(f_on) != 0) && !(a.dbg & 16384);
     // one buffer resource for the three detail planes of the image (band = scalar offset), one for the approximation; a row
     // the segment does not own is stored at a per-lane offset beyond every resource (dropped) — the resources never change
     const uint32_t dbytes = (a.dbg & 1) ? 0u : a.dspan[0] + ((uint32_t)(a.H[1] - 1) * (uint32_t)a.ds_h[0] + (uint32_t)a.W[1]) * 4u;
@@ -688,7 +700,7 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
           f_dst = 4u * (uint32_t)(kPyrPad + sh1 + e - cA[1]);
         }
       }
-      const bool f_any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(f_on) != 0);
+      const bool f_any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(f_on) != 0) && !(a.dbg & 32768);
       const uint32_t dbytes = (a.dbg & 1) ? 0u : a.dspan[1] + ((uint32_t)(a.H[2] - 1) * (uint32_t)a.ds_h[1] + (uint32_t)a.W[2]) * 4u;
       const uint32_t abytes = (a.dbg & 1) ? 0u : ((uint32_t)(a.H[NLEV] - 1) * (uint32_t)a.as_h + (uint32_t)a.W[NLEV]) * 4u;
       const rsrc_t rd = pyr_rsrc(a.det[1] + (int64_t)img * a.ds_b[1], dbytes);
@@ -726,7 +738,96 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
           }
         }
       };
+      if ((a.exp & 3) == 1) __builtin_amdgcn_s_setprio(1);
+      if ((a.exp & 3) == 2) __builtin_amdgcn_s_setprio(2);
+      if ((a.exp & 3) == 3) __builtin_amdgcn_s_setprio(3);
       int ph = 0;  // pair index modulo L/2 of the next block
+      // Round 5: the step's two row pairs in the step's two HALVES, one each (a.l2split).  Until then a level-2 wave did a whole step's
+      // work (two pairs, ~330 instructions) behind the step's second barrier and sat out the first half: per-wave clocks had it waiting
+      // for about half of its life, i.e. never in its own half — it was what the second half of every step waited for (a level-1 wave
+      // needs ~290 instructions per half).  The rows pair 0 reads (pair indices up to 4 (s - D2) + L/2 of level 1) are complete one
+      // barrier earlier than those of pair 1 wherever 4 D2 >= L/2 + 1, which the lags guarantee — except where pair 0 reads MIRRORED rows
+      // at the top of the plane (the first step of a top segment): that pair then runs with pair 1, as before.  Bit-identical.
+      if constexpr (!ST16) {
+        if (a.l2split) {
+          auto do_pair = [&](auto r_tag, auto jj_tag, int s, const uint32_t (&so_r)[4]) {
+            constexpr int R = decltype(r_tag)::value, jj = decltype(jj_tag)::value;
+            f2 wa[NW2], wb[NW2];
+            load_win(ring1 + so_r[2 * jj] + win, wa);
+            load_win(ring1 + so_r[2 * jj + 1] + win, wb);
+            f2 ha[2], hb[2];
+            h_pair(wa, wb, ha, hb);
+            acc.template feed<0, R>(tap, ha);
+            acc.template feed<1, R>(tap, hb);
+            const int p = 2 * (s - D2) + jj;
+            const int i = rA[2] + p - (HP - 1);
+            const f2 (&lo)[2] = acc.lo[PyrAcc<L, 2>::done(R)];
+            const f2 (&hi)[2] = acc.hi[PyrAcc<L, 2>::done(R)];
+            if constexpr (NLEV >= 3) {
+              unsigned char* rr = ring2 + (p & (kPyrRing - 1)) * a.pitch2;
+              const bool mine = i < lim[2];
+              *reinterpret_cast<float*>(rr + (mine ? rw[0] : 0u)) = lo[0].x;
+              *reinterpret_cast<float*>(rr + (mine ? rw[1] : 0u)) = lo[1].x;
+            }
+            const bool own = i >= oA[2] && i < oB[2];
+            const uint32_t v2 = own ? sv2 : kPyrOob;
+            const uint32_t so = own ? (uint32_t)i * (uint32_t)a.ds_h[1] * 4u : 0u;
+            __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].x, hi[1].x}, rd, v2, so + o0, MIFWT_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].y, lo[1].y}, rd, v2, so + o1, MIFWT_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64((f2){hi[0].y, hi[1].y}, rd, v2, so + o2, MIFWT_ST_AUX);
+            if (rag) {
+              const uint32_t v1 = own ? sv1 : kPyrOob;
+              pyr_store1(hi[0].x, rd, v1, so + o0);
+              pyr_store1(lo[0].y, rd, v1, so + o1);
+              pyr_store1(hi[0].y, rd, v1, so + o2);
+            }
+            if constexpr (NLEV == 2) {
+              const uint32_t sa = own ? (uint32_t)i * (uint32_t)a.as_h * 4u : 0u;
+              __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].x, lo[1].x}, ra, v2, sa, MIFWT_ST_AUX);
+              if (rag) pyr_store1(lo[0].x, ra, own ? sv1 : kPyrOob, sa);
+            }
+          };
+          auto half = [&](auto jj_tag, int s, const uint32_t (&so_r)[4]) {
+            constexpr int jj = decltype(jj_tag)::value;
+            if (f_any) {  // the pads of the pair's two rows
+              const uint32_t fo = f_r == 0 ? so_r[0] : (f_r == 1 ? so_r[1] : (f_r == 2 ? so_r[2] : so_r[3]));
+              const float v = *reinterpret_cast<const float*>(ring1 + fo + f_src);
+              wave_lds_fence();
+              if (f_on && (f_r >> 1) == jj) *reinterpret_cast<float*>(ring1 + fo + f_dst) = v;
+              wave_lds_fence();
+            }
+            pyr_dispatch<HP>((ph + jj) % HP, [&](auto r_tag) { do_pair(r_tag, jj_tag, s, so_r); });
+          };
+#pragma unroll 1
+          for (int s = 0; s < nsteps; ++s) {
+            pyr_barrier<PROF>(waited);
+            const bool act = s >= D2 && 2 * (s - D2) < npair2 && !(a.dbg & 4);
+            uint32_t so_r[4] = {0u, 0u, 0u, 0u};
+            bool early = false;
+            if (act) {
+              int qmax0 = 0;  // the newest level-1 pair index pair 0 reads
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int e = E1 + 4 * (s - D2) + r;
+                const bool dead = zero_mode && (unsigned)e >= (unsigned)a.H[1];
+                const int q = fold(e, a.H[1]) + ro1;
+                so_r[r] = (uint32_t)((dead ? kPyrRing : (q & (kPyrRing - 1))) * a.pitch1);
+                if (r < 2 && !dead) qmax0 = max(qmax0, q);
+              }
+              early = qmax0 <= 4 * s - 1;  // (written in an earlier step: complete behind this step's first barrier)
+              if (early) half(std::integral_constant<int, 0>{}, s, so_r);
+            }
+            pyr_barrier<PROF>(waited);
+            if (act) {
+              if (!early) half(std::integral_constant<int, 0>{}, s, so_r);
+              half(std::integral_constant<int, 1>{}, s, so_r);
+              ph = (ph + 2) % HP;
+            }
+          }
+          prof_out();
+          return;
+        }
+      }
 #pragma unroll 1
       for (int s = 0; s < nsteps; ++s) {
         pyr_barrier<PROF>(waited);
@@ -846,7 +947,7 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
         f_dst = 4u * (uint32_t)(kPyrPad + e - cA[2]);
       }
     }
-    const bool f_any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(f_on) != 0);
+    const bool f_any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(f_on) != 0) && !(a.dbg & 32768);
     const uint32_t dbytes = (a.dbg & 1) ? 0u : a.dspan[2] + ((uint32_t)(a.H[3] - 1) * (uint32_t)a.ds_h[2] + (uint32_t)a.W[3]) * 4u;
     const uint32_t abytes = (a.dbg & 1) ? 0u : ((uint32_t)(a.H[3] - 1) * (uint32_t)a.as_h + (uint32_t)a.W[3]) * 4u;
     const rsrc_t rd = pyr_rsrc(a.det[2] + (int64_t)img * a.ds_b[2], dbytes);
@@ -874,6 +975,8 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
         vfma_hi(hb[0], tap[L - 2 - 2 * k], wb[k]);
       }
     };
+    if (((a.exp >> 2) & 3) == 1) __builtin_amdgcn_s_setprio(1);
+    if (((a.exp >> 2) & 3) == 2) __builtin_amdgcn_s_setprio(2);
     int ph = 0;
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
@@ -1033,6 +1136,52 @@ static bool pyr_plan(int nlev, const mifwt_level_desc* const* d, PyrPlan* p) {
   p->nseg = (HN + p->seg_rows - 1) / p->seg_rows;
   if (p->nseg > 1 && HN - (p->nseg - 1) * p->seg_rows < 8) --p->nseg;
   p->seg0_rows = p->seg_rows;
+  // Round 5: segments of equal TIME, not of equal rows.  Per-workgroup wall clocks (tools/pyr_clock.py, profiles/r05a_clock.txt) on
+  // config 2 with 34 / 34 / 34 / 32 level-3 rows: the four segments of an image end 97.5 / 104.3 / 101.1 / 90.5 us after the launch
+  // starts, and the launch lasts as long as its longest workgroup (+ 4.5 us until the next one's first wave).  A step in which the
+  // level-1 waves run (prologue or owned rows) costs 2.5 us, a drain step (deep levels only, no memory traffic) 1.1 us — that fits the
+  // top (35 + 9 steps), middle (40 + 2) and bottom (32 + 8) segments within 1 %.  So: first-segment rows and inner-segment rows are
+  // searched around the equal split for the smallest modelled maximum (config 2: 34 / 32 / 32 / 36).
+  if (p->nseg > 1 && g_options[MIFWT_OPT_PAIR_ROWS] <= 0 && !(g_options[MIFWT_OPT_DEBUG] & 4096)) {
+    const int HP = L / 2;
+    int Hl[4] = {0, 0, 0, 0};
+    for (int l = 1; l <= nlev; ++l) Hl[l] = (int)d[l - 1]->coef_extent[0];
+    auto seg_time = [&](int oA, int oB) {
+      int rA[4], rB[4];
+      rA[nlev] = oA;
+      rB[nlev] = oB;
+      for (int l = nlev - 1; l >= 1; --l) {
+        rA[l] = std::max(0, 2 * rA[l + 1] - HL);
+        rB[l] = std::min(Hl[l], 2 * rB[l + 1]);
+      }
+      const bool top = oA == 0;
+      const int D2 = top ? pyr_lag2(L) : pyr_lag2_inner(L), D3 = top ? pyr_lag3(L) : pyr_lag3_inner(L);
+      const int nsteps1 = (rB[1] - rA[1] + HP - 1 + 3) / 4;
+      int nsteps = nsteps1;
+      if (nlev >= 2) nsteps = std::max(nsteps, D2 + (rB[2] - rA[2] + HP - 1 + 1) / 2);
+      if (nlev >= 3) nsteps = std::max(nsteps, D3 + rB[3] - rA[3] + HP - 1);
+      return nsteps1 + 0.45 * (nsteps - nsteps1);
+    };
+    const int base = p->seg_rows, ns = p->nseg;
+    double best = 1e30;
+    int best0 = base, bestr = base;
+    for (int r = std::max(8, base - 6); r <= base + 2; ++r)
+      for (int a0 = std::max(8, base - 6); a0 <= base + 6; ++a0) {
+        const int last = HN - a0 - (ns - 2) * r;
+        if (last < 8 || (ns > 2 && a0 + (ns - 3) * r >= HN)) continue;
+        double t = seg_time(0, a0);
+        if (ns > 2) t = std::max(t, seg_time(a0, a0 + r));  // (the inner segments are alike)
+        t = std::max(t, seg_time(a0 + (ns - 2) * r, HN));
+        if (t < best - 1e-9) best = t, best0 = a0, bestr = r;
+      }
+    p->seg0_rows = best0;
+    p->seg_rows = bestr;
+  }
+  // (experiments: explicit first / inner segment rows, tools/pyr_segs.py)
+  if (p->nseg > 1 && g_options[MIFWT_OPT_PYR_SEG0_ROWS] > 0 && g_options[MIFWT_OPT_PYR_SEG_ROWS] > 0) {
+    const int a0 = g_options[MIFWT_OPT_PYR_SEG0_ROWS], r = g_options[MIFWT_OPT_PYR_SEG_ROWS];
+    if (a0 >= 8 && r >= 8 && HN - a0 - (p->nseg - 2) * r >= 8) p->seg0_rows = a0, p->seg_rows = r;
+  }
   // (Round 4: a first segment SHORTER by the two level-3 rows its longer top-of-plane lags cost — 42 / 42 / 42 / 42 steps of 8 rows per
   // workgroup instead of 44 / 42 / 42 / 40 — measured the same, 104.4-106.5 against 104.4-105.1 us in three alternating runs,
   // profiles/r04t_segment_balance.txt: as with round 3's longer first segment, the launch does not wait for its longest workgroup.)
@@ -1178,6 +1327,8 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
       if (l + 1 == NLEV) st16 = st16 && al16(a.approx) && a.as_h % 4 == 0 && a.as_b % 4 == 0;
     }
   }
+  a.l2split = (g_options[MIFWT_OPT_DEBUG] & 8192) ? 0 : 1;
+  a.exp = g_options[MIFWT_OPT_EXP];
   a.handover = 0;
   a.nonce = 0;
   a.flags = nullptr;
@@ -1186,6 +1337,7 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
   if (p.handover && ws && ws_bytes >= p.ws_bytes && !a.xcd_map) {
     const size_t nsegs = (size_t)d[0]->batch * p.nseg;
     a.handover = 1;
+    a.l2split = 0;  // (the exchange wave places handed-over rows by the old schedule)
     a.nonce = nonce;
     a.flags = static_cast<unsigned long long*>(ws);
     a.xrows = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + ((nsegs * 8 + 255) & ~size_t(255)));
