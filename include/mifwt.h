@@ -136,18 +136,16 @@ int mifwt_dwt2_fwd_pair(const mifwt_level_desc* d1, const mifwt_level_desc* d2, 
 int mifwt_dwt2_fwd_pyramid_supported(int nlevels, const mifwt_level_desc* const* descs);
 int mifwt_dwt2_fwd_pyramid(int nlevels, const mifwt_level_desc* const* descs, const void* x, void* const* const* details, void* approx,
                            const double* dec_lo, const double* dec_hi, void* stream);
-/* The same call with a device WORKSPACE for kernel (1): a plane of few images is cut into row segments, one per workgroup, and a
- * segment needs, for its deeper levels, approximation rows that depend on input rows above it.  Without a workspace every segment
- * streams a prologue of (2^nlevels - 1)(L - 2) input rows (42 for three levels of db4: 12 % more reads on 64 x 1024^2, half as many
- * again on a batch of 16); with one, a segment starts its deeper levels where its own rows suffice and the segment BELOW deposits the
- * L - 2 (+ 1) approximation rows per level that the end of this one lacks (64-bit flags in the workspace, release / acquire at agent
- * scope; a flag is set when it holds `call_id`, which must differ from the ids of earlier calls on the same workspace — nothing is
- * ever cleared).  Identical sums in identical order: bit-identical results.  mifwt_dwt2_fwd_pyramid_workspace() = the bytes it wants
- * (0: the call would not use one); a smaller or NULL workspace selects the prologue form.
- * The handover form is an EXPERIMENT (measured slower than the prologues): mifwt_dwt2_fwd_pyramid_workspace answers 0
- * unless MIFWT_OPT_DEBUG bit 8 is set.  Contract when it is used: `call_id` unique per workspace, the workspace not shared by launches
- * in flight at the same time, and the whole grid resident at once (one workgroup per CU: batch x segments <= CUs) — a segment that
- * waits ~1 s for a flag that never comes TRAPS (the launch fails loudly at the next synchronisation) instead of returning wrong rows. */
+/* Kernel (1) runs PERSISTENT workgroups: the rows of the last fused level of all images, laid end to end, are cut into one chunk per
+ * workgroup (one workgroup per CU and column group; chunks of equal modelled time), a workgroup runs the parts of images in its chunk
+ * one after the other (a part that starts inside an image streams a prologue of (2^nlevels - 1)(L - 2) input rows first).  Results do
+ * not depend on the cut.  mifwt_dwt2_fwd_pyramid_schedule writes the cuts of a call into wg_start[0 .. n] (global row indices,
+ * wg_start[0] = 0, wg_start[n] = batch x rows) and returns n — diagnostics and tests; MIFWT_ERR_UNSUPPORTED where kernel (1) does not
+ * serve the call, MIFWT_ERR_BADARG if `capacity` < n + 1.
+ * mifwt_dwt2_fwd_pyramid_ws / _workspace: the entry points of round 3's segment HANDOVER experiment (row segments handing
+ * approximation rows over through a device workspace instead of prologues; measured slower, removed in round 5).  Kept for ABI
+ * compatibility: _workspace answers 0, _ws ignores its workspace and call id and is mifwt_dwt2_fwd_pyramid. */
+int mifwt_dwt2_fwd_pyramid_schedule(int nlevels, const mifwt_level_desc* const* descs, unsigned int* wg_start, int capacity);
 size_t mifwt_dwt2_fwd_pyramid_workspace(int nlevels, const mifwt_level_desc* const* descs);
 int mifwt_dwt2_fwd_pyramid_ws(int nlevels, const mifwt_level_desc* const* descs, const void* x, void* const* const* details, void* approx,
                               const double* dec_lo, const double* dec_hi, void* workspace, size_t workspace_bytes, unsigned long long call_id,
@@ -347,8 +345,7 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
 #define MIFWT_OPT_PAIR_ROWS 9      /* >0 overrides the pair kernels' level-2 rows per tile (4, 6, 8, 12) / per strip segment (multiple of 8) */
 #define MIFWT_OPT_PYRAMID_MODE 12 /* mifwt_dwt2_fwd_pyramid: 0 = auto (each of its two kernels where it is the fastest route), 1 = the streaming kernel wherever it can run, 3 = the small-plane kernel wherever it can run, 2 = never (it answers UNSUPPORTED / 0; the two-level and per-level kernels then serve the call) */
 #define MIFWT_OPT_DEBUG 11        /* A/B measurement switches of the multi-level kernels (results are then wrong): 1 = no stores, 2 = no loads, 4 = no deep levels, 16 = loader wave at default priority (streaming kernel); 32 / 64 / 128 = no pad fills / no horizontal / no vertical pass (small-plane analysis kernel, tools/small_ab.py).  Switches that keep the results right (A/B runs and parity tests of alternative code paths): 256 = the streaming analysis kernel's row segments hand rows over through a workspace instead of prologues, 512 = never its 16-byte store path, 1024 = analysis adjoints with a boundary extension on the generic per-axis passes instead of synthesis launch + border kernel, 2048 = the streaming analysis kernel in its compact form (eight-wave workgroups, two per CU).  The 3-D walking kernels (ids 24 / 25) read the same word: 1 / 2 / 4 = no stores / no loads / no W and H passes, 8 = band rows on a 128-sample pitch (analysis; results are then wrong), 16 = non-temporal requests (analysis), 64 = column strips of 64 instead of balanced strips (analysis), 512 = 8-byte instead of 16-byte output stores (synthesis; results stay right) */
-#define MIFWT_OPT_PYR_SEG0_ROWS 13 /* with MIFWT_OPT_PYR_SEG_ROWS: >0 overrides the rows of the last level the FIRST row segment of an image owns in the streaming analysis kernel (id 16; A/B runs of the segment balance) */
-#define MIFWT_OPT_PYR_SEG_ROWS 14  /* ... and the rows every inner segment owns (the last segment takes the rest; the segment count stays) */
+#define MIFWT_OPT_PYR_WGS 13 /* >0: the streaming analysis kernel (id 16) cuts the batch's rows into this many chunks (workgroups per column group) instead of one per CU — parity tests of units that start and end anywhere */
 #define MIFWT_OPT_EXP 15           /* experiment word of the A/B run in progress (tools/); 0 in the product */
 #define MIFWT_OPT_SYNC_STAGE 10    /* non-zero: tile kernels keep the workgroup barrier between staging and the horizontal pass (A/B) */
 int mifwt_set_option(int key, int value);

@@ -184,6 +184,8 @@ OPT_PAIR_MODE = 8
 OPT_PAIR_ROWS = 9
 OPT_DEBUG = 11
 OPT_PYRAMID_MODE = 12
+OPT_PYR_WGS = 13  # >0: kernel 16 cuts the batch's rows into this many chunks (tests of units that start / end anywhere)
+OPT_EXP = 15  # experiment word of an A/B run (tools/)
 KID_PAIR = 12
 KID_INV_PAIR = 13
 KID_TAIL = 14

@@ -543,6 +543,16 @@ int mifwt_dwt2_fwd_pyramid(int nlevels, const mifwt_level_desc* const* descs, co
                            const double* dec_lo, const double* dec_hi, void* stream) {
   return mifwt_dwt2_fwd_pyramid_ws(nlevels, descs, x, details, approx, dec_lo, dec_hi, nullptr, 0, 0, stream);
 }
+int mifwt_dwt2_fwd_pyramid_schedule(int nlevels, const mifwt_level_desc* const* descs, unsigned int* wg_start, int capacity) {
+  if (!descs || !wg_start || nlevels < 1 || nlevels > 3) return MIFWT_ERR_BADARG;
+  for (int l = 0; l < nlevels; ++l) {
+    if (!descs[l]) return MIFWT_ERR_BADARG;
+    const int rc = validate(descs[l], 0);
+    if (rc != MIFWT_OK) return rc;
+  }
+  if (pyramid_route(nlevels, descs) != 1) return MIFWT_ERR_UNSUPPORTED;
+  return dwt2_fwd_pyr_schedule(nlevels, descs, wg_start, capacity);
+}
 size_t mifwt_dwt2_fwd_pyramid_workspace(int nlevels, const mifwt_level_desc* const* descs) {
   if (!descs || nlevels < 1 || nlevels > 3) return 0;
   for (int l = 0; l < nlevels; ++l)

@@ -200,7 +200,8 @@ int dwt2_inv_pyr(int nlev, const mifwt_level_desc* const* d, const void* approx,
 bool dwt2_fwd_pyr_supported(int nlev, const mifwt_level_desc* const* d);
 int dwt2_fwd_pyr(int nlev, const mifwt_level_desc* const* d, const void* x, void* const* const* details, void* approx,
                   const double* dec_lo, const double* dec_hi, void* ws, size_t ws_bytes, unsigned long long nonce, hipStream_t stream);
-size_t dwt2_fwd_pyr_workspace(int nlev, const mifwt_level_desc* const* d);  // bytes the segment handover wants (0: none)
+size_t dwt2_fwd_pyr_workspace(int nlev, const mifwt_level_desc* const* d);  // 0 (round 3's segment handover wanted a workspace)
+int dwt2_fwd_pyr_schedule(int nlev, const mifwt_level_desc* const* d, uint32_t* wg_start, int capacity);  // the row chunks of the launch
 
 // two consecutive 2-D synthesis levels in one launch (mifwt_idwt2_pair.hip): f32, even L <= 8; d2 = the coarser level
 bool dwt2_inv_pair_supported(const mifwt_level_desc* d2, const mifwt_level_desc* d1);

@@ -98,22 +98,16 @@ def test_pyramid_row_segments(wavelet):
 
 
 def test_pyramid_store_paths_ragged_widths():
-    """Both store paths of the streaming kernel against the oracle on level-1 / level-2 widths of every residue modulo four (a ragged
-    last lane pair stores 1 .. 3 single columns), with short row segments (rows a lane pair stores belong to different segments at
-    odd ownership boundaries); `mifwt_launch_count` pins which variant ran."""
+    """The streaming kernel's stores against the oracle on level-1 / level-2 widths of every residue modulo four (a ragged last lane
+    stores a single column), with short row chunks (odd ownership boundaries); `mifwt_launch_count` pins that the kernel ran."""
     g = torch.Generator().manual_seed(21)
-    st16 = _engine.PYRAMID_ROW_ALIGN >= 16
     for width in (512, 514, 516, 518, 1024, 1030):
         x = torch.randn(2, 140, width, generator=g, dtype=torch.float32)
         for wavelet, level in (("haar", 3), ("db2", 2), ("db3", 3), ("db4", 3), ("db4", 1)):
-            n16, n8 = _engine.launch_count(_engine.VARIANT_FWD_PYR_ST16), _engine.launch_count(_engine.VARIANT_FWD_PYR_ST8)
+            n8 = _engine.launch_count(_engine.VARIANT_FWD_PYR_ST8)
             check(x, wavelet, "symmetric", level, want_kids=[_engine.KID_PYRAMID])
             check(x, wavelet, "zero", level, want_kids=[_engine.KID_PYRAMID], seg_rows=8)
-            d16, d8 = _engine.launch_count(_engine.VARIANT_FWD_PYR_ST16) - n16, _engine.launch_count(_engine.VARIANT_FWD_PYR_ST8) - n8
-            if st16:
-                assert (d16, d8) == (2, 0), (width, wavelet, level, d16, d8)
-            else:
-                assert d16 + d8 == 2
+            assert _engine.launch_count(_engine.VARIANT_FWD_PYR_ST8) - n8 == 2
 
 
 def test_pyramid_many_strips_two_groups():
@@ -243,43 +237,45 @@ def test_pyramid_rows_of_any_length_and_alignment(mode):
 
 
 @pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4"])
-def test_pyramid_segment_handover_option(wavelet):
-    """MIFWT_OPT_DEBUG bit 8: the row segments of an image hand their first approximation rows over through a workspace instead of
-    streaming prologues (measured slower, hence off by default; the path stays pinned): same sums in the same order — bit-identical to
-    the default form, and against the oracle."""
+def test_pyramid_persistent_units_any_cut(wavelet):
+    """Round 5: persistent workgroups.  The rows of the last level of all images, laid end to end, are cut into chunks, a workgroup
+    runs the units of its chunk one after the other (end of one image, whole images, start of the next).  MIFWT_OPT_PYR_WGS forces
+    chunk counts that make workgroups take several units: same sums in the same order — bit-identical to the one-chunk-per-CU launch
+    whatever the cut, and against the oracle."""
     g = torch.Generator().manual_seed(31)
-    for shape, level in (((3, 520, 600), 3), ((1, 1024, 1024), 3), ((2, 333, 517), 2), ((5, 640, 512), 3)):
-        x = torch.randn(*shape, generator=g)
-        for mode in ("reflect", "zero"):
-            ref = ptwt_amd.wavedec2(x.to(dev()), wavelet, mode=mode, level=level)
-            _engine.set_option(_engine.OPT_DEBUG, 256)
-            try:
-                check(x, wavelet, mode, level, [_engine.KID_PYRAMID])
-                got = ptwt_amd.wavedec2(x.to(dev()), wavelet, mode=mode, level=level)
-            finally:
-                _engine.set_option(_engine.OPT_DEBUG, 0)
-            for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(ref)):
-                assert torch.equal(a, b), (shape, wavelet, mode, n)
-
-
-@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4"])
-def test_pyramid_compact_layout_option(wavelet):
-    """MIFWT_OPT_DEBUG bit 11: eight-wave workgroups (3 + 2 + 2 level waves, one loader), two per CU, on column groups of about half a
-    1024-column plane (round 4: measured slower than the sixteen-wave form — 124 against 104 us on config 2 — hence off by default; the
-    path stays pinned): the same sums in the same order — bit-identical to the default form, and against the oracle."""
-    g = torch.Generator().manual_seed(41)
-    for shape, level in (((3, 520, 1000), 3), ((1, 1024, 1024), 3), ((2, 333, 517), 2), ((2, 300, 2048), 3), ((4, 257, 771), 1)):
+    for shape, level in (((5, 520, 600), 3), ((7, 264, 512), 3), ((3, 333, 517), 2), ((9, 200, 512), 1), ((2, 300, 2048), 3)):
         x = torch.randn(*shape, generator=g)
         for mode in ("reflect", "zero", "symmetric"):
             ref = ptwt_amd.wavedec2(x.to(dev()), wavelet, mode=mode, level=level)
-            _engine.set_option(_engine.OPT_DEBUG, 2048)
-            try:
-                check(x, wavelet, mode, level, [_engine.KID_PYRAMID])
-                got = ptwt_amd.wavedec2(x.to(dev()), wavelet, mode=mode, level=level)
-            finally:
-                _engine.set_option(_engine.OPT_DEBUG, 0)
-            for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(ref)):
-                assert torch.equal(a, b), (shape, wavelet, mode, n)
+            for wgs in (1, 2, 3, 7):
+                _engine.set_option(_engine.OPT_PYR_WGS, wgs)
+                try:
+                    if wgs == 3:
+                        check(x, wavelet, mode, level, [_engine.KID_PYRAMID])
+                    got = ptwt_amd.wavedec2(x.to(dev()), wavelet, mode=mode, level=level)
+                finally:
+                    _engine.set_option(_engine.OPT_PYR_WGS, 0)
+                for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(ref)):
+                    assert torch.equal(a, b), (shape, wavelet, mode, wgs, n)
+
+
+def test_pyramid_batches_that_do_not_divide_the_chip():
+    """Batches around multiples of the CU count / 4 (65, 100 images of 1024^2 took 1.7 / 1.4 x the time per image of 64 until round 4:
+    a last round of a few workgroups): chunks that start and end inside images, checked image by image against one-image calls
+    (bit-identical: the results do not depend on the cut) and, for the first and last image, against the oracle."""
+    g = torch.Generator().manual_seed(32)
+    for B, H, W in ((65, 264, 512), (37, 520, 1024), (100, 136, 640)):
+        x = torch.randn(B, H, W, generator=g)
+        xd = x.to(dev())
+        got = ptwt_amd.wavedec2(xd, "db4", level=3)
+        for i in (0, 1, B // 2, B - 2, B - 1):
+            one = ptwt_amd.wavedec2(xd[i : i + 1], "db4", level=3)
+            for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(one)):
+                assert torch.equal(a[i : i + 1], b), (B, i, n)
+        for i in (0, B - 1):
+            want = O.wavedec2(x[i : i + 1].numpy().astype(np.float64), "db4", level=3)
+            for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(want)):
+                assert G.relerr(a[i : i + 1].cpu().numpy(), b) < TOL32, (B, i, n)
 
 
 def test_pyramid_randomised_against_per_level_kernels():

@@ -13,7 +13,7 @@ if dbg: _engine.set_option(11, dbg)
 for i in range(10): ptwt_amd.wavedec2(xs[i % 3], 'db4', level=3)
 torch.cuda.synchronize()
 nl = 6
-nwg = 4 * B if B <= 64 else 1024
+nwg = 320
 bufs = [torch.zeros(nwg * 16 * 2, dtype=torch.int64, device='cuda') for _ in range(nl)]
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
@@ -35,6 +35,18 @@ for k in range(nl):
     if prev_end is not None: line += f'; gap after previous launch\'s last end {t0 - prev_end:.1f} us'
     prev_end = en.max()
     print(line)
+    if k == nl - 1 and B != 64:
+        glo, ghi = b[used, 13, 0], b[used, 13, 1]
+        hn = 134
+        cls = {}
+        for i in range(int(used.sum())):
+            lo, hi = int(glo[i]), int(ghi[i])
+            units, g = [], lo
+            while g < hi:
+                r0 = g % hn; n = min(hn - r0, hi - g); units.append(('T' if r0 == 0 else '') + ('B' if r0 + n == hn else '') + str(n)); g += n
+            cls.setdefault(' + '.join(units), []).append(float(en[i] - st[i]))
+        for key, v in sorted(cls.items(), key=lambda kv: -max(kv[1])):
+            print(f'   chunk of units [{key}] (T = top of an image, B = bottom; rows): {len(v)} workgroups, duration mean {sum(v) / len(v):.1f} max {max(v):.1f} us')
     if k == nl - 1:
         for s in range(4):
             m = seg == s
