@@ -721,8 +721,13 @@ static int pyr_group_cols(int L, int nlev, bool first) {
 struct PyrGeom {
   int L, nlev, H[4];
 };
-constexpr double kDrainStep = 0.45, kUnitStart = 1.0;
+constexpr double kUnitStart = 1.0;
 static double pyr_unit_time(const PyrGeom& gm, int u_lo, int u_hi) {
+  // (calibration runs, tools/pyr_calib.py: MIFWT_OPT_EXP bits 8-11 = drain weight in twentieths over 0.25, bits 12-15 = what a unit
+  // at the top of its image saves — no prologue to request, nothing to wait for — in tenths of a step)
+  const int ex = g_options[MIFWT_OPT_EXP];
+  const double kDrainStep = ((ex >> 8) & 15) ? 0.25 + 0.05 * ((ex >> 8) & 15) : 0.45;
+  const double kTopBonus = ((ex >> 12) & 15) ? 0.1 * ((ex >> 12) & 15) : 1.0;  // (35 / 32 / 32 / 35 rows on config 2: 0.5-1 % ahead of 34 / 32 / 32 / 36, profiles/r05i_calib.txt)
   const int L = gm.L, HL = L - 2, HP = L / 2, nlev = gm.nlev;
   int rA[4], rB[4];
   rA[nlev] = u_lo;
@@ -737,7 +742,7 @@ static double pyr_unit_time(const PyrGeom& gm, int u_lo, int u_hi) {
   int nsteps = nsteps1;
   if (nlev >= 2) nsteps = std::max(nsteps, D2 + (rB[2] - rA[2] + HP - 1 + 1) / 2);
   if (nlev >= 3) nsteps = std::max(nsteps, D3 + rB[3] - rA[3] + HP - 1);
-  return nsteps1 + kDrainStep * (nsteps - nsteps1) + kUnitStart;
+  return nsteps1 + kDrainStep * (nsteps - nsteps1) + kUnitStart - (top ? kTopBonus : 0.0);
 }
 
 // Cuts the B x HN rows into at most `gmax` chunks whose modelled times do not exceed `budget`: greedy, a chunk takes whole rests of
@@ -792,17 +797,17 @@ static void pyr_schedule(const PyrGeom& gm, int64_t B, int gwant, PyrPlan* p) {
   const int HN = gm.H[gm.nlev];
   // one-entry cache (a call loop asks for the same schedule every time; the search below is ~0.1 ms)
   struct Key {
-    int L, nlev, H[4], gwant;
+    int L, nlev, H[4], gwant, ex;
     int64_t B;
     bool operator==(const Key& o) const {
-      return L == o.L && nlev == o.nlev && H[1] == o.H[1] && H[2] == o.H[2] && H[3] == o.H[3] && gwant == o.gwant && B == o.B;
+      return L == o.L && nlev == o.nlev && H[1] == o.H[1] && H[2] == o.H[2] && H[3] == o.H[3] && gwant == o.gwant && ex == o.ex && B == o.B;
     }
   };
   static std::mutex mu;
-  static Key last_key = {0, 0, {0, 0, 0, 0}, 0, 0};
+  static Key last_key = {0, 0, {0, 0, 0, 0}, 0, 0, 0};
   static int last_n = 0;
   static uint32_t last_cut[kPyrMaxWG + 1];
-  Key key = {gm.L, gm.nlev, {0, gm.nlev >= 1 ? gm.H[1] : 0, gm.nlev >= 2 ? gm.H[2] : 0, gm.nlev >= 3 ? gm.H[3] : 0}, gwant, B};
+  Key key = {gm.L, gm.nlev, {0, gm.nlev >= 1 ? gm.H[1] : 0, gm.nlev >= 2 ? gm.H[2] : 0, gm.nlev >= 3 ? gm.H[3] : 0}, gwant, g_options[MIFWT_OPT_EXP], B};
   {
     std::lock_guard<std::mutex> lk(mu);
     if (last_n > 0 && key == last_key) {
@@ -1003,6 +1008,10 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
   a.nl3 = p.nl3;
   a.mode = d[0]->mode;
   a.dbg = g_options[MIFWT_OPT_DEBUG];
+  // (timing experiments, results wrong: the nearly empty last wave of level 1 / 2 / 3 switched off)
+  if ((a.dbg & 65536) && a.nl1 > 1) --a.nl1;
+  if ((a.dbg & 131072) && a.nl2 > 1) --a.nl2;
+  if ((a.dbg & 262144) && a.nl3 > 1) --a.nl3;
   a.prof = g_pyr_prof;
   a.l2split = (g_options[MIFWT_OPT_DEBUG] & 8192) ? 0 : 1;
   a.exp = g_options[MIFWT_OPT_EXP];

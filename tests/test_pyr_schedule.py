@@ -65,7 +65,7 @@ def _unit_time(lo, hi, L, Hs, nlev):
         n = max(n, (l2 if top else l2i) + (rB[2] - rA[2] + HP - 1 + 1) // 2)
     if nlev >= 3:
         n = max(n, (l3 if top else l3i) + rB[3] - rA[3] + HP - 1)
-    return n1 + 0.45 * (n - n1) + 1.0
+    return n1 + 0.45 * (n - n1) + 1.0 - (1.0 if top else 0.0)
 
 
 def _chunk_times(cuts, hn, L, Hs, nlev):

@@ -1,0 +1,37 @@
+"""Calibration of the schedule model of kernel 16 (drain weight, top-unit bonus: MIFWT_OPT_EXP) on config 2: cuts + whole-call time."""
+import ctypes, sys, torch
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import ptwt_amd
+from ptwt_amd import _engine
+from test_pyr_schedule import _schedule
+def t(fn, n=60):
+    for _ in range(10): fn()
+    torch.cuda.synchronize()
+    r = []
+    for _ in range(7):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n): fn()
+        e1.record(); torch.cuda.synchronize(); r.append(e0.elapsed_time(e1) / n * 1e3)
+    return sorted(r)[3], min(r)
+xs = [torch.randn(64, 1024, 1024, device='cuda') for _ in range(3)]
+i = [0]
+def f():
+    i[0] += 1; return ptwt_amd.wavedec2(xs[i[0] % 3], 'db4', level=3)
+held = [None, None, None]
+def frot():
+    i[0] += 1; held[i[0] % 3] = ptwt_amd.wavedec2(xs[i[0] % 3], 'db4', level=3)
+seen = {}
+for rep in range(2):
+    for drain in (0, 2, 6, 8, 10, 13):
+        for bonus in (0, 10, 15):
+            ex = (drain << 8) | (bonus << 12)
+            _engine.set_option(_engine.OPT_EXP, ex)
+            cuts, hn = _schedule(64, 1024, 1024, 8, 3)
+            rows = tuple(int(v) for v in (cuts[1:5] - cuts[0:4]))
+            if rep == 0 and rows in seen: continue
+            if rep == 1 and seen.get(rows) != ex: continue
+            seen[rows] = ex
+            m, lo = t(f); mr, lor = t(frot); held[:] = [None] * 3
+            print(f'drain weight {0.25 + 0.05 * drain if drain else 0.45:.2f} top bonus {0.1 * bonus:.1f}: rows {rows} ({len(cuts) - 1} chunks): same output {m:.1f} (min {lo:.1f}) us; rotating {mr:.1f} (min {lor:.1f}) us', flush=True)
+_engine.set_option(_engine.OPT_EXP, 0)
