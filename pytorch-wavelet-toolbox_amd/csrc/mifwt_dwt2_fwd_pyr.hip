@@ -15,7 +15,9 @@
 //   * a unit is one row segment of one column GROUP of one image (the whole width of a plane up to 1280 columns; wider planes are
 //     cut into groups that recompute L - 2 halo columns per level at their left seam); the workgroup runs one wave per role:
 //     level-1 waves (two columns per lane, 128 columns per wave), level-2 waves (two per lane), level-3 waves (one per
-//     lane), two LOADER waves.  Config 2: 5 + 3 + 3 + 2 waves.  The waves of a level tile the group's columns densely and
+//     lane), two LOADER waves, and (round 5) a TAIL wave for the last few columns of each level where they would leave a level
+//     wave nearly empty.  Config 2: 4 + 2 + 2 level waves + tail + 2 loaders in the TWELVE-wave form (three waves per SIMD: 168
+//     registers a lane; until round 4: 5 + 3 + 3 + 2 of sixteen).  The waves of a level tile the group's columns densely and
 //     SHARE one staged level-0 row and one ring row per level (private 256-column strips with private halos, the first
 //     design, requested every row 1.25 times and needed 5 + 5 + 5 waves: 4-9 % slower on every shape tried);
 //   * rows STREAM through a wave: the vertical pass of every level keeps the L/2 outputs in flight in registers (rolling
@@ -57,6 +59,9 @@ constexpr int kPyrCtl = 64;   // bytes in front of the staging area
 constexpr int kPyrWaves = 16;
 constexpr int kPyrMaxChunks = 5;  // 1 KiB requests per staged row (three for the first loader wave, two for the second)
 constexpr int kPyrMaxWG = 320;    // row chunks (= workgroups per column group) of a launch
+constexpr int kPyrTailCols = 8;                                   // columns of a level the tail wave can take (its job grids: 4 / 6 / 6)
+constexpr int kPyrTailRows = kPyrRing + 8;                        // rows of a tail image: 16 slots + the first 8 once more
+constexpr int kPyrTailBytes = kPyrTailRows * kPyrTailCols * 8;    // one level's image of horizontally filtered (lo, hi) pairs
 
 template <int L, int NLEV>
 struct PyrArgs {
@@ -73,6 +78,8 @@ struct PyrArgs {
   int nchunks, nbuf;            // 1 KiB requests per level-0 row, staging sub-buffers of kPyrSub rows
   int pitch0, pitch1, pitch2;   // bytes of a staged row / a ring-1 row / a ring-2 row
   int nl1, nl2, nl3;            // waves of level 1 / 2 / 3
+  int nt[3], tc0[3];            // TAIL columns of level l + 1: the nt last columns, from tc0 on, are the tail wave's (0: none)
+  int twave;                    // the wave that runs them (-1: none)
   int mode;
   int exp;      // MIFWT_OPT_EXP: experiment word of the current A/B run (0 in the product)
   int l2split;  // the level-2 waves take one row pair in each half of a step (else both behind the step's second barrier)
@@ -110,10 +117,24 @@ __device__ __forceinline__ void pyr_load_win2(const unsigned char* row, f2 (&w)[
 // 13, level 2 = 5-7, level 3 = 9-11, loaders = 15 and 14; with five level-1 waves the classes hold {L1, L1} {L1, L2, L3}
 // {L1, L2, L3, loader} {L1, L2, L3, loader}.  Waves 0 and 4 share a SIMD: they take interior columns, not the first / last
 // level-1 wave, which also copy the boundary extension of every staged row.
-__device__ __forceinline__ void pyr_role(int wave, int nl1, int nchunks, int& role, int& idx) {
+template <int NW>
+__device__ __forceinline__ void pyr_role(int wave, int nl1, int nchunks, int twave, int& role, int& idx) {
   role = -1;
   idx = 0;
-  if (wave < 5) {
+  if constexpr (NW == 12) {
+    // TWELVE waves (at most 4 + 2 + 2 level waves: a workgroup of three waves per SIMD may use 168 registers a lane, and the
+    // three-level 8-tap kernel wants more than the 128 of a sixteen-wave workgroup): level 1 = waves 0-3, level 2 = 4-5, level 3 =
+    // 6-7, the tail wave = 9, loaders = 11 and 10; SIMD classes {L1, L2} {L1, L2, tail} {L1, L3, loader} {L1, L3, loader}
+    if (wave == twave) role = kRoleTail;
+    else if (wave < 4) role = kRoleL1, idx = wave;
+    else if (wave < 6) role = kRoleL2, idx = wave - 4;
+    else if (wave < 8) role = kRoleL3, idx = wave - 6;
+    else if (wave == 11 || (wave == 10 && nchunks >= 2)) role = kRoleLoad, idx = 11 - wave;
+    return;
+  }
+  if (wave == twave) {
+    role = kRoleTail;
+  } else if (wave < 5) {
     role = kRoleL1;
     idx = nl1 < 5 ? wave : (wave == 0 ? 1 : (wave == 1 ? 0 : (wave == 2 ? 3 : (wave == 3 ? 4 : 2))));
   } else if (wave == 13) {
@@ -131,8 +152,8 @@ __device__ __forceinline__ void pyr_role(int wave, int nl1, int nchunks, int& ro
   }
 }
 
-template <int L, int NLEV, bool PROF>
-__global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrArgs<L, NLEV> a) {
+template <int L, int NLEV, bool PROF, int NW>
+__global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, NLEV> a) {
   constexpr int HL = L - 2, HP = L / 2;
   constexpr int NC1 = 2;          // columns per level-1 lane (three were measured: 112.6 against 108.5 us on config 2)
   constexpr int NP = 2 * HL + 1;  // extension columns of a row: HL on the left, HL + 1 on the right
@@ -141,7 +162,7 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int role, widx;
-  pyr_role(wave, a.nl1, a.nchunks, role, widx);
+  pyr_role<NW>(wave, a.nl1, a.nchunks, a.twave, role, widx);
   if (role < 0 || (role == kRoleL1 && widx >= a.nl1) || (role == kRoleL2 && (NLEV < 2 || widx >= a.nl2)) ||
       (role == kRoleL3 && (NLEV < 3 || widx >= a.nl3)))
     return;  // (a wave that has ended does not take part in the barriers of the others)
@@ -177,6 +198,7 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
   unsigned char* const stage = smem + kPyrCtl;
   unsigned char* const ring1 = stage + a.nbuf * kPyrSub * a.pitch0;
   unsigned char* const ring2 = ring1 + (kPyrRing + 1) * a.pitch1;
+  unsigned char* const tailimg = ring2 + (kPyrRing + 1) * a.pitch2;  // (three images of kPyrTailBytes, if there is a tail wave)
 
   unsigned long long waited = 0;
   const unsigned long long t_start = PROF ? __builtin_readcyclecounter() : 0;
@@ -486,6 +508,9 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
             }
           }
         };
+        if ((a.exp & 3) == 1) __builtin_amdgcn_s_setprio(1);
+        if ((a.exp & 3) == 2) __builtin_amdgcn_s_setprio(2);
+        if ((a.exp & 3) == 3) __builtin_amdgcn_s_setprio(3);
         int ph = 0;  // pair index modulo L/2 of the next block
         // One row pair in each HALF of a step (a.l2split, round 5).  Until then a level-2 wave did a whole step's work (two pairs, ~330
         // instructions) behind the step's second barrier and sat out the first half: per-wave clocks had it waiting for about half of
@@ -493,15 +518,30 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
         // instructions per half).  The rows pair 0 reads (pair indices up to 4 (s - D2) + L/2 of level 1) are complete one barrier
         // earlier than those of pair 1 wherever 4 D2 >= L/2 + 1, which the lags guarantee — except where pair 0 reads MIRRORED rows at
         // the top of the plane (the first step of a top unit): that pair then runs with pair 1, as before.  Bit-identical.
+        unsigned long long tsec[4] = {0, 0, 0, 0};  // (profiling build: cycles in window loads / arithmetic / ring write + stores / pad fill)
         auto do_pair = [&](auto r_tag, auto jj_tag, int s, const uint32_t (&so_r)[4]) {
           constexpr int R = decltype(r_tag)::value, jj = decltype(jj_tag)::value;
+          unsigned long long t0 = 0;
+          if constexpr (PROF) t0 = __builtin_readcyclecounter();
           f2 wa[NW2], wb[NW2];
           load_win(ring1 + so_r[2 * jj] + win, wa);
           load_win(ring1 + so_r[2 * jj + 1] + win, wb);
+          if constexpr (PROF) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long t1 = __builtin_readcyclecounter();
+            tsec[0] += t1 - t0;
+            t0 = t1;
+          }
           f2 ha[2], hb[2];
           h_pair(wa, wb, ha, hb);
           acc.template feed<0, R>(tap, ha);
           acc.template feed<1, R>(tap, hb);
+          if constexpr (PROF) {
+            asm volatile("" ::: "memory");
+            const unsigned long long t1 = __builtin_readcyclecounter();
+            tsec[1] += t1 - t0;
+            t0 = t1;
+          }
           const int p = 2 * (s - D2) + jj;
           const int i = rA[2] + p - (HP - 1);
           const f2 (&lo)[2] = acc.lo[PyrAcc<L, 2>::done(R)];
@@ -529,9 +569,15 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
             __builtin_amdgcn_raw_buffer_store_b64((f2){lo[0].x, lo[1].x}, ra, v2, sa, MIFWT_ST_AUX);
             if (rag) pyr_store1(lo[0].x, ra, own ? sv1 : kPyrOob, sa);
           }
+          if constexpr (PROF) {
+            asm volatile("" ::: "memory");
+            tsec[2] += __builtin_readcyclecounter() - t0;
+          }
         };
         auto half = [&](auto jj_tag, int s, const uint32_t (&so_r)[4]) {
           constexpr int jj = decltype(jj_tag)::value;
+          unsigned long long tp = 0;
+          if constexpr (PROF) tp = __builtin_readcyclecounter();
           if (f_any) {  // the pads of the pair's two rows
             const uint32_t fo = f_r == 0 ? so_r[0] : (f_r == 1 ? so_r[1] : (f_r == 2 ? so_r[2] : so_r[3]));
             const float v = *reinterpret_cast<const float*>(ring1 + fo + f_src);
@@ -539,6 +585,7 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
             if (f_on && (f_r >> 1) == jj) *reinterpret_cast<float*>(ring1 + fo + f_dst) = v;
             wave_lds_fence();
           }
+          if constexpr (PROF) tsec[3] += __builtin_readcyclecounter() - tp;
           pyr_dispatch<HP>((ph + jj) % HP, [&](auto r_tag) { do_pair(r_tag, jj_tag, s, so_r); });
         };
 #pragma unroll 1
@@ -549,14 +596,26 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
           bool early = false;
           if (act) {
             int qmax0 = 0;  // the newest level-1 pair index pair 0 reads
+            const int e0 = E1 + 4 * (s - D2);
+            if (e0 >= 0 && e0 + 3 < a.H[1]) {
+              // rows inside the plane (every step but the first / last few of a plane): consecutive ring slots, no index map — the map
+              // and its four selections were 130 of the ~530 instructions of a level-2 wave's step
+              const int q0 = e0 + ro1;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int e = E1 + 4 * (s - D2) + r;
-              const bool dead = zero_mode && (unsigned)e >= (unsigned)a.H[1];
-              const int q = fold(e, a.H[1]) + ro1;
-              so_r[r] = (uint32_t)((dead ? kPyrRing : (q & (kPyrRing - 1))) * a.pitch1);
-              if (r < 2 && !dead) qmax0 = max(qmax0, q);
+              for (int r = 0; r < 4; ++r) so_r[r] = (uint32_t)(((q0 + r) & (kPyrRing - 1)) * a.pitch1);
+              qmax0 = q0 + 1;
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int e = e0 + r;
+                const bool dead = zero_mode && (unsigned)e >= (unsigned)a.H[1];
+                const int q = fold(e, a.H[1]) + ro1;
+                so_r[r] = (uint32_t)((dead ? kPyrRing : (q & (kPyrRing - 1))) * a.pitch1);
+                if (r < 2 && !dead) qmax0 = max(qmax0, q);
+              }
             }
+            // (for the tail wave, which filters the same rows behind the step's second barrier)
+            if (NW == 12 && widx == 0 && a.twave >= 0 && lane == 0) *reinterpret_cast<u4*>(smem) = (u4){so_r[0], so_r[1], so_r[2], so_r[3]};
             early = a.l2split && qmax0 <= 4 * s - 1;  // (written in an earlier step: complete behind this step's first barrier)
             if (early) half(std::integral_constant<int, 0>{}, s, so_r);
           }
@@ -566,6 +625,10 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
             half(std::integral_constant<int, 1>{}, s, so_r);
             ph = (ph + 2) % HP;
           }
+        }
+        if (PROF && widx == 0 && lane == 0) {
+          unsigned long long* o = a.prof + ((size_t)blockIdx.x * kPyrWaves + 14) * 2;
+          o[0] += tsec[0], o[1] += tsec[1], o[2] += tsec[2], o[3] += tsec[3];
         }
       }
     } else if (NLEV >= 3 && role == kRoleL3) {
@@ -626,12 +689,19 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
           pyr_barrier<PROF>(waited);
           if (s >= D3 && s - D3 < npair3 && !(a.dbg & 4)) {
             uint32_t so_r[2];
+            const int e0 = E2 + 2 * (s - D3);
+            if (e0 >= 0 && e0 + 1 < a.H[2]) {
+              so_r[0] = (uint32_t)(((e0 + ro2) & (kPyrRing - 1)) * a.pitch2);
+              so_r[1] = (uint32_t)(((e0 + 1 + ro2) & (kPyrRing - 1)) * a.pitch2);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-              const int e = E2 + 2 * (s - D3) + r;
-              const bool dead = zero_mode && (unsigned)e >= (unsigned)a.H[2];
-              so_r[r] = (uint32_t)((dead ? kPyrRing : ((fold(e, a.H[2]) + ro2) & (kPyrRing - 1))) * a.pitch2);
+              for (int r = 0; r < 2; ++r) {
+                const int e = e0 + r;
+                const bool dead = zero_mode && (unsigned)e >= (unsigned)a.H[2];
+                so_r[r] = (uint32_t)((dead ? kPyrRing : ((fold(e, a.H[2]) + ro2) & (kPyrRing - 1))) * a.pitch2);
+              }
             }
+            if (NW == 12 && widx == 0 && a.twave >= 0 && lane == 0) *reinterpret_cast<u2*>(smem + 16) = (u2){so_r[0], so_r[1]};
             if (f_any) {
               const uint32_t fo = f_r == 0 ? so_r[0] : so_r[1];
               const float v = *reinterpret_cast<const float*>(ring2 + fo + f_src);
@@ -664,6 +734,167 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
         }
       }
     }
+    else if (NW == 12 && role == kRoleTail) {  // (the sixteen-wave form has no registers for it: 128 a lane)
+      if constexpr (NW == 12) {
+      // ===================================================================================================================
+      // TAIL wave (round 5).  515 / 261 / 134 columns are 4 x 128 + 3, 2 x 128 + 5, 2 x 64 + 6: a fifth level-1 wave, a third level-2
+      // and a third level-3 wave ran the whole instruction stream of their level for two, three and six lanes (1066 of the 4600
+      // instructions a workgroup issues per 8-row step).  The last few columns of a level are cheap in DIRECT form, one lane per
+      // (row, column): stage 1 = the horizontal pass of every row that arrived this half step, for each tail column, into a small LDS
+      // image of (lo, hi) pairs; stage 2 = the vertical pass of every row the half step completes, from the L newest rows of that
+      // image — the same products in the same order as the rolling accumulators of the level waves (bit-identical), all three levels
+      // in one instruction stream (lanes differ in where they read and write).  The samples come through the boundary index map
+      // (a window that reaches beyond the plane reads the mirrored / clamped column itself), so nobody fills pads for the tail.
+      // Level 1 rows are filtered in the half step they land in (a staging buffer is recycled after it), levels 2 and 3 behind the
+      // step's second barrier — where the level-2 waves used to run their whole step.
+      const int nt1 = a.nt[0], nt2 = NLEV >= 2 ? a.nt[1] : 0, nt3 = NLEV >= 3 ? a.nt[2] : 0;
+      // stage-1 job of the lane: (level, row of the half step's new rows, tail column)
+      int j_lvl = 0, j_r = 0, j_c = 0;
+      {
+        int idx = lane;
+        if (idx < 4 * nt1) {
+          j_lvl = 1, j_r = idx / max(nt1, 1), j_c = idx - j_r * nt1;
+        } else {
+          idx -= 4 * nt1;
+          if (idx < 4 * nt2) {
+            j_lvl = 2, j_r = idx / max(nt2, 1), j_c = idx - j_r * nt2;
+          } else {
+            idx -= 4 * nt2;
+            if (idx < 2 * nt3) j_lvl = 3, j_r = idx / max(nt3, 1), j_c = idx - j_r * nt3;
+          }
+        }
+      }
+      // byte offsets of the job's L samples from the start of its source row (zero mode: float 1 of every row is a zero nobody writes)
+      uint32_t soff[L];
+      {
+        const int Wp = j_lvl <= 1 ? a.W[0] : (j_lvl == 2 ? a.W[NLEV >= 2 ? 1 : 0] : a.W[NLEV >= 3 ? 2 : 0]);
+        const int tc = j_lvl <= 1 ? a.tc0[0] : (j_lvl == 2 ? a.tc0[1] : a.tc0[2]);
+        const int body0 = j_lvl <= 1 ? kPyrPad - g0 : (j_lvl == 2 ? kPyrPad + sh1 - cA[1] : kPyrPad - cA[NLEV >= 2 ? 2 : 1]);
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+          const int x = 2 * (tc + j_c) - HL + k;
+          const bool oob = (unsigned)x >= (unsigned)Wp;
+          soff[k] = (oob && zero_mode) ? 4u : 4u * (uint32_t)(body0 + (zero_mode ? x : fold(x, Wp)));
+        }
+      }
+      const uint32_t m_l1 = j_lvl == 1 ? ~0u : 0u, m_l2 = j_lvl == 2 ? ~0u : 0u, m_l3 = j_lvl == 3 ? ~0u : 0u;
+      const uint32_t m_r0 = j_r == 0 ? ~0u : 0u, m_r1 = j_r == 1 ? ~0u : 0u, m_r2 = j_r == 2 ? ~0u : 0u, m_r3 = j_r == 3 ? ~0u : 0u;
+      const uint32_t j_rp0 = (uint32_t)j_r * (uint32_t)a.pitch0, r1off = (uint32_t)(ring1 - smem), r2off = (uint32_t)(ring2 - smem);
+      const uint32_t img1 = (uint32_t)(tailimg - smem) + (uint32_t)(max(j_lvl, 1) - 1) * (uint32_t)kPyrTailBytes + 8u * (uint32_t)j_c;
+      // stage-2 job of the lane: (level, output row of the half step, tail column)
+      int k_lvl = 0, k_o = 0, k_c = 0;
+      {
+        int idx = lane;
+        if (idx < 2 * nt1) {
+          k_lvl = 1, k_o = idx / max(nt1, 1), k_c = idx - k_o * nt1;
+        } else {
+          idx -= 2 * nt1;
+          if (idx < 2 * nt2) {
+            k_lvl = 2, k_o = idx / max(nt2, 1), k_c = idx - k_o * nt2;
+          } else {
+            idx -= 2 * nt2;
+            if (idx < nt3) k_lvl = 3, k_c = idx;
+          }
+        }
+      }
+      constexpr int I2 = NLEV >= 2 ? 1 : 0, I3 = NLEV >= 3 ? 2 : 0;
+      const int kC = (k_lvl <= 1 ? a.tc0[0] : (k_lvl == 2 ? a.tc0[1] : a.tc0[2])) + k_c;  // the column of the job's level
+      const int k_rA = k_lvl <= 1 ? rA[1] : (k_lvl == 2 ? rA[I2 + 1] : rA[I3 + 1]);
+      const int k_rB = k_lvl <= 1 ? rB[1] : (k_lvl == 2 ? rB[I2 + 1] : rB[I3 + 1]);
+      const int k_oA = k_lvl <= 1 ? oA[1] : (k_lvl == 2 ? oA[I2 + 1] : oA[I3 + 1]);
+      const int k_oB = k_lvl <= 1 ? oB[1] : (k_lvl == 2 ? oB[I2 + 1] : oB[I3 + 1]);
+      const bool k_last = k_lvl == NLEV;  // the level whose approximation leaves the workgroup
+      // the job's column in the three detail planes / the approximation plane of its image, and in the ring its approximation feeds
+      const int kl = max(k_lvl, 1) - 1;
+      unsigned char* const k_dptr = reinterpret_cast<unsigned char*>((kl == 0 ? a.det[0] : (kl == 1 ? a.det[I2] : a.det[I3])) +
+                                                                      (int64_t)img * (kl == 0 ? a.ds_b[0] : (kl == 1 ? a.ds_b[I2] : a.ds_b[I3])) + kC);
+      const uint32_t k_dpitch = 4u * (uint32_t)(kl == 0 ? a.ds_h[0] : (kl == 1 ? a.ds_h[I2] : a.ds_h[I3]));
+      const uint32_t k_o0 = kl == 0 ? a.doff[0][0] : (kl == 1 ? a.doff[I2][0] : a.doff[I3][0]);
+      const uint32_t k_o1 = kl == 0 ? a.doff[0][1] : (kl == 1 ? a.doff[I2][1] : a.doff[I3][1]);
+      const uint32_t k_o2 = kl == 0 ? a.doff[0][2] : (kl == 1 ? a.doff[I2][2] : a.doff[I3][2]);
+      unsigned char* const k_aptr = reinterpret_cast<unsigned char*>(a.approx + (int64_t)img * a.as_b + kC);
+      const uint32_t k_apitch = 4u * (uint32_t)a.as_h;
+      const uint32_t k_ring = k_lvl <= 1 ? (uint32_t)(ring1 - smem) + 4u * (uint32_t)(kPyrPad + sh1 + kC - cA[1])
+                                         : (uint32_t)(ring2 - smem) + 4u * (uint32_t)(kPyrPad + kC - cA[I2 + 1]);
+      const uint32_t k_rpitch = k_lvl <= 1 ? (uint32_t)a.pitch1 : (uint32_t)a.pitch2;
+      const uint32_t img2 = (uint32_t)(tailimg - smem) + (uint32_t)kl * (uint32_t)kPyrTailBytes + 8u * (uint32_t)k_c;
+      const uint32_t n_l1 = k_lvl == 1 ? ~0u : 0u, n_l2 = k_lvl == 2 ? ~0u : 0u, n_l3 = k_lvl == 3 ? ~0u : 0u;
+      const bool nostore = a.dbg & 1;
+      int bi = 0;
+      if (((a.exp >> 4) & 3) == 0) __builtin_amdgcn_s_setprio(2);  // (short dependent chains that every half step waits for)
+      if (((a.exp >> 4) & 3) == 1) __builtin_amdgcn_s_setprio(1);
+      if (((a.exp >> 4) & 3) == 3) __builtin_amdgcn_s_setprio(3);
+
+      // stage 1 then stage 2 of one half step; rb1 = LDS offset of the staged rows of the half step (level 1), v2 / v3 = ring offsets
+      // of the rows levels 2 / 3 consume in this step (published by the first level-2 / level-3 wave); act = which levels run
+      auto run_half = [&](int s, int half, bool act1, bool act2, bool act3, uint32_t rb1, const u4 v2, const u2 v3) {
+        // ---- stage 1 ------------------------------------------------------------------------------------------------------
+        const bool on1 = (j_lvl == 1 && act1) || (j_lvl == 2 && act2) || (j_lvl == 3 && act3);
+        if (on1) {
+          // (selections as mask arithmetic: a chain of conditionals over these became a switch over a scratch array)
+          const uint32_t rowb = (m_l1 & (rb1 + j_rp0)) | (m_l2 & (r1off + ((m_r0 & v2.x) | (m_r1 & v2.y) | (m_r2 & v2.z) | (m_r3 & v2.w)))) |
+                                (m_l3 & (r2off + ((m_r0 & v3.x) | (m_r1 & v3.y))));
+          const int seq = j_r + (int)((m_l1 & (uint32_t)(8 * s + 4 * half)) | (m_l2 & (uint32_t)(4 * (s - D2))) | (m_l3 & (uint32_t)(2 * (s - D3))));
+          float xs[L];
+#pragma unroll
+          for (int k = 0; k < L; ++k) xs[k] = *reinterpret_cast<const float*>(smem + rowb + soff[k]);
+          f2 h;
+#pragma unroll
+          for (int k = 0; k < HP; ++k) {
+            const f2 pr = (f2){xs[2 * k], xs[2 * k + 1]};
+            if (k == 0) h = vmul_lo(tap[L - 1], pr);
+            else vfma_lo(h, tap[L - 1 - 2 * k], pr);
+            vfma_hi(h, tap[L - 2 - 2 * k], pr);
+          }
+          const uint32_t slot = (uint32_t)seq & (kPyrRing - 1);
+          *reinterpret_cast<f2*>(smem + img1 + slot * (8u * kPyrTailCols)) = h;
+          *reinterpret_cast<f2*>(smem + img1 + (slot < 8u ? slot + kPyrRing : slot) * (8u * kPyrTailCols)) = h;
+        }
+        wave_lds_fence();
+        // ---- stage 2 ------------------------------------------------------------------------------------------------------
+        const int P = k_o + (int)((n_l1 & (uint32_t)(4 * s + 2 * half)) | (n_l2 & (uint32_t)(2 * (s - D2))) | (n_l3 & (uint32_t)(s - D3)));  // pair index of the output row
+        const bool on2 = ((k_lvl == 1 && act1) || (k_lvl == 2 && act2) || (k_lvl == 3 && act3)) && P >= HP - 1;
+        if (on2) {
+          const uint32_t b = (uint32_t)(2 * P + 2 - L) & (kPyrRing - 1);
+          const unsigned char* hp = smem + img2 + b * (8u * kPyrTailCols);
+          f2 hv[L];
+#pragma unroll
+          for (int n = 0; n < L; ++n) hv[n] = *reinterpret_cast<const f2*>(hp + n * (8 * kPyrTailCols));
+          f2 lo = vmul_lo(tap[L - 1], hv[0]), hi = vmul_hi(tap[L - 1], hv[0]);
+#pragma unroll
+          for (int n = 1; n < L; ++n) {
+            vfma_lo(lo, tap[L - 1 - n], hv[n]);
+            vfma_hi(hi, tap[L - 1 - n], hv[n]);
+          }
+          const int i = k_rA + P - (HP - 1);
+          if (!k_last && i < k_rB) *reinterpret_cast<float*>(smem + k_ring + ((uint32_t)P & (kPyrRing - 1)) * k_rpitch) = lo.x;
+          if (i >= k_oA && i < k_oB && !nostore) {
+            unsigned char* drow = k_dptr + (size_t)i * k_dpitch;
+            *reinterpret_cast<float*>(drow + k_o0) = hi.x;
+            *reinterpret_cast<float*>(drow + k_o1) = lo.y;
+            *reinterpret_cast<float*>(drow + k_o2) = hi.y;
+            if (k_last) *reinterpret_cast<float*>(k_aptr + (size_t)i * k_apitch) = lo.x;
+          }
+        }
+      };
+#pragma unroll 1
+      for (int s = 0; s < nsteps; ++s) {
+        const bool act1 = s < nsteps1;
+        const bool act2 = NLEV >= 2 && s >= D2 && 2 * (s - D2) < npair2 && !(a.dbg & 4);
+        const bool act3 = NLEV >= 3 && s >= D3 && s - D3 < npair3 && !(a.dbg & 4);
+        pyr_barrier<PROF>(waited);
+        uint32_t rb1 = (uint32_t)(stage - smem) + (uint32_t)bi * (uint32_t)(kPyrSub * a.pitch0);
+        if (act1) bi = bi + 1 == a.nbuf ? 0 : bi + 1;
+        run_half(s, 0, act1, false, false, rb1, (u4){0u, 0u, 0u, 0u}, (u2){0u, 0u});
+        pyr_barrier<PROF>(waited);
+        const u4 v2 = *reinterpret_cast<const u4*>(smem);
+        const u2 v3 = *reinterpret_cast<const u2*>(smem + 16);
+        rb1 = (uint32_t)(stage - smem) + (uint32_t)bi * (uint32_t)(kPyrSub * a.pitch0);
+        if (act1) bi = bi + 1 == a.nbuf ? 0 : bi + 1;
+        run_half(s, 1, act1, act2, act3, rb1, v2, v3);
+      }
+      }
+    }
     // the next unit's first requests land in staging buffers, its level-1 rows in ring slots, that this unit's last sub-step may
     // still be read from: everybody is through with it behind this barrier
     __syncthreads();
@@ -688,6 +919,8 @@ __global__ void __launch_bounds__(64 * kPyrWaves) dwt2_fwd_pyr_kernel(const PyrA
 // ---- host side ------------------------------------------------------------------------------------------------------------
 struct PyrPlan {
   int ngroups, cpg0, cpg, nchunks, nbuf, pitch0, pitch1, pitch2, nl1, nl2, nl3, lds;
+  int nt[3], tc0[3], twave;            // tail columns per level and the wave that runs them (PyrArgs)
+  int nwaves;                          // waves of a workgroup: 12 or 16 (pyr_role)
   int nwg;                             // row chunks = workgroups per column group
   uint32_t wg_start[kPyrMaxWG + 1];
 };
@@ -887,12 +1120,43 @@ static bool pyr_plan(int nlev, const mifwt_level_desc* const* d, PyrPlan* p) {
   p->nl2 = nlev >= 2 ? (n[2] + 127) / 128 : 0;
   p->nl3 = nlev >= 3 ? (n[3] + 63) / 64 : 0;
   if (p->nl1 > 6 || p->nl2 > 3 || p->nl3 > 3) return false;
+  // The last few columns of a level (one column group: 1024-column planes have 515 = 4 x 128 + 3, 261 = 2 x 128 + 5, 134 = 2 x 64 + 6)
+  // go to the TAIL wave instead of a nearly empty level wave: at most 4 / 6 / 6 columns (its lane grid holds 4 rows x 4 + 4 x 6 +
+  // 2 x 6 jobs).  MIFWT_OPT_DEBUG bit 19 keeps the level waves (A/B runs, parity of the two forms).
+  p->twave = -1;
+  for (int l = 0; l < 3; ++l) p->nt[l] = p->tc0[l] = 0;
+  if (p->ngroups == 1 && !(g_options[MIFWT_OPT_DEBUG] & 524288)) {
+    const int cap[3] = {64 * nc1, 128, 64}, ntmax[3] = {4, 6, 6};
+    int* nl[3] = {&p->nl1, &p->nl2, &p->nl3};
+    bool any = false;
+    for (int l = 0; l < nlev; ++l) {
+      const int cols = (int)d[l]->coef_extent[1], full = cols / cap[l], rem = cols - full * cap[l];
+      if (full >= 1 && rem >= 1 && rem <= ntmax[l]) {
+        p->nt[l] = rem;
+        p->tc0[l] = full * cap[l];
+        *nl[l] = full;
+        any = true;
+      }
+    }
+    // ... in the twelve-wave form only (pyr_role<12>: 168 registers a lane; the sixteen-wave form keeps its level waves)
+    const bool fits12 = p->nl1 <= 4 && p->nl2 <= 2 && p->nl3 <= 2 && !(g_options[MIFWT_OPT_DEBUG] & 1048576);
+    if (any && fits12) {
+      p->twave = 9;
+    } else if (any) {
+      for (int l = 0; l < 3; ++l) p->nt[l] = p->tc0[l] = 0;
+      p->nl1 = (n[1] + 64 * nc1 - 1) / (64 * nc1);
+      p->nl2 = nlev >= 2 ? (n[2] + 127) / 128 : 0;
+      p->nl3 = nlev >= 3 ? (n[3] + 63) / 64 : 0;
+    }
+  }
+  // twelve waves where they suffice
+  p->nwaves = (p->nl1 <= 4 && p->nl2 <= 2 && p->nl3 <= 2 && !(g_options[MIFWT_OPT_DEBUG] & 1048576)) ? 12 : 16;
   p->nchunks = (body + 255) / 256;
   if (p->nchunks < 1 || p->nchunks > kPyrMaxChunks) return false;
   p->pitch0 = (kPyrPad + 256 * p->nchunks + 8) * 4;
   p->pitch1 = nlev >= 2 ? ((kPyrPad + n[1] + HL + 8 + 3) & ~3) * 4 : 0;
   p->pitch2 = nlev >= 3 ? ((kPyrPad + n[2] + HL + 8 + 3) & ~3) * 4 : 0;
-  const int rings = (kPyrRing + 1) * (p->pitch1 + p->pitch2);
+  const int rings = (kPyrRing + 1) * (p->pitch1 + p->pitch2) + (p->twave >= 0 ? 3 * kPyrTailBytes : 0);
   // as many staging sub-buffers as fit (the loaders run nbuf - 1 sub-steps ahead; a wave holds at most 63 requests in flight)
   p->nbuf = g_options[MIFWT_OPT_PREFETCH_PAIRS] > 1 ? std::min(8, g_options[MIFWT_OPT_PREFETCH_PAIRS]) : 4;  // (3 .. 6 measured alike on config 2)
   const int lds_cap = 160 * 1024, per_loader = (p->nchunks + 1) / 2;
@@ -1006,6 +1270,8 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
   a.nl1 = p.nl1;
   a.nl2 = p.nl2;
   a.nl3 = p.nl3;
+  for (int l = 0; l < 3; ++l) a.nt[l] = p.nt[l], a.tc0[l] = p.tc0[l];
+  a.twave = p.twave;
   a.mode = d[0]->mode;
   a.dbg = g_options[MIFWT_OPT_DEBUG];
   // (timing experiments, results wrong: the nearly empty last wave of level 1 / 2 / 3 switched off)
@@ -1022,15 +1288,20 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
   const int64_t nwg = (int64_t)p.nwg * p.ngroups;
   // (the per-wave cycle profile of tools/pyr_prof.py exists for the three-level 8-tap kernel only)
   constexpr bool kCanProf = L == 8 && NLEV == 3;
-  static DynLdsOnce lds_once, lds_once_prof;
-  if (!lds_once.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, false>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
-  if (kCanProf && !lds_once_prof.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, kCanProf>), 160 * 1024))
-    return MIFWT_ERR_LAUNCH;
+  static DynLdsOnce lds_once12, lds_once16, lds_once_prof12, lds_once_prof16;
+  if (!lds_once12.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, false, 12>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
+  if (!lds_once16.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, false, 16>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
+  if (kCanProf && !lds_once_prof12.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, 12>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
+  if (kCanProf && !lds_once_prof16.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, 16>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
   count_launch(MIFWT_VARIANT_FWD_PYR_ST8);
-  if (kCanProf && a.prof)
-    hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, kCanProf>), dim3((unsigned)nwg), dim3(64 * kPyrWaves), p.lds, stream, a);
-  else
-    hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, false>), dim3((unsigned)nwg), dim3(64 * kPyrWaves), p.lds, stream, a);
+  const dim3 grid((unsigned)nwg), block(64 * p.nwaves);
+  if (p.nwaves == 12) {
+    if (kCanProf && a.prof) hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, 12>), grid, block, p.lds, stream, a);
+    else hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, false, 12>), grid, block, p.lds, stream, a);
+  } else {
+    if (kCanProf && a.prof) hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, 16>), grid, block, p.lds, stream, a);
+    else hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, false, 16>), grid, block, p.lds, stream, a);
+  }
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 

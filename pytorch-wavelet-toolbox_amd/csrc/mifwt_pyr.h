@@ -9,7 +9,7 @@ namespace mifwt {
 
 extern unsigned long long* g_pyr_prof;
 
-enum PyrRole { kRoleL1 = 0, kRoleL2 = 1, kRoleL3 = 2, kRoleLoad = 3, kRoleXchg = 4 };  // what a wave of a workgroup does
+enum PyrRole { kRoleL1 = 0, kRoleL2 = 1, kRoleL3 = 2, kRoleLoad = 3, kRoleTail = 4 };  // what a wave of a workgroup does
 
 constexpr uint32_t kPyrOob = 0x80000000u;  // byte offset beyond every buffer resource: loads return 0, stores are dropped
 

@@ -259,6 +259,30 @@ def test_pyramid_persistent_units_any_cut(wavelet):
                     assert torch.equal(a, b), (shape, wavelet, mode, wgs, n)
 
 
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4"])
+def test_pyramid_tail_wave_and_twelve_wave_form_are_bit_identical_to_the_level_waves(wavelet):
+    """Round 5: the last few columns of a level (1024-column planes: 515 = 4 x 128 + 3, 261 = 2 x 128 + 5, 134 = 2 x 64 + 6) go to a
+    TAIL wave that filters them in direct form, one lane per (row, column), and workgroups that get by with 4 + 2 + 2 level waves have
+    twelve waves.  Same products in the same order: bit-identical to the sixteen-wave form with a level wave for the tail
+    (MIFWT_OPT_DEBUG bits 19 / 20), for widths whose tails have every size 1 .. 6 at some level, every mode, 1-3 levels."""
+    g = torch.Generator().manual_seed(51)
+    for shape, level in (((3, 200, 1024), 3), ((2, 264, 1018), 3), ((2, 136, 1000), 3), ((2, 200, 520), 3), ((2, 300, 1030), 2), ((3, 130, 1032), 1),
+                         ((2, 140, 514), 3), ((1, 1024, 1024), 3), ((2, 150, 1010), 3)):
+        x = torch.randn(*shape, generator=g).to(dev())
+        for mode in MODES:
+            got = ptwt_amd.wavedec2(x, wavelet, mode=mode, level=level)
+            for dbg in (524288, 1048576):
+                _engine.set_option(_engine.OPT_DEBUG, dbg)
+                try:
+                    ref = ptwt_amd.wavedec2(x, wavelet, mode=mode, level=level)
+                finally:
+                    _engine.set_option(_engine.OPT_DEBUG, 0)
+                for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(ref)):
+                    assert torch.equal(a, b), (shape, wavelet, mode, level, dbg, n)
+    check(torch.randn(2, 200, 1024, generator=g), wavelet, "symmetric", 3, [_engine.KID_PYRAMID])
+    check(torch.randn(2, 136, 1000, generator=g), wavelet, "zero", 3, [_engine.KID_PYRAMID], seg_rows=8)
+
+
 def test_pyramid_batches_that_do_not_divide_the_chip():
     """Batches around multiples of the CU count / 4 (65, 100 images of 1024^2 took 1.7 / 1.4 x the time per image of 64 until round 4:
     a last round of a few workgroups): chunks that start and end inside images, checked image by image against one-image calls

@@ -56,7 +56,12 @@ for k in range(nl):
         hw = b[used, 12, 0]
         print('   WGs per XCC:', [int((xcc == i).sum()) for i in range(8)], ' distinct (xcc, se, sh, cu):', len(set(zip(xcc.tolist(), ((hw >> 13) & 7).tolist(), ((hw >> 12) & 1).tolist(), ((hw >> 8) & 15).tolist()))))
         roles = {0: 'L1.1', 1: 'L1.0(left edge)', 2: 'L1.3', 3: 'L1.4(right edge, 2 lanes)', 4: 'L1.2', 5: 'L2.0', 6: 'L2.1', 7: 'L2.2', 9: 'L3.0', 10: 'L3.1', 11: 'L3.2'}
+        if b[used][:, 12, 0].sum() == 0 and b[used][:, 9, 0].sum() > 0 and b[used][:, 10, 0].sum() == 0:  # the twelve-wave form
+            roles = {0: 'L1.0', 1: 'L1.1', 2: 'L1.2', 3: 'L1.3', 4: 'L2.0', 5: 'L2.1', 6: 'L3.0', 7: 'L3.1', 9: 'tail'}
         bb = b[used].double()
         print('   share of a wave\'s cycles spent in barriers: ' + '  '.join(f'{n}: {100 * bb[:, w, 1].sum() / bb[:, w, 0].sum():.0f}%' for w, n in roles.items()))
+        sec = bb[:, 14:16, :].reshape(-1, 4)
+        l2w = 4 if bb[:, 12, 0].sum() == 0 else 5
+        print(f'   first level-2 wave (wave {l2w}): total {bb[:, l2w, 0].mean():.0f} cycles, in barriers {bb[:, l2w, 1].mean():.0f}; window loads {sec[:, 0].mean():.0f}, arithmetic {sec[:, 1].mean():.0f}, ring write + stores {sec[:, 2].mean():.0f}, pad fill {sec[:, 3].mean():.0f}')
         cyc = b[used][:, :5, 0].double()
         print(f'   level-1 wave cycles per WG mean {cyc.mean():.0f} -> {cyc.mean() / (en - st).mean():.0f} cycles per us')
