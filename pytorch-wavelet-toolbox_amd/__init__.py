@@ -18,6 +18,7 @@ from .constants import (
     WaveletDetailTuple2d,
     WaveletTensorTuple,
     set_half_storage,
+    half_storage,
 )
 from .conv_transform import wavedec, waverec
 from .conv_transform_2 import wavedec2, waverec2
@@ -48,6 +49,7 @@ __all__ = [
     "fswaverec2",
     "fswaverec3",
     "set_half_storage",
+    "half_storage",
     "WaveletPacket",
     "swt",
     "iswt",

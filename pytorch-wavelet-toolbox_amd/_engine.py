@@ -10,6 +10,7 @@ import ctypes
 import itertools
 import os
 import threading
+import warnings
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -142,8 +143,13 @@ def load_library() -> ctypes.CDLL:
         lib.mifwt_launch_count.argtypes = [ctypes.c_int]
     lib.mifwt_set_option.restype = ctypes.c_int
     lib.mifwt_set_option.argtypes = [ctypes.c_int, ctypes.c_int]
-    if lib.mifwt_abi_version() != ABI_VERSION and not experiment:
-        raise RuntimeError("ptwt_amd: libmifwt.so ABI version mismatch; rebuild the extension")
+    if lib.mifwt_abi_version() != ABI_VERSION:
+        # (an experiment build loaded through MIFWT_LIB is held to the same check: its mifwt_level_desc / entry-point signatures must be
+        # the ones declared above, or a call corrupts memory instead of failing; MIFWT_ALLOW_ABI_MISMATCH=1 is the explicit way around)
+        if os.environ.get("MIFWT_ALLOW_ABI_MISMATCH") != "1":
+            raise RuntimeError(f"ptwt_amd: {os.path.basename(LIB_PATH)} has ABI version {lib.mifwt_abi_version()}, this package expects "
+                               f"{ABI_VERSION}; rebuild the extension (MIFWT_ALLOW_ABI_MISMATCH=1 loads it anyway, at your own risk)")
+        warnings.warn("ptwt_amd: ABI version mismatch accepted through MIFWT_ALLOW_ABI_MISMATCH=1")
     _lib = lib
     return lib
 

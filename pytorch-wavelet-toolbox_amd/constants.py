@@ -3,6 +3,8 @@ src/ptwt/constants.py:27-253) so annotations and ``isinstance`` checks written a
 """
 from __future__ import annotations
 
+import contextlib
+import contextvars
 from typing import Dict, Literal, NamedTuple, Protocol, Sequence, Tuple, Union
 
 import torch
@@ -11,6 +13,7 @@ __all__ = [
     "BoundaryMode",
     "SUPPORTED_DTYPES",
     "set_half_storage",
+    "half_storage",
     "Wavelet",
     "WaveletCoeff1d",
     "WaveletCoeff2d",
@@ -25,19 +28,35 @@ __all__ = [
 SUPPORTED_DTYPES = {torch.float32, torch.float64}
 
 #: Engine extension (NOT in the reference, which raises ``ValueError`` for it): float16 STORAGE with float32
-#: arithmetic (C ABI ``MIFWT_F16``).  Off by default so that error behaviour matches the reference; switch it on
-#: with :func:`set_half_storage` (BASELINE.json configs[4] is an fp16 workload).
-_half_storage = False
+#: arithmetic (C ABI ``MIFWT_F16``).  Off by default so that error behaviour matches the reference.  Switched on for a
+#: scope with :func:`half_storage` (a context manager over a ``contextvars`` variable: local to the thread / task, so
+#: one caller's fp16 workload does not change what another thread's call accepts); :func:`set_half_storage` sets the
+#: process-wide DEFAULT the scoped value falls back to (BASELINE.json configs[4] is an fp16 workload).
+_half_storage_default = False
+_half_storage_scoped: "contextvars.ContextVar[object]" = contextvars.ContextVar("ptwt_amd_half_storage", default=None)
 
 
 def set_half_storage(enabled: bool) -> None:
-    """Accept ``torch.float16`` inputs (coefficients are returned in float16, accumulated in float32)."""
-    global _half_storage
-    _half_storage = bool(enabled)
+    """Process-wide default: accept ``torch.float16`` inputs (coefficients are returned in float16, accumulated in
+    float32).  Prefer ``with ptwt_amd.half_storage(): ...`` — scoped, thread-local."""
+    global _half_storage_default
+    _half_storage_default = bool(enabled)
+
+
+@contextlib.contextmanager
+def half_storage(enabled: bool = True):
+    """``with half_storage():`` — calls in this scope (this thread / task only) accept ``torch.float16`` tensors."""
+    token = _half_storage_scoped.set(bool(enabled))
+    try:
+        yield
+    finally:
+        _half_storage_scoped.reset(token)
 
 
 def supported_dtypes():
-    return SUPPORTED_DTYPES | {torch.float16} if _half_storage else SUPPORTED_DTYPES
+    scoped = _half_storage_scoped.get()
+    on = _half_storage_default if scoped is None else scoped
+    return SUPPORTED_DTYPES | {torch.float16} if on else SUPPORTED_DTYPES
 
 #: boundary rules (src/ptwt/constants.py:85): zero | constant (edge replicate) | reflect (whole-sample
 #: mirror) | periodic | symmetric (half-sample mirror)

@@ -570,3 +570,34 @@ def test_every_kernel_id_is_documented_in_the_header():
     documented = {int(v) for head in re.findall(r"^ \*\s{3}((?:\d+ / )?\d+)\s+\S", block, flags=re.M) for v in head.split(" / ")}
     documented.add(0)
     assert set(ids) <= documented, sorted(set(ids) - documented)
+
+
+def test_half_storage_is_scoped_and_thread_local():
+    """fp16 storage is an engine extension the reference refuses (src/ptwt/constants.py:27): `with ptwt_amd.half_storage():` switches it
+    on for the calls of this thread / task only; `set_half_storage` is the process-wide default it falls back to."""
+    import threading
+
+    import torch
+
+    import ptwt_amd
+    from ptwt_amd import constants as C
+
+    assert torch.float16 not in C.supported_dtypes()
+    seen = {}
+    with ptwt_amd.half_storage():
+        assert torch.float16 in C.supported_dtypes()
+        t = threading.Thread(target=lambda: seen.setdefault("other", torch.float16 in C.supported_dtypes()))
+        t.start()
+        t.join()
+        with ptwt_amd.half_storage(False):
+            assert torch.float16 not in C.supported_dtypes()
+        assert torch.float16 in C.supported_dtypes()
+    assert seen["other"] is False
+    assert torch.float16 not in C.supported_dtypes()
+    ptwt_amd.set_half_storage(True)
+    try:
+        assert torch.float16 in C.supported_dtypes()
+        with ptwt_amd.half_storage(False):
+            assert torch.float16 not in C.supported_dtypes()
+    finally:
+        ptwt_amd.set_half_storage(False)
