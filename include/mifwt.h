@@ -103,6 +103,24 @@ int mifwt_dwt_inv(const mifwt_level_desc* desc, const void* approx, const void* 
                   const double* rec_lo, const double* rec_hi, void* workspace, size_t workspace_bytes,
                   void* stream);
 
+/* DEVICE-RESIDENT TAPS (round 5).  The entry points above take the filter as HOST doubles (the kernels receive it in their launch
+ * arguments); a learnable filter bank that lives on the GPU (the reference keeps its taps as tensors with autograd,
+ * src/ptwt/_util.py:115-132; examples/network_compression/wavelet_linear.py:118,150) would have to be copied to the host — a stream
+ * synchronisation — on every call.  These four take DEVICE pointers to L doubles each; the kernels read the taps themselves: no copy,
+ * no synchronisation, capturable into a HIP graph.  They run the generic per-axis passes (kernel id 0: every dtype, mode, stride set
+ * and filter length) — slower per byte than the fused kernels, which is the price of not knowing the taps on the host.
+ * Same results as the host-tap entry points routed through the generic passes (MIFWT_OPT_FORCE_GENERIC), bit for bit.
+ * Workspace: mifwt_workspace_bytes_dtaps(desc, direction), direction as for mifwt_workspace_bytes (0 .. 3). */
+size_t mifwt_workspace_bytes_dtaps(const mifwt_level_desc* desc, int direction);
+int mifwt_dwt_fwd_dtaps(const mifwt_level_desc* desc, const void* x, void* approx, void* const* details, const double* d_dec_lo,
+                        const double* d_dec_hi, void* workspace, size_t workspace_bytes, void* stream);
+int mifwt_dwt_inv_dtaps(const mifwt_level_desc* desc, const void* approx, const void* const* details, void* y, const double* d_rec_lo,
+                        const double* d_rec_hi, void* workspace, size_t workspace_bytes, void* stream);
+int mifwt_dwt_fwd_adjoint_dtaps(const mifwt_level_desc* desc, const void* g_approx, const void* const* g_details, void* g_x,
+                                const double* d_dec_lo, const double* d_dec_hi, void* workspace, size_t workspace_bytes, void* stream);
+int mifwt_dwt_inv_adjoint_dtaps(const mifwt_level_desc* desc, const void* g_y, void* g_approx, void* const* g_details,
+                                const double* d_rec_lo, const double* d_rec_hi, void* workspace, size_t workspace_bytes, void* stream);
+
 /* TWO consecutive 2-D analysis levels in one launch — two trips of the reference's level loop
  * (src/ptwt/conv_transform_2.py:142-149) whose intermediate approximation never reaches HBM: a pyramid returns only the
  * detail bands of a level that is not the last (conv_transform_2.py:150-156), so the write + re-read of that

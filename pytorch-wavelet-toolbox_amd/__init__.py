@@ -27,6 +27,7 @@ from .packets import WaveletPacket, WaveletPacket2D
 from .stationary_transform import iswt, swt
 from .separable_conv_transform import fswavedec2, fswavedec3, fswaverec2, fswaverec3
 from .graphs import CapturedCall, capture
+from ._wavelets import set_device_taps
 
 __version__ = "0.1.0"
 
@@ -50,6 +51,7 @@ __all__ = [
     "fswaverec3",
     "set_half_storage",
     "half_storage",
+    "set_device_taps",
     "WaveletPacket",
     "swt",
     "iswt",

@@ -137,6 +137,14 @@ def load_library() -> ctypes.CDLL:
     lib.mifwt_dwt1_inv_tail.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, vp, ctypes.c_int64,
                                         ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32), vp,
                                         ctypes.c_int64, dbl_p, dbl_p, vp]
+    lib.mifwt_workspace_bytes_dtaps.restype = ctypes.c_size_t
+    lib.mifwt_workspace_bytes_dtaps.argtypes = [desc_p, ctypes.c_int]
+    for name in ("mifwt_dwt_fwd_dtaps", "mifwt_dwt_inv_dtaps", "mifwt_dwt_fwd_adjoint_dtaps", "mifwt_dwt_inv_adjoint_dtaps"):
+        getattr(lib, name).restype = ctypes.c_int
+    lib.mifwt_dwt_fwd_dtaps.argtypes = [desc_p, vp, vp, vpp, vp, vp, vp, ctypes.c_size_t, vp]
+    lib.mifwt_dwt_inv_dtaps.argtypes = [desc_p, vp, vpp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    lib.mifwt_dwt_fwd_adjoint_dtaps.argtypes = [desc_p, vp, vpp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    lib.mifwt_dwt_inv_adjoint_dtaps.argtypes = [desc_p, vp, vp, vpp, vp, vp, vp, ctypes.c_size_t, vp]
     experiment = "MIFWT_LIB" in os.environ  # (tools/: an older build for a same-run comparison may lack the newest entry points)
     if not experiment or hasattr(lib, "mifwt_launch_count"):
         lib.mifwt_launch_count.restype = ctypes.c_uint64
@@ -246,6 +254,31 @@ _call_ids = itertools.count((int.from_bytes(os.urandom(7), "little") << 8) | 1) 
 _taps_cache: dict = {}
 
 
+class DevTaps:
+    """A filter of a bank that LIVES ON THE GPU (a learnable wavelet's parameter): float64, contiguous, L values.  Level methods that
+    receive their taps as ``DevTaps`` call the ``mifwt_*_dtaps`` entry points — the kernels read the filter from device memory, nothing
+    is copied to the host, nothing synchronises, the call can be captured into a HIP graph (include/mifwt.h)."""
+
+    __slots__ = ("t",)
+
+    def __init__(self, t: torch.Tensor):
+        t = t.detach().reshape(-1)
+        if t.dtype != torch.float64 or not t.is_contiguous():
+            t = t.to(torch.float64).contiguous()  # (device-side cast, asynchronous)
+        self.t = t
+
+    def __len__(self) -> int:
+        return int(self.t.shape[0])
+
+    @property
+    def ptr(self) -> int:
+        return self.t.data_ptr()
+
+
+def _is_dev(taps) -> bool:
+    return isinstance(taps, DevTaps)
+
+
 def _taps_array(taps: Sequence[float]):
     key = tuple(taps)
     arr = _taps_cache.get(key)
@@ -346,9 +379,13 @@ class HipLevelEngine:
             return buf
         base = buf.data_ptr()
         ptrs = _band_ptrs(base, p.plane_bytes, p.nb - 1)
-        lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
         lib = _lib
         xp = x.data_ptr()
+        if _is_dev(dec_lo):
+            dl, dh = dec_lo.ptr, dec_hi.ptr
+            self._run(p, 0, x, lambda ws, wsb, stream: lib.mifwt_dwt_fwd_dtaps(p.ref, xp, base, ptrs, dl, dh, ws, wsb, stream), kid=0, dtaps=True)
+            return buf
+        lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
         self._run(p, 0, x, lambda ws, wsb, stream: lib.mifwt_dwt_fwd(p.ref, xp, base, ptrs, lo, hi, ws, wsb, stream))
         return buf
 
@@ -585,8 +622,12 @@ class HipLevelEngine:
             p.kid = lib.mifwt_kernel_id(p.ref, 1)
             _plans[key] = p
         ptrs = _arr(ctypes.c_void_p, len(details))(*[t.data_ptr() for t in details])
-        lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
         ap, yp = approx.data_ptr(), y.data_ptr()
+        if _is_dev(rec_lo):
+            dl, dh = rec_lo.ptr, rec_hi.ptr
+            self._run(p, 1, approx, lambda ws, wsb, stream: lib.mifwt_dwt_inv_dtaps(p.ref, ap, ptrs, yp, dl, dh, ws, wsb, stream), kid=0, dtaps=True)
+            return y
+        lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
         self._run(p, 1, approx, lambda ws, wsb, stream: lib.mifwt_dwt_inv(p.ref, ap, ptrs, yp, lo, hi, ws, wsb, stream))
         return y
 
@@ -853,8 +894,12 @@ class HipLevelEngine:
             _plans[key] = p
         base = g_buf.data_ptr()
         ptrs = _band_ptrs(base, p.plane_bytes, p.nb - 1)
-        lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
         gp = g_x.data_ptr()
+        if _is_dev(dec_lo):
+            dl, dh = dec_lo.ptr, dec_hi.ptr
+            self._run(p, 2, g_buf, lambda ws, wsb, stream: lib.mifwt_dwt_fwd_adjoint_dtaps(p.ref, base, ptrs, gp, dl, dh, ws, wsb, stream), kid=0, dtaps=True)
+            return g_x
+        lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
         self._run(p, 2, g_buf, lambda ws, wsb, stream: lib.mifwt_dwt_fwd_adjoint(p.ref, base, ptrs, gp, lo, hi, ws, wsb, stream))
         return g_x
 
@@ -898,8 +943,12 @@ class HipLevelEngine:
             p.kid = lib.mifwt_kernel_id(p.ref, 2)
             _plans[key] = p
         ptrs = _arr(ctypes.c_void_p, p.nb - 1)(*[t.data_ptr() for t in g_details])
-        lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
         ap, gp = g_approx.data_ptr(), g_x.data_ptr()
+        if _is_dev(dec_lo):
+            dl, dh = dec_lo.ptr, dec_hi.ptr
+            self._run(p, 2, g_approx, lambda ws, wsb, stream: lib.mifwt_dwt_fwd_adjoint_dtaps(p.ref, ap, ptrs, gp, dl, dh, ws, wsb, stream), kid=0, dtaps=True)
+            return g_x
+        lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
         self._run(p, 2, g_approx, lambda ws, wsb, stream: lib.mifwt_dwt_fwd_adjoint(p.ref, ap, ptrs, gp, lo, hi, ws, wsb, stream))
         return g_x
 
@@ -939,8 +988,12 @@ class HipLevelEngine:
             _plans[key] = p
         base = g_buf.data_ptr()
         ptrs = _band_ptrs(base, p.plane_bytes, nb - 1)
-        lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
         yp = g_y.data_ptr()
+        if _is_dev(rec_lo):
+            dl, dh = rec_lo.ptr, rec_hi.ptr
+            self._run(p, 3, g_y, lambda ws, wsb, stream: lib.mifwt_dwt_inv_adjoint_dtaps(p.ref, yp, base, ptrs, dl, dh, ws, wsb, stream), kid=0, dtaps=True)
+            return g_buf
+        lo, hi = _taps_array(rec_lo), _taps_array(rec_hi)
         self._run(p, 3, g_y, lambda ws, wsb, stream: lib.mifwt_dwt_inv_adjoint(p.ref, yp, base, ptrs, lo, hi, ws, wsb, stream))
         return g_buf
 
@@ -978,12 +1031,13 @@ class HipLevelEngine:
         _check(rc)
 
     @staticmethod
-    def _run(p: _Plan, direction: int, anchor: torch.Tensor, call, kid: Optional[int] = None) -> None:
+    def _run(p: _Plan, direction: int, anchor: torch.Tensor, call, kid: Optional[int] = None, dtaps: bool = False) -> None:
         dev = anchor.device
         if dev.index is not None and dev.index != torch.cuda.current_device():
             with torch.cuda.device(dev):
-                return HipLevelEngine._run(p, direction, anchor, call, kid)
-        wsb = p.ws_bytes
+                return HipLevelEngine._run(p, direction, anchor, call, kid, dtaps)
+        # (device-resident taps run the generic passes, whose scratch differs from the plan's route)
+        wsb = int(_lib.mifwt_workspace_bytes_dtaps(p.ref, direction)) if dtaps else p.ws_bytes
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
         if level_events is None:
             rc = call(ws.data_ptr() if ws is not None else None, wsb, _raw_stream(dev.index if dev.index is not None else torch.cuda.current_device()))

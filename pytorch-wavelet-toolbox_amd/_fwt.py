@@ -14,7 +14,8 @@ from typing import Dict, List, Optional, Sequence, Tuple, Union
 import torch
 
 from . import _engine
-from ._wavelets import dwtn_max_level, filter_length, host_taps
+from . import _wavelets
+from ._wavelets import device_bank, dwtn_max_level, filter_length, host_taps
 from .constants import WaveletDetailTuple2d, supported_dtypes
 
 AxisHint = Union[int, Sequence[int], None]
@@ -106,7 +107,16 @@ def _synthesis_tap_grads(g_y, approx, details, rec_lo, rec_hi):
 # keeps the taps in the graph).  The fused level kernels serve the forward and the first-order backward as before; only a backward
 # that is asked for a graph (create_graph=True) with a learnable filter bank re-runs the level through these ops.  Taps travel to the
 # kernels as host floats (one device-to-host copy per op).
-def _host_taps_of(t: torch.Tensor) -> List[float]:
+def _host_floats_of(t: torch.Tensor) -> List[float]:
+    """Host copy of a filter tensor (the stationary-transform kernels take their taps in the launch arguments)."""
+    return [float(v) for v in t.detach().double().cpu().reshape(-1).tolist()]
+
+
+def _host_taps_of(t: torch.Tensor):
+    """The taps of a filter tensor for a level call: the tensor itself (kernels read device memory) when it lives on the GPU and device
+    taps are not switched off, else host floats (one device-to-host copy)."""
+    if t.is_cuda and _wavelets._device_taps_mode != "never":
+        return _engine.DevTaps(t)
     return [float(v) for v in t.detach().double().cpu().reshape(-1).tolist()]
 
 
@@ -717,7 +727,12 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
     axes = _ensure_axes(axes, ndim)
     layout = _Layout(data, ndim, axes)
     x = layout.fold(data)
-    dec_lo, dec_hi, _, _ = host_taps(wavelet)
+    dbank = device_bank(wavelet, x.device) if x.is_cuda else None
+    if dbank is not None:  # the taps stay on the GPU: per-level generic route, nothing read back (include/mifwt.h, mifwt_*_dtaps)
+        dec_lo, dec_hi = _engine.DevTaps(dbank[0]), _engine.DevTaps(dbank[1])
+    else:
+        dec_lo, dec_hi, _, _ = host_taps(wavelet)
+    on_device = dbank is not None
     tap_t = _tap_tensors(wavelet)
     flen = len(dec_lo)
     if level is None:
@@ -729,7 +744,7 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
         mode_id = _mode_id(mode)
         _check_pad(cur.shape[1:], flen, "reflect" if mode is None else mode)
         differentiable = torch.is_grad_enabled() and (cur.requires_grad or tap_t is not None)
-        if ndim == 2 and (not differentiable or tap_t is None):
+        if ndim == 2 and not on_device and (not differentiable or tap_t is None):
             # several levels per launch (three of a big plane, the whole pyramid of a small one), the approximations between them kept
             # on chip (mifwt_dwt2_fwd_pyramid); the pad
             # checks of the fused trips are the reference's own and run before anything is launched
@@ -755,7 +770,7 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
                     cur = pyr[-1][:, 0]
                     done += len(pyr)
                     continue
-        if ndim == 2 and level - done >= 2 and not differentiable:
+        if ndim == 2 and level - done >= 2 and not differentiable and not on_device:
             # two levels per launch, the approximation between them kept on chip (mifwt_dwt2_fwd_pair); the second
             # level's reflect / periodic pad check is the reference's own (it would raise inside the next trip)
             n1 = [(n + flen - 1) // 2 for n in cur.shape[1:]]
@@ -766,7 +781,7 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
                 cur = pair[1][:, 0]
                 done += 2
                 continue
-        if ndim == 1 and level - done >= 2 and (not differentiable or tap_t is None):
+        if ndim == 1 and level - done >= 2 and not on_device and (not differentiable or tap_t is None):
             # the deep levels of a 1-D pyramid in one launch (mifwt_dwt1_fwd_tail) once a row fits into LDS, several levels of
             # longer rows per launch before that (mifwt_dwt1_fwd_long); the pad checks of the fused trips are the reference's
             # own and run before anything is launched
@@ -841,7 +856,12 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
         if not isinstance(t, torch.Tensor):
             raise ValueError(f"Unexpected input type {type(t)}")
     _check_same_device_dtype(flat)
-    _, _, rec_lo, rec_hi = host_taps(wavelet)
+    dbank = device_bank(wavelet, approx.device) if approx.is_cuda else None
+    if dbank is not None:  # (see analysis)
+        rec_lo, rec_hi = _engine.DevTaps(dbank[2]), _engine.DevTaps(dbank[3])
+    else:
+        _, _, rec_lo, rec_hi = host_taps(wavelet)
+    on_device = dbank is not None
     tap_t = _tap_tensors(wavelet)
     flen = len(rec_lo)
     cur = layout.fold(approx)
@@ -870,7 +890,7 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
         return out_ext
 
     pos = 0
-    if ndim == 1 and not separable and len(folded) >= 2:
+    if ndim == 1 and not separable and len(folded) >= 2 and not on_device:
         # the coarse levels of a 1-D reconstruction in one launch (mifwt_dwt1_inv_tail) while a level's output still fits into
         # LDS; every fused trip passes the reference's own checks first
         differentiable = torch.is_grad_enabled() and (tap_t is not None or any(t.requires_grad for t in flat))
@@ -925,7 +945,7 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
     # reference's trims: the adjoint of a level sees a gradient of the cropped extents and treats the rest as zeros — same backward)
     fused_grad = any_grad and tap_t is None
     gkey = None
-    if ndim == 2 and folded and (not any_grad or fused_grad):
+    if ndim == 2 and folded and not on_device and (not any_grad or fused_grad):
         # geometry of the call (every band's shape: the reference's shape checks are part of what is remembered)
         gkey = (cur.dtype, cur.shape, cur.stride(), tuple((lv[0].stride(), *[t.shape for t in lv]) for lv in folded), flen, separable)
     # (the finest level's four coefficient planes alone must fit into LDS: 10 240 samples each at most)
@@ -1009,7 +1029,7 @@ def synthesis(approx: torch.Tensor, levels: List[List[torch.Tensor]], wavelet, a
         differentiable = torch.is_grad_enabled() and (cur.requires_grad or any(t.requires_grad for t in det) or tap_t is not None)
         # levels go in pairs counted from the FINEST one of those left to this loop (that is where the bytes are): an odd count
         # starts with a single level
-        if (ndim == 2 and not differentiable and (len(folded) - tail - pos) % 2 == 0 and len(folded) - tail - pos >= 2
+        if (ndim == 2 and not differentiable and not on_device and (len(folded) - tail - pos) % 2 == 0 and len(folded) - tail - pos >= 2
                 and not (torch.is_grad_enabled() and any(t.requires_grad for t in folded[pos + 1]))):
             # two levels per launch, the approximation between them kept on chip (mifwt_dwt2_inv_pair); the checks of the
             # second trip are the reference's own and run before anything is launched.  Separable containers: the crop of the

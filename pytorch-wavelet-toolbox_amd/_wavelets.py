@@ -111,6 +111,43 @@ def host_taps(wavelet) -> Tuple[Tuple[float, ...], Tuple[float, ...], Tuple[floa
     return taps  # type: ignore[return-value]
 
 
+# ---- device-resident taps -------------------------------------------------------------------------------------------------------
+# A filter bank given as four tensors on the GPU (a learnable wavelet, src/ptwt/_util.py:115-132) can stay there: the level kernels
+# of the generic route read their taps from device memory (C ABI mifwt_*_dtaps), so a call copies nothing to the host, synchronises
+# nothing and can be captured into a HIP graph.  The price: those levels run the generic per-axis passes, not the fused kernels.
+#   "auto"   (default) device taps for banks that are learnable (a tensor requires grad, grad mode on) or while a HIP graph is being
+#            captured; anything else is read to the host once per call (fused kernels);
+#   "always" every tensor-valued bank on the GPU stays there;   "never" round 4's behaviour.
+_device_taps_mode = "auto"
+
+
+def set_device_taps(mode: str) -> None:
+    """"auto" | "always" | "never": when a tensor-valued filter bank on the GPU is handed to the kernels as device memory."""
+    global _device_taps_mode
+    if mode not in ("auto", "always", "never"):
+        raise ValueError("mode must be 'auto', 'always' or 'never'")
+    _device_taps_mode = mode
+
+
+def device_bank(wavelet, device):
+    """The four filters as tensors if this call keeps its taps on the GPU (see above), else None."""
+    if _device_taps_mode == "never" or isinstance(wavelet, str):
+        return None
+    import torch
+
+    bank = wavelet if isinstance(wavelet, tuple) else getattr(wavelet, "filter_bank", ())
+    if len(bank) != 4 or not all(isinstance(t, torch.Tensor) and t.is_cuda and t.device == device for t in bank):
+        return None
+    if not (bank[0].numel() == bank[1].numel() and bank[2].numel() == bank[3].numel()):
+        raise ValueError("low- and high-pass filters must have the same length")
+    if _device_taps_mode == "always":
+        return tuple(bank)
+    learnable = torch.is_grad_enabled() and any(t.requires_grad for t in bank)
+    if learnable or torch.cuda.is_current_stream_capturing():
+        return tuple(bank)
+    return None
+
+
 def filter_length(wavelet) -> int:
     """Number of taps for any accepted wavelet form (src/ptwt/_util.py:87-92)."""
     if isinstance(wavelet, tuple):

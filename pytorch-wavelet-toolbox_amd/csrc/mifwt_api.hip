@@ -470,6 +470,85 @@ int mifwt_dwt_inv_adjoint(const mifwt_level_desc* desc, const void* g_y, void* g
   return run_fwd(&z, g_y, g_approx, g_details, lo, hi, workspace, workspace_bytes, stream);
 }
 
+// ---- device-resident taps (include/mifwt.h): the four level operations on the generic axis passes, the filter read from device
+// memory by the kernels.  Nothing here touches the taps on the host.
+namespace {
+struct DtapsScope {
+  DtapsScope(const double* lo, const double* hi, int rev) { mifwt::g_dtaps = {lo, hi, rev}; }
+  ~DtapsScope() { mifwt::g_dtaps = {nullptr, nullptr, 0}; }
+};
+const double kNoHostTaps[MIFWT_MAX_FILT] = {0};
+}  // namespace
+
+size_t mifwt_workspace_bytes_dtaps(const mifwt_level_desc* desc, int direction) {
+  if (direction == 3) {
+    const mifwt_level_desc z = as_zero_mode(desc);
+    return validate(&z, 0) == MIFWT_OK ? generic_ws(&z, 0) : 0;
+  }
+  if (validate(desc, direction == 1 ? 1 : 0) != MIFWT_OK) return 0;
+  return generic_ws(desc, direction == 0 ? 0 : 1);
+}
+
+int mifwt_dwt_fwd_dtaps(const mifwt_level_desc* desc, const void* x, void* approx, void* const* details, const double* d_dec_lo,
+                        const double* d_dec_hi, void* workspace, size_t workspace_bytes, void* stream) {
+  const int rc = validate(desc, 0);
+  if (rc != MIFWT_OK) return rc;
+  if (!x || !approx || !details || !d_dec_lo || !d_dec_hi) return MIFWT_ERR_BADARG;
+  for (int s = 1; s < (1 << desc->ndim); ++s)
+    if (!details[s - 1]) return MIFWT_ERR_BADARG;
+  if (desc->batch == 0) return MIFWT_OK;
+  const size_t need = generic_ws(desc, 0);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return MIFWT_ERR_WORKSPACE;
+  DtapsScope scope(d_dec_lo, d_dec_hi, 0);
+  return generic_fwd(desc, x, approx, details, kNoHostTaps, kNoHostTaps, workspace, static_cast<hipStream_t>(stream));
+}
+
+int mifwt_dwt_inv_dtaps(const mifwt_level_desc* desc, const void* approx, const void* const* details, void* y, const double* d_rec_lo,
+                        const double* d_rec_hi, void* workspace, size_t workspace_bytes, void* stream) {
+  const int rc = validate(desc, 1);
+  if (rc != MIFWT_OK) return rc;
+  if (!y || !approx || !details || !d_rec_lo || !d_rec_hi) return MIFWT_ERR_BADARG;
+  for (int s = 1; s < (1 << desc->ndim); ++s)
+    if (!details[s - 1]) return MIFWT_ERR_BADARG;
+  if (desc->batch == 0) return MIFWT_OK;
+  const size_t need = generic_ws(desc, 1);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return MIFWT_ERR_WORKSPACE;
+  DtapsScope scope(d_rec_lo, d_rec_hi, 0);
+  return generic_inv(desc, approx, details, y, kNoHostTaps, kNoHostTaps, workspace, static_cast<hipStream_t>(stream));
+}
+
+int mifwt_dwt_fwd_adjoint_dtaps(const mifwt_level_desc* desc, const void* g_approx, const void* const* g_details, void* g_x,
+                                const double* d_dec_lo, const double* d_dec_hi, void* workspace, size_t workspace_bytes, void* stream) {
+  const int rc = validate(desc, 0);
+  if (rc != MIFWT_OK) return rc;
+  if (!g_x || !g_approx || !g_details || !d_dec_lo || !d_dec_hi) return MIFWT_ERR_BADARG;
+  for (int s = 1; s < (1 << desc->ndim); ++s)
+    if (!g_details[s - 1]) return MIFWT_ERR_BADARG;
+  if (desc->batch == 0) return MIFWT_OK;
+  const size_t need = generic_ws(desc, 1);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return MIFWT_ERR_WORKSPACE;
+  DtapsScope scope(d_dec_lo, d_dec_hi, 0);
+  return generic_inv(desc, g_approx, g_details, g_x, kNoHostTaps, kNoHostTaps, workspace, static_cast<hipStream_t>(stream), true);
+}
+
+int mifwt_dwt_inv_adjoint_dtaps(const mifwt_level_desc* desc, const void* g_y, void* g_approx, void* const* g_details,
+                                const double* d_rec_lo, const double* d_rec_hi, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = validate(desc, 1);
+  if (rc != MIFWT_OK) return rc;
+  if (!g_y || !g_approx || !g_details || !d_rec_lo || !d_rec_hi) return MIFWT_ERR_BADARG;
+  // (a zero-mode analysis level with the rec taps reversed: mifwt_dwt_inv_adjoint)
+  const mifwt_level_desc z = as_zero_mode(desc);
+  rc = validate(&z, 0);
+  if (rc != MIFWT_OK) return rc;
+  for (int s = 1; s < (1 << desc->ndim); ++s)
+    if (!g_details[s - 1]) return MIFWT_ERR_BADARG;
+  if (desc->batch == 0) return MIFWT_OK;
+  const size_t need = generic_ws(&z, 0);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return MIFWT_ERR_WORKSPACE;
+  DtapsScope scope(d_rec_lo, d_rec_hi, 1);
+  return generic_fwd(&z, g_y, g_approx, g_details, kNoHostTaps, kNoHostTaps, workspace, static_cast<hipStream_t>(stream));
+}
+
 // Two consecutive 2-D analysis levels in one launch (mifwt_dwt2_fwd_pair.hip); d2 describes the second level, whose
 // input is the (never materialised) approximation of d1.
 int mifwt_dwt2_fwd_pair_supported(const mifwt_level_desc* d1, const mifwt_level_desc* d2) {

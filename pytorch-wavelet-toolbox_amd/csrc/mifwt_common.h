@@ -101,6 +101,16 @@ struct AxisJob {
   int64_t in0_stride[4], in1_stride[4], out0_stride[4], out1_stride[4];
 };
 
+// DEVICE-RESIDENT TAPS (round 5): while `g_dtaps.lo` is set (mifwt_*_dtaps entry points, this thread only) the generic axis kernels
+// read their filter from these device arrays of L doubles instead of their launch arguments — a learnable filter bank that lives on
+// the GPU then needs no device-to-host copy, no stream synchronisation, and the calls can be captured into a HIP graph.  `rev`:
+// tap m of the pass is element L - 1 - m of the arrays (the adjoint of a synthesis level is an analysis level with reversed taps).
+struct DeviceTaps {
+  const double* lo;
+  const double* hi;
+  int rev;
+};
+extern thread_local DeviceTaps g_dtaps;
 int launch_axis_fwd(int dtype, const AxisJob* jobs, int njobs, const int64_t out_ext[4], int taxis, int64_t n_in,
                     int mode, int filt_len, const double* lo, const double* hi, hipStream_t stream);
 int launch_axis_inv(int dtype, const AxisJob* jobs, int njobs, const int64_t out_ext[4], int taxis, int64_t m_in,

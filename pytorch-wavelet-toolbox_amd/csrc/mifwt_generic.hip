@@ -36,8 +36,17 @@ struct AxisJobs {
   AxisJob job[4];
 };
 
-template <typename T, typename A>
-__global__ void __launch_bounds__(256) axis_fwd_kernel(AxisJobs jobs, AxisGeom g, Taps<A> taps) {
+thread_local DeviceTaps g_dtaps = {nullptr, nullptr, 0};
+
+// tap m of the pass: from the launch arguments, or (DT) from the device arrays of a filter bank that lives on the GPU
+template <bool DT, typename A>
+__device__ __forceinline__ A tap_of(const A* arg, const double* dev, int rev, int L, int m) {
+  if constexpr (DT) return (A)dev[rev ? L - 1 - m : m];
+  else return arg[m];
+}
+
+template <typename T, typename A, bool DT>
+__global__ void __launch_bounds__(256) axis_fwd_kernel(AxisJobs jobs, AxisGeom g, Taps<A> taps, DeviceTaps dt) {
   const AxisJob& jb = jobs.job[blockIdx.y];
   const T* __restrict__ in = static_cast<const T*>(jb.in0);
   T* __restrict__ lo = static_cast<T*>(jb.out0);
@@ -64,16 +73,16 @@ __global__ void __launch_bounds__(256) axis_fwd_kernel(AxisJobs jobs, AxisGeom g
     for (int m = 0; m < g.filt_len; ++m) {
       const int src = ext_index(2 * k + 1 - m, g.n_src, g.mode);
       const A v = src >= 0 ? (A)in[ibase + (int64_t)src * stride_t] : A(0);
-      acc_lo = fma(taps.lo[m], v, acc_lo);
-      acc_hi = fma(taps.hi[m], v, acc_hi);
+      acc_lo = fma(tap_of<DT, A>(taps.lo, dt.lo, dt.rev, g.filt_len, m), v, acc_lo);
+      acc_hi = fma(tap_of<DT, A>(taps.hi, dt.hi, dt.rev, g.filt_len, m), v, acc_hi);
     }
     lo[lbase] = (T)acc_lo;
     hi[hbase] = (T)acc_hi;
   }
 }
 
-template <typename T, typename A>
-__global__ void __launch_bounds__(256) axis_inv_kernel(AxisJobs jobs, AxisGeom g, Taps<A> taps) {
+template <typename T, typename A, bool DT>
+__global__ void __launch_bounds__(256) axis_inv_kernel(AxisJobs jobs, AxisGeom g, Taps<A> taps, DeviceTaps dt) {
   const AxisJob& jb = jobs.job[blockIdx.y];
   const T* __restrict__ a = static_cast<const T*>(jb.in0);
   const T* __restrict__ dd = static_cast<const T*>(jb.in1);
@@ -107,8 +116,8 @@ __global__ void __launch_bounds__(256) axis_inv_kernel(AxisJobs jobs, AxisGeom g
     A acc = 0;
     for (int k = k_lo; k <= k_hi; ++k) {
       const int t = q - 2 * k;
-      acc = fma(taps.lo[t], (A)a[abase + (int64_t)k * sa], acc);
-      acc = fma(taps.hi[t], (A)dd[dbase + (int64_t)k * sd], acc);
+      acc = fma(tap_of<DT, A>(taps.lo, dt.lo, dt.rev, L, t), (A)a[abase + (int64_t)k * sa], acc);
+      acc = fma(tap_of<DT, A>(taps.hi, dt.hi, dt.rev, L, t), (A)dd[dbase + (int64_t)k * sd], acc);
     }
     y[ybase] = (T)acc;
   }
@@ -119,8 +128,8 @@ __global__ void __launch_bounds__(256) axis_inv_kernel(AxisJobs jobs, AxisGeom g
 //     u[e] = sum_k g_lo[k] h_lo[2k + 1 - e] + g_hi[k] h_hi[2k + 1 - e],
 // the gradient folds the halo back through the boundary index map:  g_x[i] = sum_{e : ext_index(e) = i} u[e].
 // (The reference gets this from ATen autograd through F.pad / _pad_symmetric + F.conv*d.)
-template <typename T, typename A>
-__global__ void __launch_bounds__(256) axis_adj_kernel(AxisJobs jobs, AxisGeom g, Taps<A> taps) {
+template <typename T, typename A, bool DT>
+__global__ void __launch_bounds__(256) axis_adj_kernel(AxisJobs jobs, AxisGeom g, Taps<A> taps, DeviceTaps dt) {
   const AxisJob& jb = jobs.job[blockIdx.y];
   const T* __restrict__ a = static_cast<const T*>(jb.in0);
   const T* __restrict__ dd = static_cast<const T*>(jb.in1);
@@ -156,8 +165,8 @@ __global__ void __launch_bounds__(256) axis_adj_kernel(AxisJobs jobs, AxisGeom g
       A acc = 0;
       for (int k = k_lo; k <= k_hi; ++k) {
         const int m = 2 * k + 1 - e;
-        acc = fma(taps.lo[m], (A)a[abase + (int64_t)k * sa], acc);
-        acc = fma(taps.hi[m], (A)dd[dbase + (int64_t)k * sd], acc);
+        acc = fma(tap_of<DT, A>(taps.lo, dt.lo, dt.rev, L, m), (A)a[abase + (int64_t)k * sa], acc);
+        acc = fma(tap_of<DT, A>(taps.hi, dt.hi, dt.rev, L, m), (A)dd[dbase + (int64_t)k * sd], acc);
       }
       return acc;
     };
@@ -191,20 +200,28 @@ static int launch_axis(int kind, const AxisJob* jobs, int njobs, const int64_t o
   g.n_sig = (int)n_sig;
   g.mode = mode;
   g.filt_len = filt_len;
+  const DeviceTaps dt = g_dtaps;  // (this thread's: set around the call by a mifwt_*_dtaps entry point)
   Taps<A> taps;
   for (int m = 0; m < kMaxFilt; ++m) {
-    taps.lo[m] = m < filt_len ? (A)lo[m] : A(0);
-    taps.hi[m] = m < filt_len ? (A)hi[m] : A(0);
+    taps.lo[m] = (!dt.lo && m < filt_len) ? (A)lo[m] : A(0);
+    taps.hi[m] = (!dt.lo && m < filt_len) ? (A)hi[m] : A(0);
   }
   const int64_t want = (g.total + 255) / 256;
   const unsigned gx = (unsigned)(want < 8192 ? want : 8192);  // grid-stride beyond 256 CUs x 32 blocks
   dim3 grid(gx, (unsigned)njobs), block(256);
-  if (kind == 2)
-    hipLaunchKernelGGL((axis_adj_kernel<T, A>), grid, block, 0, stream, js, g, taps);
+  if (dt.lo) {
+    if (kind == 2)
+      hipLaunchKernelGGL((axis_adj_kernel<T, A, true>), grid, block, 0, stream, js, g, taps, dt);
+    else if (kind == 1)
+      hipLaunchKernelGGL((axis_inv_kernel<T, A, true>), grid, block, 0, stream, js, g, taps, dt);
+    else
+      hipLaunchKernelGGL((axis_fwd_kernel<T, A, true>), grid, block, 0, stream, js, g, taps, dt);
+  } else if (kind == 2)
+    hipLaunchKernelGGL((axis_adj_kernel<T, A, false>), grid, block, 0, stream, js, g, taps, dt);
   else if (kind == 1)
-    hipLaunchKernelGGL((axis_inv_kernel<T, A>), grid, block, 0, stream, js, g, taps);
+    hipLaunchKernelGGL((axis_inv_kernel<T, A, false>), grid, block, 0, stream, js, g, taps, dt);
   else
-    hipLaunchKernelGGL((axis_fwd_kernel<T, A>), grid, block, 0, stream, js, g, taps);
+    hipLaunchKernelGGL((axis_fwd_kernel<T, A, false>), grid, block, 0, stream, js, g, taps, dt);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 

@@ -91,7 +91,7 @@ class _Swt1(torch.autograd.Function):
     def forward(ctx, x, lo_t, hi_t, dilation, scale):
         ctx.meta = (dilation, scale)
         ctx.save_for_backward(x, lo_t, hi_t)
-        return _level_fwd(x, _fwt._host_taps_of(lo_t), _fwt._host_taps_of(hi_t), dilation, scale)
+        return _level_fwd(x, _fwt._host_floats_of(lo_t), _fwt._host_floats_of(hi_t), dilation, scale)
 
     @staticmethod
     def backward(ctx, g):
@@ -110,7 +110,7 @@ class _Iswt1(torch.autograd.Function):
     def forward(ctx, a, d, lo_t, hi_t, dilation, scale):
         ctx.meta = (dilation, scale)
         ctx.save_for_backward(a, d, lo_t, hi_t)
-        return _level_inv(a, d, _fwt._host_taps_of(lo_t), _fwt._host_taps_of(hi_t), dilation, scale)
+        return _level_inv(a, d, _fwt._host_floats_of(lo_t), _fwt._host_floats_of(hi_t), dilation, scale)
 
     @staticmethod
     def backward(ctx, g_y):

@@ -605,3 +605,89 @@ def test_tensor_taps_are_read_live_on_every_call():
     c2 = ptwt_amd.wavedec(x, "db2", level=2)
     for u, w in zip(c1, c2):
         assert torch.equal(u, w)
+
+
+def test_learnable_taps_stay_on_the_gpu_no_sync_and_capturable():
+    """Device-resident taps (round 5).  A filter bank of leaf tensors on the GPU — the reference's learnable
+    wavelets keep their taps as tensors in the graph, src/ptwt/_util.py:115-132; examples/network_compression/wavelet_linear.py:118,150
+    — reaches the kernels as device memory (C ABI mifwt_*_dtaps): forward AND backward of the ten level transforms run without a
+    single host synchronisation (`torch.cuda.set_sync_debug_mode("error")` turns any into an exception), and the gradients still
+    match the reference's own autograd (tests/golden/ptwt_ref_tapgrads.npz; fp64, 1e-10 norm-wise).  A forward with device taps can
+    also be captured into a HIP graph; after an in-place update of the taps the replay sees the new filter."""
+    import json
+    import os
+
+    from ptwt_amd import WaveletTensorTuple
+
+    z, idx = G.load("ptwt_ref_tapgrads.npz")
+    with open(os.path.join(G.GOLDEN, "pywt_filter_banks.json")) as f:
+        banks = json.load(f)
+    ran = 0
+    for case in idx:
+        if case["fn"].startswith("packet") or case["fn"] in ("swt", "iswt"):
+            continue  # (packet trees and the stationary transform read their taps on the host: other kernels)
+        k = case["key"]
+        kw = {a: (tuple(v) if isinstance(v, list) else v) for a, v in case["kw"].items()}
+        x = torch.from_numpy(z[k + "_x"]).to(dev())
+        name = "haar" if case["wavelet"] == "db1" else case["wavelet"]
+        taps = [torch.tensor(banks[name][f], dtype=torch.float64, device=dev(), requires_grad=True)
+                for f in ("dec_lo", "dec_hi", "rec_lo", "rec_hi")]
+        wt = WaveletTensorTuple(*taps)
+        rkw = {a: v for a, v in kw.items() if a in ("axis", "axes")}
+        # weights of the losses, made outside the no-sync region (shapes from a first, ordinary call)
+        with torch.no_grad():
+            c0 = getattr(ptwt_amd, case["fn"])(x, wt, **kw)
+            w_c = [weight(t, i) for i, t in enumerate(flat(c0))]
+            w_y = weight(getattr(ptwt_amd, case["rec"])(c0, wt, **rkw), 7)
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            coeffs = getattr(ptwt_amd, case["fn"])(x, wt, **kw)
+            loss = sum((w * t).sum() for w, t in zip(w_c, flat(coeffs)))
+            g_dec = torch.autograd.grad(loss, taps[:2], retain_graph=True)
+            y = getattr(ptwt_amd, case["rec"])(coeffs, wt, **rkw)
+            g_all = torch.autograd.grad((w_y * y).sum(), taps)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        assert G.relerr(g_dec[0].cpu().numpy(), z[k + "_gdec_lo"]) < 1e-10, (case, "dec_lo")
+        assert G.relerr(g_dec[1].cpu().numpy(), z[k + "_gdec_hi"]) < 1e-10, (case, "dec_hi")
+        for nme, g in zip(("dec_lo", "dec_hi", "rec_lo", "rec_hi"), g_all):
+            assert G.relerr(g.cpu().numpy(), z["%s_gall_%s" % (k, nme)]) < 1e-10, (case, nme)
+        ran += 1
+    assert ran >= 20, ran
+
+    # negative control: with device taps switched off the same call reads the bank back, and the sync detector says so
+    xs = torch.randn(2, 40, 52, dtype=torch.float64).to(dev())
+    lt = [torch.tensor(banks["db2"][f], dtype=torch.float64, device=dev(), requires_grad=True) for f in ("dec_lo", "dec_hi", "rec_lo", "rec_hi")]
+    ptwt_amd.set_device_taps("never")
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        with pytest.raises(RuntimeError):
+            ptwt_amd.wavedec2(xs, tuple(lt), level=1)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+        ptwt_amd.set_device_taps("auto")
+
+    # values: device taps against host taps (fused kernels), forward only; and capture + replay after an in-place tap update
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 96, 130, generator=g).to(dev())
+    bank = [torch.tensor(banks["db3"][f], dtype=torch.float32, device=dev()) for f in ("dec_lo", "dec_hi", "rec_lo", "rec_hi")]
+    ptwt_amd.set_device_taps("always")
+    try:
+        got = ptwt_amd.wavedec2(x, tuple(bank), level=2, mode="symmetric")
+        cap = ptwt_amd.capture(lambda t: ptwt_amd.waverec2(ptwt_amd.wavedec2(t, tuple(bank), level=2, mode="symmetric"), tuple(bank)), x)
+        y0 = [cap(x).clone()]
+        with torch.no_grad():
+            bank[0].mul_(1.25)
+        y1 = [cap(x).clone()]
+        want1 = ptwt_amd.waverec2(ptwt_amd.wavedec2(x, tuple(bank), level=2, mode="symmetric"), tuple(bank))
+        with torch.no_grad():
+            bank[0].div_(1.25)
+    finally:
+        ptwt_amd.set_device_taps("auto")
+    want = ptwt_amd.wavedec2(x, "db3", level=2, mode="symmetric")
+    for (n, a), (_, b) in zip(G.flatten_coeffs(got), G.flatten_coeffs(want)):
+        assert G.relerr(a.cpu().numpy(), b.cpu().double().numpy()) < 2e-6, n
+    assert not torch.equal(y0[0], y1[0]), "the replay did not see the updated taps"
+    assert torch.equal(y1[0], want1), "replay after the update differs from an eager call with the updated taps"
