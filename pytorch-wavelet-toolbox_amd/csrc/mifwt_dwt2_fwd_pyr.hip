@@ -327,24 +327,32 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
       uint32_t rw[NC1];
 #pragma unroll
       for (int k = 0; k < NC1; ++k) rw[k] = (real && c0 + k >= cA[1] && c0 + k < cB[1]) ? 4u * (uint32_t)(kPyrPad + sh1 + c0 + k - cA[1]) : 0u;
-      // level-0 pad fill, by the waves whose windows reach the pads: lane -> (row kk of the sub-step, pad column)
-      uint32_t f_src = 0, f_dst = 0;
-      bool f_on = false;
-      {
+      // level-0 pad fill, by the waves whose windows reach the pads: lane -> (row kk of the sub-step, pad column); a second pass
+      // where the four rows' pads are more than a wave's lanes (ten taps: 4 x 17)
+      constexpr int NFP = (kPyrSub * NP + 63) / 64;
+      uint32_t f_src[NFP], f_dst[NFP];
+      bool f_on[NFP];
+      bool f_some = false;
+#pragma unroll
+      for (int ps = 0; ps < NFP; ++ps) {
+        f_src[ps] = f_dst[ps] = 0;
+        f_on[ps] = false;
         const int wlo = 2 * (o1 + NC1 * min(64 * widx, gmax)) - HL, whi = 2 * (o1 + NC1 * min(64 * widx + 63, gmax) + NC1 - 1) + 1;
-        const int kk = lane / NP, p = lane - kk * NP;
+        const int fl = lane + 64 * ps;
+        const int kk = fl / NP, p = fl - kk * NP;
         const bool left = p < HL;
         const int e = left ? p - HL : a.W[0] + (p - HL);
         // (zero mode: the pads are zeros from the LDS initialisation — except the right one of rows that are not a multiple of 4
         // samples long, where the last lane of a row's DMA request brings up to three samples of whatever follows the row)
         const bool zfix = zero_mode && !left && (a.W[0] & 3) != 0;
         if (kk < kPyrSub && (!zero_mode || zfix) && (left ? wlo < 0 : whi >= a.W[0])) {
-          f_on = true;
-          f_src = (uint32_t)(kk * a.pitch0) + 4u * (uint32_t)(kPyrPad + (zero_mode ? 0 : fold(e, a.W[0])) - g0);
-          f_dst = (uint32_t)(kk * a.pitch0) + 4u * (uint32_t)(kPyrPad + e - g0);
+          f_on[ps] = true;
+          f_some = true;
+          f_src[ps] = (uint32_t)(kk * a.pitch0) + 4u * (uint32_t)(kPyrPad + (zero_mode ? 0 : fold(e, a.W[0])) - g0);
+          f_dst[ps] = (uint32_t)(kk * a.pitch0) + 4u * (uint32_t)(kPyrPad + e - g0);
         }
       }
-      const bool f_any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(f_on) != 0) && !(a.dbg & 16384);
+      const bool f_any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(f_some) != 0) && !(a.dbg & 16384);
       // one buffer resource for the three detail planes of the image (band = scalar offset), one for the approximation; a row
       // the unit does not own is stored at a per-lane offset beyond every resource (dropped) — the resources never change
       const uint32_t dbytes = (a.dbg & 1) ? 0u : a.dspan[0] + ((uint32_t)(a.H[1] - 1) * (uint32_t)a.ds_h[0] + (uint32_t)a.W[1]) * 4u;
@@ -389,9 +397,13 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
             unsigned char* sb = stage + bi * (kPyrSub * a.pitch0);
             bi = bi + 1 == a.nbuf ? 0 : bi + 1;
             if (f_any) {
-              const float v = zero_mode ? 0.f : *reinterpret_cast<const float*>(sb + f_src);
+              float v[NFP];
+#pragma unroll
+              for (int ps = 0; ps < NFP; ++ps) v[ps] = zero_mode ? 0.f : *reinterpret_cast<const float*>(sb + f_src[ps]);
               wave_lds_fence();
-              if (f_on) *reinterpret_cast<float*>(sb + f_dst) = v;
+#pragma unroll
+              for (int ps = 0; ps < NFP; ++ps)
+                if (f_on[ps]) *reinterpret_cast<float*>(sb + f_dst[ps]) = v[ps];
               wave_lds_fence();
             }
             f2 w[kPyrSub][NW2];
@@ -437,9 +449,9 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
       int sm = 0;
 #pragma unroll 1
       for (int s = 0; s < nsteps; ++s) {
-        if constexpr (HP == 3) {
-          pyr_dispatch<3>(sm, [&](auto t) { step1(t, s); });
-          sm = sm == 2 ? 0 : sm + 1;
+        if constexpr (HP == 3 || HP == 5) {  // (4 s + j) mod L/2 depends on s
+          pyr_dispatch<HP>(sm, [&](auto t) { step1(t, s); });
+          sm = sm == HP - 1 ? 0 : sm + 1;
         } else {
           step1(std::integral_constant<int, 0>{}, s);
         }
@@ -1028,26 +1040,29 @@ static int pyr_cut(const PyrGeom& gm, int64_t B, double budget, int gmax, uint32
 
 static void pyr_schedule(const PyrGeom& gm, int64_t B, int gwant, PyrPlan* p) {
   const int HN = gm.H[gm.nlev];
-  // one-entry cache (a call loop asks for the same schedule every time; the search below is ~0.1 ms)
-  struct Key {
-    int L, nlev, H[4], gwant, ex;
+  // a small cache (a call loop asks for the same few schedules over and over — a five-level call of the reference's shape takes this
+  // kernel for two of its levels; the search below is ~0.1 ms)
+  struct Entry {
+    int L, nlev, H[4], gwant, ex, n;
     int64_t B;
-    bool operator==(const Key& o) const {
-      return L == o.L && nlev == o.nlev && H[1] == o.H[1] && H[2] == o.H[2] && H[3] == o.H[3] && gwant == o.gwant && ex == o.ex && B == o.B;
-    }
+    uint32_t cut[kPyrMaxWG + 1];
   };
+  constexpr int kEntries = 16;
   static std::mutex mu;
-  static Key last_key = {0, 0, {0, 0, 0, 0}, 0, 0, 0};
-  static int last_n = 0;
-  static uint32_t last_cut[kPyrMaxWG + 1];
-  Key key = {gm.L, gm.nlev, {0, gm.nlev >= 1 ? gm.H[1] : 0, gm.nlev >= 2 ? gm.H[2] : 0, gm.nlev >= 3 ? gm.H[3] : 0}, gwant, g_options[MIFWT_OPT_EXP], B};
+  static Entry cache[kEntries];
+  static int used = 0, next = 0;
+  const int ex = g_options[MIFWT_OPT_EXP];
+  auto same = [&](const Entry& e) {
+    return e.L == gm.L && e.nlev == gm.nlev && e.H[1] == gm.H[1] && e.H[2] == gm.H[2] && e.H[3] == gm.H[3] && e.gwant == gwant && e.ex == ex && e.B == B;
+  };
   {
     std::lock_guard<std::mutex> lk(mu);
-    if (last_n > 0 && key == last_key) {
-      p->nwg = last_n;
-      std::copy(last_cut, last_cut + last_n + 1, p->wg_start);
-      return;
-    }
+    for (int i = 0; i < used; ++i)
+      if (same(cache[i])) {
+        p->nwg = cache[i].n;
+        std::copy(cache[i].cut, cache[i].cut + cache[i].n + 1, p->wg_start);
+        return;
+      }
   }
   const int g = std::max(1, std::min(gwant, kPyrMaxWG));
   // the smallest budget the rows fit into g chunks with
@@ -1061,9 +1076,12 @@ static void pyr_schedule(const PyrGeom& gm, int64_t B, int gwant, PyrPlan* p) {
   p->nwg = pyr_cut(gm, B, hi, g, p->wg_start);
   {
     std::lock_guard<std::mutex> lk(mu);
-    last_key = key;
-    last_n = p->nwg;
-    std::copy(p->wg_start, p->wg_start + p->nwg + 1, last_cut);
+    Entry& e = cache[next];
+    next = (next + 1) % kEntries;
+    used = std::min(used + 1, kEntries);
+    e.L = gm.L, e.nlev = gm.nlev, e.gwant = gwant, e.ex = ex, e.B = B, e.n = p->nwg;
+    for (int l = 0; l < 4; ++l) e.H[l] = gm.H[l];
+    std::copy(p->wg_start, p->wg_start + p->nwg + 1, e.cut);
   }
 }
 
@@ -1190,8 +1208,12 @@ bool dwt2_fwd_pyr_supported(int nlev, const mifwt_level_desc* const* d) {
   if (nlev < 1 || nlev > 3 || g_options[MIFWT_OPT_PAIR_MODE] == 2 || g_options[MIFWT_OPT_PYRAMID_MODE] == 2) return false;
   const mifwt_level_desc* d0 = d[0];
   const int L = d0->filt_len;
-  if (d0->ndim != 2 || d0->dtype != MIFWT_F32 || L < 2 || L > 8 || (L & 1)) return false;
-  if (d0->mode == MIFWT_MODE_PERIODIC || d0->mode < 0 || d0->mode > MIFWT_MODE_SYMMETRIC) return false;
+  if (d0->ndim != 2 || d0->dtype != MIFWT_F32 || L < 2 || L > 10 || (L & 1)) return false;
+  // ten taps and the periodic extension: ONE level per launch (round 5) — a single level needs nothing from the far side of the plane
+  // but index maps (rows through the loader's map, pad columns from the staged row itself); the rings of a second level would need
+  // rows of the plane's other end (periodic) / 32 rows a level (ten taps: more LDS than a CU has)
+  if ((L == 10 || d0->mode == MIFWT_MODE_PERIODIC) && nlev != 1) return false;
+  if (d0->mode < 0 || d0->mode > MIFWT_MODE_SYMMETRIC) return false;
   if (d0->batch < 1 || d0->sig_stride[2] != 1) return false;
   // (rows of any length and alignment: the LDS-DMA engine takes 16 bytes per lane from 4-byte aligned addresses, tools/dma_probe.hip)
   const int64_t lim = int64_t(1) << 29;  // byte offsets inside one image stay below 2^31
@@ -1210,11 +1232,15 @@ bool dwt2_fwd_pyr_supported(int nlev, const mifwt_level_desc* const* d) {
   if (dn->approx_stride[2] != 1 || dn->coef_extent[0] * dn->approx_stride[1] >= lim) return false;
   PyrPlan p;
   if (!pyr_plan(nlev, d, &p)) return false;
+  if (L == 10 && p.nwaves != 12) return false;
   // Where it pays (tools/pyr_where.py, profiles/r03m_pyr_where.txt; round 2: tools/pyr_matrix.py, tools/pyr_big.py;
   // MIFWT_OPT_PYRAMID_MODE 1 overrides): planes of 448 .. ~2560 columns, i.e. one or two column groups.  A workgroup then reads whole
   // rows (or halves of them), one after the other.  Four column groups (4096 columns: 4 KB pieces 16 KB apart) ran at 0.44 of the HBM
   // peak against 0.65 for the per-level tile kernel; narrower planes leave most lanes of the level-2 / 3 waves idle (256^2: 75 against 55 us).
   if (g_options[MIFWT_OPT_PYRAMID_MODE] != 1 && (p.ngroups > 2 || d0->sig_extent[1] < 448)) return false;
+  // ONE level alone pays on planes of about a thousand columns (64 x 1024^2 db4: 83.6 against 105 us for the tile kernel; equal at
+  // 515^2, behind at 1400^2: tools/fwd1_probe.py, profiles/r04r_fwd1_probe.txt)
+  if (g_options[MIFWT_OPT_PYRAMID_MODE] != 1 && nlev == 1 && (d0->sig_extent[1] < 896 || d0->sig_extent[1] > 1280 || d0->sig_extent[0] < 256)) return false;
   return true;
 }
 
@@ -1288,19 +1314,22 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
   const int64_t nwg = (int64_t)p.nwg * p.ngroups;
   // (the per-wave cycle profile of tools/pyr_prof.py exists for the three-level 8-tap kernel only)
   constexpr bool kCanProf = L == 8 && NLEV == 3;
+  constexpr bool kHas16 = L <= 8;  // (ten taps: the twelve-wave form only — the level-1 waves want 157 registers a lane)
   static DynLdsOnce lds_once12, lds_once16, lds_once_prof12, lds_once_prof16;
   if (!lds_once12.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, false, 12>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
-  if (!lds_once16.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, false, 16>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
   if (kCanProf && !lds_once_prof12.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, 12>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
-  if (kCanProf && !lds_once_prof16.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, 16>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
   count_launch(MIFWT_VARIANT_FWD_PYR_ST8);
   const dim3 grid((unsigned)nwg), block(64 * p.nwaves);
   if (p.nwaves == 12) {
     if (kCanProf && a.prof) hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, 12>), grid, block, p.lds, stream, a);
     else hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, false, 12>), grid, block, p.lds, stream, a);
-  } else {
+  } else if constexpr (kHas16) {
+    if (!lds_once16.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, false, 16>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
+    if (kCanProf && !lds_once_prof16.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, 16>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
     if (kCanProf && a.prof) hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, 16>), grid, block, p.lds, stream, a);
     else hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, false, 16>), grid, block, p.lds, stream, a);
+  } else {
+    return MIFWT_ERR_UNSUPPORTED;
   }
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
@@ -1326,6 +1355,7 @@ int dwt2_fwd_pyr(int nlev, const mifwt_level_desc* const* d, const void* x, void
     case 4: return launch_pyr_l<4>(nlev, d, x, details, approx, lo, hi, stream);
     case 6: return launch_pyr_l<6>(nlev, d, x, details, approx, lo, hi, stream);
     case 8: return launch_pyr_l<8>(nlev, d, x, details, approx, lo, hi, stream);
+    case 10: return nlev == 1 ? launch_pyr<10, 1>(d, x, details, approx, lo, hi, stream) : MIFWT_ERR_UNSUPPORTED;
     default: return MIFWT_ERR_UNSUPPORTED;
   }
 }

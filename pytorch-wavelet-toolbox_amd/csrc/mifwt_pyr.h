@@ -218,14 +218,24 @@ __device__ __forceinline__ void pyr_dispatch(int r, F&& f) {
     if (r == 0) f(std::integral_constant<int, 0>{});
     else if (r == 1) f(std::integral_constant<int, 1>{});
     else f(std::integral_constant<int, 2>{});
-  } else {
-    static_assert(N == 4, "filter lengths up to 8");
+  } else if constexpr (N == 4) {
     if (r < 2) {
       if (r == 0) f(std::integral_constant<int, 0>{});
       else f(std::integral_constant<int, 1>{});
     } else {
       if (r == 2) f(std::integral_constant<int, 2>{});
       else f(std::integral_constant<int, 3>{});
+    }
+  } else {
+    static_assert(N == 5, "filter lengths up to 10");
+    if (r < 2) {
+      if (r == 0) f(std::integral_constant<int, 0>{});
+      else f(std::integral_constant<int, 1>{});
+    } else if (r == 2) {
+      f(std::integral_constant<int, 2>{});
+    } else {
+      if (r == 3) f(std::integral_constant<int, 3>{});
+      else f(std::integral_constant<int, 4>{});
     }
   }
 }

@@ -206,7 +206,11 @@ def test_pyramid_declines_what_it_cannot_serve():
         assert (got is not None) == served, shape
     _engine.set_option(_engine.OPT_PYRAMID_MODE, 1)
     x = torch.randn(2, 640, 640, device=dev())  # (a plane too big for the small-plane kernel, which does serve periodic)
-    assert _engine.ENGINE.analysis_pyramid(x, *ptwt_amd._fwt.host_taps("db4")[:2], _engine.MODE_IDS["periodic"], 3) is None
+    # (round 5: the periodic extension is served one level per launch — the rings of a second level would need the plane's far side)
+    got = _engine.ENGINE.analysis_pyramid(x, *ptwt_amd._fwt.host_taps("db4")[:2], _engine.MODE_IDS["periodic"], 3)
+    assert got is not None and len(got) == 1
+    got = _engine.ENGINE.analysis_pyramid(x, *ptwt_amd._fwt.host_taps("db6")[:2], _engine.MODE_IDS["reflect"], 3)
+    assert got is None  # twelve taps
     x = torch.randn(2, 128, 128, device=dev())
     assert _engine.ENGINE.analysis_pyramid(x.double(), *ptwt_amd._fwt.host_taps("db4")[:2], _engine.MODE_IDS["reflect"], 3) is None
     # results of unsupported geometries still come from the other kernels
@@ -281,6 +285,34 @@ def test_pyramid_tail_wave_and_twelve_wave_form_are_bit_identical_to_the_level_w
                     assert torch.equal(a, b), (shape, wavelet, mode, level, dbg, n)
     check(torch.randn(2, 200, 1024, generator=g), wavelet, "symmetric", 3, [_engine.KID_PYRAMID])
     check(torch.randn(2, 136, 1000, generator=g), wavelet, "zero", 3, [_engine.KID_PYRAMID], seg_rows=8)
+
+
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4", "db5", "sym5"])
+def test_pyramid_one_level_periodic_and_ten_taps(wavelet):
+    """Round 5: ONE level per launch also with the periodic extension and with ten taps (the reference's own speed-test wavelet and mode,
+    examples/speed_tests/timeitconv_2d.py:38-57: db5, periodic) — a single level needs nothing from the far side of the plane but index
+    maps.  Every mode, odd / even extents, several row chunks, against the oracle; multi-level calls take the kernel level by level."""
+    g = torch.Generator().manual_seed(61)
+    ten = wavelet in ("db5", "sym5")
+    for shape in ((2, 300, 1000), (3, 131, 517), (2, 96, 1001), (1, 1000, 1000)):
+        x = torch.randn(*shape, generator=g, dtype=torch.float32)
+        for mode in ALL_MODES:
+            if not ten and mode != "periodic":
+                continue  # (covered above)
+            check(x, wavelet, mode, 1, want_kids=[_engine.KID_PYRAMID])
+            check(x, wavelet, mode, 1, want_kids=[_engine.KID_PYRAMID], seg_rows=8)
+    x = torch.randn(2, 520, 1000, generator=g, dtype=torch.float32)
+    got, kids = run_traced(lambda: ptwt_amd.wavedec2(x.to(dev()), wavelet, mode="periodic", level=3))
+    assert kids and kids[0] == _engine.KID_PYRAMID, kids
+    check(x, wavelet, "periodic", 3)
+    _engine.set_option(_engine.OPT_PYRAMID_MODE, 0)  # auto mode: the reference's shape takes kernel 16 for its first level
+    try:
+        xr = torch.randn(4, 1000, 1000, generator=g, dtype=torch.float32)
+        _, kids = run_traced(lambda: ptwt_amd.wavedec2(xr.to(dev()), "db5", mode="periodic", level=5))
+        assert kids[0] == _engine.KID_PYRAMID, kids
+        check(xr, "db5", "periodic", 5)
+    finally:
+        _engine.set_option(_engine.OPT_PYRAMID_MODE, 1)
 
 
 def test_pyramid_batches_that_do_not_divide_the_chip():

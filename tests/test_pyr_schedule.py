@@ -33,10 +33,12 @@ def _schedule(batch, H, W, L, nlev, wgs=0):
     arr = (ctypes.POINTER(_engine.LevelDesc) * nlev)(*[ctypes.pointer(d) for d in descs])
     out = (ctypes.c_uint32 * 400)()
     _engine.set_option(_engine.OPT_PYR_WGS, wgs)
+    _engine.set_option(_engine.OPT_PYRAMID_MODE, 1)  # (wherever the kernel can run, not only where it is the fastest route)
     try:
         n = lib.mifwt_dwt2_fwd_pyramid_schedule(nlev, arr, out, 400)
     finally:
         _engine.set_option(_engine.OPT_PYR_WGS, 0)
+        _engine.set_option(_engine.OPT_PYRAMID_MODE, 0)
     assert n >= 1, n
     return np.array(out[: n + 1], dtype=np.int64), hn
 
