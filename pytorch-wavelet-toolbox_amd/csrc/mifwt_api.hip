@@ -246,7 +246,9 @@ int pick_kernel(const mifwt_level_desc* d, int direction) {
     if (dwt3_fwd_walk_supported(d)) {
       const int tm = g_options[MIFWT_OPT_TILE_MODE];
       const int64_t vol = d->sig_extent[0] * d->sig_extent[1] * d->sig_extent[2];
-      if (tm == 4 || (tm == 0 && ((d->filt_len <= 6 && vol >= (int64_t(1) << 22)) || d->filt_len == 8))) return kDwt3FwdWalk;
+      // (8 taps: from ~1 M samples on — the one measurement is 16 x 128^3; small 8-tap volumes such as the deep levels of a decomposition
+      // are latency-bound persistent workgroups there and take the composed route instead)
+      if (tm == 4 || (tm == 0 && ((d->filt_len <= 6 && vol >= (int64_t(1) << 22)) || (d->filt_len == 8 && vol >= (int64_t(1) << 20))))) return kDwt3FwdWalk;
     }
     if (g_options[MIFWT_OPT_TILE_MODE] != 2 && dwt3_fwd_tile_supported(d)) return kDwt3FwdTile;
     if (plane3_route_ok(d, 0)) return kDwt3FwdStream;

@@ -251,7 +251,9 @@ bool rows_route_ok(const mifwt_level_desc* d, int direction) {
 }
 
 bool plane3_route_ok(const mifwt_level_desc* d, int direction) {
-  if (d->ndim != 3 || d->dtype != MIFWT_F32 || !rows_route_ok(d, direction)) return false;
+  // (f32, and since round 5 f64: the tile kernels compute doubles, the depth pass is the streaming axis kernel of either precision —
+  // two passes over the volume instead of the three single-axis passes f64 volumes took until then)
+  if (d->ndim != 3 || (d->dtype != MIFWT_F32 && d->dtype != MIFWT_F64) || !rows_route_ok(d, direction)) return false;
   bool foldable;
   const mifwt_level_desc p = plane_desc(d, d->sig_extent[0], &foldable);
   return direction == 0 ? dwt2_fwd_choice(&p) >= 0 : dwt2_inv_choice(&p) >= 0;
@@ -259,7 +261,7 @@ bool plane3_route_ok(const mifwt_level_desc* d, int direction) {
 
 size_t plane3_ws_bytes(const mifwt_level_desc* d, int direction) {
   (void)direction;  // analysis: [B, D, 4, Ho, Wo];  synthesis: [B, Dout, 4, Ho, Wo]
-  return (size_t)(4 * d->batch * d->sig_extent[0] * d->coef_extent[1] * d->coef_extent[2]) * sizeof(float);
+  return (size_t)(4 * d->batch * d->sig_extent[0] * d->coef_extent[1] * d->coef_extent[2]) * (size_t)elem_size(d->dtype);
 }
 
 size_t rows_ws_bytes(const mifwt_level_desc* d, int direction) {
@@ -287,7 +289,8 @@ size_t rows_ws_bytes(const mifwt_level_desc* d, int direction) {
 int plane3_fwd(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo,
                const double* hi, void* ws, hipStream_t stream) {
   const int64_t D = d->sig_extent[0], plane = d->coef_extent[1] * d->coef_extent[2];
-  float* scratch = static_cast<float*>(ws);  // [B, D, 4, Ho, Wo]
+  const int64_t esz = elem_size(d->dtype);
+  char* scratch = static_cast<char*>(ws);  // [B, D, 4, Ho, Wo] elements of the level's dtype (byte arithmetic below)
   bool foldable;
   const mifwt_level_desc p = plane_desc(d, D, &foldable);
   mifwt_level_desc pall = p;  // every slice of every volume in ONE launch: a two-level batch of the tile kernel's input
@@ -295,7 +298,7 @@ int plane3_fwd(const mifwt_level_desc* d, const void* x, void* approx, void* con
   if (!foldable && dwt2_fwd_tile_supported(&pall) && d->batch * D < (int64_t(1) << 31)) {
     // (the input of a deeper level is plane 0 of the previous level's [B, 8, D, H, W] buffer: volumes 8 D H W apart, slices H W apart —
     // one launch per volume cost 32 launches of 5 us each on 32 x 54^3, profiles/r03h_kernel_trace_refshapes.txt)
-    void* det[3] = {scratch + plane, scratch + 2 * plane, scratch + 3 * plane};
+    void* det[3] = {scratch + plane * esz, scratch + 2 * plane * esz, scratch + 3 * plane * esz};
     g_batch_split = {D, d->sig_stride[0]};
     const int rc = dwt2_fwd_tile(&pall, x, scratch, det, lo, hi, stream);
     g_batch_split = {0, 0};
@@ -303,9 +306,9 @@ int plane3_fwd(const mifwt_level_desc* d, const void* x, void* approx, void* con
   } else {
     const int64_t nb = foldable ? 1 : d->batch;
     for (int64_t b = 0; b < nb; ++b) {
-      const float* xb = static_cast<const float*>(x) + b * d->sig_stride[0];
-      float* sb = scratch + b * D * 4 * plane;
-      void* det[3] = {sb + plane, sb + 2 * plane, sb + 3 * plane};
+      const char* xb = static_cast<const char*>(x) + b * d->sig_stride[0] * esz;
+      char* sb = scratch + b * D * 4 * plane * esz;
+      void* det[3] = {sb + plane * esz, sb + 2 * plane * esz, sb + 3 * plane * esz};
       const int rc = dwt2_fwd_fused(&p, xb, sb, det, lo, hi, stream);
       if (rc != MIFWT_OK) return rc;
     }
@@ -314,7 +317,7 @@ int plane3_fwd(const mifwt_level_desc* d, const void* x, void* approx, void* con
   for (int s = 0; s < 4; ++s) {  // plane band s (axes H, W) -> bands s (depth low) and 4 + s (depth high)
     StreamJob& j = jobs[s];
     memset(&j, 0, sizeof(j));
-    j.in0 = scratch + s * plane;
+    j.in0 = scratch + s * plane * esz;
     set3(j.in0_s, D * 4 * plane, 4 * plane, 0);
     j.out0 = s == 0 ? approx : details[s - 1];
     j.out1 = details[s + 4 - 1];
@@ -335,13 +338,14 @@ int plane3_fwd(const mifwt_level_desc* d, const void* x, void* approx, void* con
   c.lo = lo;
   c.hi = hi;
   c.stream = stream;
-  return stream_call(MIFWT_F32, kOuterFwd, c);
+  return stream_call(d->dtype, kOuterFwd, c);
 }
 
 int plane3_inv(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y, const double* lo,
                const double* hi, void* ws, hipStream_t stream) {
   const int64_t Dout = d->sig_extent[0], plane = d->coef_extent[1] * d->coef_extent[2];
-  float* scratch = static_cast<float*>(ws);  // [B, Dout, 4, Ho, Wo]
+  const int64_t esz = elem_size(d->dtype);
+  char* scratch = static_cast<char*>(ws);  // [B, Dout, 4, Ho, Wo] elements of the level's dtype
   StreamJob jobs[4];
   for (int s = 0; s < 4; ++s) {
     StreamJob& j = jobs[s];
@@ -351,7 +355,7 @@ int plane3_inv(const mifwt_level_desc* d, const void* approx, const void* const*
     const int64_t* is = s == 0 ? d->approx_stride : d->detail_stride;
     set3(j.in0_s, is[0], is[1], 0);
     set3(j.in1_s, d->detail_stride[0], d->detail_stride[1], 0);
-    j.out0 = scratch + s * plane;
+    j.out0 = scratch + s * plane * esz;
     set3(j.out0_s, Dout * 4 * plane, 4 * plane, 0);
   }
   StreamCall c;
@@ -366,15 +370,15 @@ int plane3_inv(const mifwt_level_desc* d, const void* approx, const void* const*
   c.lo = lo;
   c.hi = hi;
   c.stream = stream;
-  int rc = stream_call(MIFWT_F32, kOuterInv, c);
+  int rc = stream_call(d->dtype, kOuterInv, c);
   if (rc != MIFWT_OK) return rc;
   bool foldable;
   const mifwt_level_desc p = plane_desc(d, Dout, &foldable);
   const int64_t nb = foldable ? 1 : d->batch;
   for (int64_t b = 0; b < nb; ++b) {
-    float* yb = static_cast<float*>(y) + b * d->sig_stride[0];
-    const float* sb = scratch + b * Dout * 4 * plane;
-    const void* det[3] = {sb + plane, sb + 2 * plane, sb + 3 * plane};
+    char* yb = static_cast<char*>(y) + b * d->sig_stride[0] * esz;
+    const char* sb = scratch + b * Dout * 4 * plane * esz;
+    const void* det[3] = {sb + plane * esz, sb + 2 * plane * esz, sb + 3 * plane * esz};
     rc = dwt2_inv_fused(&p, sb, det, yb, lo, hi, stream);
     if (rc != MIFWT_OK) return rc;
   }

@@ -324,7 +324,10 @@ def test_stream_routes_selected():
     assert kid(1, torch.float64, "reflect", 2, 1, (4096,)) == 3
     assert kid(3, torch.float32, "zero", 4, 8, (256, 256, 256)) == 24 and kid(3, torch.float32, "zero", 4, 8, (129, 129, 129)) == 9  # 3-D analysis: depth-walking kernel on big volumes (round 4), LDS bricks below
     assert kid(3, torch.float32, "zero", 8, 8, (256, 256, 256)) == 24 and kid(3, torch.float32, "zero", 12, 8, (256, 256, 256)) == 5 and kid(3, torch.float32, "zero", 4, 8, (256, 256, 256), direction=1) == 25 and kid(3, torch.float32, "zero", 4, 8, (64, 64, 64), direction=1) == 10 and kid(3, torch.float32, "zero", 10, 8, (256, 256, 256), direction=1) == 6
-    assert kid(3, torch.float64, "zero", 4, 2, (33, 34, 35)) == 3  # f64: inner pass + two outer passes
+    # f64 volumes (round 5): the composed route — the f64 tile kernel over every depth slice + one depth pass — instead of three axis passes
+    assert kid(3, torch.float64, "zero", 4, 2, (33, 34, 35)) == 5 and kid(3, torch.float64, "zero", 4, 2, (33, 34, 35), direction=1) == 6
+    assert kid(3, torch.float64, "zero", 24, 2, (60, 60, 60)) == 3  # f64, long filter: inner pass + two outer passes
+    assert kid(3, torch.float32, "zero", 8, 8, (54, 54, 54)) == 5  # 8 taps on a small volume: composed route, not the walking kernel
     assert kid(2, torch.float64, "reflect", 8, 2, (64, 64)) == 7 and kid(2, torch.float64, "reflect", 8, 2, (64, 64), direction=1) == 8  # f64 tiles
     assert kid(2, torch.float64, "reflect", 24, 2, (64, 64)) == 3  # f64, long filter: inner + outer pass
     assert kid(2, torch.float32, "symmetric", 32, 2, (300, 300)) == 7  # sym16 analysis: LDS-tile kernel
