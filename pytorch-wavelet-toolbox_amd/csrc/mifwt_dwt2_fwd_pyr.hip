@@ -523,7 +523,6 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
         if ((a.exp & 3) == 1) __builtin_amdgcn_s_setprio(1);
         if ((a.exp & 3) == 2) __builtin_amdgcn_s_setprio(2);
         if ((a.exp & 3) == 3) __builtin_amdgcn_s_setprio(3);
-        int ph = 0;  // pair index modulo L/2 of the next block
         // One row pair in each HALF of a step (a.l2split, round 5).  Until then a level-2 wave did a whole step's work (two pairs, ~330
         // instructions) behind the step's second barrier and sat out the first half: per-wave clocks had it waiting for about half of
         // its life, i.e. never in its own half — it was what the second half of every step waited for (a level-1 wave needs ~290
@@ -586,7 +585,10 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
             tsec[2] += __builtin_readcyclecounter() - t0;
           }
         };
-        auto half = [&](auto jj_tag, int s, const uint32_t (&so_r)[4]) {
+        // (the pair index modulo L/2 — the accumulators' slot rotation — is a COMPILE-TIME constant of every pair: a step takes two pairs,
+        // so the step loop is unrolled over the period of 2 k mod L/2.  Until round 5 a runtime switch picked one of L/2 variants of the
+        // pair's code per pair: a branch tree, and 14 accumulator copies per pair where the variants' register assignments met again)
+        auto half = [&](auto r_tag, auto jj_tag, int s, const uint32_t (&so_r)[4]) {
           constexpr int jj = decltype(jj_tag)::value;
           unsigned long long tp = 0;
           if constexpr (PROF) tp = __builtin_readcyclecounter();
@@ -598,12 +600,15 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
             wave_lds_fence();
           }
           if constexpr (PROF) tsec[3] += __builtin_readcyclecounter() - tp;
-          pyr_dispatch<HP>((ph + jj) % HP, [&](auto r_tag) { do_pair(r_tag, jj_tag, s, so_r); });
+          do_pair(r_tag, jj_tag, s, so_r);
         };
-#pragma unroll 1
-        for (int s = 0; s < nsteps; ++s) {
+        // one step: its two pairs have indices R0, R0 + 1 modulo L/2
+        auto step2 = [&](auto r0_tag, int s) {
+          constexpr int R0 = decltype(r0_tag)::value;
+          using RA = std::integral_constant<int, R0 % HP>;
+          using RB = std::integral_constant<int, (R0 + 1) % HP>;
           pyr_barrier<PROF>(waited);
-          const bool act = s >= D2 && 2 * (s - D2) < npair2 && !(a.dbg & 4);
+          const bool act = 2 * (s - D2) < npair2 && !(a.dbg & 4);
           uint32_t so_r[4] = {0u, 0u, 0u, 0u};  // ring-1 byte offsets of the step's four rows
           bool early = false;
           if (act) {
@@ -629,13 +634,28 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
             // (for the tail wave, which filters the same rows behind the step's second barrier)
             if (NW == 12 && widx == 0 && a.twave >= 0 && lane == 0) *reinterpret_cast<u4*>(smem) = (u4){so_r[0], so_r[1], so_r[2], so_r[3]};
             early = a.l2split && qmax0 <= 4 * s - 1;  // (written in an earlier step: complete behind this step's first barrier)
-            if (early) half(std::integral_constant<int, 0>{}, s, so_r);
+            if (early) half(RA{}, std::integral_constant<int, 0>{}, s, so_r);
           }
           pyr_barrier<PROF>(waited);  // level 1's first two rows of this step (and everything before) are in ring 1
           if (act) {
-            if (!early) half(std::integral_constant<int, 0>{}, s, so_r);
-            half(std::integral_constant<int, 1>{}, s, so_r);
-            ph = (ph + 2) % HP;
+            if (!early) half(RA{}, std::integral_constant<int, 0>{}, s, so_r);
+            half(RB{}, std::integral_constant<int, 1>{}, s, so_r);
+          }
+        };
+        {
+          int s = 0;
+#pragma unroll 1
+          for (; s < D2 && s < nsteps; ++s) {  // (the lag: level 1 has not produced the first rows yet)
+            pyr_barrier<PROF>(waited);
+            pyr_barrier<PROF>(waited);
+          }
+          constexpr int PERIOD = (HP % 2 == 0) ? (HP / 2 > 0 ? HP / 2 : 1) : HP;  // steps until 2 k mod L/2 repeats
+#pragma unroll 1
+          for (; s < nsteps; s += PERIOD) {
+            pyr_static_for<PERIOD>([&](auto k_tag) {
+              constexpr int k = decltype(k_tag)::value;
+              if (k == 0 || s + k < nsteps) step2(std::integral_constant<int, (2 * k) % HP>{}, s + k);
+            });
           }
         }
         if (PROF && widx == 0 && lane == 0) {
@@ -695,11 +715,11 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
             vfma_hi(hb[0], tap[L - 2 - 2 * k], wb[k]);
           }
         };
-        int ph = 0;
-#pragma unroll 1
-        for (int s = 0; s < nsteps; ++s) {
+        // (as in the level-2 waves: the pair index modulo L/2 is a compile-time constant, the step loop unrolled over its period)
+        auto step3 = [&](auto r_tag, int s) {
+          constexpr int R = decltype(r_tag)::value;  // (s - D3) mod L/2
           pyr_barrier<PROF>(waited);
-          if (s >= D3 && s - D3 < npair3 && !(a.dbg & 4)) {
+          if (s - D3 < npair3 && !(a.dbg & 4)) {
             uint32_t so_r[2];
             const int e0 = E2 + 2 * (s - D3);
             if (e0 >= 0 && e0 + 1 < a.H[2]) {
@@ -721,28 +741,39 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
               if (f_on) *reinterpret_cast<float*>(ring2 + fo + f_dst) = v;
               wave_lds_fence();
             }
-            pyr_dispatch<HP>(ph, [&](auto r_tag) {
-              constexpr int R = decltype(r_tag)::value;  // (s - D3) mod L/2
-              f2 w[2][HP];
-              load_win(ring2 + so_r[0] + win, w[0]);
-              load_win(ring2 + so_r[1] + win, w[1]);
-              f2 ha[1], hb[1];
-              h_pair(w[0], w[1], ha, hb);
-              acc.template feed<0, R>(tap, ha);
-              acc.template feed<1, R>(tap, hb);
-              const int i = rA[3] + (s - D3) - (HP - 1);
-              const f2 lo = acc.lo[PyrAcc<L, 1>::done(R)][0], hi = acc.hi[PyrAcc<L, 1>::done(R)][0];
-              const bool own = i >= oA[3] && i < oB[3];
-              const uint32_t v = own ? sv : kPyrOob;
-              const uint32_t so = own ? (uint32_t)i * (uint32_t)a.ds_h[2] * 4u : 0u;
-              pyr_store1(hi.x, rd, v, so + o0);
-              pyr_store1(lo.y, rd, v, so + o1b);
-              pyr_store1(hi.y, rd, v, so + o2);
-              pyr_store1(lo.x, ra, v, own ? (uint32_t)i * (uint32_t)a.as_h * 4u : 0u);
-            });
-            ph = ph + 1 == HP ? 0 : ph + 1;
+            f2 w[2][HP];
+            load_win(ring2 + so_r[0] + win, w[0]);
+            load_win(ring2 + so_r[1] + win, w[1]);
+            f2 ha[1], hb[1];
+            h_pair(w[0], w[1], ha, hb);
+            acc.template feed<0, R>(tap, ha);
+            acc.template feed<1, R>(tap, hb);
+            const int i = rA[3] + (s - D3) - (HP - 1);
+            const f2 lo = acc.lo[PyrAcc<L, 1>::done(R)][0], hi = acc.hi[PyrAcc<L, 1>::done(R)][0];
+            const bool own = i >= oA[3] && i < oB[3];
+            const uint32_t v = own ? sv : kPyrOob;
+            const uint32_t so = own ? (uint32_t)i * (uint32_t)a.ds_h[2] * 4u : 0u;
+            pyr_store1(hi.x, rd, v, so + o0);
+            pyr_store1(lo.y, rd, v, so + o1b);
+            pyr_store1(hi.y, rd, v, so + o2);
+            pyr_store1(lo.x, ra, v, own ? (uint32_t)i * (uint32_t)a.as_h * 4u : 0u);
           }
           pyr_barrier<PROF>(waited);
+        };
+        {
+          int s = 0;
+#pragma unroll 1
+          for (; s < D3 && s < nsteps; ++s) {
+            pyr_barrier<PROF>(waited);
+            pyr_barrier<PROF>(waited);
+          }
+#pragma unroll 1
+          for (; s < nsteps; s += HP) {
+            pyr_static_for<HP>([&](auto k_tag) {
+              constexpr int k = decltype(k_tag)::value;
+              if (k == 0 || s + k < nsteps) step3(k_tag, s + k);
+            });
+          }
         }
       }
     }
