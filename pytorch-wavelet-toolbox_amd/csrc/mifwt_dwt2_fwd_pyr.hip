@@ -169,7 +169,8 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
 
   // the chunk of this workgroup: rows [g_lo, g_hi) of the batch's level-NLEV rows laid end to end
   const int grp = blockIdx.x % a.ngroups;
-  const int chunk = blockIdx.x / a.ngroups;
+  int chunk = blockIdx.x / a.ngroups;
+  if (a.exp >> 16) chunk = (chunk + ((a.exp >> 16) & 15)) % (int)(gridDim.x / a.ngroups);  // (experiment: which chunk runs on which XCD)
   const uint32_t g_lo = a.wg_start[chunk], g_hi = a.wg_start[chunk + 1];
   if (g_lo >= g_hi) return;
   const bool zero_mode = a.mode == MIFWT_MODE_ZERO;
@@ -996,6 +997,7 @@ static int pyr_group_cols(int L, int nlev, bool first) {
 // starts behind one more barrier with cold staging buffers (kUnitStart).
 struct PyrGeom {
   int L, nlev, H[4];
+  int parity;  // 1: chunk k runs on XCD k mod 8 (one column group) — the odd XCDs are the slower ones, see pyr_cut
 };
 constexpr double kUnitStart = 1.0;
 static double pyr_unit_time(const PyrGeom& gm, int u_lo, int u_hi) {
@@ -1030,6 +1032,9 @@ static int pyr_cut(const PyrGeom& gm, int64_t B, double budget, int gmax, uint32
   int64_t img = 0;
   int row = 0, n = 0;
   if (cut) cut[0] = 0;
+  // (XCD-aware budgets were measured and dropped, round 5: workgroup b runs on XCD b mod 8 and the workgroups of the ODD XCDs end 3-5 us
+  // (of ~92) behind those of the even ones whatever rows they are given — but giving odd chunks 2-4 % less to do bought nothing with
+  // the results dropped, 99.1 -> 98.8 us, and cost 2 us with rotating outputs: profiles/r05u_xcd_parity.txt)
   while (img < B) {
     if (n == gmax) return gmax + 1;
     double used = 0;
@@ -1074,7 +1079,7 @@ static void pyr_schedule(const PyrGeom& gm, int64_t B, int gwant, PyrPlan* p) {
   // a small cache (a call loop asks for the same few schedules over and over — a five-level call of the reference's shape takes this
   // kernel for two of its levels; the search below is ~0.1 ms)
   struct Entry {
-    int L, nlev, H[4], gwant, ex, n;
+    int L, nlev, H[4], gwant, ex, n, parity;
     int64_t B;
     uint32_t cut[kPyrMaxWG + 1];
   };
@@ -1084,7 +1089,7 @@ static void pyr_schedule(const PyrGeom& gm, int64_t B, int gwant, PyrPlan* p) {
   static int used = 0, next = 0;
   const int ex = g_options[MIFWT_OPT_EXP];
   auto same = [&](const Entry& e) {
-    return e.L == gm.L && e.nlev == gm.nlev && e.H[1] == gm.H[1] && e.H[2] == gm.H[2] && e.H[3] == gm.H[3] && e.gwant == gwant && e.ex == ex && e.B == B;
+    return e.L == gm.L && e.nlev == gm.nlev && e.H[1] == gm.H[1] && e.H[2] == gm.H[2] && e.H[3] == gm.H[3] && e.gwant == gwant && e.ex == ex && e.parity == gm.parity && e.B == B;
   };
   {
     std::lock_guard<std::mutex> lk(mu);
@@ -1110,7 +1115,7 @@ static void pyr_schedule(const PyrGeom& gm, int64_t B, int gwant, PyrPlan* p) {
     Entry& e = cache[next];
     next = (next + 1) % kEntries;
     used = std::min(used + 1, kEntries);
-    e.L = gm.L, e.nlev = gm.nlev, e.gwant = gwant, e.ex = ex, e.B = B, e.n = p->nwg;
+    e.L = gm.L, e.nlev = gm.nlev, e.gwant = gwant, e.ex = ex, e.B = B, e.n = p->nwg, e.parity = gm.parity;
     for (int l = 0; l < 4; ++l) e.H[l] = gm.H[l];
     std::copy(p->wg_start, p->wg_start + p->nwg + 1, e.cut);
   }
@@ -1224,6 +1229,7 @@ static bool pyr_plan(int nlev, const mifwt_level_desc* const* d, PyrPlan* p) {
   PyrGeom gm;
   gm.L = L;
   gm.nlev = nlev;
+  gm.parity = p->ngroups == 1 ? 1 : 0;
   gm.H[0] = (int)d[0]->sig_extent[0];
   for (int l = 1; l <= 3; ++l) gm.H[l] = l <= nlev ? (int)d[l - 1]->coef_extent[0] : 0;
   const int64_t rows = d[0]->batch * (int64_t)HN;

@@ -10,6 +10,8 @@ lib = _engine.load_library()
 lib.mifwt_pyr_profile_buffer.argtypes = [ctypes.c_void_p]
 xs = [torch.randn(B, 1024, 1024, device='cuda') for _ in range(3)]
 if dbg: _engine.set_option(11, dbg)
+ex = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+if ex: _engine.set_option(15, ex)
 for i in range(10): ptwt_amd.wavedec2(xs[i % 3], 'db4', level=3)
 torch.cuda.synchronize()
 nl = 6
@@ -30,7 +32,7 @@ for k in range(nl):
     used = b[:, 8, 0] > 0
     st, en = b[used, 8, 0].double() / 100.0, b[used, 8, 1].double() / 100.0  # us
     t0 = st.min()
-    seg = torch.arange(nwg)[used] % 4
+    seg = (b[used, 13, 0] % 134 > 0).long() * 0 + torch.div(b[used, 13, 0] % 134, 33, rounding_mode='floor').clamp(max=3)  # segment of the image from the chunk's first row
     line = f' launch {k}: {int(used.sum())} WGs; starts +0 .. +{st.max() - t0:.1f} us; ends +{en.min() - t0:.1f} .. +{en.max() - t0:.1f} us (median {en.median() - t0:.1f})'
     if prev_end is not None: line += f'; gap after previous launch\'s last end {t0 - prev_end:.1f} us'
     prev_end = en.max()
@@ -53,6 +55,9 @@ for k in range(nl):
             d = (en - st)[m]
             print(f'   segment {s}: start +{(st[m] - t0).mean():.1f} (max {(st[m] - t0).max():.1f}), duration mean {d.mean():.1f} min {d.min():.1f} max {d.max():.1f}, end mean +{(en[m] - t0).mean():.1f} max +{(en[m] - t0).max():.1f}')
         xcc = b[used, 12, 1] & 15
+        dur = (en - st)
+        print('   duration by XCC: ' + '  '.join(f'{i}: {dur[xcc == i].mean():.1f}' for i in range(8)))
+        print('   duration by image (first 8): ' + '  '.join(f'{dur[torch.arange(len(dur)) // 4 == i].mean():.1f}' for i in range(8)))
         hw = b[used, 12, 0]
         print('   WGs per XCC:', [int((xcc == i).sum()) for i in range(8)], ' distinct (xcc, se, sh, cu):', len(set(zip(xcc.tolist(), ((hw >> 13) & 7).tolist(), ((hw >> 12) & 1).tolist(), ((hw >> 8) & 15).tolist()))))
         roles = {0: 'L1.1', 1: 'L1.0(left edge)', 2: 'L1.3', 3: 'L1.4(right edge, 2 lanes)', 4: 'L1.2', 5: 'L2.0', 6: 'L2.1', 7: 'L2.2', 9: 'L3.0', 10: 'L3.1', 11: 'L3.2'}
