@@ -454,11 +454,14 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
     const uint32_t svr = nrag ? 16u * (uint32_t)G : kPyrOob;
     const uint32_t win = 8u * (uint32_t)Gr;
     constexpr int NB1 = NLEV == 1 ? 4 : 3;
-    int eb = 0, ph = 0;
-#pragma unroll 1
-    for (int t = 0; t < nsub; ++t) {
+    int eb = 0;
+    // (round 5: the phase of a sub-step's two coefficient rows — the accumulators' slot rotation — is a COMPILE-TIME constant: the
+    // sub-step loop is unrolled over the period of 2 k mod L/2 instead of switching between L/2 variants of the body at run time,
+    // which cost a branch tree and a dozen accumulator copies per sub-step where the variants' register assignments met again;
+    // as in the analysis kernel, mifwt_dwt2_fwd_pyr.hip)
+    auto substep1 = [&](auto r0_tag, int t) {
       __syncthreads();
-      if (t >= T1 && !(a.dbg & 4)) {
+      if (!(a.dbg & 4)) {
         const int r1 = ra[1] + 2 * (t - T1);
         const unsigned char* ent = smem + stage_off + eb * a.entry_bytes + a.offL[0];
         const unsigned char* src[2][4];
@@ -469,7 +472,7 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
             if (b == 0 && NLEV >= 2) src[j][b] = smem + ring1_off + ((r1 + j) & (kIpRing1 - 1)) * a.pitchR[0] + win;
             else src[j][b] = ent + (2 * (b - (4 - NB1)) + j) * a.pitchS[0] + win;
           }
-        ipyr_phase2<HL>(ph, [&](auto r0_tag) {
+        {
           rows2(r0_tag, src, [&](auto j_tag, auto slot_tag) {
             constexpr int j = decltype(j_tag)::value, slot = decltype(slot_tag)::value;
             const int p = r1 + j - (HL - 1);
@@ -489,10 +492,25 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
               }
             }
           });
-        });
-        ph = (ph + 2) % HL;
+        }
       }
       if (t >= TW) eb = eb + 1 == a.nbuf ? 0 : eb + 1;
+    };
+    {
+      int t = 0;
+#pragma unroll 1
+      for (; t < T1 && t < nsub; ++t) {  // (the lag: the coarser levels have not produced the first rows yet)
+        __syncthreads();
+        if (t >= TW) eb = eb + 1 == a.nbuf ? 0 : eb + 1;
+      }
+      constexpr int PERIOD = (HL % 2 == 0) ? (HL / 2 > 0 ? HL / 2 : 1) : HL;  // sub-steps until 2 k mod L/2 repeats
+#pragma unroll 1
+      for (; t < nsub; t += PERIOD) {
+        pyr_static_for<PERIOD>([&](auto k_tag) {
+          constexpr int k = decltype(k_tag)::value;
+          if (k == 0 || t + k < nsub) substep1(std::integral_constant<int, (2 * k) % HL>{}, t + k);
+        });
+      }
     }
     return;
   }
