@@ -94,6 +94,7 @@ WORKLOADS = {
     "wavedec2_db4_L3_64x1024x1024_f64": ("wavedec2", (64, 1024, 1024), "db4", 3, "reflect", torch.float64),
     "waverec2_db4_L3_64x1024x1024_f64": ("waverec2", (64, 1024, 1024), "db4", 3, "reflect", torch.float64),
     "wavedec3_db2_L3_8x256x256x256_f64": ("wavedec3", (8, 256, 256, 256), "db2", 3, "zero", torch.float64),
+    "waverec3_db2_L3_8x256x256x256_f64": ("waverec3", (8, 256, 256, 256), "db2", 3, "zero", torch.float64),
     # dry runs of the control flow (MIFWT_BENCH_DEVICE=cpu), not a benchmark shape
     "dryrun_wavedec2_db4_L2_6x96x96_f32": ("wavedec2", (6, 96, 96), "db4", 2, "reflect", torch.float32),
 }
@@ -256,7 +257,7 @@ SECONDARY = ["waverec2_db4_L3_64x1024x1024_f32", "wavedec3_db2_L3_8x256x256x256_
              "wavedec2_db8_L4_64x4096x4096_f32", "waverec2_db8_L4_64x4096x4096_f32", "wavedec2_bwd_db4_L3_64x1024x1024_f32",
              # round 5: config 5's per-GPU slice both ways, the f64 forms of configs 2 / 3, the reference's own published shapes
              "fswavedec2_sym16_L5_32x8192x8192_f16", "fswaverec2_sym16_L5_32x8192x8192_f16",
-             "wavedec2_db4_L3_64x1024x1024_f64", "wavedec3_db2_L3_8x256x256x256_f64",
+             "wavedec2_db4_L3_64x1024x1024_f64", "wavedec3_db2_L3_8x256x256x256_f64", "waverec3_db2_L3_8x256x256x256_f64",
              "wavedec2_db5_L5_32x1000x1000_f32_periodic", "wavedec3_db5_L3_32x100x100x100_f32_periodic"]
 
 

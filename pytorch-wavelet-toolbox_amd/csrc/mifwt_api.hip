@@ -249,6 +249,11 @@ int pick_kernel(const mifwt_level_desc* d, int direction) {
       // (8 taps: from ~1 M samples on — the one measurement is 16 x 128^3; small 8-tap volumes such as the deep levels of a decomposition
       // are latency-bound persistent workgroups there and take the composed route instead)
       if (tm == 4 || (tm == 0 && ((d->filt_len <= 6 && vol >= (int64_t(1) << 22)) || (d->filt_len == 8 && vol >= (int64_t(1) << 20))))) return kDwt3FwdWalk;
+      // f64 has no bricks: the walk kernel against the composed route (planes + depth pass) — 8 x 256^3 / 129^3 / 66^3 / 40^3, us: db2 444 / 69 /
+      // 17 / 14 against 945 / 158 / 25 / 25; db3 547 / 91 / 22 / 20 against 947 / 166 / 34 / 18; db4 733 / 155 / 35 / 29 against 1019 / 170 /
+      // 28 / 27; db5 1033 / 225 / 63 / 38 against 979 / 184 / 40 / 21 (profiles/r05w_f64_walk_vs_planes.txt)
+      if (tm == 0 && d->dtype == MIFWT_F64 && d->filt_len <= 8 && vol >= (int64_t(1) << (d->filt_len <= 4 ? 15 : d->filt_len == 6 ? 17 : 19)))
+        return kDwt3FwdWalk;
     }
     if (g_options[MIFWT_OPT_TILE_MODE] != 2 && dwt3_fwd_tile_supported(d)) return kDwt3FwdTile;
     if (plane3_route_ok(d, 0)) return kDwt3FwdStream;
@@ -264,6 +269,9 @@ int pick_kernel(const mifwt_level_desc* d, int direction) {
       const int tm = g_options[MIFWT_OPT_TILE_MODE];
       const int64_t vol = d->sig_extent[0] * d->sig_extent[1] * d->sig_extent[2];
       if (tm == 4 || (tm == 0 && vol >= (int64_t(1) << 20))) return kDwt3InvWalk;
+      // f64 (no bricks), same file: db2 421 / 66 / 17 / 17 against 926 / 152 / 24 / 14; db3 592 / 102 / 29 / 28 against 942 / 163 / 28 / 18;
+      // db4 — / 145 / 44 / 30 against 981 / 171 / 27 / 15 (a row group's pieces of 256^3 exceed 5 KiB)
+      if (tm == 0 && d->dtype == MIFWT_F64 && vol >= (int64_t(1) << (d->filt_len <= 4 ? 16 : 19))) return kDwt3InvWalk;
     }
     if (g_options[MIFWT_OPT_TILE_MODE] != 2 && dwt3_inv_tile_supported(d)) return kDwt3InvTile;
     if (plane3_route_ok(d, 1)) return kDwt3InvStream;

@@ -17,23 +17,25 @@
 //   * boundary extension: slices and rows through the index map of the request (zero mode: requests through an empty resource land
 //     zeros), pad columns filled in LDS by the waves that read them;  every mode, periodic included (a level needs nothing but
 //     index maps), even L <= 10.
-// Algorithmic traffic: 4 B D H W read + 8 * 4 B Do Ho Wo written.
+// f32 and f64 (template parameter T; f64: rows of at most 256 samples — a staged row is one or two 1-KiB requests either way — and two
+// v_fma_f64 where f32 has one packed FMA).
+// Algorithmic traffic: sizeof(T) (B D H W read + 8 B Do Ho Wo written).
 #include "mifwt_pyr.h"
 
 namespace mifwt {
 
 namespace {
 
-constexpr int kW3Pad = 8;        // floats behind a staged row's body (the right pad samples: at most L - 1)
-// floats in front of it (the L - 2 left pad samples; the body stays 16-byte aligned).  Four for filters up to six taps: five staged slices
+constexpr int kW3Pad = 8;        // samples behind a staged row's body (the right pad samples: at most L - 1)
+// samples in front of it (the L - 2 left pad samples; the body stays 16-byte aligned).  Four for filters up to six taps: five staged slices
 // of ten 256-sample rows are then 53 600 bytes, and THREE workgroups fit a CU's 160 KB (with eight: 54 400, two)
 constexpr int walk3_lpad(int L) { return L <= 6 ? 4 : 8; }
 constexpr int kW3MaxStrips = 4;  // compute waves per workgroup
 
-template <int L>
+template <typename T, int L>
 struct Walk3Args {
-  const float* x;
-  float* out[8];  // band s: bit 2 = depth high, bit 1 = row high, bit 0 = column high
+  const T* x;
+  T* out[8];  // band s: bit 2 = depth high, bit 1 = row high, bit 0 = column high
   int64_t xs_b, os_b[2];  // batch strides: input; [0] approximation, [1] details
   uint32_t xs_d, xs_h;
   uint32_t os_d[2], os_h[2];
@@ -44,7 +46,7 @@ struct Walk3Args {
   int nslots;         // staged slices
   int mode, nt, dbg;
   FastDiv div_g, div_s;
-  f2 tap[L];
+  typename TileArith<T>::vec2 tap[L];
 };
 
 template <int N>
@@ -78,21 +80,28 @@ __device__ __forceinline__ void walk3_dma_row(const uint32_t (&voff)[3], rsrc_t 
   }
 }
 
-// a staged row: BODY samples (128, 160, 256 or 512: one request of BODY / 4 lanes, or two of 1 KiB) between two pads
-constexpr int walk3_pitch(int L, int BODY) { return (walk3_lpad(L) + BODY + kW3Pad) * 4; }
-constexpr int walk3_nreq(int BODY) { return BODY > 256 ? 2 : 1; }
+// a staged row: BODY samples of ES bytes (f32: 128, 160, 256 or 512; f64: 128 or 256 — one request of BODY ES / 16 lanes, or two of
+// 1 KiB) between two pads
+constexpr int walk3_pitch(int L, int BODY, int ES) { return (walk3_lpad(L) + BODY + kW3Pad) * ES; }
+constexpr int walk3_nreq(int BODY, int ES) { return BODY * ES > 1024 ? 2 : 1; }
 // loader waves: the requests of four slices ahead must fit a wave's vmcnt counter (63)
-constexpr int walk3_nload(int IRW, int BODY) { return IRW * walk3_nreq(BODY) * 4 > 63 ? 2 : 1; }
+constexpr int walk3_nload(int IRW, int BODY, int ES) { return IRW * walk3_nreq(BODY, ES) * 4 > 63 ? 2 : 1; }
 constexpr int kW3MaxWaves = 10;  // compute waves (column strips x row sub-groups, at most 8) + loaders
 
-template <int L, int TR, int BODY, int NRG>
-__global__ void __launch_bounds__(64 * kW3MaxWaves) dwt3_fwd_walk_kernel(const Walk3Args<L> a) {
+// (f64: one row sub-group, so at most 4 + 2 waves — and the 256 VGPRs that leaves a wave hold the accumulators without scratch)
+template <typename T> constexpr int walk3_max_waves() { return sizeof(T) == 8 ? 6 : kW3MaxWaves; }
+
+template <typename T, int L, int TR, int BODY, int NRG>
+__global__ void __launch_bounds__(64 * walk3_max_waves<T>()) dwt3_fwd_walk_kernel(const Walk3Args<T, L> a) {
+  using V2 = typename TileArith<T>::vec2;
+  constexpr int ES = (int)sizeof(T);
   // a workgroup owns NRG row sub-groups of TR output rows: compute wave w filters strip w % nstrips of sub-group w / nstrips
   constexpr int HL = L - 2, HP = L / 2, IR = 2 * TR + HL, NC = 2 * TR;
   constexpr int IRW = 2 * TR * NRG + HL;  // staged rows of a slice
-  constexpr int PITCH = walk3_pitch(L, BODY);
+  constexpr int PITCH = walk3_pitch(L, BODY, ES);
   constexpr int SLAB = IRW * PITCH;
-  constexpr int NLOAD = walk3_nload(IRW, BODY), NCHE = walk3_nreq(BODY);
+  constexpr int NLOAD = walk3_nload(IRW, BODY, ES), NCHE = walk3_nreq(BODY, ES);
+  static_assert(BODY * ES <= 2048 && PITCH % 16 == 0, "a staged row is at most two 1-KiB requests; rows stay 16-byte aligned");
   static_assert(IRW % NLOAD == 0, "the loaders take every NLOAD-th row: equal shares");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -114,10 +123,10 @@ __global__ void __launch_bounds__(64 * kW3MaxWaves) dwt3_fwd_walk_kernel(const W
   if (wave >= ncomp) {
     const int l = wave - ncomp;
     constexpr int NR = IRW / NLOAD;
-    const uint32_t vol_bytes = (uint32_t)(((int64_t)(a.D - 1) * a.xs_d + (int64_t)(a.H - 1) * a.xs_h + a.W) * 4);
+    const uint32_t vol_bytes = (uint32_t)(((int64_t)(a.D - 1) * a.xs_d + (int64_t)(a.H - 1) * a.xs_h + a.W) * ES);
     const rsrc_t xr = pyr_rsrc(a.x + (int64_t)img * a.xs_b, vol_bytes);
     const rsrc_t xr_dead = pyr_rsrc(a.x + (int64_t)img * a.xs_b, 0);  // every lane out of range: zeros land
-    const uint32_t row_bytes = a.xs_h * 4u, slice_bytes = a.xs_d * 4u;
+    const uint32_t row_bytes = a.xs_h * (uint32_t)ES, slice_bytes = a.xs_d * (uint32_t)ES;
     const int r_first = 2 * j0 - HL;
     const int nr_need = 2 * (min(j0 + TR * NRG, a.Ho) - j0) + HL;
     uint32_t roff[NR];
@@ -132,14 +141,14 @@ __global__ void __launch_bounds__(64 * kW3MaxWaves) dwt3_fwd_walk_kernel(const W
     uint32_t voff[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int c = 256 * j + 4 * lane;
-      voff[j] = (j < NCHE && c < a.W) ? 4u * (uint32_t)c : kPyrOob;
+      const int cb = 1024 * j + 16 * lane;  // byte offset of this lane's 16 bytes inside the row
+      voff[j] = (j < NCHE && cb < a.W * ES) ? (uint32_t)cb : kPyrOob;
     }
     __builtin_amdgcn_s_setprio(3);
     constexpr int PER = NR * NCHE;
     int ib = 0;  // slot of the next slice to be requested
     auto issue = [&](int t) {
-      const uint32_t buf = (uint32_t)ib * (uint32_t)SLAB + walk3_lpad(L) * 4u;
+      const uint32_t buf = (uint32_t)ib * (uint32_t)SLAB + (uint32_t)(walk3_lpad(L) * ES);
       ib = ib + 1 == a.nslots ? 0 : ib + 1;
       if (a.dbg & 2) return;
       const int e = E0 + t;
@@ -151,8 +160,8 @@ __global__ void __launch_bounds__(64 * kW3MaxWaves) dwt3_fwd_walk_kernel(const W
         const uint32_t so = __builtin_amdgcn_readfirstlane(sbase + roff[i]), la = __builtin_amdgcn_readfirstlane(buf + (uint32_t)((l + NLOAD * i) * PITCH));
         // default cache policy: the first and last L - 2 rows are staged by the row groups next door as well, about now, and a non-temporal
         // request does not leave them in L2 for the neighbour (config 3, level 1: HBM reads 1.23 x the volume and 261 us, against 227 us)
-        if constexpr (BODY < 256) {
-          if (lane < BODY / 4) walk3_dma_row<1, false>(voff, dead ? xr_dead : xr, so, la);  // masked lanes write nothing: 4 BODY bytes land
+        if constexpr (BODY * ES < 1024) {
+          if (lane < BODY * ES / 16) walk3_dma_row<1, false>(voff, dead ? xr_dead : xr, so, la);  // masked lanes write nothing: BODY ES bytes land
         } else {
           if (a.dbg & 16) walk3_dma_row<NCHE, true>(voff, dead ? xr_dead : xr, so, la);
           else walk3_dma_row<NCHE, false>(voff, dead ? xr_dead : xr, so, la);
@@ -182,47 +191,47 @@ __global__ void __launch_bounds__(64 * kW3MaxWaves) dwt3_fwd_walk_kernel(const W
   const bool first = strip == 0, last = strip == a.nstrips - 1;
   const int nrp = 2 * a.Wo - a.W;  // pad samples behind a row (0 .. L - 1)
 
-  float* obase[8];
+  T* obase[8];
 #pragma unroll
   for (int b = 0; b < 8; ++b) obase[b] = a.out[b] + (int64_t)img * a.os_b[b == 0 ? 0 : 1];
 
-  PyrAcc<L, NC> acc;
+  PyrAcc<L, NC, V2> acc;
   acc.clear();
   int slot = 0;
 
   // one slice: pads, W pass, H pass -> hv[2 j] = (Ha Wa, Hd Wa), hv[2 j + 1] = (Ha Wd, Hd Wd) of row j
-  auto filter_slice = [&](f2 (&hv)[NC]) {
+  auto filter_slice = [&](V2 (&hv)[NC]) {
     unsigned char* const sl = smem + slot * SLAB + sub * (2 * TR * PITCH);  // the wave's 2 TR + L - 2 rows
     slot = slot + 1 == a.nslots ? 0 : slot + 1;
     if constexpr (HL > 0) {
       if (first)
       for (int it = lane; it < IR * HL; it += 64) {
         const int r = it / HL, i = it - r * HL;
-        float* row = reinterpret_cast<float*>(sl + r * PITCH) + walk3_lpad(L);
-        row[i - HL] = zero_mode ? 0.f : row[fold(i - HL, a.W)];
+        T* row = reinterpret_cast<T*>(sl + r * PITCH) + walk3_lpad(L);
+        row[i - HL] = zero_mode ? T(0) : row[fold(i - HL, a.W)];
       }
     }
     if (last && nrp > 0) {
       for (int it = lane; it < IR * nrp; it += 64) {
         const int r = it / nrp, i = it - r * nrp;
-        float* row = reinterpret_cast<float*>(sl + r * PITCH) + walk3_lpad(L);
-        row[a.W + i] = zero_mode ? 0.f : row[fold(a.W + i, a.W)];
+        T* row = reinterpret_cast<T*>(sl + r * PITCH) + walk3_lpad(L);
+        row[a.W + i] = zero_mode ? T(0) : row[fold(a.W + i, a.W)];
       }
     }
     wave_lds_fence();
     if (a.dbg & 4) {
 #pragma unroll
-      for (int c = 0; c < NC; ++c) hv[c] = (f2){1.f, 2.f};
+      for (int c = 0; c < NC; ++c) hv[c] = (V2){T(1), T(2)};
       return;
     }
-    f2 rowv[IR];  // (W-low, W-high) of column k, row i
-    const unsigned char* wb = sl + (walk3_lpad(L) + 2 * kk - HL) * 4;
+    V2 rowv[IR];  // (W-low, W-high) of column k, row i
+    const unsigned char* wb = sl + (walk3_lpad(L) + 2 * kk - HL) * ES;
 #pragma unroll
     for (int i = 0; i < IR; ++i) {
-      const f2* row = reinterpret_cast<const f2*>(wb + i * PITCH);
+      const V2* row = reinterpret_cast<const V2*>(wb + i * PITCH);
 #pragma unroll
       for (int p = 0; p < HP; ++p) {
-        const f2 xx = row[p];  // samples 2 k - HL + 2 p, + 1  <->  taps L - 1 - 2 p, L - 2 - 2 p
+        const V2 xx = row[p];  // samples 2 k - HL + 2 p, + 1  <->  taps L - 1 - 2 p, L - 2 - 2 p
         if (p == 0) rowv[i] = vmul_lo(a.tap[L - 1], xx);
         else vfma_lo(rowv[i], a.tap[L - 1 - 2 * p], xx);
         vfma_hi(rowv[i], a.tap[L - 2 - 2 * p], xx);
@@ -232,7 +241,7 @@ __global__ void __launch_bounds__(64 * kW3MaxWaves) dwt3_fwd_walk_kernel(const W
     for (int j = 0; j < TR; ++j) {
 #pragma unroll
       for (int m = 0; m < L; ++m) {
-        const f2 v = rowv[2 * j + (L - 1) - m];
+        const V2 v = rowv[2 * j + (L - 1) - m];
         if (m == 0) {
           hv[2 * j] = vmul_lo(a.tap[0], v);
           hv[2 * j + 1] = vmul_hi(a.tap[0], v);
@@ -293,7 +302,7 @@ __global__ void __launch_bounds__(64 * kW3MaxWaves) dwt3_fwd_walk_kernel(const W
         done = true;
         return;
       }
-      f2 hv[NC];
+      V2 hv[NC];
       __syncthreads();
       filter_slice(hv);
       acc.template feed<0, R>(a.tap, hv);
@@ -301,20 +310,21 @@ __global__ void __launch_bounds__(64 * kW3MaxWaves) dwt3_fwd_walk_kernel(const W
       filter_slice(hv);
       acc.template feed<1, R>(a.tap, hv);
       const int z = zA + p - (HP - 1);
-      if (p >= HP - 1 && z < zB) emit(std::integral_constant<int, PyrAcc<L, NC>::done(R)>{}, z);
+      if (p >= HP - 1 && z < zB) emit(std::integral_constant<int, PyrAcc<L, NC, V2>::done(R)>{}, z);
     });
   }
 }
 
-template <int L, int TR, int BODY, int NRG>
+template <typename T, int L, int TR, int BODY, int NRG>
 int launch_walk3(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo, const double* hi,
                  hipStream_t stream) {
   constexpr int HL = L - 2, IRW = 2 * TR * NRG + HL;
-  constexpr int PITCH = walk3_pitch(L, BODY), SLAB = IRW * PITCH;
-  constexpr int NLOAD = walk3_nload(IRW, BODY), PER = IRW / NLOAD * walk3_nreq(BODY);
-  Walk3Args<L> a;
-  a.x = static_cast<const float*>(x);
-  for (int s = 0; s < 8; ++s) a.out[s] = static_cast<float*>(s == 0 ? approx : details[s - 1]);
+  constexpr int ES = (int)sizeof(T);
+  constexpr int PITCH = walk3_pitch(L, BODY, ES), SLAB = IRW * PITCH;
+  constexpr int NLOAD = walk3_nload(IRW, BODY, ES), PER = IRW / NLOAD * walk3_nreq(BODY, ES);
+  Walk3Args<T, L> a;
+  a.x = static_cast<const T*>(x);
+  for (int s = 0; s < 8; ++s) a.out[s] = static_cast<T*>(s == 0 ? approx : details[s - 1]);
   a.xs_b = d->sig_stride[0];
   a.xs_d = (uint32_t)d->sig_stride[1];
   a.xs_h = (uint32_t)d->sig_stride[2];
@@ -332,15 +342,23 @@ int launch_walk3(const mifwt_level_desc* d, const void* x, void* approx, void* c
   a.Wo = (int)d->coef_extent[2];
   a.mode = d->mode;
   a.nt = g_options[MIFWT_OPT_NT_STORE];
-  a.dbg = g_options[MIFWT_OPT_DEBUG] & 31;
-  for (int m = 0; m < L; ++m) a.tap[m] = (f2){(float)lo[m], (float)hi[m]};
+  a.dbg = g_options[MIFWT_OPT_DEBUG] & 31;  // (bits 6, 7: the strip layout, above)
+  for (int m = 0; m < L; ++m) a.tap[m] = (typename TileArith<T>::vec2){(T)lo[m], (T)hi[m]};
   a.nstrips = (a.Wo + 63) / 64;
   a.nq = (g_options[MIFWT_OPT_DEBUG] & 64) ? 64 : (a.Wo + a.nstrips - 1) / a.nstrips;
+  if ((g_options[MIFWT_OPT_DEBUG] & 128) && a.Wo > 64 && a.Wo % 64 != 0) {  // (timing experiment, results wrong: the columns behind the last full strip of 64 are not computed)
+    a.nstrips = a.Wo / 64;
+    a.nq = 64;
+  }
+  if (const int ns = g_options[MIFWT_OPT_EXP] & 15; ns > 0 && ns * NRG <= 8 && ns <= a.Wo) {  // (experiment: narrower strips, more waves)
+    a.nstrips = ns;
+    a.nq = (a.Wo + ns - 1) / ns;
+  }
   a.ngroups = (a.Ho + TR * NRG - 1) / (TR * NRG);
   // staged slices: four ahead of the one being filtered (config 3 level 1: 2 / 3 / 4 / 5 / 6 ahead = 271 / 259 / 241 / 252 / 256 us)
   // (volumes below ~4 M samples are latency-bound: workgroups per CU beat depth — 8 x 129^3, 1 / 2 / 3 / 4 ahead: 37 / 34 / 50 / 46 us)
   const int64_t in_vol = d->sig_extent[0] * d->sig_extent[1] * d->sig_extent[2];
-  int nslots = (L == 10 || in_vol < (int64_t(1) << 22)) ? 3 : 5;
+  int nslots = (L == 10 || in_vol < (int64_t(1) << 22) || ES == 8) ? 3 : 5;  // (f64: three slices of 2-KiB rows leave two workgroups per CU)
   if (g_options[MIFWT_OPT_PREFETCH_PAIRS] > 0) nslots = g_options[MIFWT_OPT_PREFETCH_PAIRS] + 1;
   if (nslots < 2) nslots = 2;
   if (nslots > 7) nslots = 7;
@@ -368,9 +386,9 @@ int launch_walk3(const mifwt_level_desc* d, const void* x, void* approx, void* c
   const int64_t nblk = base * a.nseg;
   if (nblk > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
   static DynLdsOnce lds_once;
-  if (!lds_once.ensure(reinterpret_cast<const void*>(&dwt3_fwd_walk_kernel<L, TR, BODY, NRG>), 7 * SLAB > 160 * 1024 ? 160 * 1024 : 7 * SLAB))
+  if (!lds_once.ensure(reinterpret_cast<const void*>(&dwt3_fwd_walk_kernel<T, L, TR, BODY, NRG>), 7 * SLAB > 160 * 1024 ? 160 * 1024 : 7 * SLAB))
     return MIFWT_ERR_LAUNCH;
-  hipLaunchKernelGGL((dwt3_fwd_walk_kernel<L, TR, BODY, NRG>), dim3((unsigned)nblk), dim3(64 * (a.nstrips * NRG + NLOAD)), lds_bytes, stream, a);
+  hipLaunchKernelGGL((dwt3_fwd_walk_kernel<T, L, TR, BODY, NRG>), dim3((unsigned)nblk), dim3(64 * (a.nstrips * NRG + NLOAD)), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 
@@ -385,16 +403,34 @@ int launch_walk3_l(const mifwt_level_desc* d, const void* x, void* approx, void*
   int nrg = (L == 10 && nstrips <= 2) ? 2 : 1;
   if (g_options[MIFWT_OPT_PAIR_ROWS] > 0) nrg = g_options[MIFWT_OPT_PAIR_ROWS];
   const bool two = nrg >= 2 && L == 10 && nstrips <= 4;  // (instantiated for ten taps only)
-  if (W <= 128) return two ? launch_walk3<L, TR, 128, (L == 10 ? 2 : 1)>(d, x, approx, details, lo, hi, stream) : launch_walk3<L, TR, 128, 1>(d, x, approx, details, lo, hi, stream);
-  if (W <= 160) return two ? launch_walk3<L, TR, 160, (L == 10 ? 2 : 1)>(d, x, approx, details, lo, hi, stream) : launch_walk3<L, TR, 160, 1>(d, x, approx, details, lo, hi, stream);
-  if (W <= 256) return two ? launch_walk3<L, TR, 256, (L == 10 ? 2 : 1)>(d, x, approx, details, lo, hi, stream) : launch_walk3<L, TR, 256, 1>(d, x, approx, details, lo, hi, stream);
-  return launch_walk3<L, TR, 512, 1>(d, x, approx, details, lo, hi, stream);
+  if (W <= 128) return two ? launch_walk3<float, L, TR, 128, (L == 10 ? 2 : 1)>(d, x, approx, details, lo, hi, stream) : launch_walk3<float, L, TR, 128, 1>(d, x, approx, details, lo, hi, stream);
+  if (W <= 160) return two ? launch_walk3<float, L, TR, 160, (L == 10 ? 2 : 1)>(d, x, approx, details, lo, hi, stream) : launch_walk3<float, L, TR, 160, 1>(d, x, approx, details, lo, hi, stream);
+  if (W <= 256) return two ? launch_walk3<float, L, TR, 256, (L == 10 ? 2 : 1)>(d, x, approx, details, lo, hi, stream) : launch_walk3<float, L, TR, 256, 1>(d, x, approx, details, lo, hi, stream);
+  return launch_walk3<float, L, TR, 512, 1>(d, x, approx, details, lo, hi, stream);
+}
+
+// f64: rows of at most 256 samples (2 KiB = two requests), one row sub-group
+template <int L>
+int launch_walk3_l64(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo, const double* hi,
+                     hipStream_t stream) {
+  constexpr int TR = L <= 4 ? 4 : 2;  // (six taps with four rows: 255 VGPRs and scratch)
+  if constexpr (L <= 4) {
+    // two output rows per workgroup on small volumes (8 x 66^3 db2: 17.0 against 22.5 us; 129^3: 68.2 against 66.6; 256^3: 465-505 against 443)
+    const int64_t vol = d->sig_extent[0] * d->sig_extent[1] * d->sig_extent[2];
+    if (g_options[MIFWT_OPT_TILE_ROWS] == 2 || (g_options[MIFWT_OPT_TILE_ROWS] == 0 && vol < (int64_t(1) << 20))) {
+      if (d->sig_extent[2] <= 128) return launch_walk3<double, L, 2, 128, 1>(d, x, approx, details, lo, hi, stream);
+      return launch_walk3<double, L, 2, 256, 1>(d, x, approx, details, lo, hi, stream);
+    }
+  }
+  if (d->sig_extent[2] <= 128) return launch_walk3<double, L, TR, 128, 1>(d, x, approx, details, lo, hi, stream);
+  return launch_walk3<double, L, TR, 256, 1>(d, x, approx, details, lo, hi, stream);
 }
 
 }  // namespace
 
 bool dwt3_fwd_walk_supported(const mifwt_level_desc* d) {
-  if (d->ndim != 3 || d->dtype != MIFWT_F32) return false;
+  if (d->ndim != 3 || (d->dtype != MIFWT_F32 && d->dtype != MIFWT_F64)) return false;
+  const bool f64 = d->dtype == MIFWT_F64;
   const int L = d->filt_len;
   if (L < 2 || L > 10 || (L & 1)) return false;
   if (d->sig_stride[3] != 1 || d->approx_stride[3] != 1 || d->detail_stride[3] != 1) return false;
@@ -404,10 +440,10 @@ bool dwt3_fwd_walk_supported(const mifwt_level_desc* d) {
   for (int i = 0; i < 3; ++i)
     if (d->sig_extent[i] < L) return false;
   // a row is one or two 1-KiB requests; at most four column strips of 64
-  if (d->sig_extent[2] > 512 || d->coef_extent[2] > 64 * kW3MaxStrips) return false;
+  if (d->sig_extent[2] > (f64 ? 256 : 512) || d->coef_extent[2] > 64 * kW3MaxStrips) return false;
   // one batch element addressable with 32-bit byte offsets (buffer-resource requests), 32-bit element offsets inside a band
   const int64_t span = (d->sig_extent[0] - 1) * d->sig_stride[1] + (d->sig_extent[1] - 1) * d->sig_stride[2] + d->sig_extent[2];
-  if (span >= (int64_t(1) << 29)) return false;
+  if (span >= (int64_t(1) << (f64 ? 28 : 29))) return false;
   if (d->coef_extent[0] * d->approx_stride[1] >= (int64_t(1) << 31) || d->coef_extent[0] * d->detail_stride[1] >= (int64_t(1) << 31))
     return false;
   return true;
@@ -415,6 +451,16 @@ bool dwt3_fwd_walk_supported(const mifwt_level_desc* d) {
 
 int dwt3_fwd_walk(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo, const double* hi,
                   hipStream_t stream) {
+  if (d->dtype == MIFWT_F64) {
+    switch (d->filt_len) {
+      case 2: return launch_walk3_l64<2>(d, x, approx, details, lo, hi, stream);
+      case 4: return launch_walk3_l64<4>(d, x, approx, details, lo, hi, stream);
+      case 6: return launch_walk3_l64<6>(d, x, approx, details, lo, hi, stream);
+      case 8: return launch_walk3_l64<8>(d, x, approx, details, lo, hi, stream);
+      case 10: return launch_walk3_l64<10>(d, x, approx, details, lo, hi, stream);
+      default: return MIFWT_ERR_UNSUPPORTED;
+    }
+  }
   switch (d->filt_len) {
     case 2: return launch_walk3_l<2>(d, x, approx, details, lo, hi, stream);
     case 4: return launch_walk3_l<4>(d, x, approx, details, lo, hi, stream);

@@ -16,8 +16,9 @@
 //     512 contiguous bytes per wave, row and slice.
 // Valid outputs never touch a coefficient row / column / slice beyond the bands' extents (n < 2 M - L + 2), so ragged last groups
 // need no zero fill: what lands behind a piece is only read for outputs that are not stored.
-// f32, even L <= 8, dense coefficient rows (row stride = row length), unit innermost strides, rows of at most 512 outputs.
-// Algorithmic traffic: 8 * 4 B Md Mh Mw read + 4 B D H W written.
+// f32 and f64 (template parameter T; f64: two row pairs per workgroup, 8-byte-aligned 16-byte LDS reads, two v_fma_f64 where f32 has
+// one packed FMA), even L <= 8, dense coefficient rows (row stride = row length), unit innermost strides, rows of at most 512 outputs.
+// Algorithmic traffic: sizeof(T) (8 B Md Mh Mw read + B D H W written).
 #include "mifwt_pyr.h"
 
 namespace mifwt {
@@ -26,10 +27,14 @@ namespace {
 
 constexpr int kIW3MaxStrips = 4;
 
-template <int L>
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+template <typename T> struct IW3Pair { typedef f2u type; };
+template <> struct IW3Pair<double> { typedef d2u type; };
+
+template <typename T, int L>
 struct IWalk3Args {
-  const float* in[8];  // band s: bit 2 = depth high, bit 1 = row high, bit 0 = column high
-  float* y;
+  const T* in[8];  // band s: bit 2 = depth high, bit 1 = row high, bit 0 = column high
+  T* y;
   int64_t is_b[2], ys_b;  // batch strides: [0] approximation, [1] details; output
   uint32_t is_d[2];       // slice strides of the bands (rows are dense)
   uint32_t ys_d, ys_h;
@@ -41,7 +46,7 @@ struct IWalk3Args {
   int yvec, nt, dbg;
   int st16;  // 16-byte output stores: lanes l and l + 32 own neighbouring column pairs and exchange rows (W, strides, base: multiples of 4)
   FastDiv div_g, div_s;
-  f2 tlo[L / 2], thi[L / 2];  // (rec_lo[2j], rec_lo[2j+1]), (rec_hi[2j], rec_hi[2j+1])
+  typename TileArith<T>::vec2 tlo[L / 2], thi[L / 2];  // (rec_lo[2j], rec_lo[2j+1]), (rec_hi[2j], rec_hi[2j+1])
 };
 
 template <int N>
@@ -61,8 +66,11 @@ __device__ __forceinline__ void iwalk3_dma(uint32_t voff, rsrc_t rsrc, uint32_t 
                : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds) : "memory");
 }
 
-template <int L, int CY, int NKB>
-__global__ void __launch_bounds__(64 * (kIW3MaxStrips + 2)) idwt3_walk_kernel(const IWalk3Args<L> a) {
+template <typename T, int L, int CY, int NKB>
+__global__ void __launch_bounds__(64 * (kIW3MaxStrips + 2)) idwt3_walk_kernel(const IWalk3Args<T, L> a) {
+  using V2 = typename TileArith<T>::vec2;
+  using V2U = typename IW3Pair<T>::type;
+  constexpr int ES = (int)sizeof(T);
   constexpr int HL = L / 2, IY = CY + HL - 1;
   constexpr int BANDB = NKB * 1024, SLOTB = 8 * BANDB;  // bytes of a band's piece / of a staged slice
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -81,7 +89,7 @@ __global__ void __launch_bounds__(64 * (kIW3MaxStrips + 2)) idwt3_walk_kernel(co
   if (wave >= a.nstrips) {
     const int l = wave - a.nstrips;
     const int nrows = min(IY, a.Mh - py0);
-    const uint32_t piece = (uint32_t)(nrows * a.Mw) * 4u;  // bytes of a band's rows py0 .. py0 + nrows - 1 of one slice: contiguous
+    const uint32_t piece = (uint32_t)(nrows * a.Mw) * (uint32_t)ES;  // bytes of a band's rows py0 .. py0 + nrows - 1 of one slice: contiguous
     uint32_t voff[NKB];
 #pragma unroll
     for (int j = 0; j < NKB; ++j) {
@@ -93,9 +101,9 @@ __global__ void __launch_bounds__(64 * (kIW3MaxStrips + 2)) idwt3_walk_kernel(co
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int s = 4 * l + b, k = s == 0 ? 0 : 1;
-      const uint32_t bytes = (uint32_t)(((int64_t)(a.Md - 1) * a.is_d[k] + (int64_t)a.Mh * a.Mw) * 4);
-      rs[b] = pyr_rsrc(a.in[s] + (int64_t)img * a.is_b[k] + (int64_t)py0 * a.Mw, bytes - (uint32_t)(py0 * a.Mw) * 4u);
-      sd[b] = a.is_d[k] * 4u;
+      const uint32_t bytes = (uint32_t)(((int64_t)(a.Md - 1) * a.is_d[k] + (int64_t)a.Mh * a.Mw) * ES);
+      rs[b] = pyr_rsrc(a.in[s] + (int64_t)img * a.is_b[k] + (int64_t)py0 * a.Mw, bytes - (uint32_t)(py0 * a.Mw) * (uint32_t)ES);
+      sd[b] = a.is_d[k] * (uint32_t)ES;
     }
     __builtin_amdgcn_s_setprio(3);
     constexpr int PER = 4 * NKB;
@@ -128,55 +136,55 @@ __global__ void __launch_bounds__(64 * (kIW3MaxStrips + 2)) idwt3_walk_kernel(co
   // compute wave: output column pairs 64 wave .. 64 wave + 63
   // (16-byte stores: lane l < 32 owns pair 2 l of the wave's 64, lane l + 32 pair 2 l + 1 — after the exchange each lane holds four
   // columns of one row)
-  const int p = 64 * wave + (a.st16 ? 2 * (lane & 31) + (lane >> 5) : lane);
+  const int p = 64 * wave + ((ES == 4 && a.st16) ? 2 * (lane & 31) + (lane >> 5) : lane);
   const int xo = 2 * p;
   const bool active = xo < a.W, both = xo + 1 < a.W;
   const int pc = min(p, a.Mw - HL);  // idle lanes read the row's last window
   uint32_t rowaddr[IY];
 #pragma unroll
-  for (int yy = 0; yy < IY; ++yy) rowaddr[yy] = (uint32_t)(yy * a.Mw + pc) * 4u;
-  float* const yb = a.y + (int64_t)img * a.ys_b;
+  for (int yy = 0; yy < IY; ++yy) rowaddr[yy] = (uint32_t)(yy * a.Mw + pc) * (uint32_t)ES;
+  T* const yb = a.y + (int64_t)img * a.ys_b;
   const rsrc_t yr = pyr_rsrc(yb, a.st16 ? (uint32_t)(((int64_t)(a.D - 1) * a.ys_d + (int64_t)(a.H - 1) * a.ys_h + a.W) * 4) : 0u);
   const uint32_t c16 = 4u * (uint32_t)(128 * wave + 4 * (lane & 31));  // byte offset of the lane's four columns (16-byte path)
 
-  f2 acc[HL][CY][2][2];  // [slot of the output slice pair][row pair q][column c][row r of the pair]: (slice 2P, slice 2P + 1)
+  V2 acc[HL][CY][2][2];  // [slot of the output slice pair][row pair q][column c][row r of the pair]: (slice 2P, slice 2P + 1)
 #pragma unroll
   for (int s = 0; s < HL; ++s)
 #pragma unroll
     for (int q = 0; q < CY; ++q)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) acc[s][q][c][0] = acc[s][q][c][1] = (f2){0.f, 0.f};
+      for (int c = 0; c < 2; ++c) acc[s][q][c][0] = acc[s][q][c][1] = V2{};
   int slot = 0;
 
   // coefficient slice -> himg[d][q][c] = (row 2q, row 2q + 1) of column c of the depth-low / depth-high image
-  auto filter_slice = [&](f2 (&himg)[2][CY][2]) {
+  auto filter_slice = [&](V2 (&himg)[2][CY][2]) {
     const unsigned char* const sl = smem + slot * SLOTB;
     slot = slot + 1 == a.nslots ? 0 : slot + 1;
     if (a.dbg & 4) {
 #pragma unroll
       for (int d = 0; d < 2; ++d)
 #pragma unroll
-        for (int q = 0; q < CY; ++q) himg[d][q][0] = himg[d][q][1] = (f2){1.f, 2.f};
+        for (int q = 0; q < CY; ++q) himg[d][q][0] = himg[d][q][1] = (V2){T(1), T(2)};
       return;
     }
-    f2 wimg[2][2][IY];  // [d][h][row]: (column 2p, 2p + 1)
+    V2 wimg[2][2][IY];  // [d][h][row]: (column 2p, 2p + 1)
 #pragma unroll
     for (int dh = 0; dh < 4; ++dh) {
       const unsigned char* const lo_b = sl + (2 * dh) * BANDB;      // band (d, h, W low)
       const unsigned char* const hi_b = sl + (2 * dh + 1) * BANDB;  // band (d, h, W high)
 #pragma unroll
       for (int yy = 0; yy < IY; ++yy) {
-        f2 w;
+        V2 w;
 #pragma unroll
         for (int i2 = 0; i2 < (HL + 1) / 2; ++i2) {
-          const f2 pa = *reinterpret_cast<const f2u*>(lo_b + rowaddr[yy] + 8 * i2);  // coefficients p + 2 i2, p + 2 i2 + 1
-          const f2 pd = *reinterpret_cast<const f2u*>(hi_b + rowaddr[yy] + 8 * i2);
-          if (i2 == 0) w = pkmul_lo(a.tlo[HL - 1], pa);
-          else pkfma_lo(w, a.tlo[HL - 1 - 2 * i2], pa);
-          pkfma_lo(w, a.thi[HL - 1 - 2 * i2], pd);
+          const V2 pa = *reinterpret_cast<const V2U*>(lo_b + rowaddr[yy] + 2 * ES * i2);  // coefficients p + 2 i2, p + 2 i2 + 1
+          const V2 pd = *reinterpret_cast<const V2U*>(hi_b + rowaddr[yy] + 2 * ES * i2);
+          if (i2 == 0) w = amul_lo(a.tlo[HL - 1], pa);
+          else afma_lo(w, a.tlo[HL - 1 - 2 * i2], pa);
+          afma_lo(w, a.thi[HL - 1 - 2 * i2], pd);
           if (2 * i2 + 1 < HL) {
-            pkfma_hi(w, a.tlo[HL - 2 - 2 * i2], pa);
-            pkfma_hi(w, a.thi[HL - 2 - 2 * i2], pd);
+            afma_hi(w, a.tlo[HL - 2 - 2 * i2], pa);
+            afma_hi(w, a.thi[HL - 2 - 2 * i2], pd);
           }
         }
         wimg[dh >> 1][dh & 1][yy] = w;
@@ -186,18 +194,18 @@ __global__ void __launch_bounds__(64 * (kIW3MaxStrips + 2)) idwt3_walk_kernel(co
     for (int d = 0; d < 2; ++d)
 #pragma unroll
       for (int q = 0; q < CY; ++q) {
-        f2 h0, h1;
+        V2 h0, h1;
 #pragma unroll
         for (int i = 0; i < HL; ++i) {
           if (i == 0) {
-            h0 = pkmul_lo(a.tlo[HL - 1], wimg[d][0][q]);
-            h1 = pkmul_hi(a.tlo[HL - 1], wimg[d][0][q]);
+            h0 = amul_lo(a.tlo[HL - 1], wimg[d][0][q]);
+            h1 = amul_hi(a.tlo[HL - 1], wimg[d][0][q]);
           } else {
-            pkfma_lo(h0, a.tlo[HL - 1 - i], wimg[d][0][q + i]);
-            pkfma_hi(h1, a.tlo[HL - 1 - i], wimg[d][0][q + i]);
+            afma_lo(h0, a.tlo[HL - 1 - i], wimg[d][0][q + i]);
+            afma_hi(h1, a.tlo[HL - 1 - i], wimg[d][0][q + i]);
           }
-          pkfma_lo(h0, a.thi[HL - 1 - i], wimg[d][1][q + i]);
-          pkfma_hi(h1, a.thi[HL - 1 - i], wimg[d][1][q + i]);
+          afma_lo(h0, a.thi[HL - 1 - i], wimg[d][1][q + i]);
+          afma_hi(h1, a.thi[HL - 1 - i], wimg[d][1][q + i]);
         }
         himg[d][q][0] = h0;
         himg[d][q][1] = h1;
@@ -205,7 +213,7 @@ __global__ void __launch_bounds__(64 * (kIW3MaxStrips + 2)) idwt3_walk_kernel(co
   };
 
   // D pass: slice of relative index t (R = t mod HL) feeds the output slice pairs t - i, i < HL (slot (R - i) mod HL)
-  auto feed = [&](auto r_tag, const f2 (&himg)[2][CY][2]) {
+  auto feed = [&](auto r_tag, const V2 (&himg)[2][CY][2]) {
     constexpr int R = decltype(r_tag)::value;
     pyr_static_for<HL>([&](auto i_tag) {
       constexpr int i = decltype(i_tag)::value, s = (R - i + HL) % HL;
@@ -214,14 +222,14 @@ __global__ void __launch_bounds__(64 * (kIW3MaxStrips + 2)) idwt3_walk_kernel(co
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           if constexpr (i == 0) {
-            acc[s][q][c][0] = pkmul_lo(a.tlo[HL - 1], himg[0][q][c]);
-            acc[s][q][c][1] = pkmul_hi(a.tlo[HL - 1], himg[0][q][c]);
+            acc[s][q][c][0] = amul_lo(a.tlo[HL - 1], himg[0][q][c]);
+            acc[s][q][c][1] = amul_hi(a.tlo[HL - 1], himg[0][q][c]);
           } else {
-            pkfma_lo(acc[s][q][c][0], a.tlo[HL - 1 - i], himg[0][q][c]);
-            pkfma_hi(acc[s][q][c][1], a.tlo[HL - 1 - i], himg[0][q][c]);
+            afma_lo(acc[s][q][c][0], a.tlo[HL - 1 - i], himg[0][q][c]);
+            afma_hi(acc[s][q][c][1], a.tlo[HL - 1 - i], himg[0][q][c]);
           }
-          pkfma_lo(acc[s][q][c][0], a.thi[HL - 1 - i], himg[1][q][c]);
-          pkfma_hi(acc[s][q][c][1], a.thi[HL - 1 - i], himg[1][q][c]);
+          afma_lo(acc[s][q][c][0], a.thi[HL - 1 - i], himg[1][q][c]);
+          afma_hi(acc[s][q][c][1], a.thi[HL - 1 - i], himg[1][q][c]);
         }
     });
   };
@@ -230,6 +238,7 @@ __global__ void __launch_bounds__(64 * (kIW3MaxStrips + 2)) idwt3_walk_kernel(co
   auto emit = [&](auto s_tag, int P) {
     constexpr int S = decltype(s_tag)::value;
     if (a.dbg & 1) return;
+    if constexpr (ES == 4) {
     if (a.st16) {
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
@@ -246,6 +255,7 @@ __global__ void __launch_bounds__(64 * (kIW3MaxStrips + 2)) idwt3_walk_kernel(co
       }
       return;
     }
+    }
     if (!active) return;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -257,11 +267,11 @@ __global__ void __launch_bounds__(64 * (kIW3MaxStrips + 2)) idwt3_walk_kernel(co
         for (int rr = 0; rr < 2; ++rr) {
           const int n = 2 * (py0 + q) + rr;
           if (n >= a.H) continue;
-          float* dst = yb + ((uint32_t)z * a.ys_d + (uint32_t)n * a.ys_h + (uint32_t)xo);
-          const f2 v = {r ? acc[S][q][0][rr].y : acc[S][q][0][rr].x, r ? acc[S][q][1][rr].y : acc[S][q][1][rr].x};
+          T* dst = yb + ((uint32_t)z * a.ys_d + (uint32_t)n * a.ys_h + (uint32_t)xo);
+          const V2 v = {r ? acc[S][q][0][rr].y : acc[S][q][0][rr].x, r ? acc[S][q][1][rr].y : acc[S][q][1][rr].x};
           if (a.yvec && both) {
-            if (a.nt) __builtin_nontemporal_store(v, reinterpret_cast<f2*>(dst));
-            else *reinterpret_cast<f2*>(dst) = v;
+            if (a.nt) __builtin_nontemporal_store(v, reinterpret_cast<V2*>(dst));
+            else *reinterpret_cast<V2*>(dst) = v;
           } else {
             dst[0] = v.x;
             if (both) dst[1] = v.y;
@@ -279,7 +289,7 @@ __global__ void __launch_bounds__(64 * (kIW3MaxStrips + 2)) idwt3_walk_kernel(co
         done = true;
         return;
       }
-      f2 himg[2][CY][2];
+      V2 himg[2][CY][2];
       __syncthreads();
       filter_slice(himg);
       feed(r_tag, himg);
@@ -288,18 +298,19 @@ __global__ void __launch_bounds__(64 * (kIW3MaxStrips + 2)) idwt3_walk_kernel(co
   }
 }
 
-template <int L, int CY, int NKB>
+template <typename T, int L, int CY, int NKB>
 int launch_iwalk3(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y, const double* lo, const double* hi,
                   hipStream_t stream) {
   constexpr int HL = L / 2;
   constexpr int SLOTB = 8 * NKB * 1024;
-  IWalk3Args<L> a;
-  for (int s = 0; s < 8; ++s) a.in[s] = static_cast<const float*>(s == 0 ? approx : details[s - 1]);
+  constexpr int ES = (int)sizeof(T);
+  IWalk3Args<T, L> a;
+  for (int s = 0; s < 8; ++s) a.in[s] = static_cast<const T*>(s == 0 ? approx : details[s - 1]);
   a.is_b[0] = d->approx_stride[0];
   a.is_b[1] = d->detail_stride[0];
   a.is_d[0] = (uint32_t)d->approx_stride[1];
   a.is_d[1] = (uint32_t)d->detail_stride[1];
-  a.y = static_cast<float*>(y);
+  a.y = static_cast<T*>(y);
   a.ys_b = d->sig_stride[0];
   a.ys_d = (uint32_t)d->sig_stride[1];
   a.ys_h = (uint32_t)d->sig_stride[2];
@@ -311,16 +322,16 @@ int launch_iwalk3(const mifwt_level_desc* d, const void* approx, const void* con
   a.W = (int)d->sig_extent[2];
   a.nt = g_options[MIFWT_OPT_NT_STORE];
   a.dbg = g_options[MIFWT_OPT_DEBUG] & 7;
-  a.yvec = (a.ys_h % 2 == 0 && a.ys_d % 2 == 0 && a.ys_b % 2 == 0 && reinterpret_cast<uintptr_t>(y) % 8 == 0) ? 1 : 0;
+  a.yvec = (a.ys_h % 2 == 0 && a.ys_d % 2 == 0 && a.ys_b % 2 == 0 && reinterpret_cast<uintptr_t>(y) % (2 * ES) == 0) ? 1 : 0;
   // 16-byte stores where every row piece of four columns is aligned and inside the row (MIFWT_OPT_DEBUG 512: never, as for kernel 16)
   {
     const int64_t span = (int64_t)(a.D - 1) * a.ys_d + (int64_t)(a.H - 1) * a.ys_h + a.W;
-    a.st16 = (a.W % 4 == 0 && a.ys_h % 4 == 0 && a.ys_d % 4 == 0 && a.ys_b % 4 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
+    a.st16 = (ES == 4 && a.W % 4 == 0 && a.ys_h % 4 == 0 && a.ys_d % 4 == 0 && a.ys_b % 4 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
               span < (int64_t(1) << 30) && !(g_options[MIFWT_OPT_DEBUG] & 512)) ? 1 : 0;
   }
   for (int j = 0; j < HL; ++j) {
-    a.tlo[j] = (f2){(float)lo[2 * j], (float)lo[2 * j + 1]};
-    a.thi[j] = (f2){(float)hi[2 * j], (float)hi[2 * j + 1]};
+    a.tlo[j] = (typename TileArith<T>::vec2){(T)lo[2 * j], (T)lo[2 * j + 1]};
+    a.thi[j] = (typename TileArith<T>::vec2){(T)hi[2 * j], (T)hi[2 * j + 1]};
   }
   a.nstrips = ((a.W + 1) / 2 + 63) / 64;
   a.ngroups = ((a.H + 1) / 2 + CY - 1) / CY;
@@ -356,30 +367,34 @@ int launch_iwalk3(const mifwt_level_desc* d, const void* approx, const void* con
   const int64_t nblk = base * a.nseg;
   if (nblk > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
   static DynLdsOnce lds_once;
-  if (!lds_once.ensure(reinterpret_cast<const void*>(&idwt3_walk_kernel<L, CY, NKB>), 6 * SLOTB > 160 * 1024 ? 160 * 1024 : 6 * SLOTB))
+  if (!lds_once.ensure(reinterpret_cast<const void*>(&idwt3_walk_kernel<T, L, CY, NKB>), 6 * SLOTB > 160 * 1024 ? 160 * 1024 : 6 * SLOTB))
     return MIFWT_ERR_LAUNCH;
-  hipLaunchKernelGGL((idwt3_walk_kernel<L, CY, NKB>), dim3((unsigned)nblk), dim3(64 * (a.nstrips + 2)), lds_bytes, stream, a);
+  hipLaunchKernelGGL((idwt3_walk_kernel<T, L, CY, NKB>), dim3((unsigned)nblk), dim3(64 * (a.nstrips + 2)), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 
-constexpr int iwalk3_cy(int L) { return L <= 6 ? 4 : 2; }
+constexpr int iwalk3_cy(int L, int ES) { return (L <= 6 && ES == 4) ? 4 : 2; }  // (f64: the accumulators of four row pairs would not fit)
 
-template <int L>
+template <typename T, int L>
 int launch_iwalk3_l(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y, const double* lo, const double* hi,
                     hipStream_t stream) {
-  constexpr int CY = iwalk3_cy(L), IY = CY + L / 2 - 1;
-  const int64_t piece = (int64_t)IY * d->coef_extent[2] * 4;
-  if (piece <= 1024) return launch_iwalk3<L, CY, 1>(d, approx, details, y, lo, hi, stream);
-  if (piece <= 2048) return launch_iwalk3<L, CY, 2>(d, approx, details, y, lo, hi, stream);
-  if (piece <= 3072) return launch_iwalk3<L, CY, 3>(d, approx, details, y, lo, hi, stream);
-  if (piece <= 5120) return launch_iwalk3<L, CY, 5>(d, approx, details, y, lo, hi, stream);
+  constexpr int CY = iwalk3_cy(L, (int)sizeof(T)), IY = CY + L / 2 - 1;
+  const int64_t piece = (int64_t)IY * d->coef_extent[2] * (int64_t)sizeof(T);
+  if (piece <= 1024) return launch_iwalk3<T, L, CY, 1>(d, approx, details, y, lo, hi, stream);
+  if (piece <= 2048) return launch_iwalk3<T, L, CY, 2>(d, approx, details, y, lo, hi, stream);
+  if (piece <= 3072) return launch_iwalk3<T, L, CY, 3>(d, approx, details, y, lo, hi, stream);
+  if constexpr (sizeof(T) == 8) {  // (config 3's finest level in f64: three rows of 129 coefficients = 3096 bytes)
+    if (piece <= 4096) return launch_iwalk3<T, L, CY, 4>(d, approx, details, y, lo, hi, stream);
+  }
+  if (piece <= 5120) return launch_iwalk3<T, L, CY, 5>(d, approx, details, y, lo, hi, stream);
   return MIFWT_ERR_UNSUPPORTED;
 }
 
 }  // namespace
 
 bool dwt3_inv_walk_supported(const mifwt_level_desc* d) {
-  if (d->ndim != 3 || d->dtype != MIFWT_F32) return false;
+  if (d->ndim != 3 || (d->dtype != MIFWT_F32 && d->dtype != MIFWT_F64)) return false;
+  const int ES = d->dtype == MIFWT_F64 ? 8 : 4;
   const int L = d->filt_len;
   if (L < 2 || L > 8 || (L & 1)) return false;
   if (d->sig_stride[3] != 1 || d->approx_stride[3] != 1 || d->detail_stride[3] != 1) return false;
@@ -389,11 +404,11 @@ bool dwt3_inv_walk_supported(const mifwt_level_desc* d) {
   }
   // dense coefficient rows: the rows of a band a row group needs are one contiguous piece per slice, at most 5 KiB
   if (d->approx_stride[2] != d->coef_extent[2] || d->detail_stride[2] != d->coef_extent[2]) return false;
-  const int IY = iwalk3_cy(L) + L / 2 - 1;
-  if ((int64_t)IY * d->coef_extent[2] * 4 > 5120 || d->sig_extent[2] > 128 * kIW3MaxStrips) return false;
+  const int IY = iwalk3_cy(L, ES) + L / 2 - 1;
+  if ((int64_t)IY * d->coef_extent[2] * ES > 5120 || d->sig_extent[2] > 128 * kIW3MaxStrips) return false;
   for (const int64_t* st : {d->approx_stride, d->detail_stride}) {
     const int64_t span = (d->coef_extent[0] - 1) * st[1] + d->coef_extent[1] * d->coef_extent[2];
-    if (span >= (int64_t(1) << 29) || st[1] >= (int64_t(1) << 29)) return false;
+    if (span >= (int64_t(1) << (ES == 8 ? 28 : 29)) || st[1] >= (int64_t(1) << 29)) return false;
   }
   // 32-bit element offsets inside one batch element of the output
   if (d->sig_extent[0] * d->sig_stride[1] >= (int64_t(1) << 31) || d->sig_stride[2] >= (int64_t(1) << 29)) return false;
@@ -402,11 +417,20 @@ bool dwt3_inv_walk_supported(const mifwt_level_desc* d) {
 
 int dwt3_inv_walk(const mifwt_level_desc* d, const void* approx, const void* const* details, void* y, const double* lo, const double* hi,
                   hipStream_t stream) {
+  if (d->dtype == MIFWT_F64) {
+    switch (d->filt_len) {
+      case 2: return launch_iwalk3_l<double, 2>(d, approx, details, y, lo, hi, stream);
+      case 4: return launch_iwalk3_l<double, 4>(d, approx, details, y, lo, hi, stream);
+      case 6: return launch_iwalk3_l<double, 6>(d, approx, details, y, lo, hi, stream);
+      case 8: return launch_iwalk3_l<double, 8>(d, approx, details, y, lo, hi, stream);
+      default: return MIFWT_ERR_UNSUPPORTED;
+    }
+  }
   switch (d->filt_len) {
-    case 2: return launch_iwalk3_l<2>(d, approx, details, y, lo, hi, stream);
-    case 4: return launch_iwalk3_l<4>(d, approx, details, y, lo, hi, stream);
-    case 6: return launch_iwalk3_l<6>(d, approx, details, y, lo, hi, stream);
-    case 8: return launch_iwalk3_l<8>(d, approx, details, y, lo, hi, stream);
+    case 2: return launch_iwalk3_l<float, 2>(d, approx, details, y, lo, hi, stream);
+    case 4: return launch_iwalk3_l<float, 4>(d, approx, details, y, lo, hi, stream);
+    case 6: return launch_iwalk3_l<float, 6>(d, approx, details, y, lo, hi, stream);
+    case 8: return launch_iwalk3_l<float, 8>(d, approx, details, y, lo, hi, stream);
     default: return MIFWT_ERR_UNSUPPORTED;
   }
 }

@@ -164,19 +164,25 @@ __device__ __forceinline__ f2 vmul_hi(const f2 tap, const f2 pair) {
 // rolling vertical pass: the L/2 outputs in flight of NC columns; lo = (aa, da), hi = (ad, dd) per column.  Output i lives in
 // slot i mod L/2 for its whole life, so nothing is ever copied: the pair index modulo L/2 (R) is a compile-time constant at
 // every call site (the callers unroll or switch over it)
-template <int L, int NC>
+// (f64 callers: the same roles with two v_fma_f64 per step, mifwt_stream.h)
+__device__ __forceinline__ void vfma_lo(d2& acc, const d2 tap, const d2 pair) { afma_lo(acc, tap, pair); }
+__device__ __forceinline__ void vfma_hi(d2& acc, const d2 tap, const d2 pair) { afma_hi(acc, tap, pair); }
+__device__ __forceinline__ d2 vmul_lo(const d2 tap, const d2 pair) { return amul_lo(tap, pair); }
+__device__ __forceinline__ d2 vmul_hi(const d2 tap, const d2 pair) { return amul_hi(tap, pair); }
+
+template <int L, int NC, typename V = f2>
 struct PyrAcc {
   static constexpr int HP = L / 2;
-  f2 lo[HP][NC], hi[HP][NC];
+  V lo[HP][NC], hi[HP][NC];
   __device__ __forceinline__ void clear() {
 #pragma unroll
     for (int q = 0; q < HP; ++q)
 #pragma unroll
-      for (int c = 0; c < NC; ++c) lo[q][c] = hi[q][c] = (f2){0.f, 0.f};
+      for (int c = 0; c < NC; ++c) lo[q][c] = hi[q][c] = V{};
   }
   // one row of horizontally filtered samples hv[c] = (h_lo, h_hi) of pair p (R = p mod HP); PH = 0: first row of the pair, 1: second
   template <int PH, int R>
-  __device__ __forceinline__ void feed(const f2 (&tap)[L], const f2 (&hv)[NC]) {
+  __device__ __forceinline__ void feed(const V (&tap)[L], const V (&hv)[NC]) {
 #pragma unroll
     for (int q = 0; q < HP; ++q) {
       const int sl = (R - q + HP) % HP;  // output p - q

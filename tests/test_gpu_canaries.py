@@ -186,7 +186,9 @@ CASES_3D = [
     ((2, 45, 47, 49), "db3", 2, "reflect", torch.float32, {}),       # 9 / 10 bricks
     ((3, 52, 60, 70), "db5", 2, "periodic", torch.float32, {}),      # 5 / 6 composed
     ((2, 130, 131, 132), "db4", 1, "symmetric", torch.float32, {}),  # 24 / 25 with eight taps
-    ((2, 40, 41, 42), "db2", 2, "zero", torch.float64, {}),          # f64: streaming axis passes
+    ((2, 40, 41, 42), "db2", 2, "zero", torch.float64, {}),          # f64: 24 / 25 (two rows per workgroup), then the composed route on 21 x 22 x 22
+    ((1, 70, 67, 131), "db3", 2, "symmetric", torch.float64, {}),    # f64: 24 / 25, odd extents, two 1-KiB requests per staged row
+    ((1, 128, 66, 250), "db2", 1, "periodic", torch.float64, {}),    # f64: 24 / 25, four rows per workgroup (>= 2^20 samples)
 ]
 
 

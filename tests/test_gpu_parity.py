@@ -324,8 +324,16 @@ def test_stream_routes_selected():
     assert kid(1, torch.float64, "reflect", 2, 1, (4096,)) == 3
     assert kid(3, torch.float32, "zero", 4, 8, (256, 256, 256)) == 24 and kid(3, torch.float32, "zero", 4, 8, (129, 129, 129)) == 9  # 3-D analysis: depth-walking kernel on big volumes (round 4), LDS bricks below
     assert kid(3, torch.float32, "zero", 8, 8, (256, 256, 256)) == 24 and kid(3, torch.float32, "zero", 12, 8, (256, 256, 256)) == 5 and kid(3, torch.float32, "zero", 4, 8, (256, 256, 256), direction=1) == 25 and kid(3, torch.float32, "zero", 4, 8, (64, 64, 64), direction=1) == 10 and kid(3, torch.float32, "zero", 10, 8, (256, 256, 256), direction=1) == 6
-    # f64 volumes (round 5): the composed route — the f64 tile kernel over every depth slice + one depth pass — instead of three axis passes
-    assert kid(3, torch.float64, "zero", 4, 2, (33, 34, 35)) == 5 and kid(3, torch.float64, "zero", 4, 2, (33, 34, 35), direction=1) == 6
+    # f64 volumes (round 5): the f64 instances of the walk kernels from 32^3 samples on (rows of at most 256 samples; synthesis up to 8 taps),
+    # below and beyond the composed route — the f64 tile kernel over every depth slice + one depth pass — instead of three axis passes
+    assert kid(3, torch.float64, "zero", 4, 2, (33, 34, 35)) == 24 and kid(3, torch.float64, "zero", 4, 2, (33, 34, 35), direction=1) == 6
+    assert kid(3, torch.float64, "zero", 4, 2, (41, 42, 43), direction=1) == 25
+    assert kid(3, torch.float64, "zero", 4, 2, (20, 21, 22)) == 5 and kid(3, torch.float64, "zero", 4, 2, (20, 21, 22), direction=1) == 6
+    assert kid(3, torch.float64, "zero", 4, 2, (40, 40, 300)) == 5 and kid(3, torch.float64, "zero", 10, 2, (64, 64, 64), direction=1) == 6
+    assert kid(3, torch.float64, "zero", 10, 2, (128, 128, 128)) == 5  # ten taps: the composed route stays ahead in f64
+    assert kid(3, torch.float64, "zero", 8, 2, (100, 100, 100)) == 24 and kid(3, torch.float64, "zero", 8, 2, (66, 66, 66)) == 5
+    assert kid(3, torch.float64, "zero", 6, 2, (66, 66, 66)) == 24 and kid(3, torch.float64, "zero", 6, 2, (66, 66, 66), direction=1) == 6
+    assert kid(3, torch.float64, "zero", 8, 2, (100, 100, 100), direction=1) == 25 and kid(3, torch.float64, "zero", 8, 2, (256, 256, 256), direction=1) == 6
     assert kid(3, torch.float64, "zero", 24, 2, (60, 60, 60)) == 3  # f64, long filter: inner pass + two outer passes
     assert kid(3, torch.float32, "zero", 8, 8, (54, 54, 54)) == 5  # 8 taps on a small volume: composed route, not the walking kernel
     assert kid(2, torch.float64, "reflect", 8, 2, (64, 64)) == 7 and kid(2, torch.float64, "reflect", 8, 2, (64, 64), direction=1) == 8  # f64 tiles

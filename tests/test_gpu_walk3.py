@@ -10,7 +10,7 @@ import ptwt_amd
 from ptwt_amd import _engine
 from oracle import fwt_oracle as O
 from tests import _golden as G
-from tests.test_gpu_parity import MODES, TOL32, check_tree, dev, to_np
+from tests.test_gpu_parity import MODES, TOL32, TOL64, check_tree, dev, to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -49,6 +49,40 @@ def test_walk3_vs_oracle(wavelet):
             got, kids = _walk(lambda: ptwt_amd.wavedec3(xg, wavelet, mode=mode, level=level))
             assert kids and kids[0] == 24, (kids, shape, mode)
             check_tree(got, want, TOL32, f"dwt3 walk {wavelet} {mode} {shape}")
+
+
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4", "db5"])
+def test_walk3_f64_vs_oracle(wavelet):
+    """The f64 instance of the walk kernel (rows of at most 256 samples = two 1-KiB requests): every mode, 1e-12 against the oracle;
+    with MIFWT_OPT_TILE_ROWS = 2 the two-row form of the short filters."""
+    rng = np.random.default_rng(len(wavelet) + 140)
+    flen = len(O.filter_bank(wavelet)[0])
+    shapes = [(2, 21, 37, 141), (1, 2 * flen + 1, 2 * flen, 2 * flen + 3), (3, 9, 70, 66), (2, 12, 21, 130), (1, 40, 20, 256),
+              (1, 11, 13, 127), (1, 33, 9, 129)]
+    for shape in shapes:
+        if min(shape[1:]) < flen:
+            continue
+        x = rng.standard_normal(shape)
+        xg = torch.from_numpy(x).to(dev())
+        for mode in MODES:
+            level = 2 if min(shape[1:]) >= 3 * flen else 1
+            try:
+                want = O.wavedec3(x, wavelet, mode=mode, level=level)
+            except RuntimeError:
+                continue
+            for rows in ((0, 2) if flen <= 4 else (0,)):
+                _engine.set_option(_engine.OPT_TILE_ROWS, rows)
+                try:
+                    got, kids = _walk(lambda: ptwt_amd.wavedec3(xg, wavelet, mode=mode, level=level))
+                finally:
+                    _engine.set_option(_engine.OPT_TILE_ROWS, 0)
+                assert kids and kids[0] == 24, (kids, shape, mode)
+                assert got[0].dtype == torch.float64
+                check_tree(got, want, TOL64, f"dwt3 walk f64 {wavelet} {mode} {shape} rows {rows}")
+    # rows of more than 256 doubles are not the kernel's: the composed route serves them
+    xg = torch.randn(1, 12, 12, 300, device=dev(), dtype=torch.float64)
+    _, kids = _walk(lambda: ptwt_amd.wavedec3(xg, wavelet, mode="zero", level=1))
+    assert kids == [5], kids
 
 
 def test_walk3_many_segments_and_strided_input():
@@ -124,6 +158,54 @@ def test_iwalk3_vs_oracle(wavelet):
             assert tuple(got.shape) == tuple(want.shape)
             assert G.relerr(to_np(got), want) < TOL32, (wavelet, mode, shape)
             assert G.relerr(to_np(got), to_np(ref)) < 5e-7, (wavelet, mode, shape)
+
+
+@pytest.mark.parametrize("wavelet", ["haar", "db2", "db3", "db4"])
+def test_iwalk3_f64_vs_oracle(wavelet):
+    """The f64 instance of the synthesis walk (two row pairs per workgroup, pieces of at most 5 KiB): 1e-12 against the oracle, and
+    bit-for-bit-close to the composed route."""
+    rng = np.random.default_rng(len(wavelet) + 151)
+    flen = len(O.filter_bank(wavelet)[0])
+    for shape in [(2, 21, 37, 141), (1, 2 * flen + 1, 2 * flen, 2 * flen + 3), (3, 9, 70, 66), (1, 12, 21, 250), (2, 40, 33, 128), (1, 20, 9, 200),
+                  (2, 9, 9, 40)]:
+        if min(shape[1:]) < flen:
+            continue
+        x = rng.standard_normal(shape)
+        for mode in MODES:
+            level = 2 if min(shape[1:]) >= 3 * flen else 1
+            try:
+                coeffs = O.wavedec3(x, wavelet, mode=mode, level=level)
+            except RuntimeError:
+                continue
+            cdev = [torch.from_numpy(coeffs[0]).to(dev())] + [{k: torch.from_numpy(v).to(dev()) for k, v in c.items()} for c in coeffs[1:]]
+            want = O.waverec3(coeffs, wavelet)
+            _engine.set_option(_engine.OPT_TILE_MODE, 2)
+            try:
+                ref = ptwt_amd.waverec3(cdev, wavelet)
+            finally:
+                _engine.set_option(_engine.OPT_TILE_MODE, 0)
+            got, kids = _walk(lambda: ptwt_amd.waverec3(cdev, wavelet))
+            assert kids == [25] * level, (wavelet, mode, shape, kids)
+            assert got.dtype == torch.float64 and tuple(got.shape) == tuple(want.shape)
+            assert G.relerr(to_np(got), want) < TOL64, (wavelet, mode, shape)
+            assert G.relerr(to_np(got), to_np(ref)) < TOL64, (wavelet, mode, shape)
+
+
+def test_walk3_f64_auto_routes_and_round_trip():
+    """f64 volumes take the walk kernels from 32^3 (analysis) / 2^16 (synthesis) samples on for four taps (no bricks for f64; thresholds
+    per filter length in mifwt_api.hip); round trip to 1e-12."""
+    x = torch.randn(2, 128, 96, 160, device=dev(), dtype=torch.float64)
+    _engine.level_events = []
+    try:
+        c = ptwt_amd.wavedec3(x, "db2", mode="symmetric", level=3)
+        y = ptwt_amd.waverec3(c, "db2")
+        kids = [e[1] for e in _engine.level_events]
+    finally:
+        _engine.level_events = None
+    assert kids == [24, 24, 24, 6, 25, 25], kids
+    assert G.relerr(to_np(y[..., :128, :96, :160]), to_np(x)) < TOL64
+    want = O.wavedec3(to_np(x), "db2", mode="symmetric", level=3)
+    check_tree(c, want, TOL64, "f64 auto route")
 
 
 def test_iwalk3_many_segments_round_trip_config3_shape():
