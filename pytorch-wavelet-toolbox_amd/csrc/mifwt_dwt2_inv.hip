@@ -57,7 +57,7 @@ struct ICfg {
 constexpr int kInvLdsRow = (128 + 8) * 2;  // floats: 128 columns (+ slack) x (row0,row1)
 
 template <int L, int D>
-__global__ void __launch_bounds__(256, D <= 2 ? 3 : 2) dwt2_inv_stream_kernel(const Dwt2InvArgs<L> a) {
+__global__ void __launch_bounds__(256, 3) dwt2_inv_stream_kernel(const Dwt2InvArgs<L> a) {
   using C = ICfg<L, D>;
   constexpr int HL = C::HL, KQ = C::KQ, RING = C::RING, U = C::U, NRD = C::NRD;
   __shared__ __attribute__((aligned(16))) float lds_all[4][2][2][kInvLdsRow];  // [wave][p parity][lo/hi][col x 2]
@@ -268,10 +268,7 @@ int dwt2_inv_stream(const mifwt_level_desc* d, const void* approx, const void* c
     case 10: return launch<10, 1>(d, approx, details, y, lo, hi, stream);
     case 12: return launch<12, 1>(d, approx, details, y, lo, hi, stream);
     case 14: return launch<14, 1>(d, approx, details, y, lo, hi, stream);
-    case 16:
-      if ((g_options[MIFWT_OPT_EXP] & 3) == 2) return launch<16, 2>(d, approx, details, y, lo, hi, stream);
-      if ((g_options[MIFWT_OPT_EXP] & 3) == 3) return launch<16, 3>(d, approx, details, y, lo, hi, stream);
-      return launch<16, 1>(d, approx, details, y, lo, hi, stream);
+    case 16: return launch<16, 1>(d, approx, details, y, lo, hi, stream);  // (prefetch depth 2 / 3: 1.71 / 1.67-1.76 against 1.66 ms on config 4, EXPERIMENTS R5.10)
     default: return MIFWT_ERR_UNSUPPORTED;
   }
 }

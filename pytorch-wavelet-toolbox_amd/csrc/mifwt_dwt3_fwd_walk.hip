@@ -342,15 +342,11 @@ int launch_walk3(const mifwt_level_desc* d, const void* x, void* approx, void* c
   a.Wo = (int)d->coef_extent[2];
   a.mode = d->mode;
   a.nt = g_options[MIFWT_OPT_NT_STORE];
-  a.dbg = g_options[MIFWT_OPT_DEBUG] & 31;  // (bits 6, 7: the strip layout, above)
+  a.dbg = g_options[MIFWT_OPT_DEBUG] & 31;  // (bit 6: strips of 64 columns, below)
   for (int m = 0; m < L; ++m) a.tap[m] = (typename TileArith<T>::vec2){(T)lo[m], (T)hi[m]};
   a.nstrips = (a.Wo + 63) / 64;
   a.nq = (g_options[MIFWT_OPT_DEBUG] & 64) ? 64 : (a.Wo + a.nstrips - 1) / a.nstrips;
-  if ((g_options[MIFWT_OPT_DEBUG] & 128) && a.Wo > 64 && a.Wo % 64 != 0) {  // (timing experiment, results wrong: the columns behind the last full strip of 64 are not computed)
-    a.nstrips = a.Wo / 64;
-    a.nq = 64;
-  }
-  if (const int ns = g_options[MIFWT_OPT_EXP] & 15; ns > 0 && ns * NRG <= 8 && ns <= a.Wo) {  // (experiment: narrower strips, more waves)
+  if (const int ns = g_options[MIFWT_OPT_EXP] & 15; ns >= a.nstrips && ns * NRG <= (ES == 8 ? 4 : 8)) {  // (A/B: narrower strips, more waves — 8 x 256^3 db2, 3 / 4 / 5 / 6 / 8 strips: 232 / 233 / 243 / 249 / 347 us)
     a.nstrips = ns;
     a.nq = (a.Wo + ns - 1) / ns;
   }

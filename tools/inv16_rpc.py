@@ -25,9 +25,9 @@ def f():
 y0 = f().clone()
 byt = (4 * B * M * M + B * 4096 * 4096) * 4
 for rep in range(2):
-    for rpc, ex in ((0, 0), (64, 0), (32, 2), (64, 2), (128, 2), (32, 3), (64, 3), (128, 3)):
-        _engine.set_option(_engine.OPT_ROWS_PER_CHUNK, rpc); _engine.set_option(15, ex)
+    for rpc in (0, 16, 32, 48, 64, 96, 128, 256, 512, 1024, 2048, 4096):
+        _engine.set_option(_engine.OPT_ROWS_PER_CHUNK, rpc)
         ms = t(f)
         same = torch.equal(f(), y0)
-        print(f'rows per task {rpc:5d} depth {ex}: {ms:.3f} ms  {byt / ms / 1e9:.2f} TB/s = {byt / ms / 8e9:.3f}  bit-identical {same}', flush=True)
-_engine.set_option(_engine.OPT_ROWS_PER_CHUNK, 0); _engine.set_option(15, 0)
+        print(f'rows per task {rpc:5d}: {ms:.3f} ms  {byt / ms / 1e9:.2f} TB/s = {byt / ms / 8e9:.3f}  bit-identical {same}', flush=True)
+_engine.set_option(_engine.OPT_ROWS_PER_CHUNK, 0)

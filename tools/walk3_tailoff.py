@@ -1,4 +1,5 @@
-"""Upper bound for a tail-column scheme in the 3-D walking analysis kernel: level 1 of config 3 with the 129th column not computed."""
+"""Level 1 of config 3 on the 3-D walking analysis kernel: loads / stores switched off (MIFWT_OPT_DEBUG 1, 2), then 3-8 column strips
+(MIFWT_OPT_EXP)."""
 import sys, torch
 sys.path.insert(0, '.')
 import ptwt_amd
@@ -24,3 +25,7 @@ for rep in range(2):
         _engine.set_option(11, dbg)
         print(f'level 1 of 8 x 256^3 db2, debug {dbg} (1: no stores, 2: no loads): {t(f):.1f} us', flush=True)
 _engine.set_option(11, 0)
+for ns in (0, 3, 4, 5, 6, 8):
+    _engine.set_option(15, ns)
+    print(f'level 1 of 8 x 256^3 db2, {ns} strips: {t(f):.1f} us', flush=True)
+_engine.set_option(15, 0)
