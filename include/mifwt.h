@@ -362,7 +362,7 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
                                       3 = rolling strips wherever they apply */
 #define MIFWT_OPT_PAIR_ROWS 9      /* >0 overrides the pair kernels' level-2 rows per tile (4, 6, 8, 12) / per strip segment (multiple of 8) */
 #define MIFWT_OPT_PYRAMID_MODE 12 /* mifwt_dwt2_fwd_pyramid: 0 = auto (each of its two kernels where it is the fastest route), 1 = the streaming kernel wherever it can run, 3 = the small-plane kernel wherever it can run, 2 = never (it answers UNSUPPORTED / 0; the two-level and per-level kernels then serve the call) */
-#define MIFWT_OPT_DEBUG 11        /* A/B measurement switches of the multi-level kernels (results are then wrong): 1 = no stores, 2 = no loads, 4 = no deep levels, 16 = loader wave at default priority (streaming kernel); 32 / 64 / 128 = no pad fills / no horizontal / no vertical pass (small-plane analysis kernel, tools/small_ab.py).  Switches that keep the results right (A/B runs and parity tests of alternative code paths): 256 = the streaming analysis kernel's row segments hand rows over through a workspace instead of prologues, 512 = never its 16-byte store path, 1024 = analysis adjoints with a boundary extension on the generic per-axis passes instead of synthesis launch + border kernel, 2048 = the streaming analysis kernel in its compact form (eight-wave workgroups, two per CU).  The 3-D walking kernels (ids 24 / 25) read the same word: 1 / 2 / 4 = no stores / no loads / no W and H passes, 8 = band rows on a 128-sample pitch (analysis; results are then wrong), 16 = non-temporal requests (analysis), 64 = column strips of 64 instead of balanced strips (analysis), 512 = 8-byte instead of 16-byte output stores (synthesis; results stay right) */
+#define MIFWT_OPT_DEBUG 11        /* A/B measurement switches of the multi-level kernels (results are then wrong): 1 = no stores, 2 = no loads, 4 = no deep levels, 16 = loader wave at default priority (streaming kernel); 32 / 64 / 128 = no pad fills / no horizontal / no vertical pass (small-plane analysis kernel, tools/small_ab.py).  Switches that keep the results right (A/B runs and parity tests of alternative code paths): 256 = the streaming analysis kernel's row segments hand rows over through a workspace instead of prologues, 512 = never its 16-byte store path, 1024 = analysis adjoints with a boundary extension on the generic per-axis passes instead of synthesis launch + border kernel, 2048 = the streaming analysis kernel in its compact form (eight-wave workgroups, two per CU), 4096 = the border part of a 2-D analysis adjoint on the one-thread-per-sample kernel instead of the one-thread-per-border-line kernel.  The 3-D walking kernels (ids 24 / 25) read the same word: 1 / 2 / 4 = no stores / no loads / no W and H passes, 8 = band rows on a 128-sample pitch (analysis; results are then wrong), 16 = non-temporal requests (analysis), 64 = column strips of 64 instead of balanced strips (analysis), 512 = 8-byte instead of 16-byte output stores (synthesis; results stay right) */
 #define MIFWT_OPT_PYR_WGS 13 /* >0: the streaming analysis kernel (id 16) cuts the batch's rows into this many chunks (workgroups per column group) instead of one per CU — parity tests of units that start and end anywhere */
 #define MIFWT_OPT_EXP 15           /* experiment word of the A/B run in progress (tools/); 0 in the product */
 #define MIFWT_OPT_SYNC_STAGE 10    /* non-zero: tile kernels keep the workgroup barrier between staging and the horizontal pass (A/B) */

@@ -208,6 +208,150 @@ __global__ void __launch_bounds__(256) adjoint_border_kernel(const BorderArgs<T,
   a.gx[ox] += acc;  // (on top of the sample's own term, which the zero-mode adjoint launch has written)
 }
 
+// ---- two axes, one thread per border LINE ---------------------------------------------------------------------------------------------
+// The kernel above spends ~25 instructions of loop and address arithmetic per 4 loads and shares nothing between the samples of a border:
+// config 2's backward (64 x 1024^2 db4 reflect) paid 56 + 37 + 21 us for the three levels' borders next to 145 us of synthesis launches.
+// The extended adjoint is separable, u[e0, e1] = sum_k0 h[2 k0 + 1 - e0] X[k0][e1]: here a thread owns
+//   * one COLUMN n1 (N1 threads) and every border row of it, top and bottom: for each preimage e1 of n1 it synthesises the few coefficient
+//     rows within reach of the two row frames along its column ONCE (X_lo, X_hi per row, kept in LDS), then folds them into the 2 B0
+//     border rows (every preimage pair but (n0, n1) itself);  or
+//   * one interior ROW n0 (N0 - 2 B0 threads) and its left / right border columns: the same with the axes exchanged — an interior row has
+//     no other preimage, so only the pad columns are synthesised.
+// Rows inside the row slabs belong to the column threads, the rest of the column slabs to the row threads: every border sample has one
+// owner, one launch, no atomics.  ~750 instructions per thread, ~2 N threads per image instead of ~450 x 4 B N.
+template <typename T>
+struct BPair {
+  T x, y;
+};
+
+constexpr int kBorder2Threads = 128;
+
+template <typename T, int G>
+__global__ void __launch_bounds__(kBorder2Threads) adjoint_border2_kernel(const BorderArgs<T, 2> a, int krmax) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* const s_lo = reinterpret_cast<T*>(smem_raw);
+  T* const s_hi = s_lo + kMaxTaps;
+  // G lanes of a wave share a line: each synthesises every G-th coefficient row of the frames, then folds every G-th border sample
+  const int tid = (int)threadIdx.x, sub = tid % G;
+  BPair<T>* const X = reinterpret_cast<BPair<T>*>(s_hi + kMaxTaps) + (tid / G) * (2 * krmax);  // [frame][row of the frame] of this line
+  if (tid < kMaxTaps) {
+    s_lo[tid] = a.lo[tid];
+    s_hi[tid] = a.hi[tid];
+  }
+  __syncthreads();
+  const int N0 = a.N[0], N1 = a.N[1];
+  const int inner_rows = max(0, N0 - 2 * a.B[0]);
+  const int line = (int)blockIdx.x * (kBorder2Threads / G) + tid / G;
+  if (line >= N1 + inner_rows) return;  // (the G lanes of a line leave together)
+  const bool col = line < N1;          // a column thread (border axis 0) or a row thread (border axis 1)
+  const int b = col ? 0 : 1, o = 1 - b;
+  const int c = col ? line : a.B[0] + (line - N1);  // the thread's coordinate along its own axis o
+  const int Nb = a.N[b], Mb = a.M[b], Bb = a.B[b], plb = a.pl[b], prb = a.pr[b], Mo = a.M[o];
+  const int L = a.L;
+  const int64_t img = a.img0 + blockIdx.y;
+  // bands by (high along b, high along o): band index bit 1 = axis 0 high, bit 0 = axis 1 high
+  const T* const pLL = a.gband[0] + img * a.as[0];
+  const T* const pLH = a.gband[col ? 1 : 2] + img * a.ds[0];  // low along b, high along o
+  const T* const pHL = a.gband[col ? 2 : 1] + img * a.ds[0];
+  const T* const pHH = a.gband[3] + img * a.ds[0];
+  const int as_b = (int)a.as[1 + b], as_o = (int)a.as[1 + o], ds_b = (int)a.ds[1 + b], ds_o = (int)a.ds[1 + o];
+  T* const gx = a.gx + img * a.xs[0] + (int64_t)c * a.xs[1 + o];
+  const int64_t xs_b = a.xs[1 + b];
+  int oa[3], ob[3];
+  if (col) {
+    preimages(c, a.N[o], a.pl[o], a.pr[o], a.mode, oa, ob);
+  } else {  // an interior row is its own only preimage
+    oa[0] = ob[0] = c;
+    oa[1] = oa[2] = 0;
+    ob[1] = ob[2] = -1;
+  }
+  for (int qo = 0; qo < 3; ++qo)
+    for (int eo = oa[qo]; eo <= ob[qo]; ++eo) {
+      const bool self_o = qo == 0;
+      const int ko_lo = max(0, eo >> 1), ko_hi = min(Mo - 1, (eo + L - 2) >> 1);
+      // the two frames of extended positions along b whose u the border needs: pad positions, and (unless eo is the thread's own
+      // coordinate: that pair is the sample itself) the slab's own rows
+      int klo[2], khi[2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const int e_first = f == 0 ? -plb : (self_o ? Nb : Nb - Bb);
+        const int e_last = f == 0 ? (self_o ? -1 : Bb - 1) : Nb + prb - 1;
+        klo[f] = max(0, e_first >> 1);
+        khi[f] = e_last < e_first ? klo[f] - 1 : min(Mb - 1, (e_last + L - 2) >> 1);
+        for (int kb = klo[f] + sub; kb <= khi[f]; kb += G) {
+          T xl = 0, xh = 0;
+          // (all requests of four coefficients before the first use: positions beyond the window are clamped and weighted zero)
+          for (int k4 = ko_lo; k4 <= ko_hi; k4 += 4) {
+            T va[4], vb[4], vc[4], vd[4], wl[4], wh[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int ko = min(k4 + j, ko_hi);
+              const int offa = kb * as_b + ko * as_o, offd = kb * ds_b + ko * ds_o;
+              va[j] = pLL[offa];
+              vb[j] = pLH[offd];
+              vc[j] = pHL[offd];
+              vd[j] = pHH[offd];
+              const int m = 2 * ko + 1 - eo;
+              const bool on = k4 + j <= ko_hi;
+              wl[j] = on ? s_lo[m] : T(0);
+              wh[j] = on ? s_hi[m] : T(0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              xl += va[j] * wl[j] + vb[j] * wh[j];
+              xh += vc[j] * wl[j] + vd[j] * wh[j];
+            }
+          }
+          X[f * krmax + (kb - klo[f])] = BPair<T>{xl, xh};
+        }
+      }
+      wave_lds_fence();  // (the lanes of a line sit in one wave: DS operations of a wave execute in order)
+      {
+        for (int di = sub; di < 2 * Bb; di += G) {
+          const int t = di < Bb ? di : Nb - 2 * Bb + di;
+          int ta[3], tb[3];
+          preimages(t, Nb, plb, prb, a.mode, ta, tb);
+          T sum = 0;
+          bool any = false;
+          for (int q = self_o ? 1 : 0; q < 3; ++q)
+            for (int eb = ta[q]; eb <= tb[q]; ++eb) {
+              const int f = eb < Bb ? 0 : 1;
+              const int kl = max(0, eb >> 1), kh = min(Mb - 1, (eb + L - 2) >> 1);
+              for (int kb = kl; kb <= kh; ++kb) {
+                const int m = 2 * kb + 1 - eb;
+                const BPair<T> x = X[f * krmax + (kb - klo[f])];
+                sum += s_lo[m] * x.x + s_hi[m] * x.y;
+              }
+              any = true;
+            }
+          if (any) gx[(int64_t)t * xs_b] += sum;  // (on top of what the zero-mode adjoint launch and earlier preimages of the column have written)
+        }
+      }
+      wave_lds_fence();
+    }
+}
+
+// rows of a frame within reach: the frame spans at most pl + B positions, its coefficients (span + L - 2) / 2 + 1
+inline int border2_krmax(int L) { return (3 * L) / 2 + 2; }
+
+template <typename T>
+bool border2_fits(const mifwt_level_desc* d, int* threads, size_t* lds) {
+  // from eight taps on (border part of a level's adjoint on 64 x 1024^2 / 515^2 / 261^2, us, this kernel against one thread per sample:
+  // db2 27 / 16 / 10 against 24 / 10 / 9; db3 34 / 21 / 14 against 33 / 21 / 14; db4 36 / 22 / 15 against 52 / 37 / 21; db8 58 / 36 / 26
+  // against 228 / 148 / 99; profiles/r05x_border_ab.txt)
+  if (d->ndim != 2 || d->filt_len < 8 || (g_options[MIFWT_OPT_DEBUG] & 4096)) return false;
+  for (int i = 0; i <= 2; ++i)
+    if (d->approx_stride[i] < 0 || d->detail_stride[i] < 0) return false;
+  // 32-bit element offsets inside one image of a band
+  if ((d->coef_extent[0] - 1) * d->approx_stride[1] + (d->coef_extent[1] - 1) * d->approx_stride[2] >= (int64_t(1) << 31) ||
+      (d->coef_extent[0] - 1) * d->detail_stride[1] + (d->coef_extent[1] - 1) * d->detail_stride[2] >= (int64_t(1) << 31))
+    return false;
+  const int kr = border2_krmax(d->filt_len);
+  *threads = kBorder2Threads;
+  *lds = 2 * kMaxTaps * sizeof(T) + (size_t)2 * kr * (kBorder2Threads / 8) * sizeof(BPair<T>);
+  return true;
+}
+
 template <typename T, int ND>
 int launch_border(const mifwt_level_desc* d, const void* g_approx, const void* const* g_details, void* g_x, const double* lo,
                   const double* hi, hipStream_t stream) {
@@ -252,6 +396,22 @@ int launch_border(const mifwt_level_desc* d, const void* g_approx, const void* c
     a.hi[m] = m < a.L ? (T)hi[m] : (T)0;
   }
   if (per_image == 0 || d->batch == 0) return MIFWT_OK;
+  if constexpr (ND == 2) {
+    int threads = 0;
+    size_t lds = 0;
+    if (border2_fits<T>(d, &threads, &lds)) {
+      const int64_t lines = a.N[1] + std::max(0, a.N[0] - 2 * a.B[0]);
+      constexpr int G = 8;  // lanes per line (64 x 1024^2 / 515^2 / 261^2 db4, border part alone: 4 lanes 41 / 22 / 17 us, 8: 36 / 22 / 15, 16: 50 / 24 / 22)
+      const int lpb = threads / G;
+      const unsigned gl = (unsigned)((lines + lpb - 1) / lpb);
+      for (int64_t b0 = 0; b0 < d->batch; b0 += 32768) {
+        a.img0 = b0;
+        const unsigned gy = (unsigned)std::min<int64_t>(32768, d->batch - b0);
+        hipLaunchKernelGGL((adjoint_border2_kernel<T, G>), dim3(gl, gy), dim3(threads), lds, stream, a, border2_krmax(a.L));
+      }
+      return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
+    }
+  }
   const unsigned gx = (unsigned)((per_image * kLanesPerSample + 255) / 256);
   for (int64_t b0 = 0; b0 < d->batch; b0 += 32768) {  // (grid.y is 16 bits)
     a.img0 = b0;

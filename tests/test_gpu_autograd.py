@@ -335,6 +335,7 @@ def test_analysis_adjoint_fast_route_vs_generic_passes(mode, dtype):
     eng = _engine.ENGINE
     tol = 2e-6 if dtype == torch.float32 else 1e-12
     for shape, wavelet in [((3, 200), "db4"), ((2, 201), "haar"), ((5, 96), "db10"), ((2, 64, 70), "db4"), ((3, 61, 128), "db2"), ((1, 300, 301), "sym8"),
+                           ((2, 33, 40), "haar"), ((2, 45, 42), "db10"), ((1, 131, 67), "db3"), ((70, 18, 19), "db4"), ((1, 140, 90), "coif5"),
                            ((2, 24, 26, 31), "db2"), ((1, 40, 33, 36), "db3"), ((2, 18, 20, 19), "haar")]:
         dec_lo, dec_hi, _, _ = ptwt_amd._wavelets.host_taps(wavelet)
         flen, nd = len(dec_lo), len(shape) - 1
@@ -352,6 +353,13 @@ def test_analysis_adjoint_fast_route_vs_generic_passes(mode, dtype):
         assert G.relerr(fast.cpu().numpy(), slow.cpu().numpy()) < tol, (shape, wavelet)
         assert float((fast - slow).abs().max()) < 50 * tol * float(slow.abs().max()), (shape, wavelet)  # (every border sample, not only the norm)
         assert G.relerr(bands.cpu().numpy(), slow.cpu().numpy()) < tol, (shape, wavelet, "per-band entry")
+        if nd == 2:  # the border on the one-thread-per-sample kernel (MIFWT_OPT_DEBUG 4096) instead of one thread per border line
+            _engine.set_option(_engine.OPT_DEBUG, 4096)
+            try:
+                per_sample = eng.analysis_adjoint(g, shape[1:], dec_lo, dec_hi, _engine.MODE_IDS[mode])
+            finally:
+                _engine.set_option(_engine.OPT_DEBUG, 0)
+            assert float((fast - per_sample).abs().max()) < 50 * tol * float(slow.abs().max()), (shape, wavelet, "border kernels")
         lhs, rhs = (buf.double() * g.double()).sum().item(), (x.double() * fast.double()).sum().item()
         # (sums of up to 1e5 products of unit-variance numbers: |lhs| ~ 3e2, fp32 rounding of the terms ~ 1e-2 in all)
         assert abs(lhs - rhs) <= ((2e-5, 2e-2) if dtype == torch.float32 else (1e-12, 1e-9))[0] * abs(rhs) + ((2e-5, 2e-2) if dtype == torch.float32 else (1e-12, 1e-9))[1], (shape, wavelet, lhs, rhs)
