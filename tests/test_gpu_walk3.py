@@ -79,6 +79,20 @@ def test_walk3_f64_vs_oracle(wavelet):
                 assert kids and kids[0] == 24, (kids, shape, mode)
                 assert got[0].dtype == torch.float64
                 check_tree(got, want, TOL64, f"dwt3 walk f64 {wavelet} {mode} {shape} rows {rows}")
+    # a slice of a bigger tensor (strides larger than the extents, rows that start on odd 8-byte boundaries), short depth segments
+    big = torch.from_numpy(rng.standard_normal((2, 40, 45, 141))).to(dev())
+    xs = big[:, 3:37, 2:43, 5:138]
+    for mode in ("reflect", "periodic"):
+        want = O.wavedec3(to_np(xs), wavelet, mode=mode, level=1)
+        _engine.set_option(_engine.OPT_ROWS_PER_CHUNK, 8)
+        try:
+            got, kids = _walk(lambda: ptwt_amd.wavedec3(xs, wavelet, mode=mode, level=1))
+        finally:
+            _engine.set_option(_engine.OPT_ROWS_PER_CHUNK, 0)
+        assert kids == [24], kids
+        check_tree(got, want, TOL64, f"dwt3 walk f64 strided {wavelet} {mode}")
+        rec, kids = _walk(lambda: ptwt_amd.waverec3(got, wavelet))
+        assert G.relerr(to_np(rec[..., :34, :41, :133]), to_np(xs)) < 1e-11, (wavelet, mode)
     # rows of more than 256 doubles are not the kernel's: the composed route serves them
     xg = torch.randn(1, 12, 12, 300, device=dev(), dtype=torch.float64)
     _, kids = _walk(lambda: ptwt_amd.wavedec3(xg, wavelet, mode="zero", level=1))
