@@ -593,10 +593,28 @@ class _SynthesisPyramid(torch.autograd.Function):
         rec_lo, rec_hi, coef_shapes = ctx.meta
         grads: list = []
         g = g_y
-        for shp in reversed(coef_shapes):  # finest level first: its adjoint yields the gradient of its four bands
-            gb = _SynthesisAdjointLevel.apply(g, shp, rec_lo, rec_hi)
-            grads = [gb[:, 1], gb[:, 2], gb[:, 3]] + grads
-            g = gb[:, 0]  # = the gradient of the coarser level's (trimmed) output
+        todo = list(reversed(coef_shapes))  # finest level first: its adjoint yields the gradient of its four bands
+        # No graph of the backward wanted: the adjoint of a synthesis level is a zero-mode analysis level with the rec taps reversed, and a
+        # trimmed output row / column is a zero the zero extension supplies anyway — so the adjoint of the whole reconstruction is ONE
+        # multi-level analysis launch (kernels 16 / 20) where the library serves it (the mirror of _AnalysisPyramid.backward).
+        fused = not torch.is_grad_enabled() and not _engine._is_dev(rec_lo) and g_y.dim() == 3 and g_y.dtype == torch.float32
+        zero = _engine.MODE_IDS["zero"]
+        while todo:
+            bufs = None
+            if fused and len(todo) >= 2:
+                bufs = _engine.ENGINE.analysis_pyramid(g if g.stride(-1) == 1 else g.contiguous(), list(rec_lo)[::-1], list(rec_hi)[::-1], zero, len(todo))
+                if bufs is not None and (len(bufs) < 2 or any(tuple(b.shape[2:]) != tuple(shp) for b, shp in zip(bufs, todo))):
+                    bufs = None
+            if bufs is None:
+                gb = _SynthesisAdjointLevel.apply(g, todo[0], rec_lo, rec_hi)
+                grads = [gb[:, 1], gb[:, 2], gb[:, 3]] + grads
+                g = gb[:, 0]  # = the gradient of the coarser level's (trimmed) output
+                todo = todo[1:]
+            else:
+                for b in bufs:
+                    grads = list(b.unbind(1)[-3:]) + grads
+                g = bufs[-1][:, 0]
+                todo = todo[len(bufs):]
         return (None, None, None, None, None, g, *grads)
 
 

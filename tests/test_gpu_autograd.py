@@ -250,6 +250,23 @@ def test_fused_synthesis_of_differentiable_calls(shape, wavelet, level, pmode, f
         _engine.set_option(_engine.OPT_PAIR_MODE, 0)
     for i, (a, b) in enumerate(zip(gl, gl_ref)):
         assert G.relerr(a.detach().cpu().numpy(), b.cpu().numpy()) < 2e-6, i
+    # a plain backward (no graph of the backward wanted): the adjoint of the whole reconstruction is ONE zero-mode multi-level ANALYSIS
+    # launch with the rec taps reversed (kernels 16 / 20) where the library serves the geometry — same gradients
+    _engine.set_option(_engine.OPT_PYRAMID_MODE, pmode)
+    try:
+        leaves3 = [t.detach().clone().requires_grad_(True) for t in leaves]
+        y3 = getattr(ptwt_amd, rec)(rebuild(coeffs, leaves3), wavelet)
+        _engine.level_events = []
+        gl3 = torch.autograd.grad((v * y3).sum(), leaves3)
+        torch.cuda.synchronize()
+        kids_b = [e[1] for e in _engine.level_events]
+    finally:
+        _engine.level_events = None
+        _engine.set_option(_engine.OPT_PYRAMID_MODE, 0)
+    for i, (a, b) in enumerate(zip(gl3, gl_ref)):
+        assert a.shape == b.shape and G.relerr(a.cpu().numpy(), b.cpu().numpy()) < 2e-6, (i, kids_b)
+    if shape in ((2, 600, 520), (6, 95, 81)) and rec == "waverec2":
+        assert kids_b and kids_b[0] in (_engine.KID_PYRAMID, _engine.KID_SMALL) and len(kids_b) < level, kids_b
 
 
 @pytest.mark.parametrize("mode", ["zero", "reflect", "periodic", "symmetric"])
