@@ -508,10 +508,27 @@ class _SynthesisChain1d(torch.autograd.Function):
         rec_lo, rec_hi, coef_shapes = ctx.meta
         grads: list = []
         g = g_y
-        for shp in reversed(coef_shapes):
-            gb = _SynthesisAdjointLevel.apply(g, shp, rec_lo, rec_hi)
-            grads.insert(0, gb[:, 1])
-            g = gb[:, 0]
+        todo = list(reversed(coef_shapes))  # finest level first
+        # no graph of the backward wanted: the adjoint of the chain is a zero-mode multi-level ANALYSIS with the rec taps reversed (a
+        # trimmed output sample is a zero of the zero extension) — the 1-D multi-level launches (kernels 17 / 14), see _SynthesisPyramid
+        fused = not torch.is_grad_enabled() and not _engine._is_dev(rec_lo) and g_y.dim() == 2
+        zero = _engine.MODE_IDS["zero"]
+        while todo:
+            bufs = None
+            if fused and len(todo) >= 2:
+                bufs = _engine.ENGINE.analysis_tail(g if g.stride(-1) == 1 else g.contiguous(), list(rec_lo)[::-1], list(rec_hi)[::-1], zero, len(todo))
+                if bufs is not None and (len(bufs) < 2 or any(tuple(b.shape[2:]) != tuple(shp) for b, shp in zip(bufs, todo))):
+                    bufs = None
+            if bufs is None:
+                gb = _SynthesisAdjointLevel.apply(g, todo[0], rec_lo, rec_hi)
+                grads.insert(0, gb[:, 1])
+                g = gb[:, 0]
+                todo = todo[1:]
+            else:
+                for b in bufs:
+                    grads.insert(0, b[:, -1])
+                g = bufs[-1][:, 0]
+                todo = todo[len(bufs):]
         return (None, None, None, g, *grads)
 
 

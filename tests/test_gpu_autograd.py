@@ -300,7 +300,12 @@ def test_fused_1d_launches_of_differentiable_calls(mode, shape, wavelet, level):
     _engine.level_events = None
     assert any(k in (15, 18) for k in rkids), rkids
     v = torch.randn_like(y)
-    gl = torch.autograd.grad((v * y).sum(), leaves)
+    _engine.level_events = []
+    gl = torch.autograd.grad((v * y).sum(), leaves)  # (a plain backward: the multi-level analysis launches with the rec taps reversed)
+    torch.cuda.synchronize()
+    bkids = [e[1] for e in _engine.level_events]
+    _engine.level_events = None
+    assert any(k in (14, 17) for k in bkids), bkids
     _engine.set_option(_engine.OPT_PAIR_MODE, 2)  # every multi-level launch off
     try:
         x2 = x.detach().clone().requires_grad_(True)
