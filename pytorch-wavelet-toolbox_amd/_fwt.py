@@ -619,7 +619,10 @@ class _SynthesisPyramid(torch.autograd.Function):
         while todo:
             bufs = None
             if fused and len(todo) >= 2:
-                bufs = _engine.ENGINE.analysis_pyramid(g if g.stride(-1) == 1 else g.contiguous(), list(rec_lo)[::-1], list(rec_hi)[::-1], zero, len(todo))
+                gin = g if g.stride(-1) == 1 else g.contiguous()
+                k = _engine.ENGINE.pyramid_levels(gin, len(rec_lo), zero, len(todo))  # (a query: nothing is launched)
+                if k >= 2:
+                    bufs = _engine.ENGINE.analysis_pyramid(gin, list(rec_lo)[::-1], list(rec_hi)[::-1], zero, k)
                 if bufs is not None and (len(bufs) < 2 or any(tuple(b.shape[2:]) != tuple(shp) for b, shp in zip(bufs, todo))):
                     bufs = None
             if bufs is None:
