@@ -616,7 +616,7 @@ __global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaAr
       }
       typedef _Float16 h4 __attribute__((ext_vector_type(4)));
       if (a.dbg & 1) {
-      } else if (cur.k0 + kMC <= a.Wo) {
+      } else {
         // Transposed through LDS, wave-local: this wave is the only reader of ring columns bh * 64 + cg * 32 + (0 .. 31) in the
         // vertical pass, and their OLDER half is dead once its fragments above are in registers (the next horizontal pass rewrites it
         // behind barrier A).  Row r = (vertical band, output row) of the 32 x 32 block goes to the older half of ring column r:
@@ -633,8 +633,17 @@ __global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaAr
           const int sb = 2 * (r >> 4) + bh;  // band: bit 1 = vertical (axis -2) high, bit 0 = horizontal high
           const int j = (cur.tr0 + g - 1) * kMR + (r & 15);
           const h8 v = *reinterpret_cast<const h8*>(colbase + r * kHP + 8 * pc);
-          if (j < a.Ho) {
-            _Float16* dst = a.out[sb] + (int64_t)cur.img * a.os_b[sb] + (int64_t)j * a.os_h[sb] + cur.k0 + cg * 32 + 8 * pc;
+          const int kc = cur.k0 + cg * 32 + 8 * pc;  // first of the piece's eight columns
+          if (j < a.Ho && kc + 8 > a.Wo) {
+            // the LAST panel of a plane: the piece that straddles the plane's last column leaves sample by sample, pieces beyond it do
+            // not leave at all.  (Until round 5 the whole last panel was stored column by column, sixteen 2-byte stores per lane and tile:
+            // its units were the long pole of every launch on planes of few panels.)
+            _Float16* dst = a.out[sb] + (int64_t)cur.img * a.os_b[sb] + (int64_t)j * a.os_h[sb] + kc;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (kc + e < a.Wo) dst[e] = v[e];
+          } else if (j < a.Ho) {
+            _Float16* dst = a.out[sb] + (int64_t)cur.img * a.os_b[sb] + (int64_t)j * a.os_h[sb] + kc;
             // (16-byte stores to 2-byte aligned addresses — rows of an odd pitch — are fine on this hardware, tools/align_probe.hip;
             // the compiler would split them)
             // non-temporal: nothing reads these lines back (config-5 slice, level 1: 2.29 -> 2.15 ms analysis, 2.21 -> 2.18 synthesis;
@@ -643,19 +652,6 @@ __global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaAr
             else if (a.dbg & 16) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
             else asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
           }
-        }
-      } else {  // the last panel of a plane: column by column
-        const int bv = n >> 4, jr = n & 15;
-        const int sb = 2 * bv + bh;
-        const int j = (cur.tr0 + g - 1) * kMR + jr;
-        const int k = cur.k0 + cg * 32 + 4 * half;
-        if (j < a.Ho) {
-          _Float16* base = a.out[sb] + (int64_t)cur.img * a.os_b[sb] + (int64_t)j * a.os_h[sb] + k;
-#pragma unroll
-          for (int gg = 0; gg < 4; ++gg)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (k + 8 * gg + e < a.Wo) base[8 * gg + e] = (_Float16)acc[4 * gg + e];
         }
       }
     }
