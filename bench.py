@@ -232,6 +232,9 @@ def profiled_traffic(workload, kernel_label=""):
             try:
                 with open(os.path.join(pdir, name)) as f:
                     prof = json.load(f)
+                token = (kernel_label.split() or [""])[0]
+                if token.endswith("_kernel") and token not in prof.get("kernel", ""):
+                    continue  # (a summary taken when another kernel served this workload: not this launch's traffic)
                 return prof.get("hbm_traffic_bytes"), "profiles/" + name
             except Exception:
                 return None, None
