@@ -327,9 +327,10 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  *   5 / 6  3-D analysis / synthesis (f32, even L <= 16; what the brick kernels 9 / 10 do not take): fused 2-D kernel over every
  *          depth slice + one streaming pass along depth
  *   9 / 10  fully fused 3-D analysis / synthesis level, LDS bricks (f32, L in {2, 4, 6}; synthesis also 8): the small volumes
- *   24 / 25  fully fused 3-D analysis / synthesis level, workgroups walking along the depth axis (f32; analysis: even L <= 10, every
- *          mode, rows <= 512 samples, picked from 2^22 samples per volume on and for 8 taps; synthesis: even L <= 8, dense coefficient
- *          rows, picked from 2^20 output samples on)
+ *   24 / 25  fully fused 3-D analysis / synthesis level, workgroups walking along the depth axis (f32 and f64; analysis: even L <= 10,
+ *          every mode, rows <= 512 samples (f64: 256), picked from 2^22 samples per volume on and for 8 taps; synthesis: even L <= 8,
+ *          dense coefficient rows, picked from 2^20 output samples on; f64, which has no bricks: analysis from 2^15 / 2^17 / 2^19 samples
+ *          on for <= 4 / 6 / 8 taps, synthesis from 2^16 (<= 4 taps) / 2^19 output samples on)
  *   11 / 23  fused 2-D analysis / synthesis level on the matrix cores (banded-Toeplitz MFMA; f16 storage, even L in [18, 32]; both walk down
  *          column panels; the synthesis kernel from 16 tiles of 32 x 128 samples per call on, the vector tile kernel 8 below that)
  *   12 / 13  two fused 2-D analysis / synthesis levels per launch (mifwt_dwt2_fwd_pair / mifwt_dwt2_inv_pair; never
