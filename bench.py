@@ -258,6 +258,7 @@ def profiled_traffic(workload, kernel_label=""):
 # BASELINE configs' per-GPU shapes, both directions, so that they are driver-timed figures and not builder-run ones.
 SECONDARY = ["waverec2_db4_L3_64x1024x1024_f32", "wavedec3_db2_L3_8x256x256x256_f32", "waverec3_db2_L3_8x256x256x256_f32",
              "wavedec2_db8_L4_64x4096x4096_f32", "waverec2_db8_L4_64x4096x4096_f32", "wavedec2_bwd_db4_L3_64x1024x1024_f32",
+             "waverec2_bwd_db4_L3_64x1024x1024_f32",
              # round 5: config 5's per-GPU slice both ways, the f64 forms of configs 2 / 3, the reference's own published shapes
              "fswavedec2_sym16_L5_32x8192x8192_f16", "fswaverec2_sym16_L5_32x8192x8192_f16",
              "wavedec2_db4_L3_64x1024x1024_f64", "wavedec3_db2_L3_8x256x256x256_f64", "waverec3_db2_L3_8x256x256x256_f64",
@@ -278,7 +279,18 @@ def secondary_lines(dev, steps=20, warmup=5, buffers=3):
             bwd = fn_name.endswith("_bwd")
             fn = getattr(ptwt_amd, fn_name[:-4] if bwd else fn_name)
             xs = [torch.randn(*shape, dtype=torch.float32 if dtype == torch.float16 else dtype, device=dev).to(dtype) for _ in range(buffers)]
-            if bwd:
+            if bwd and "rec" in fn_name:  # (2-D containers: the approximation, then three detail bands per level)
+                ana = getattr(ptwt_amd, fn_name[:-4].replace("rec", "dec"))
+                with torch.no_grad():
+                    sets = [ana(x, wavelet, mode=mode, level=level) for x in xs]
+                args_ = [[t.contiguous().requires_grad_(True) for _, t in _flatten(c)] for c in sets]
+                del sets, xs
+                gout = torch.randn(*shape, dtype=dtype, device=dev)
+
+                def call(lv):
+                    y = fn((lv[0], *[tuple(lv[1 + 3 * k : 4 + 3 * k]) for k in range((len(lv) - 1) // 3)]), wavelet)
+                    return torch.autograd.grad(y, lv, gout)
+            elif bwd:
                 args_ = [x.requires_grad_(True) for x in xs]
                 with torch.no_grad():
                     gouts = [torch.randn_like(t) for _, t in _flatten(fn(xs[0], wavelet, mode=mode, level=level))]
