@@ -196,7 +196,9 @@ int launch_idwt_tr(const mifwt_level_desc* d, const void* approx, const void* co
   int tro = g_options[MIFWT_OPT_TILE_ROWS];
   if (tro <= 0) {
     const int64_t tiles_c = (d->sig_extent[1] + 2 * NQ - 1) / (2 * NQ);
-    tro = 32;  // several rounds anyway: taller tiles = longer load bursts (32 rows measured best on 1024^2)
+    // several rounds anyway: taller tiles = longer load bursts (32 rows measured best on 1024^2 in f32; f64 tiles of 32 rows leave fewer
+    // workgroups per CU: waverec2 db4 level 3 on 64 x 1024^2 f64 8 / 16 / 24 / 32 rows = 291 / 284 / 322 / 306-311 us, profiles/r05zz_f64_tile_rows.txt)
+    tro = sizeof(typename TileArith<T>::type) == 8 ? 16 : 32;
     for (int cand = 8; cand <= 32; cand += 8) {  // smallest tile height whose grid is resident in one round
       const int64_t blocks = d->batch * tiles_c * ((d->sig_extent[0] + cand - 1) / cand);
       if (blocks <= 256 * idwt_tile_occupancy(L, cand, sizeof(typename TileArith<T>::type))) {
