@@ -601,3 +601,27 @@ def test_half_storage_is_scoped_and_thread_local():
             assert torch.float16 not in C.supported_dtypes()
     finally:
         ptwt_amd.set_half_storage(False)
+
+
+def test_f64_volume_routes_without_a_gpu():
+    """`mifwt_kernel_id` answers on the host: f64 volumes take the f64 instances of the depth-walking kernels (ids 24 / 25) from the
+    measured thresholds on (per filter length, csrc/mifwt_api.hip; profiles/r05w_f64_walk_vs_planes.txt), the composed route (5 / 6)
+    below them, for ten taps, for rows of more than 256 samples and where a row group's coefficient pieces exceed 5 KiB."""
+    import torch
+    from ptwt_amd import _engine
+
+    kid = _engine.kernel_id
+    f64 = torch.float64
+    assert kid(3, f64, "zero", 4, 8, (256, 256, 256)) == 24 and kid(3, f64, "zero", 4, 8, (256, 256, 256), direction=1) == 25
+    assert kid(3, f64, "periodic", 4, 2, (33, 34, 35)) == 24 and kid(3, f64, "zero", 4, 2, (33, 34, 35), direction=1) == 6
+    assert kid(3, f64, "zero", 4, 2, (41, 42, 43), direction=1) == 25
+    assert kid(3, f64, "zero", 4, 2, (20, 21, 22)) == 5 and kid(3, f64, "zero", 4, 2, (20, 21, 22), direction=1) == 6
+    assert kid(3, f64, "zero", 4, 2, (40, 40, 300)) == 5  # rows of more than 256 doubles
+    assert kid(3, f64, "reflect", 6, 2, (66, 66, 66)) == 24 and kid(3, f64, "reflect", 6, 2, (40, 40, 40)) == 5
+    assert kid(3, f64, "reflect", 8, 2, (100, 100, 100)) == 24 and kid(3, f64, "reflect", 8, 2, (66, 66, 66)) == 5
+    assert kid(3, f64, "zero", 10, 2, (128, 128, 128)) == 5 and kid(3, f64, "zero", 10, 2, (128, 128, 128), direction=1) == 6
+    assert kid(3, f64, "zero", 8, 2, (100, 100, 100), direction=1) == 25 and kid(3, f64, "zero", 8, 2, (256, 256, 256), direction=1) == 6
+    # f32 keeps its routes: walk from 2^22 samples on, bricks below, eight taps from 2^20 on
+    f32 = torch.float32
+    assert kid(3, f32, "zero", 4, 8, (256, 256, 256)) == 24 and kid(3, f32, "zero", 4, 8, (129, 129, 129)) == 9
+    assert kid(3, f32, "zero", 8, 8, (128, 128, 128)) == 24 and kid(3, f32, "zero", 8, 8, (54, 54, 54)) == 5
