@@ -150,6 +150,8 @@ FWD_CASES = [
     ((14, 22, 40), "db3", 4, 1, 5, 4, True),
     ((17, 9, 33), "db4", 2, 1, 2, 3, True),       # eight taps: two rows per wave, segments of two output slices
     ((20, 21, 24), "db5", 2, 2, 6, 3, True),      # ten taps: two row sub-groups share a staged slice
+    ((18, 17, 70), "db2", 2, 1, 4, 3, True),      # the f64 instances' shapes: two rows per workgroup on small volumes, three staged slices
+    ((16, 15, 44), "db3", 2, 1, 5, 3, True),      # f64, six taps: two rows (four would not fit the registers)
 ]
 
 
@@ -308,6 +310,8 @@ INV_CASES = [
     ((10, 9, 260), "haar", 4, 2, 3),     # three strips
     ((14, 22, 40), "db3", 4, 4, 2),      # odd L/2: the W pass reads one coefficient pair too far, and never uses it
     ((17, 11, 36), "db4", 2, 5, 3),
+    ((18, 17, 70), "db2", 2, 4, 3),      # the f64 instances' shape: two row pairs per workgroup for every filter length
+    ((16, 15, 44), "db3", 2, 3, 2),
 ]
 
 
