@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define MIFWT_ABI_VERSION 2
+#define MIFWT_ABI_VERSION 3
 #define MIFWT_MAX_NDIM 3
 #define MIFWT_MAX_FILT 128 /* longest PyWavelets discrete filter is coif17 = 102 taps */
 
@@ -159,15 +159,8 @@ int mifwt_dwt2_fwd_pyramid(int nlevels, const mifwt_level_desc* const* descs, co
  * one after the other (a part that starts inside an image streams a prologue of (2^nlevels - 1)(L - 2) input rows first).  Results do
  * not depend on the cut.  mifwt_dwt2_fwd_pyramid_schedule writes the cuts of a call into wg_start[0 .. n] (global row indices,
  * wg_start[0] = 0, wg_start[n] = batch x rows) and returns n — diagnostics and tests; MIFWT_ERR_UNSUPPORTED where kernel (1) does not
- * serve the call, MIFWT_ERR_BADARG if `capacity` < n + 1.
- * mifwt_dwt2_fwd_pyramid_ws / _workspace: the entry points of round 3's segment HANDOVER experiment (row segments handing
- * approximation rows over through a device workspace instead of prologues; measured slower, removed in round 5).  Kept for ABI
- * compatibility: _workspace answers 0, _ws ignores its workspace and call id and is mifwt_dwt2_fwd_pyramid. */
+ * serve the call, MIFWT_ERR_BADARG if `capacity` < n + 1. */
 int mifwt_dwt2_fwd_pyramid_schedule(int nlevels, const mifwt_level_desc* const* descs, unsigned int* wg_start, int capacity);
-size_t mifwt_dwt2_fwd_pyramid_workspace(int nlevels, const mifwt_level_desc* const* descs);
-int mifwt_dwt2_fwd_pyramid_ws(int nlevels, const mifwt_level_desc* const* descs, const void* x, void* const* const* details, void* approx,
-                              const double* dec_lo, const double* dec_hi, void* workspace, size_t workspace_bytes, unsigned long long call_id,
-                              void* stream);
 
 /* SEVERAL levels of a 2-D reconstruction in one launch — trips of waverec2's level loop (src/ptwt/conv_transform_2.py:222-249);
  * the running approximation never reaches HBM.
@@ -363,13 +356,14 @@ int mifwt_kernel_id(const mifwt_level_desc* desc, int direction);
                                       3 = rolling strips wherever they apply */
 #define MIFWT_OPT_PAIR_ROWS 9      /* >0 overrides the pair kernels' level-2 rows per tile (4, 6, 8, 12) / per strip segment (multiple of 8) */
 #define MIFWT_OPT_PYRAMID_MODE 12 /* mifwt_dwt2_fwd_pyramid: 0 = auto (each of its two kernels where it is the fastest route), 1 = the streaming kernel wherever it can run, 3 = the small-plane kernel wherever it can run, 2 = never (it answers UNSUPPORTED / 0; the two-level and per-level kernels then serve the call) */
-#define MIFWT_OPT_DEBUG 11        /* A/B measurement switches of the multi-level kernels (results are then wrong): 1 = no stores, 2 = no loads, 4 = no deep levels, 16 = loader wave at default priority (streaming kernel); 32 / 64 / 128 = no pad fills / no horizontal / no vertical pass (small-plane analysis kernel, tools/small_ab.py).  Switches that keep the results right (A/B runs and parity tests of alternative code paths): 256 = the streaming analysis kernel's row segments hand rows over through a workspace instead of prologues, 512 = never its 16-byte store path, 1024 = analysis adjoints with a boundary extension on the generic per-axis passes instead of synthesis launch + border kernel, 2048 = the streaming analysis kernel in its compact form (eight-wave workgroups, two per CU), 4096 = the border part of a 2-D analysis adjoint on the one-thread-per-sample kernel instead of the one-thread-per-border-line kernel.  The 3-D walking kernels (ids 24 / 25) read the same word: 1 / 2 / 4 = no stores / no loads / no W and H passes, 8 = band rows on a 128-sample pitch (analysis; results are then wrong), 16 = non-temporal requests (analysis), 64 = column strips of 64 instead of balanced strips (analysis), 512 = 8-byte instead of 16-byte output stores (synthesis; results stay right) */
+#define MIFWT_OPT_DEBUG 11        /* ROUTING bits: alternative code paths with the SAME results (A/B runs, parity tests): 8 = the streaming synthesis kernel (id 22) without its fast warm-up, 64 = column strips of 64 instead of balanced strips (3-D analysis walk), 512 = 8-byte instead of 16-byte output stores (3-D synthesis walk), 1024 = analysis adjoints with a boundary extension on the generic per-axis passes instead of synthesis launch + border kernel, 4096 = the border part of a 2-D analysis adjoint on the one-thread-per-sample kernel instead of the one-thread-per-border-line kernel, 8192 = the level-2 waves of the streaming analysis kernel (id 16) behind the step's second barrier, 1 << 19 = kernel 16 without its tail wave, 1 << 20 = kernel 16 in its sixteen-wave form.  Any other bit is a MEASUREMENT switch that breaks results (no stores / no loads / no deep levels / single passes off ...): those are compiled into -DMIFWT_DIAG builds only (tools/; csrc/mifwt_common.h) and the product library answers MIFWT_ERR_UNSUPPORTED to them */
 #define MIFWT_OPT_PYR_WGS 13 /* >0: the streaming analysis kernel (id 16) cuts the batch's rows into this many chunks (workgroups per column group) instead of one per CU — parity tests of units that start and end anywhere */
-#define MIFWT_OPT_EXP 15           /* experiment word of the A/B run in progress (tools/); 0 in the product */
+#define MIFWT_OPT_EXP 15           /* experiment word of the A/B run in progress (tools/): -DMIFWT_DIAG builds only; the product library accepts 0 and answers MIFWT_ERR_UNSUPPORTED to anything else */
 #define MIFWT_OPT_SYNC_STAGE 10    /* non-zero: tile kernels keep the workgroup barrier between staging and the horizontal pass (A/B) */
 int mifwt_set_option(int key, int value);
 
-/* Diagnostic: a device buffer of 2 x uint64 per wave of every workgroup that later mifwt_dwt2_fwd_pyramid launches fill with
+/* Diagnostic (-DMIFWT_DIAG builds; the product library has no profiling instances and answers MIFWT_ERR_UNSUPPORTED to a non-null
+ * buffer): a device buffer of 2 x uint64 per wave of every workgroup that later mifwt_dwt2_fwd_pyramid launches fill with
  * (cycles alive, cycles spent in workgroup barriers); NULL switches it off again. */
 int mifwt_pyr_profile_buffer(void* device_buffer);
 

@@ -7,7 +7,6 @@ raises.  PyTorch is used for device memory (caching allocator) and streams only.
 from __future__ import annotations
 
 import ctypes
-import itertools
 import os
 import threading
 import warnings
@@ -21,7 +20,7 @@ if "MIFWT_LIB" in os.environ:
     import warnings
 
     warnings.warn(f"ptwt_amd: MIFWT_LIB is set — running on the experiment build {LIB_PATH}, not on the product library", RuntimeWarning)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 MODE_IDS = {"zero": 0, "constant": 1, "reflect": 2, "periodic": 3, "symmetric": 4}
 _DTYPE_IDS = {torch.float32: 0, torch.float64: 1, torch.float16: 2}
@@ -77,6 +76,16 @@ def load_library() -> ctypes.CDLL:
     desc_p = ctypes.POINTER(LevelDesc)
     lib.mifwt_abi_version.restype = ctypes.c_int
     lib.mifwt_abi_version.argtypes = []
+    # the version check comes BEFORE any other symbol is bound: a stale library then says "rebuild" instead of failing with an
+    # AttributeError on the first entry point it lacks
+    mismatch = lib.mifwt_abi_version() != ABI_VERSION
+    if mismatch:
+        # (an experiment build loaded through MIFWT_LIB is held to the same check: its mifwt_level_desc / entry-point signatures must be
+        # the ones declared above, or a call corrupts memory instead of failing; MIFWT_ALLOW_ABI_MISMATCH=1 is the explicit way around)
+        if os.environ.get("MIFWT_ALLOW_ABI_MISMATCH") != "1":
+            raise RuntimeError(f"ptwt_amd: {os.path.basename(LIB_PATH)} has ABI version {lib.mifwt_abi_version()}, this package expects "
+                               f"{ABI_VERSION}; rebuild the extension (MIFWT_ALLOW_ABI_MISMATCH=1 loads it anyway, at your own risk)")
+        warnings.warn("ptwt_amd: ABI version mismatch accepted through MIFWT_ALLOW_ABI_MISMATCH=1")
     lib.mifwt_strerror.restype = cp
     lib.mifwt_strerror.argtypes = [ctypes.c_int]
     lib.mifwt_kernel_id.restype = ctypes.c_int
@@ -110,11 +119,6 @@ def load_library() -> ctypes.CDLL:
     lib.mifwt_dwt2_inv_pyramid.argtypes = [ctypes.c_int, ctypes.POINTER(desc_p), vp, ctypes.POINTER(vpp), vp, dbl_p, dbl_p, vp]
     lib.mifwt_dwt2_fwd_pyramid.restype = ctypes.c_int
     lib.mifwt_dwt2_fwd_pyramid.argtypes = [ctypes.c_int, ctypes.POINTER(desc_p), vp, ctypes.POINTER(vpp), vp, dbl_p, dbl_p, vp]
-    lib.mifwt_dwt2_fwd_pyramid_ws.restype = ctypes.c_int
-    lib.mifwt_dwt2_fwd_pyramid_ws.argtypes = [ctypes.c_int, ctypes.POINTER(desc_p), vp, ctypes.POINTER(vpp), vp, dbl_p, dbl_p, vp, ctypes.c_size_t,
-                                              ctypes.c_uint64, vp]
-    lib.mifwt_dwt2_fwd_pyramid_workspace.restype = ctypes.c_size_t
-    lib.mifwt_dwt2_fwd_pyramid_workspace.argtypes = [ctypes.c_int, ctypes.POINTER(desc_p)]
     lib.mifwt_dwt2_inv_pair_supported.restype = ctypes.c_int
     lib.mifwt_dwt2_inv_pair_supported.argtypes = [desc_p, desc_p]
     lib.mifwt_dwt2_inv_pair.restype = ctypes.c_int
@@ -137,27 +141,21 @@ def load_library() -> ctypes.CDLL:
     lib.mifwt_dwt1_inv_tail.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, vp, ctypes.c_int64,
                                         ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int32), vp,
                                         ctypes.c_int64, dbl_p, dbl_p, vp]
-    lib.mifwt_workspace_bytes_dtaps.restype = ctypes.c_size_t
-    lib.mifwt_workspace_bytes_dtaps.argtypes = [desc_p, ctypes.c_int]
-    for name in ("mifwt_dwt_fwd_dtaps", "mifwt_dwt_inv_dtaps", "mifwt_dwt_fwd_adjoint_dtaps", "mifwt_dwt_inv_adjoint_dtaps"):
-        getattr(lib, name).restype = ctypes.c_int
-    lib.mifwt_dwt_fwd_dtaps.argtypes = [desc_p, vp, vp, vpp, vp, vp, vp, ctypes.c_size_t, vp]
-    lib.mifwt_dwt_inv_dtaps.argtypes = [desc_p, vp, vpp, vp, vp, vp, vp, ctypes.c_size_t, vp]
-    lib.mifwt_dwt_fwd_adjoint_dtaps.argtypes = [desc_p, vp, vpp, vp, vp, vp, vp, ctypes.c_size_t, vp]
-    lib.mifwt_dwt_inv_adjoint_dtaps.argtypes = [desc_p, vp, vp, vpp, vp, vp, vp, ctypes.c_size_t, vp]
-    experiment = "MIFWT_LIB" in os.environ  # (tools/: an older build for a same-run comparison may lack the newest entry points)
+    experiment = mismatch  # (tools/: an older build accepted for a same-run comparison may lack the newest entry points)
+    if not experiment or hasattr(lib, "mifwt_workspace_bytes_dtaps"):
+        lib.mifwt_workspace_bytes_dtaps.restype = ctypes.c_size_t
+        lib.mifwt_workspace_bytes_dtaps.argtypes = [desc_p, ctypes.c_int]
+        for name in ("mifwt_dwt_fwd_dtaps", "mifwt_dwt_inv_dtaps", "mifwt_dwt_fwd_adjoint_dtaps", "mifwt_dwt_inv_adjoint_dtaps"):
+            getattr(lib, name).restype = ctypes.c_int
+        lib.mifwt_dwt_fwd_dtaps.argtypes = [desc_p, vp, vp, vpp, vp, vp, vp, ctypes.c_size_t, vp]
+        lib.mifwt_dwt_inv_dtaps.argtypes = [desc_p, vp, vpp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+        lib.mifwt_dwt_fwd_adjoint_dtaps.argtypes = [desc_p, vp, vpp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+        lib.mifwt_dwt_inv_adjoint_dtaps.argtypes = [desc_p, vp, vp, vpp, vp, vp, vp, ctypes.c_size_t, vp]
     if not experiment or hasattr(lib, "mifwt_launch_count"):
         lib.mifwt_launch_count.restype = ctypes.c_uint64
         lib.mifwt_launch_count.argtypes = [ctypes.c_int]
     lib.mifwt_set_option.restype = ctypes.c_int
     lib.mifwt_set_option.argtypes = [ctypes.c_int, ctypes.c_int]
-    if lib.mifwt_abi_version() != ABI_VERSION:
-        # (an experiment build loaded through MIFWT_LIB is held to the same check: its mifwt_level_desc / entry-point signatures must be
-        # the ones declared above, or a call corrupts memory instead of failing; MIFWT_ALLOW_ABI_MISMATCH=1 is the explicit way around)
-        if os.environ.get("MIFWT_ALLOW_ABI_MISMATCH") != "1":
-            raise RuntimeError(f"ptwt_amd: {os.path.basename(LIB_PATH)} has ABI version {lib.mifwt_abi_version()}, this package expects "
-                               f"{ABI_VERSION}; rebuild the extension (MIFWT_ALLOW_ABI_MISMATCH=1 loads it anyway, at your own risk)")
-        warnings.warn("ptwt_amd: ABI version mismatch accepted through MIFWT_ALLOW_ABI_MISMATCH=1")
     _lib = lib
     return lib
 
@@ -250,7 +248,6 @@ def _trim_plans() -> None:
         for k in list(_plans)[:1024]:
             _plans.pop(k, None)
 _tls = threading.local()
-_call_ids = itertools.count((int.from_bytes(os.urandom(7), "little") << 8) | 1)  # ids of launches that use workspace flags
 _taps_cache: dict = {}
 
 
@@ -473,8 +470,7 @@ class HipLevelEngine:
         lo, hi = _taps_array(dec_lo), _taps_array(dec_hi)
         lib = _lib
         xp, ap = x.data_ptr(), bufs[-1].data_ptr()
-        call_id = next(_call_ids)  # (a flag in the workspace is "set" when it holds this call's id: nothing needs clearing)
-        self._run(plans[0], 0, x, lambda ws, wsb, stream: lib.mifwt_dwt2_fwd_pyramid_ws(n_ok, refs, xp, det, ap, lo, hi, ws, wsb, call_id, stream), kid=kid)
+        self._run(plans[0], 0, x, lambda ws, wsb, stream: lib.mifwt_dwt2_fwd_pyramid(n_ok, refs, xp, det, ap, lo, hi, stream), kid=kid)
         return bufs
 
     def pyramid_levels(self, x: torch.Tensor, flen: int, mode_id: int, nlevels: int) -> int:
@@ -526,10 +522,8 @@ class HipLevelEngine:
                 lrefs = (ctypes.POINTER(LevelDesc) * n_ok)(*[ctypes.pointer(pl.desc) for pl in lean])
                 if lib.mifwt_dwt2_fwd_pyramid_supported(n_ok, lrefs) == route:
                     keep, refs = lean, lrefs
-            if n_ok and route == 1:
-                # the streaming kernel's row segments hand their first approximation rows over through a small workspace (instead
-                # of each streaming a prologue of input rows): mifwt_dwt2_fwd_pyramid_ws
-                keep[0].ws_bytes = int(lib.mifwt_dwt2_fwd_pyramid_workspace(n_ok, refs))
+            if n_ok:
+                keep[0].ws_bytes = 0  # (the multi-level launches need no scratch; the plan's figure is that of the per-level route)
             plan = _plans[key] = (keep, n_ok, refs, KID_SMALL if route == 2 else KID_PYRAMID)
         return key, plan
 

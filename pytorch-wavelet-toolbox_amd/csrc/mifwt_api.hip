@@ -293,6 +293,9 @@ extern "C" {
 
 int mifwt_set_option(int key, int value) {
   if (key < 0 || key >= 16) return MIFWT_ERR_BADARG;
+  // the measurement switches that break results and the experiment word exist in -DMIFWT_DIAG builds only (mifwt_common.h): the product
+  // build says so instead of measuring something else
+  if (!kDiag && ((key == MIFWT_OPT_DEBUG && (value & ~kRouteBits)) || (key == MIFWT_OPT_EXP && value != 0))) return MIFWT_ERR_UNSUPPORTED;
   g_options[key] = value;
   return MIFWT_OK;
 }
@@ -305,6 +308,7 @@ unsigned long long mifwt_launch_count(int variant) {
 
 // diagnostic: device buffer of 2 x uint64 per wave of every workgroup of mifwt_dwt2_fwd_pyramid launches (NULL = off)
 int mifwt_pyr_profile_buffer(void* device_buffer) {
+  if (!kDiag) return device_buffer ? MIFWT_ERR_UNSUPPORTED : MIFWT_OK;  // (the profiling instances are compiled in -DMIFWT_DIAG builds only)
   g_pyr_prof = static_cast<unsigned long long*>(device_buffer);
   return MIFWT_OK;
 }
@@ -607,9 +611,8 @@ int mifwt_dwt2_fwd_pyramid_supported(int nlevels, const mifwt_level_desc* const*
   return pyramid_route(nlevels, descs);
 }
 
-int mifwt_dwt2_fwd_pyramid_ws(int nlevels, const mifwt_level_desc* const* descs, const void* x, void* const* const* details, void* approx,
-                              const double* dec_lo, const double* dec_hi, void* workspace, size_t workspace_bytes, unsigned long long call_id,
-                              void* stream) {
+int mifwt_dwt2_fwd_pyramid(int nlevels, const mifwt_level_desc* const* descs, const void* x, void* const* const* details, void* approx,
+                           const double* dec_lo, const double* dec_hi, void* stream) {
   if (!descs || nlevels < 1 || nlevels > 8) return MIFWT_ERR_BADARG;
   for (int l = 0; l < nlevels; ++l) {
     if (!descs[l]) return MIFWT_ERR_BADARG;
@@ -626,11 +629,7 @@ int mifwt_dwt2_fwd_pyramid_ws(int nlevels, const mifwt_level_desc* const* descs,
   if (route == 0) return MIFWT_ERR_UNSUPPORTED;
   if (descs[0]->batch == 0) return MIFWT_OK;
   if (route == 2) return dwt2_fwd_small(nlevels, descs, x, details, approx, dec_lo, dec_hi, static_cast<hipStream_t>(stream));
-  return dwt2_fwd_pyr(nlevels, descs, x, details, approx, dec_lo, dec_hi, workspace, workspace_bytes, call_id, static_cast<hipStream_t>(stream));
-}
-int mifwt_dwt2_fwd_pyramid(int nlevels, const mifwt_level_desc* const* descs, const void* x, void* const* const* details, void* approx,
-                           const double* dec_lo, const double* dec_hi, void* stream) {
-  return mifwt_dwt2_fwd_pyramid_ws(nlevels, descs, x, details, approx, dec_lo, dec_hi, nullptr, 0, 0, stream);
+  return dwt2_fwd_pyr(nlevels, descs, x, details, approx, dec_lo, dec_hi, static_cast<hipStream_t>(stream));
 }
 int mifwt_dwt2_fwd_pyramid_schedule(int nlevels, const mifwt_level_desc* const* descs, unsigned int* wg_start, int capacity) {
   if (!descs || !wg_start || nlevels < 1 || nlevels > 3) return MIFWT_ERR_BADARG;
@@ -641,12 +640,6 @@ int mifwt_dwt2_fwd_pyramid_schedule(int nlevels, const mifwt_level_desc* const* 
   }
   if (pyramid_route(nlevels, descs) != 1) return MIFWT_ERR_UNSUPPORTED;
   return dwt2_fwd_pyr_schedule(nlevels, descs, wg_start, capacity);
-}
-size_t mifwt_dwt2_fwd_pyramid_workspace(int nlevels, const mifwt_level_desc* const* descs) {
-  if (!descs || nlevels < 1 || nlevels > 3) return 0;
-  for (int l = 0; l < nlevels; ++l)
-    if (!descs[l] || validate(descs[l], 0) != MIFWT_OK) return 0;
-  return pyramid_route(nlevels, descs) == 1 ? dwt2_fwd_pyr_workspace(nlevels, descs) : 0;
 }
 // Every level of a 2-D reconstruction of a small plane in one launch (mifwt_dwt2_inv_small.hip); descs[0] = the coarsest level.
 int mifwt_dwt2_inv_pyramid_supported(int nlevels, const mifwt_level_desc* const* descs) {

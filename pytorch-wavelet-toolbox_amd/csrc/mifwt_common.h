@@ -11,6 +11,28 @@ namespace mifwt {
 
 constexpr int kMaxFilt = MIFWT_MAX_FILT;
 extern int g_options[16];  // mifwt_set_option() switches
+
+// DIAGNOSTICS.  The measurement switches that break results (no stores / no loads / no deep levels ..., MIFWT_OPT_DEBUG), the experiment
+// word of A/B runs (MIFWT_OPT_EXP) and the per-wave profiling instances exist only in builds with -DMIFWT_DIAG (tools/: experiment builds
+// through __graft_entry__.build_variant("diag", "-DMIFWT_DIAG"), selected with MIFWT_LIB).  In the product build the kernels never read
+// those words — MIFWT_DBG / MIFWT_EXPW are the constant 0, MIFWT_PROFP a null pointer — and mifwt_set_option refuses them; what
+// MIFWT_OPT_DEBUG keeps in the product are the ROUTING bits (kRouteBits: alternative code paths with the same results, pinned by parity tests).
+#ifdef MIFWT_DIAG
+constexpr bool kDiag = true;
+#define MIFWT_DBG(a) ((a).dbg)
+#define MIFWT_EXPW(a) ((a).exp)
+#define MIFWT_PROFP(a) ((a).prof)
+#else
+constexpr bool kDiag = false;
+#define MIFWT_DBG(a) 0
+#define MIFWT_EXPW(a) 0
+#define MIFWT_PROFP(a) (static_cast<unsigned long long*>(nullptr))
+#endif
+// 8 = kernel 22 without its fast warm-up, 64 = column strips of 64 in the 3-D analysis walk, 512 = 8-byte stores in the 3-D synthesis walk,
+// 1024 = analysis adjoints on the generic passes, 4096 = the per-sample border kernel, 8192 = level-2 waves of kernel 16 behind the step's
+// second barrier, bits 19 / 20 = kernel 16 without its tail wave / in its sixteen-wave form
+constexpr int kRouteBits = 8 | 64 | 512 | 1024 | 4096 | 8192 | 524288 | 1048576;
+inline int exp_word() { return kDiag ? g_options[MIFWT_OPT_EXP] : 0; }
 extern unsigned long long g_launch_counts[16];  // mifwt_launch_count(): launches per kernel variant (MIFWT_VARIANT_*)
 inline void count_launch(int variant) { __atomic_fetch_add(&g_launch_counts[variant], 1ull, __ATOMIC_RELAXED); }
 
@@ -209,8 +231,7 @@ int dwt2_inv_pyr(int nlev, const mifwt_level_desc* const* d, const void* approx,
                  const double* rec_lo, const double* rec_hi, hipStream_t stream);
 bool dwt2_fwd_pyr_supported(int nlev, const mifwt_level_desc* const* d);
 int dwt2_fwd_pyr(int nlev, const mifwt_level_desc* const* d, const void* x, void* const* const* details, void* approx,
-                  const double* dec_lo, const double* dec_hi, void* ws, size_t ws_bytes, unsigned long long nonce, hipStream_t stream);
-size_t dwt2_fwd_pyr_workspace(int nlev, const mifwt_level_desc* const* d);  // 0 (round 3's segment handover wanted a workspace)
+                  const double* dec_lo, const double* dec_hi, hipStream_t stream);
 int dwt2_fwd_pyr_schedule(int nlev, const mifwt_level_desc* const* d, uint32_t* wg_start, int capacity);  // the row chunks of the launch
 
 // two consecutive 2-D synthesis levels in one launch (mifwt_idwt2_pair.hip): f32, even L <= 8; d2 = the coarser level

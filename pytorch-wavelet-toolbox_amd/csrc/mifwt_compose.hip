@@ -159,7 +159,7 @@ int dwt2_fwd_fused(const mifwt_level_desc* d, const void* x, void* approx, void*
     case kDwt2FwdPyr: {
       const mifwt_level_desc* dd[1] = {d};
       void* const* dp[1] = {details};
-      return dwt2_fwd_pyr(1, dd, x, dp, approx, lo, hi, nullptr, 0, 0ull, stream);
+      return dwt2_fwd_pyr(1, dd, x, dp, approx, lo, hi, stream);
     }
     default: return MIFWT_ERR_UNSUPPORTED;
   }

@@ -117,11 +117,11 @@ __device__ __forceinline__ void dwt1_long_body(const Dwt1LongArgs<L>& a, float* 
   }
   int stamp_i = 1;
   auto stamp = [&]() {
-    if (a.prof && tid == 0 && stamp_i < 12) a.prof[(size_t)blockIdx.x * 12 + stamp_i++] = __builtin_readcyclecounter();
+    if (MIFWT_PROFP(a) && tid == 0 && stamp_i < 12) MIFWT_PROFP(a)[(size_t)blockIdx.x * 12 + stamp_i++] = __builtin_readcyclecounter();
   };
   int fine_i = 0;
-  auto fine = [&](int l) {  // finer stamps of level 2 of the end-piece workgroups, behind the coarse ones (a.dbg & 8)
-    if (ENDS && a.prof && (a.dbg & 8) && tid == 0 && l == 1 && fine_i < 12) a.prof[(size_t)(gridDim.x + blockIdx.x) * 12 + fine_i++] = __builtin_readcyclecounter();
+  auto fine = [&](int l) {  // finer stamps of level 2 of the end-piece workgroups, behind the coarse ones (MIFWT_DBG(a) & 8)
+    if (ENDS && MIFWT_PROFP(a) && (MIFWT_DBG(a) & 8) && tid == 0 && l == 1 && fine_i < 12) MIFWT_PROFP(a)[(size_t)(gridDim.x + blockIdx.x) * 12 + fine_i++] = __builtin_readcyclecounter();
   };
   auto piece = [&](int p) { return (ENDS && p == 1) ? pc1 : pc0; };  // (no indexed array: it would live in scratch memory)
   // LDS index of a piece's first sample at level K - sh: piece 0 starts at 0, piece 1 follows it
@@ -134,7 +134,7 @@ __device__ __forceinline__ void dwt1_long_body(const Dwt1LongArgs<L>& a, float* 
     for (int p = 0; p < NP; ++p) {
       const LongPiece<ENDS> P = piece(p);
       const int pa = P.a(K, HL), pb = P.b(K, a.n[0]), org = origin(p, K, a.n[0]);
-      for (int i = tid; pa + i < pb; i += kLongThreads) bufA[org + i] = (a.dbg & 2) ? 0.f : xr[pa + i];
+      for (int i = tid; pa + i < pb; i += kLongThreads) bufA[org + i] = (MIFWT_DBG(a) & 2) ? 0.f : xr[pa + i];
     }
     __syncthreads();
   }
@@ -143,11 +143,11 @@ __device__ __forceinline__ void dwt1_long_body(const Dwt1LongArgs<L>& a, float* 
   f2 tap[L];
 #pragma unroll
   for (int m = 0; m < L; ++m) tap[m] = a.tap[m];
-  const rsrc_t xres = pyr_rsrc(xr, (a.dbg & 2) ? 0u : (uint32_t)a.n[0] * 4u);  // reads past the end of a row return 0
+  const rsrc_t xres = pyr_rsrc(xr, (MIFWT_DBG(a) & 2) ? 0u : (uint32_t)a.n[0] * 4u);  // reads past the end of a row return 0
 
   float* src = bufA;
   float* dst = bufB;
-  for (int l = 0; l < ((a.dbg & 4) ? 0 : K); ++l) {
+  for (int l = 0; l < ((MIFWT_DBG(a) & 4) ? 0 : K); ++l) {
     const int nl = a.n[l], nk = a.n[l + 1], sh = K - l;
     float* __restrict__ dr = a.det[l] + (int64_t)row * a.det_rs[l];
     const bool glob = direct && l == 0;
@@ -157,7 +157,7 @@ __device__ __forceinline__ void dwt1_long_body(const Dwt1LongArgs<L>& a, float* 
       const LongPiece<ENDS> P = piece(p), Q = piece(1 - p);
       const int sa = P.a(sh, HL), sb = P.b(sh, nl), sorg = origin(p, sh, nl);
       const int ka = P.a(sh - 1, HL), kb = P.b(sh - 1, nk), korg = origin(p, sh - 1, nk);
-      const int oa = P.oa(sh - 1), ob = (a.dbg & 1) ? 0 : P.ob(sh - 1, nk);  // (owned range; empty with the stores switched off)
+      const int oa = P.oa(sh - 1), ob = (MIFWT_DBG(a) & 1) ? 0 : P.ob(sh - 1, nk);  // (owned range; empty with the stores switched off)
       // outputs whose L samples all lie inside the piece: [kf0, kf1), two adjacent ones per lane and slot
       const int kf0 = ENDS ? min(kb, max(ka, (sa + HL) >> 1)) : ka, kf1 = ENDS ? max(kf0, min(kb, sb >> 1)) : kb;
       // sample 2 k - (L - 2) of the row sits at wbase[2 k].  A lane's windows start 16 bytes apart: 16-byte LDS reads are
@@ -257,7 +257,7 @@ __device__ __forceinline__ void dwt1_long_body(const Dwt1LongArgs<L>& a, float* 
           float v = 0.f;
           if (q >= 0) {
             if (glob)
-              v = (a.dbg & 2) ? 0.f : xr[q];
+              v = (MIFWT_DBG(a) & 2) ? 0.f : xr[q];
             else  // periodic: a wrapped sample lives in the other end piece
               v = src[(q >= sa && q < sb) ? sorg + (q - sa) : min(max(oorg + (q - oa_sa), 0), a.cap)];
           }
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(kLongThreads) dwt1_long_kernel(const Dwt1LongA
   float* bufA = reinterpret_cast<float*>(long_lds);
   float* bufB = bufA + (a.vec ? a.cap / 4 + 64 : a.cap) + kLongPad;
   const int K = a.nlevels;
-  if (a.prof && threadIdx.x == 0) a.prof[(size_t)blockIdx.x * 12] = __builtin_readcyclecounter();
+  if (MIFWT_PROFP(a) && threadIdx.x == 0) MIFWT_PROFP(a)[(size_t)blockIdx.x * 12] = __builtin_readcyclecounter();
   // workgroups [0, rows): the two ends of row `blockIdx.x`; then the interior chunks, row-major
   if ((int)blockIdx.x < a.rows) {
     const LongPiece<true> p0 = {0, a.end_l, a.end_l == a.n[K]}, p1 = {a.n[K] - a.end_r, a.n[K], true};

@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaAr
   auto dump = [&]() {
     if constexpr (PROF) {
       if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < 8; ++k) a.prof[((size_t)blockIdx.x * 5 + (threadIdx.x >> 6)) * 8 + k] = pc[k];
+        for (int k = 0; k < 8; ++k) MIFWT_PROFP(a)[((size_t)blockIdx.x * 5 + (threadIdx.x >> 6)) * 8 + k] = pc[k];
     }
   };
   extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaAr
   if (wave == 4) {
     constexpr uint32_t kOob = 0x80000000u;
     const uint32_t row_bytes = (uint32_t)a.xs_h * 2u;
-    const uint32_t img_bytes = (a.dbg & 2) ? 0u : ((uint32_t)(a.H - 1) * (uint32_t)a.xs_h + (uint32_t)a.W) * 2u;
+    const uint32_t img_bytes = (MIFWT_DBG(a) & 2) ? 0u : ((uint32_t)(a.H - 1) * (uint32_t)a.xs_h + (uint32_t)a.W) * 2u;
     // request j of a chunk: lane -> piece 64 j + lane = (row, piece of the row); the padding piece requests nothing, the lanes past
     // the chunk's end are switched off
     uint32_t vfast[kWDma];
@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaAr
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const h8 xf = *reinterpret_cast<const h8*>(&xb[n * kXP + 32 * kb + 16 * c + 8 * half]);
-        if (!(a.dbg & 4)) {
+        if (!(MIFWT_DBG(a) & 4)) {
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, ahi[c], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, alo[c], acc, 0, 0, 0);
         }
@@ -609,13 +609,13 @@ __global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaAr
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const h8 b = *reinterpret_cast<const h8*>(&ht[(bh * kMC + cg * 32 + n) * kHP + ((16 * c + 8 * half + old) & 63)]);
-        if (!(a.dbg & 4)) {
+        if (!(MIFWT_DBG(a) & 4)) {
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, ahi[c], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, alo[c], acc, 0, 0, 0);
         }
       }
       typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-      if (a.dbg & 1) {
+      if (MIFWT_DBG(a) & 1) {
       } else {
         // Transposed through LDS, wave-local: this wave is the only reader of ring columns bh * 64 + cg * 32 + (0 .. 31) in the
         // vertical pass, and their OLDER half is dead once its fragments above are in registers (the next horizontal pass rewrites it
@@ -648,8 +648,8 @@ __global__ void __launch_bounds__(320, 5) dwt2_fwd_mfma_walk_kernel(const MfmaAr
             // the compiler would split them)
             // non-temporal: nothing reads these lines back (config-5 slice, level 1: 2.29 -> 2.15 ms analysis, 2.21 -> 2.18 synthesis;
             // MIFWT_OPT_DEBUG 8 / 16 = write-through / default policy, tools/mfma_policy_ab.py)
-            if (a.dbg & 8) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
-            else if (a.dbg & 16) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+            if (MIFWT_DBG(a) & 8) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+            else if (MIFWT_DBG(a) & 16) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
             else asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
           }
         }
@@ -727,8 +727,13 @@ int dwt2_fwd_mfma(const mifwt_level_desc* d, const void* x, void* approx, void* 
     if (nunits < grid) grid = (nunits + 7) & ~int64_t(7);
     a.prof = g_pyr_prof;
     count_launch(MIFWT_VARIANT_FWD_MFMA_WALK);
-    if (a.prof) hipLaunchKernelGGL(dwt2_fwd_mfma_walk_kernel<true>, dim3((unsigned)grid), dim3(320), kWLdsBytes, stream, a);
-    else hipLaunchKernelGGL(dwt2_fwd_mfma_walk_kernel<false>, dim3((unsigned)grid), dim3(320), kWLdsBytes, stream, a);
+    if constexpr (kDiag) {
+      if (MIFWT_PROFP(a)) {
+        hipLaunchKernelGGL(dwt2_fwd_mfma_walk_kernel<kDiag>, dim3((unsigned)grid), dim3(320), kWLdsBytes, stream, a);
+        return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
+      }
+    }
+    hipLaunchKernelGGL(dwt2_fwd_mfma_walk_kernel<false>, dim3((unsigned)grid), dim3(320), kWLdsBytes, stream, a);
     return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
   }
   a.seg_tiles = a.segs = a.nunits = 0;

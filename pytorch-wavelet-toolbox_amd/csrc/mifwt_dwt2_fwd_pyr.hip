@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
   // the chunk of this workgroup: rows [g_lo, g_hi) of the batch's level-NLEV rows laid end to end
   const int grp = blockIdx.x % a.ngroups;
   int chunk = blockIdx.x / a.ngroups;
-  if (a.exp >> 16) chunk = (chunk + ((a.exp >> 16) & 15)) % (int)(gridDim.x / a.ngroups);  // (experiment: which chunk runs on which XCD)
+  if (MIFWT_EXPW(a) >> 16) chunk = (chunk + ((MIFWT_EXPW(a) >> 16) & 15)) % (int)(gridDim.x / a.ngroups);  // (experiment: which chunk runs on which XCD)
   const uint32_t g_lo = a.wg_start[chunk], g_hi = a.wg_start[chunk + 1];
   if (g_lo >= g_hi) return;
   const bool zero_mode = a.mode == MIFWT_MODE_ZERO;
@@ -219,12 +219,17 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
     if (NLEV >= 2 && role == kRoleL2)
       for (int i = widx * 64 + lane; i < nrg; i += 64 * a.nl2) reinterpret_cast<f4*>(ring1)[i] = (f4){0.f, 0.f, 0.f, 0.f};
   } else {
-    if (!(a.dbg & 16)) __builtin_amdgcn_s_setprio(3);  // the youngest wave of its SIMD, and the one everybody waits for
+    if (!(MIFWT_DBG(a) & 16)) __builtin_amdgcn_s_setprio(3);  // the youngest wave of its SIMD, and the one everybody waits for
   }
   __syncthreads();  // ... before the loader's first row lands
 
   // =====================================================================================================================
-  // the units of the chunk, one after the other
+  // the units of the chunk, one after the other.  The unit loop is instantiated ONCE PER ROLE (round 6): with one loop around the
+  // chain of role branches every value any role reads in its step loop was live across the step loops of all the others — 144-218
+  // spilled scalars per instance, reloaded with v_readlane inside the loops, and uniform store offsets that ended up in vector
+  // registers behind readfirstlane loops.  Inside a role's own loop only that role's values are alive.
+  auto run_units = [&](auto role_tag) {
+  constexpr int role = decltype(role_tag)::value;
 #pragma unroll 1
   for (uint32_t g = g_lo; g < g_hi;) {
     const int img = (int)a.hn_div.div(g);
@@ -282,7 +287,7 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
         auto issue = [&](int t) {
           const uint32_t buf = (uint32_t)ib * (uint32_t)(kPyrSub * a.pitch0) + (uint32_t)kPyrCtl + kPyrPad * 4u + 1024u * (uint32_t)widx;
           ib = ib + 1 == a.nbuf ? 0 : ib + 1;
-          if (a.dbg & 2) return;
+          if (MIFWT_DBG(a) & 2) return;
 #pragma unroll
           for (int kk = 0; kk < kPyrSub; ++kk) {
             const int e = E0 + kPyrSub * t + kk;
@@ -353,11 +358,11 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
           f_dst[ps] = (uint32_t)(kk * a.pitch0) + 4u * (uint32_t)(kPyrPad + e - g0);
         }
       }
-      const bool f_any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(f_some) != 0) && !(a.dbg & 16384);
+      const bool f_any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(f_some) != 0) && !(MIFWT_DBG(a) & 16384);
       // one buffer resource for the three detail planes of the image (band = scalar offset), one for the approximation; a row
       // the unit does not own is stored at a per-lane offset beyond every resource (dropped) — the resources never change
-      const uint32_t dbytes = (a.dbg & 1) ? 0u : a.dspan[0] + ((uint32_t)(a.H[1] - 1) * (uint32_t)a.ds_h[0] + (uint32_t)a.W[1]) * 4u;
-      const uint32_t abytes = (a.dbg & 1) ? 0u : ((uint32_t)(a.H[NLEV] - 1) * (uint32_t)a.as_h + (uint32_t)a.W[NLEV]) * 4u;
+      const uint32_t dbytes = (MIFWT_DBG(a) & 1) ? 0u : a.dspan[0] + ((uint32_t)(a.H[1] - 1) * (uint32_t)a.ds_h[0] + (uint32_t)a.W[1]) * 4u;
+      const uint32_t abytes = (MIFWT_DBG(a) & 1) ? 0u : ((uint32_t)(a.H[NLEV] - 1) * (uint32_t)a.as_h + (uint32_t)a.W[NLEV]) * 4u;
       const rsrc_t rd = pyr_rsrc(a.det[0] + (int64_t)img * a.ds_b[0], dbytes);
       const rsrc_t ra = pyr_rsrc(a.approx + (int64_t)img * a.as_b, NLEV == 1 ? abytes : 0u);
       const uint32_t o0 = a.doff[0][0], o1b = a.doff[0][1], o2 = a.doff[0][2];
@@ -489,9 +494,9 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
             f_dst = 4u * (uint32_t)(kPyrPad + sh1 + e - cA[1]);
           }
         }
-        const bool f_any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(f_on) != 0) && !(a.dbg & 32768);
-        const uint32_t dbytes = (a.dbg & 1) ? 0u : a.dspan[1] + ((uint32_t)(a.H[2] - 1) * (uint32_t)a.ds_h[1] + (uint32_t)a.W[2]) * 4u;
-        const uint32_t abytes = (a.dbg & 1) ? 0u : ((uint32_t)(a.H[NLEV] - 1) * (uint32_t)a.as_h + (uint32_t)a.W[NLEV]) * 4u;
+        const bool f_any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(f_on) != 0) && !(MIFWT_DBG(a) & 32768);
+        const uint32_t dbytes = (MIFWT_DBG(a) & 1) ? 0u : a.dspan[1] + ((uint32_t)(a.H[2] - 1) * (uint32_t)a.ds_h[1] + (uint32_t)a.W[2]) * 4u;
+        const uint32_t abytes = (MIFWT_DBG(a) & 1) ? 0u : ((uint32_t)(a.H[NLEV] - 1) * (uint32_t)a.as_h + (uint32_t)a.W[NLEV]) * 4u;
         const rsrc_t rd = pyr_rsrc(a.det[1] + (int64_t)img * a.ds_b[1], dbytes);
         const rsrc_t ra = pyr_rsrc(a.approx + (int64_t)img * a.as_b, NLEV == 2 ? abytes : 0u);
         const uint32_t o0 = a.doff[1][0], o1b = a.doff[1][1], o2 = a.doff[1][2];
@@ -521,9 +526,9 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
             }
           }
         };
-        if ((a.exp & 3) == 1) __builtin_amdgcn_s_setprio(1);
-        if ((a.exp & 3) == 2) __builtin_amdgcn_s_setprio(2);
-        if ((a.exp & 3) == 3) __builtin_amdgcn_s_setprio(3);
+        if ((MIFWT_EXPW(a) & 3) == 1) __builtin_amdgcn_s_setprio(1);
+        if ((MIFWT_EXPW(a) & 3) == 2) __builtin_amdgcn_s_setprio(2);
+        if ((MIFWT_EXPW(a) & 3) == 3) __builtin_amdgcn_s_setprio(3);
         // One row pair in each HALF of a step (a.l2split, round 5).  Until then a level-2 wave did a whole step's work (two pairs, ~330
         // instructions) behind the step's second barrier and sat out the first half: per-wave clocks had it waiting for about half of
         // its life, i.e. never in its own half — it was what the second half of every step waited for (a level-1 wave needs ~290
@@ -609,7 +614,7 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
           using RA = std::integral_constant<int, R0 % HP>;
           using RB = std::integral_constant<int, (R0 + 1) % HP>;
           pyr_barrier<PROF>(waited);
-          const bool act = 2 * (s - D2) < npair2 && !(a.dbg & 4);
+          const bool act = 2 * (s - D2) < npair2 && !(MIFWT_DBG(a) & 4);
           uint32_t so_r[4] = {0u, 0u, 0u, 0u};  // ring-1 byte offsets of the step's four rows
           bool early = false;
           if (act) {
@@ -660,7 +665,7 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
           }
         }
         if (PROF && widx == 0 && lane == 0) {
-          unsigned long long* o = a.prof + ((size_t)blockIdx.x * kPyrWaves + 14) * 2;
+          unsigned long long* o = MIFWT_PROFP(a) + ((size_t)blockIdx.x * kPyrWaves + 14) * 2;
           o[0] += tsec[0], o[1] += tsec[1], o[2] += tsec[2], o[3] += tsec[3];
         }
       }
@@ -688,9 +693,9 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
             f_dst = 4u * (uint32_t)(kPyrPad + e - cA[2]);
           }
         }
-        const bool f_any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(f_on) != 0) && !(a.dbg & 32768);
-        const uint32_t dbytes = (a.dbg & 1) ? 0u : a.dspan[2] + ((uint32_t)(a.H[3] - 1) * (uint32_t)a.ds_h[2] + (uint32_t)a.W[3]) * 4u;
-        const uint32_t abytes = (a.dbg & 1) ? 0u : ((uint32_t)(a.H[3] - 1) * (uint32_t)a.as_h + (uint32_t)a.W[3]) * 4u;
+        const bool f_any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(f_on) != 0) && !(MIFWT_DBG(a) & 32768);
+        const uint32_t dbytes = (MIFWT_DBG(a) & 1) ? 0u : a.dspan[2] + ((uint32_t)(a.H[3] - 1) * (uint32_t)a.ds_h[2] + (uint32_t)a.W[3]) * 4u;
+        const uint32_t abytes = (MIFWT_DBG(a) & 1) ? 0u : ((uint32_t)(a.H[3] - 1) * (uint32_t)a.as_h + (uint32_t)a.W[3]) * 4u;
         const rsrc_t rd = pyr_rsrc(a.det[2] + (int64_t)img * a.ds_b[2], dbytes);
         const rsrc_t ra = pyr_rsrc(a.approx + (int64_t)img * a.as_b, abytes);
         const uint32_t o0 = a.doff[2][0], o1b = a.doff[2][1], o2 = a.doff[2][2];
@@ -720,7 +725,7 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
         auto step3 = [&](auto r_tag, int s) {
           constexpr int R = decltype(r_tag)::value;  // (s - D3) mod L/2
           pyr_barrier<PROF>(waited);
-          if (s - D3 < npair3 && !(a.dbg & 4)) {
+          if (s - D3 < npair3 && !(MIFWT_DBG(a) & 4)) {
             uint32_t so_r[2];
             const int e0 = E2 + 2 * (s - D3);
             if (e0 >= 0 && e0 + 1 < a.H[2]) {
@@ -863,11 +868,11 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
       const uint32_t k_rpitch = k_lvl <= 1 ? (uint32_t)a.pitch1 : (uint32_t)a.pitch2;
       const uint32_t img2 = (uint32_t)(tailimg - smem) + (uint32_t)kl * (uint32_t)kPyrTailBytes + 8u * (uint32_t)k_c;
       const uint32_t n_l1 = k_lvl == 1 ? ~0u : 0u, n_l2 = k_lvl == 2 ? ~0u : 0u, n_l3 = k_lvl == 3 ? ~0u : 0u;
-      const bool nostore = a.dbg & 1;
+      const bool nostore = MIFWT_DBG(a) & 1;
       int bi = 0;
-      if (((a.exp >> 4) & 3) == 0) __builtin_amdgcn_s_setprio(2);  // (short dependent chains that every half step waits for)
-      if (((a.exp >> 4) & 3) == 1) __builtin_amdgcn_s_setprio(1);
-      if (((a.exp >> 4) & 3) == 3) __builtin_amdgcn_s_setprio(3);
+      if (((MIFWT_EXPW(a) >> 4) & 3) == 0) __builtin_amdgcn_s_setprio(2);  // (short dependent chains that every half step waits for)
+      if (((MIFWT_EXPW(a) >> 4) & 3) == 1) __builtin_amdgcn_s_setprio(1);
+      if (((MIFWT_EXPW(a) >> 4) & 3) == 3) __builtin_amdgcn_s_setprio(3);
 
       // stage 1 then stage 2 of one half step; rb1 = LDS offset of the staged rows of the half step (level 1), v2 / v3 = ring offsets
       // of the rows levels 2 / 3 consume in this step (published by the first level-2 / level-3 wave); act = which levels run
@@ -924,8 +929,8 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
 #pragma unroll 1
       for (int s = 0; s < nsteps; ++s) {
         const bool act1 = s < nsteps1;
-        const bool act2 = NLEV >= 2 && s >= D2 && 2 * (s - D2) < npair2 && !(a.dbg & 4);
-        const bool act3 = NLEV >= 3 && s >= D3 && s - D3 < npair3 && !(a.dbg & 4);
+        const bool act2 = NLEV >= 2 && s >= D2 && 2 * (s - D2) < npair2 && !(MIFWT_DBG(a) & 4);
+        const bool act3 = NLEV >= 3 && s >= D3 && s - D3 < npair3 && !(MIFWT_DBG(a) & 4);
         pyr_barrier<PROF>(waited);
         uint32_t rb1 = (uint32_t)(stage - smem) + (uint32_t)bi * (uint32_t)(kPyrSub * a.pitch0);
         if (act1) bi = bi + 1 == a.nbuf ? 0 : bi + 1;
@@ -943,13 +948,19 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
     // still be read from: everybody is through with it behind this barrier
     __syncthreads();
   }
+  };
+  if (role == kRoleLoad) run_units(std::integral_constant<int, kRoleLoad>{});
+  else if (role == kRoleL1) run_units(std::integral_constant<int, kRoleL1>{});
+  else if (role == kRoleL2) run_units(std::integral_constant<int, kRoleL2>{});
+  else if (role == kRoleL3) run_units(std::integral_constant<int, kRoleL3>{});
+  else run_units(std::integral_constant<int, kRoleTail>{});
 
   if (PROF && lane == 0 && role != kRoleLoad) {
-    unsigned long long* o = a.prof + ((size_t)blockIdx.x * kPyrWaves + wave) * 2;
+    unsigned long long* o = MIFWT_PROFP(a) + ((size_t)blockIdx.x * kPyrWaves + wave) * 2;
     o[0] = __builtin_readcyclecounter() - t_start;
     o[1] = waited;
     if (wave == 0) {
-      unsigned long long* w = a.prof + ((size_t)blockIdx.x * kPyrWaves + 8) * 2;
+      unsigned long long* w = MIFWT_PROFP(a) + ((size_t)blockIdx.x * kPyrWaves + 8) * 2;
       w[0] = w_start;
       w[1] = __builtin_amdgcn_s_memrealtime();
       w[8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
@@ -1003,7 +1014,7 @@ constexpr double kUnitStart = 1.0;
 static double pyr_unit_time(const PyrGeom& gm, int u_lo, int u_hi) {
   // (calibration runs, tools/pyr_calib.py: MIFWT_OPT_EXP bits 8-11 = drain weight in twentieths over 0.25, bits 12-15 = what a unit
   // at the top of its image saves — no prologue to request, nothing to wait for — in tenths of a step)
-  const int ex = g_options[MIFWT_OPT_EXP];
+  const int ex = exp_word();
   const double kDrainStep = ((ex >> 8) & 15) ? 0.25 + 0.05 * ((ex >> 8) & 15) : 0.45;
   const double kTopBonus = ((ex >> 12) & 15) ? 0.1 * ((ex >> 12) & 15) : 1.0;  // (35 / 32 / 32 / 35 rows on config 2: 0.5-1 % ahead of 34 / 32 / 32 / 36, profiles/r05i_calib.txt)
   const int L = gm.L, HL = L - 2, HP = L / 2, nlev = gm.nlev;
@@ -1087,7 +1098,7 @@ static void pyr_schedule(const PyrGeom& gm, int64_t B, int gwant, PyrPlan* p) {
   static std::mutex mu;
   static Entry cache[kEntries];
   static int used = 0, next = 0;
-  const int ex = g_options[MIFWT_OPT_EXP];
+  const int ex = exp_word();
   auto same = [&](const Entry& e) {
     return e.L == gm.L && e.nlev == gm.nlev && e.H[1] == gm.H[1] && e.H[2] == gm.H[2] && e.H[3] == gm.H[3] && e.gwant == gwant && e.ex == ex && e.parity == gm.parity && e.B == B;
   };
@@ -1338,19 +1349,19 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
   a.mode = d[0]->mode;
   a.dbg = g_options[MIFWT_OPT_DEBUG];
   // (timing experiments, results wrong: the nearly empty last wave of level 1 / 2 / 3 switched off)
-  if ((a.dbg & 65536) && a.nl1 > 1) --a.nl1;
-  if ((a.dbg & 131072) && a.nl2 > 1) --a.nl2;
-  if ((a.dbg & 262144) && a.nl3 > 1) --a.nl3;
+  if ((MIFWT_DBG(a) & 65536) && a.nl1 > 1) --a.nl1;
+  if ((MIFWT_DBG(a) & 131072) && a.nl2 > 1) --a.nl2;
+  if ((MIFWT_DBG(a) & 262144) && a.nl3 > 1) --a.nl3;
   a.prof = g_pyr_prof;
   a.l2split = (g_options[MIFWT_OPT_DEBUG] & 8192) ? 0 : 1;
-  a.exp = g_options[MIFWT_OPT_EXP];
+  a.exp = exp_word();
   a.hn_div = make_fastdiv((uint32_t)a.H[NLEV]);
   std::copy(p.wg_start, p.wg_start + p.nwg + 1, a.wg_start);
   for (int k = p.nwg + 1; k <= kPyrMaxWG; ++k) a.wg_start[k] = a.wg_start[p.nwg];
   for (int m = 0; m < L; ++m) a.tap[m] = (f2){(float)lo[m], (float)hi[m]};
   const int64_t nwg = (int64_t)p.nwg * p.ngroups;
   // (the per-wave cycle profile of tools/pyr_prof.py exists for the three-level 8-tap kernel only)
-  constexpr bool kCanProf = L == 8 && NLEV == 3;
+  constexpr bool kCanProf = kDiag && L == 8 && NLEV == 3;  // (-DMIFWT_DIAG builds)
   constexpr bool kHas16 = L <= 8;  // (ten taps: the twelve-wave form only — the level-1 waves want 157 registers a lane)
   static DynLdsOnce lds_once12, lds_once16, lds_once_prof12, lds_once_prof16;
   if (!lds_once12.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, false, 12>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
@@ -1358,12 +1369,12 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
   count_launch(MIFWT_VARIANT_FWD_PYR_ST8);
   const dim3 grid((unsigned)nwg), block(64 * p.nwaves);
   if (p.nwaves == 12) {
-    if (kCanProf && a.prof) hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, 12>), grid, block, p.lds, stream, a);
+    if (kCanProf && MIFWT_PROFP(a)) hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, 12>), grid, block, p.lds, stream, a);
     else hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, false, 12>), grid, block, p.lds, stream, a);
   } else if constexpr (kHas16) {
     if (!lds_once16.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, false, 16>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
     if (kCanProf && !lds_once_prof16.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, 16>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
-    if (kCanProf && a.prof) hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, 16>), grid, block, p.lds, stream, a);
+    if (kCanProf && MIFWT_PROFP(a)) hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, 16>), grid, block, p.lds, stream, a);
     else hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, false, 16>), grid, block, p.lds, stream, a);
   } else {
     return MIFWT_ERR_UNSUPPORTED;
@@ -1382,10 +1393,8 @@ static int launch_pyr_l(int nlev, const mifwt_level_desc* const* d, const void* 
   }
 }
 
-size_t dwt2_fwd_pyr_workspace(int, const mifwt_level_desc* const*) { return 0; }  // (round 3's segment handover wanted one)
-
 int dwt2_fwd_pyr(int nlev, const mifwt_level_desc* const* d, const void* x, void* const* const* details, void* approx,
-                  const double* lo, const double* hi, void*, size_t, unsigned long long, hipStream_t stream) {
+                  const double* lo, const double* hi, hipStream_t stream) {
   if (!dwt2_fwd_pyr_supported(nlev, d)) return MIFWT_ERR_UNSUPPORTED;
   switch (d[0]->filt_len) {
     case 2: return launch_pyr_l<2>(nlev, d, x, details, approx, lo, hi, stream);

@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(kSmallMaxThreads) dwt2_fwd_small_kernel(const 
   c += pk_dc;                                                                               \
   g += c >= w4 ? pk_g1 : pk_g0;                                                             \
   c -= c >= w4 ? w4 : 0u;
-  if (a.vec && !(a.dbg & 2)) {
+  if (a.vec && !(MIFWT_DBG(a) & 2)) {
     const float* xi = a.x + (int64_t)blockIdx.x * a.xs_b;
     uint32_t c = pk_c, g = pk_g;
     MIFWT_PARK8(MIFWT_PARK_LD)
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(kSmallMaxThreads) dwt2_fwd_small_kernel(const 
 
   for (int64_t img = blockIdx.x; img < a.batch; img += gridDim.x) {
     // ---- park the plane: A[r * PA0 + O + c] --------------------------------------------------------------------------------
-    if (a.dbg & 2) {
+    if (MIFWT_DBG(a) & 2) {
     } else if (a.vec) {  // rows start on 16-byte boundaries and hold whole quads; the plane is at most kParkDepth quads per lane
 #define MIFWT_PARK_ST(u)                                                                    \
   if (tid + u * nt < n4) *reinterpret_cast<float4*>(reinterpret_cast<char*>(A) + lo) = q##u; \
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(kSmallMaxThreads) dwt2_fwd_small_kernel(const 
         uint32_t rowb = r0 * PA * 4;
         const uint32_t rowb0 = dr * PA * 4, rowb1 = rowb0 + PA * 4;
         char* Ab = reinterpret_cast<char*>(A);
-        for (uint32_t it = tid; it < (uint32_t)((a.dbg & 32) ? 0 : H * (int)npc); it += nt) {
+        for (uint32_t it = tid; it < (uint32_t)((MIFWT_DBG(a) & 32) ? 0 : H * (int)npc); it += nt) {
           const int2 e = ta[j];
           const float v = e.y >= 0 ? *reinterpret_cast<const float*>(Ab + rowb + e.y) : 0.f;
           *reinterpret_cast<float*>(Ab + rowb + e.x) = v;
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(kSmallMaxThreads) dwt2_fwd_small_kernel(const 
         const uint32_t dst0 = (dr * PB + 2 * dk) * 4, dst1 = dst0 + (PB - 2 * Wo) * 4;
         const char* Ab = reinterpret_cast<const char*>(A);
         char* Bb = reinterpret_cast<char*>(B);
-        for (uint32_t it = tid; it < (uint32_t)((a.dbg & 64) ? 0 : H * Wo); it += nt) {
+        for (uint32_t it = tid; it < (uint32_t)((MIFWT_DBG(a) & 64) ? 0 : H * Wo); it += nt) {
           const f2* w = reinterpret_cast<const f2*>(Ab + src);
           f2 pr[L / 2];
 #pragma unroll
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(kSmallMaxThreads) dwt2_fwd_small_kernel(const 
         uint32_t dc;
         const uint32_t dj = a.div_wo[l].divmod(nt, dc);
         char* Bb = reinterpret_cast<char*>(B);
-        for (uint32_t it = tid; it < (uint32_t)((a.dbg & 32) ? 0 : (int)npr * Wo); it += nt) {
+        for (uint32_t it = tid; it < (uint32_t)((MIFWT_DBG(a) & 32) ? 0 : (int)npr * Wo); it += nt) {
           const int2 e = tb[j];
           const f2 v = e.y >= 0 ? *reinterpret_cast<const f2*>(Bb + e.y + c * 8) : (f2){0.f, 0.f};
           *reinterpret_cast<f2*>(Bb + e.x + c * 8) = v;
@@ -241,11 +241,11 @@ __global__ void __launch_bounds__(kSmallMaxThreads) dwt2_fwd_small_kernel(const 
       __syncthreads();
       // ---- vertical pass: item = (output row kr, column c); all four bands ------------------------------------------------------
       {
-        const uint32_t dspan = (a.dbg & 1) ? 0u : (uint32_t)Ho * (uint32_t)a.ds_h[l] * 4u;  // (a resource of no bytes drops its stores)
+        const uint32_t dspan = (MIFWT_DBG(a) & 1) ? 0u : (uint32_t)Ho * (uint32_t)a.ds_h[l] * 4u;  // (a resource of no bytes drops its stores)
         const rsrc_t r_ad = pyr_rsrc(a.det[l][0] + img * a.ds_b[l], dspan);
         const rsrc_t r_da = pyr_rsrc(a.det[l][1] + img * a.ds_b[l], dspan);
         const rsrc_t r_dd = pyr_rsrc(a.det[l][2] + img * a.ds_b[l], dspan);
-        const rsrc_t r_aa = pyr_rsrc(a.approx + img * a.as_b, last && !(a.dbg & 1) ? (uint32_t)Ho * (uint32_t)a.as_h * 4u : 0u);
+        const rsrc_t r_aa = pyr_rsrc(a.approx + img * a.as_b, last && !(MIFWT_DBG(a) & 1) ? (uint32_t)Ho * (uint32_t)a.as_h * 4u : 0u);
         const uint32_t pa_n = last ? (uint32_t)a.as_h : (uint32_t)a.PA[l + 1];  // row pitch of where aa goes
         const uint32_t ds_h = (uint32_t)a.ds_h[l], pb4 = (uint32_t)PB * 4u;
         uint32_t c;
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(kSmallMaxThreads) dwt2_fwd_small_kernel(const 
         char* Ab = reinterpret_cast<char*>(A);
         auto run = [&](auto last_tag) {  // (two copies of the loop, so that its body is one straight block)
           constexpr bool kLast = decltype(last_tag)::value;
-          for (uint32_t it = tid; it < (uint32_t)((a.dbg & 128) ? 0 : Ho * Wo); it += nt) {
+          for (uint32_t it = tid; it < (uint32_t)((MIFWT_DBG(a) & 128) ? 0 : Ho * Wo); it += nt) {
             f2 pr[L];
             uint32_t rd = src;
 #pragma unroll

@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(320, 5) idwt2_mfma_walk_kernel(const MfmaInvAr
     const bool last_live = lane < kSR * kSPieces - 64 * (kSDma - 1);
     const uint32_t lds0 = (uint32_t)(uintptr_t)xt;
     auto rsrc_of = [&](const Unit& u, int s) {
-      const uint32_t bytes = (a.dbg & 2) ? 0u : ((uint32_t)(a.Mh - 1) * (uint32_t)a.is_h[s] + (uint32_t)a.Mw) * 2u;
+      const uint32_t bytes = (MIFWT_DBG(a) & 2) ? 0u : ((uint32_t)(a.Mh - 1) * (uint32_t)a.is_h[s] + (uint32_t)a.Mw) * 2u;
       return __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.in[s] + (int64_t)u.img * a.is_b[s]), 0, bytes, 0x00020000);
     };
     auto issue_dma = [&](const Unit& u, int g, int buf) {
@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(320, 5) idwt2_mfma_walk_kernel(const MfmaInvAr
   // matrix waves
   // the matrix waves run above the loader's priority: finest level of the config-5 slice 2.17 -> 1.95 ms with any raised level
   // (1, 2 or 3), alternating rounds on one box; raising the LOADER instead: 2.33 (MIFWT_OPT_DEBUG 64 = all waves at the default)
-  if (!(a.dbg & 64)) __builtin_amdgcn_s_setprio(1);
+  if (!(MIFWT_DBG(a) & 64)) __builtin_amdgcn_s_setprio(1);
   const int n = lane & 31, half = lane >> 5;
   // S fragments: S[m][k], m = n = 2 q + r, k = 16 c + 8 half + e = 32 b + kk: g_b[L - 2 - 2 (kk - q) + r] for 0 <= kk - q < L/2;
   // f16 pairs (t = t_hi + t_lo)
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(320, 5) idwt2_mfma_walk_kernel(const MfmaInvAr
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const h8 xf = *reinterpret_cast<const h8*>(xb + (2 * bvn + (c >> 1)) * kSBand + 16 * (c & 1));
-        if (!(a.dbg & 4)) {
+        if (!(MIFWT_DBG(a) & 4)) {
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, shi[c], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf, slo[c], acc, 0, 0, 0);
         }
@@ -277,13 +277,13 @@ __global__ void __launch_bounds__(320, 5) idwt2_mfma_walk_kernel(const MfmaInvAr
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const h8 b = *reinterpret_cast<const h8*>(&hv[((c >> 1) * kSOC + 32 * kb + n) * kVP + 16 * (((c & 1) + oldh) & 1) + 8 * half]);
-        if (!(a.dbg & 4)) {
+        if (!(MIFWT_DBG(a) & 4)) {
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, shi[c], acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, slo[c], acc, 0, 0, 0);
         }
       }
       const int row0 = kSOR * (cur.tr0 + g - 1), col0 = kSOC * cur.tc + 32 * kb;
-      if (a.dbg & 1) {
+      if (MIFWT_DBG(a) & 1) {
       } else if (col0 + 32 <= a.W) {
         // Transposed through LDS, wave-local: this wave is the only reader of ring columns 32 kb + (0 .. 31) of both images, and their
         // OLDER half is dead once the fragments above are in registers.  Output row m of the 32 x 32 block = 64 bytes = the older
@@ -303,8 +303,8 @@ __global__ void __launch_bounds__(320, 5) idwt2_mfma_walk_kernel(const MfmaInvAr
             // (16-byte stores; rows of an odd pitch start 2-byte aligned: works, slowly — tools/align_probe.hip)
             // non-temporal: nothing reads these lines back (config-5 slice, level 1: 2.29 -> 2.15 ms analysis, 2.21 -> 2.18 synthesis;
             // MIFWT_OPT_DEBUG 8 / 16 = write-through / default policy, tools/mfma_policy_ab.py)
-            if (a.dbg & 8) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
-            else if (a.dbg & 16) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+            if (MIFWT_DBG(a) & 8) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+            else if (MIFWT_DBG(a) & 16) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
             else asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
           }
         }

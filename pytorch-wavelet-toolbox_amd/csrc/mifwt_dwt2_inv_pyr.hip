@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
     constexpr int N1 = 2 * NB1, N2 = NLEV >= 2 ? NB2 : 0, N3 = NLEV >= 3 ? 2 : 0;
     constexpr int NITEMS = N1 + N2 + N3;
     const uint32_t lane16 = 16u * (uint32_t)lane;
-    if (!(a.dbg & 16)) __builtin_amdgcn_s_setprio(3);  // (config 2: 90.8-92.0 us per call with, 93.6-97.1 without, tools/pyr_prio_ab.py)
+    if (!(MIFWT_DBG(a) & 16)) __builtin_amdgcn_s_setprio(3);  // (config 2: 90.8-92.0 us per call with, 93.6-97.1 without, tools/pyr_prio_ab.py)
     auto run = [&](auto w_tag) {
       constexpr int WI = decltype(w_tag)::value;
       // resources of this loader's items (a level-3 item alternates between two bands with the parity of the sub-step)
@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
           else b = 2 * v + (I - N1 - N2);
           const int sx = b == 0 ? 0 : 1;
           const uint32_t bytes = ((uint32_t)(mh - 1) * (uint32_t)a.bs_h[LV - 1][sx] + (uint32_t)mw) * 4u;
-          rs[K][v] = pyr_rsrc(a.band[LV - 1][b] + (int64_t)img * a.bs_b[LV - 1][sx], (a.dbg & 2) ? 0u : bytes);
+          rs[K][v] = pyr_rsrc(a.band[LV - 1][b] + (int64_t)img * a.bs_b[LV - 1][sx], (MIFWT_DBG(a) & 2) ? 0u : bytes);
           rowb[K][v] = (uint32_t)a.bs_h[LV - 1][sx] * 4u;
         }
         per += (mw + 255) >> 8;
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
     emit(std::integral_constant<int, 1>{}, std::integral_constant<int, IpAcc<L>::done((R0 + 1) % HL)>{});
   };
 
-  if (a.dbg & 32) __builtin_amdgcn_s_setprio(1);  // (experiment: the synthesis waves above the default priority as well — no change)
+  if (MIFWT_DBG(a) & 32) __builtin_amdgcn_s_setprio(1);  // (experiment: the synthesis waves above the default priority as well — no change)
   // ---- level 1 (the finest): output rows to global memory -----------------------------------------------------------------
   if (role == 1) {
     const int nq = (a.W + 3) >> 2;  // lanes with an output column
@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
     const bool full = 4 * G + 3 < a.W;
     const int nrag = (!full && 4 * G < a.W) ? a.W - 4 * G : 0;  // 1 .. 3 columns of the last lane of a ragged plane
     const bool rag_any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(nrag != 0) != 0);
-    const uint32_t ybytes = (a.dbg & 1) ? 0u : ((uint32_t)(a.H - 1) * (uint32_t)a.ys_h + (uint32_t)a.W) * 4u;
+    const uint32_t ybytes = (MIFWT_DBG(a) & 1) ? 0u : ((uint32_t)(a.H - 1) * (uint32_t)a.ys_h + (uint32_t)a.W) * 4u;
     const rsrc_t ry = pyr_rsrc(a.y + (int64_t)img * a.ys_b, ybytes);
     const uint32_t sv4 = full ? 16u * (uint32_t)G : kPyrOob;
     const uint32_t svr = nrag ? 16u * (uint32_t)G : kPyrOob;
@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
     // as in the analysis kernel, mifwt_dwt2_fwd_pyr.hip)
     auto substep1 = [&](auto r0_tag, int t) {
       __syncthreads();
-      if (!(a.dbg & 4)) {
+      if (!(MIFWT_DBG(a) & 4)) {
         const int r1 = ra[1] + 2 * (t - T1);
         const unsigned char* ent = smem + stage_off + eb * a.entry_bytes + a.offL[0];
         const unsigned char* src[2][4];
@@ -530,7 +530,7 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
         __syncthreads();
         const int s = t >> 1;
         const int r2 = ra[2] + 2 * (s - D2);
-        if ((t & 1) && s >= D2 && r2 <= rb[2] && !(a.dbg & 4)) {
+        if ((t & 1) && s >= D2 && r2 <= rb[2] && !(MIFWT_DBG(a) & 4)) {
           const int ebp = eb == 0 ? a.nbuf - 1 : eb - 1;  // entry t - 1
           const unsigned char* src[2][4];
 #pragma unroll
@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
     for (int t = 0; t < nsub; ++t) {
       __syncthreads();
       const int r3 = ra[3] + (t >> 1);
-      if ((t & 1) && r3 <= rb[3] && !(a.dbg & 4)) {
+      if ((t & 1) && r3 <= rb[3] && !(MIFWT_DBG(a) & 4)) {
         const int ebp = eb == 0 ? a.nbuf - 1 : eb - 1;
         const unsigned char* e0 = (t - 1 < TW ? smem + a.wu3_off + 2 * (t - 1) * a.pitchS[2] : smem + stage_off + ebp * a.entry_bytes + a.offL[2]) + win;
         const unsigned char* e1 = (t < TW ? smem + a.wu3_off + 2 * t * a.pitchS[2] : smem + stage_off + eb * a.entry_bytes + a.offL[2]) + win;

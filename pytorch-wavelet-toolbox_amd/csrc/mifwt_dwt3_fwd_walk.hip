@@ -150,7 +150,7 @@ __global__ void __launch_bounds__(64 * walk3_max_waves<T>()) dwt3_fwd_walk_kerne
     auto issue = [&](int t) {
       const uint32_t buf = (uint32_t)ib * (uint32_t)SLAB + (uint32_t)(walk3_lpad(L) * ES);
       ib = ib + 1 == a.nslots ? 0 : ib + 1;
-      if (a.dbg & 2) return;
+      if (MIFWT_DBG(a) & 2) return;
       const int e = E0 + t;
       const bool sdead = zero_mode && (unsigned)e >= (unsigned)a.D;
       const uint32_t sbase = sdead ? 0u : (uint32_t)fold(e, a.D) * slice_bytes;
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(64 * walk3_max_waves<T>()) dwt3_fwd_walk_kerne
         if constexpr (BODY * ES < 1024) {
           if (lane < BODY * ES / 16) walk3_dma_row<1, false>(voff, dead ? xr_dead : xr, so, la);  // masked lanes write nothing: BODY ES bytes land
         } else {
-          if (a.dbg & 16) walk3_dma_row<NCHE, true>(voff, dead ? xr_dead : xr, so, la);
+          if (MIFWT_DBG(a) & 16) walk3_dma_row<NCHE, true>(voff, dead ? xr_dead : xr, so, la);
           else walk3_dma_row<NCHE, false>(voff, dead ? xr_dead : xr, so, la);
         }
       }
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(64 * walk3_max_waves<T>()) dwt3_fwd_walk_kerne
       }
     }
     wave_lds_fence();
-    if (a.dbg & 4) {
+    if (MIFWT_DBG(a) & 4) {
 #pragma unroll
       for (int c = 0; c < NC; ++c) hv[c] = (V2){T(1), T(2)};
       return;
@@ -257,14 +257,14 @@ __global__ void __launch_bounds__(64 * walk3_max_waves<T>()) dwt3_fwd_walk_kerne
   // a row pair for 8-byte stores — on 129-sample rows they are only 4-byte aligned: 235 against 229 us, profiles/r04w16_walk3_st8.txt)
   auto emit = [&](auto sl_tag, int z) {
     constexpr int SL = decltype(sl_tag)::value;
-    if (a.dbg & 1) return;
+    if (MIFWT_DBG(a) & 1) return;
     const uint32_t za = (uint32_t)z * a.os_d[0] + (uint32_t)k, zd = (uint32_t)z * a.os_d[1] + (uint32_t)k;
 #pragma unroll
     for (int j = 0; j < TR; ++j) {
       const int y = jw + j;
       if (y < a.Ho && active) {
         uint32_t oa = za + (uint32_t)y * a.os_h[0], od = zd + (uint32_t)y * a.os_h[1];
-        if (a.dbg & 8) {  // A/B (wrong results): rows on a 128-sample pitch, i.e. line-aligned 256-byte stores
+        if (MIFWT_DBG(a) & 8) {  // A/B (wrong results): rows on a 128-sample pitch, i.e. line-aligned 256-byte stores
           if (k >= 128) continue;
           oa = od = ((uint32_t)z * (uint32_t)a.Ho + (uint32_t)y) * 128u + (uint32_t)k;
         }
@@ -346,7 +346,7 @@ int launch_walk3(const mifwt_level_desc* d, const void* x, void* approx, void* c
   for (int m = 0; m < L; ++m) a.tap[m] = (typename TileArith<T>::vec2){(T)lo[m], (T)hi[m]};
   a.nstrips = (a.Wo + 63) / 64;
   a.nq = (g_options[MIFWT_OPT_DEBUG] & 64) ? 64 : (a.Wo + a.nstrips - 1) / a.nstrips;
-  if (const int ns = g_options[MIFWT_OPT_EXP] & 15; ns >= a.nstrips && ns * NRG <= (ES == 8 ? 4 : 8)) {  // (A/B: narrower strips, more waves — 8 x 256^3 db2, 3 / 4 / 5 / 6 / 8 strips: 232 / 233 / 243 / 249 / 347 us)
+  if (const int ns = exp_word() & 15; ns >= a.nstrips && ns * NRG <= (ES == 8 ? 4 : 8)) {  // (A/B: narrower strips, more waves — 8 x 256^3 db2, 3 / 4 / 5 / 6 / 8 strips: 232 / 233 / 243 / 249 / 347 us)
     a.nstrips = ns;
     a.nq = (a.Wo + ns - 1) / ns;
   }

@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(64 * (kIW3MaxStrips + 2)) idwt3_walk_kernel(co
     auto issue = [&](int t) {
       const uint32_t buf = (uint32_t)ib * (uint32_t)SLOTB + (uint32_t)(4 * l) * (uint32_t)BANDB;
       ib = ib + 1 == a.nslots ? 0 : ib + 1;
-      if (a.dbg & 2) return;
+      if (MIFWT_DBG(a) & 2) return;
       const uint32_t zc = (uint32_t)(PA + t);
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(64 * (kIW3MaxStrips + 2)) idwt3_walk_kernel(co
   auto filter_slice = [&](V2 (&himg)[2][CY][2]) {
     const unsigned char* const sl = smem + slot * SLOTB;
     slot = slot + 1 == a.nslots ? 0 : slot + 1;
-    if (a.dbg & 4) {
+    if (MIFWT_DBG(a) & 4) {
 #pragma unroll
       for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(64 * (kIW3MaxStrips + 2)) idwt3_walk_kernel(co
   // output slice pair P from accumulator slot S
   auto emit = [&](auto s_tag, int P) {
     constexpr int S = decltype(s_tag)::value;
-    if (a.dbg & 1) return;
+    if (MIFWT_DBG(a) & 1) return;
     if constexpr (ES == 4) {
     if (a.st16) {
 #pragma unroll

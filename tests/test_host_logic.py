@@ -206,8 +206,27 @@ def test_cabi_library_exports_every_declared_symbol():
             "mifwt_abi_version", "mifwt_set_option"} <= set(syms)
     for s in syms:
         assert getattr(lib, s) is not None
-    assert lib.mifwt_abi_version() == _engine.ABI_VERSION == 2 and lib.mifwt_launch_count(99) == 0
+    assert lib.mifwt_abi_version() == _engine.ABI_VERSION == 3 and lib.mifwt_launch_count(99) == 0
     assert lib.mifwt_strerror(0) == b"ok" and b"argument" in lib.mifwt_strerror(-1)
+
+
+def test_product_library_has_no_result_breaking_switches():
+    """The measurement switches of MIFWT_OPT_DEBUG that break results (no stores / no loads / no deep levels ...), the experiment word and the
+    profiling instances are compiled into -DMIFWT_DIAG builds only: the product library refuses them (csrc/mifwt_common.h), keeps the
+    routing bits (alternative code paths with the same results), and no longer exports round 3's handover entry points."""
+    lib = _engine.load_library()
+    if os.environ.get("MIFWT_LIB"):
+        pytest.skip("an experiment build may be a diagnostics build")
+    for bits in (1, 2, 4, 16, 32, 128, 256, 2048, 65536, 1 | 1024):
+        assert lib.mifwt_set_option(_engine.OPT_DEBUG, bits) == -2  # MIFWT_ERR_UNSUPPORTED
+    for bits in (8, 64, 512, 1024, 4096, 8192, 1 << 19, 1 << 20, 1024 | 4096):
+        assert lib.mifwt_set_option(_engine.OPT_DEBUG, bits) == 0
+    assert lib.mifwt_set_option(_engine.OPT_DEBUG, 0) == 0
+    assert lib.mifwt_set_option(_engine.OPT_EXP, 1) == -2 and lib.mifwt_set_option(_engine.OPT_EXP, 0) == 0
+    lib.mifwt_pyr_profile_buffer.argtypes = [ctypes.c_void_p]
+    assert lib.mifwt_pyr_profile_buffer(ctypes.c_void_p(4096)) == -2 and lib.mifwt_pyr_profile_buffer(None) == 0
+    for gone in ("mifwt_dwt2_fwd_pyramid_ws", "mifwt_dwt2_fwd_pyramid_workspace"):
+        assert not hasattr(lib, gone)
 
 
 def test_cabi_descriptor_validation_and_dispatch():
