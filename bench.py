@@ -360,6 +360,72 @@ def secondary_lines(dev, steps=20, warmup=5, buffers=3):
     return out
 
 
+# headline workload -> the workload of the N > 1 "config4_shard" leg (the dry-run workload maps to itself: control flow only)
+SCALING_SHARD = {"wavedec2_db4_L3_64x1024x1024_f32": "wavedec2_db8_L4_64x4096x4096_f32",
+                 "dryrun_wavedec2_db4_L2_6x96x96_f32": "dryrun_wavedec2_db4_L2_6x96x96_f32"}
+
+
+def scaling_shard_leg(workload, dev, dist, backend, world, steps=10, warmup=3):
+    """Every rank: `steps` whole calls of `workload` on its own shard between barriers, max over ranks; then the all-gather that would
+    replicate the coefficients on every rank (one collective per level buffer, ptwt_amd.distributed.gather_coeffs).  Returns the
+    dict rank 0 prints under "config4_shard" (every rank must call this: it holds collectives)."""
+    import ptwt_amd
+    from ptwt_amd import distributed as D
+
+    fn_name, shape, wavelet, level, mode, dtype = WORKLOADS[workload]
+    fn = getattr(ptwt_amd, fn_name)
+    flen = len(ptwt_amd._wavelets.as_wavelet(wavelet))
+    info = {"workload": workload, "api": f"ptwt_amd.{fn_name}(x, '{wavelet}', mode='{mode}', level={level})", "per_gpu_shape": list(shape),
+            "global_shape": [shape[0] * world] + list(shape[1:]), "n_gpus": world, "steps": steps, "scaling": "weak"}
+    def all_ok(ok):  # (a rank that failed locally must not leave the others waiting at a barrier)
+        f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return bool(f.item())
+
+    xs, err = None, None
+    try:
+        xs = [torch.randn(*shape, dtype=dtype, device=dev) for _ in range(2)]
+        for i in range(warmup):
+            fn(xs[i & 1], wavelet, mode=mode, level=level)
+        sync()
+    except Exception as exc:
+        err = repr(exc)[:300]
+    if not all_ok(err is None):
+        info["error"] = err or "another rank failed in the warm-up"
+        return info
+    try:
+        dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(xs[i & 1], wavelet, mode=mode, level=level)
+        sync()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item()) / steps * 1e3
+        comp_b = algorithmic_bytes(shape[0], shape[1:], flen, level, torch.empty(0, dtype=dtype).element_size())[0]
+        info.update(ms_per_step=round(ms, 4), Msamples_per_s=round(prod(shape) * world / (ms * 1e-3) / 1e6, 1), compulsory_bytes_per_gpu=comp_b,
+                    frac_of_hbm_peak_per_gpu=round(comp_b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+        # the gather, outside the transform's timing: one warm-up (communicator set-up), one timed repetition
+        coeffs = fn(xs[0], wavelet, mode=mode, level=level)
+        del xs
+        D.gather_coeffs(coeffs)
+        sync()
+        dist.barrier()
+        tg = time.perf_counter()
+        full = D.gather_coeffs(coeffs)
+        sync()
+        dist.barrier()
+        tg = time.perf_counter() - tg
+        nbytes = sum(v.numel() * v.element_size() for _, v in _flatten(coeffs))
+        info["coefficient_gather"] = {"ms": round(tg * 1e3, 3), "bytes_per_rank": nbytes, "collectives": "one all_gather_into_tensor per level buffer",
+                                      "GBps_per_rank_in": round(nbytes * (world - 1) / tg / 1e9, 1)}
+        del full
+    except Exception as exc:  # (an optional leg never breaks the benchmark line — but it must not hide a hang either: barriers above)
+        info["error"] = repr(exc)[:300]
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -616,6 +682,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # N > 1, default workload: ALSO the configuration BASELINE.json quotes the multi-GPU split on — configs[3], wavedec2 db8 level 4 on
+    # 512 x 4096^2 over 8 GPUs — as its per-GPU shard of 64 images on every rank (weak scaling as the headline: at N = 8 this IS that
+    # configuration), max over ranks, and the RCCL gather of its coefficient lists (north_star: "RCCL over xGMI used only to gather the
+    # coefficient lists"), timed on its own.  Reported under "config4_shard", never part of `value`.
+    shard_info = None
+    if distributed and not args.no_secondary and args.workload in SCALING_SHARD:
+        shard_info = scaling_shard_leg(SCALING_SHARD[args.workload], dev, dist, backend, world)
+
     if rank == 0:
         samples_per_step = prod(shape) * world
         ms_per_step = elapsed / args.steps * 1e3
@@ -721,6 +795,8 @@ def main():
         }
         if gather_info is not None:
             result["coefficient_gather"] = gather_info
+        if shard_info is not None:
+            result["config4_shard"] = shard_info
         if world == 1 and not args.no_secondary and args.workload == "wavedec2_db4_L3_64x1024x1024_f32" and DEVICE_KIND == "cuda":
             del bufs
             torch.cuda.empty_cache()

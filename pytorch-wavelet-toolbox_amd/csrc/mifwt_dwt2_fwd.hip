@@ -214,32 +214,37 @@ __device__ __forceinline__ void strip_body(const Dwt2FwdArgs<L>& a, float (*lds)
       }
 
       // ---- vertical pass: two output rows, this lane's 4 columns, (lo, hi) packed -----------------------
+      // (the two rows INTERLEAVED, tap by tap: eight independent accumulation chains — with four, the compiler's hazard recogniser puts
+      // one s_nop behind every round of inline-assembly FMAs, mifwt_stream.h; same products in the same order per chain)
+      f2 v[2][4];
 #pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
-        f2 v[4];
+      for (int m = 0; m < L; ++m) {
 #pragma unroll
-        for (int m = 0; m < L; ++m) {
+        for (int rr = 0; rr < 2; ++rr) {
           // c[j] = sum_m h[m] * x_ext[2j + 1 - m];  ring index of row 2j+1-m is 4p + 2rr + (L-1) - m
           const f4 xv = ring[(4 * u + 2 * rr + (L - 1) - m) % RING];
           const f2 x01 = {xv.x, xv.y}, x23 = {xv.z, xv.w};
           if (m == 0) {
-            v[0] = pkmul_lo(a.tap[0], x01);
-            v[1] = pkmul_hi(a.tap[0], x01);
-            v[2] = pkmul_lo(a.tap[0], x23);
-            v[3] = pkmul_hi(a.tap[0], x23);
+            v[rr][0] = pkmul_lo(a.tap[0], x01);
+            v[rr][1] = pkmul_hi(a.tap[0], x01);
+            v[rr][2] = pkmul_lo(a.tap[0], x23);
+            v[rr][3] = pkmul_hi(a.tap[0], x23);
           } else {
-            pkfma_lo(v[0], a.tap[m], x01);
-            pkfma_hi(v[1], a.tap[m], x01);
-            pkfma_lo(v[2], a.tap[m], x23);
-            pkfma_hi(v[3], a.tap[m], x23);
+            pkfma_lo(v[rr][0], a.tap[m], x01);
+            pkfma_hi(v[rr][1], a.tap[m], x01);
+            pkfma_lo(v[rr][2], a.tap[m], x23);
+            pkfma_hi(v[rr][3], a.tap[m], x23);
           }
         }
+      }
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
         if (EDGE) {  // implicit-zero columns (the vertical filter commutes with the column extension)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] *= cmask[c];
+          for (int c = 0; c < 4; ++c) v[rr][c] *= cmask[c];
         }
-        *reinterpret_cast<f4*>(wr + rr * kLdsRowFloats) = (f4){v[0].x, v[0].y, v[1].x, v[1].y};
-        *reinterpret_cast<f4*>(wr + rr * kLdsRowFloats + 4) = (f4){v[2].x, v[2].y, v[3].x, v[3].y};
+        *reinterpret_cast<f4*>(wr + rr * kLdsRowFloats) = (f4){v[rr][0].x, v[rr][0].y, v[rr][1].x, v[rr][1].y};
+        *reinterpret_cast<f4*>(wr + rr * kLdsRowFloats + 4) = (f4){v[rr][2].x, v[rr][2].y, v[rr][3].x, v[rr][3].y};
       }
       wave_lds_fence();
 
@@ -255,9 +260,9 @@ __device__ __forceinline__ void strip_body(const Dwt2FwdArgs<L>& a, float (*lds)
 
       f2 ol[4], oh[4];  // ol[e] = (aa, ad), oh[e] = (da, dd) of output column e
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int m = 0; m < L; ++m) {  // (the four columns interleaved, tap by tap: eight chains, see the vertical pass)
 #pragma unroll
-        for (int m = 0; m < L; ++m) {
+        for (int e = 0; e < 4; ++e) {
           const int idx = 2 * e + 1 + R4 - m;  // extended column 2k+1-m relative to this lane's chunk base
           if (m == 0) {
             ol[e] = pkmul_lo(a.tap[0], w[idx]);

@@ -144,22 +144,11 @@ __device__ __forceinline__ void pyr_wait_vm() {
 // packed FMAs acc (+)= (tap.x, tap.y) * pair.x / pair.y with the tap pair in an SGPR pair: with the three-operand pattern of the
 // passes (accumulator, tap, sample all distinct) 4.7 cycles per wave-instruction at two waves per SIMD against 5.5 for taps held
 // in VGPR pairs (tools/ubench.hip "distinct" rows, profiles/r02_ubench_valu_copy.txt)
-__device__ __forceinline__ void vfma_lo(f2& acc, const f2 tap, const f2 pair) {
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(tap), "v"(pair));
-}
-__device__ __forceinline__ void vfma_hi(f2& acc, const f2 tap, const f2 pair) {
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(acc) : "s"(tap), "v"(pair));
-}
-__device__ __forceinline__ f2 vmul_lo(const f2 tap, const f2 pair) {
-  f2 r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "s"(tap), "v"(pair));
-  return r;
-}
-__device__ __forceinline__ f2 vmul_hi(const f2 tap, const f2 pair) {
-  f2 r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "s"(tap), "v"(pair));
-  return r;
-}
+// (one definition for every kernel: mifwt_stream.h)
+__device__ __forceinline__ void vfma_lo(f2& acc, const f2 tap, const f2 pair) { pkfma_lo(acc, tap, pair); }
+__device__ __forceinline__ void vfma_hi(f2& acc, const f2 tap, const f2 pair) { pkfma_hi(acc, tap, pair); }
+__device__ __forceinline__ f2 vmul_lo(const f2 tap, const f2 pair) { return pkmul_lo(tap, pair); }
+__device__ __forceinline__ f2 vmul_hi(const f2 tap, const f2 pair) { return pkmul_hi(tap, pair); }
 
 // rolling vertical pass: the L/2 outputs in flight of NC columns; lo = (aa, da), hi = (ad, dd) per column.  Output i lives in
 // slot i mod L/2 for its whole life, so nothing is ever copied: the pair index modulo L/2 (R) is a compile-time constant at

@@ -15,6 +15,13 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 // v_pk_fma_f32 with a PACKED TAP PAIR and a BROADCAST sample:
 //   acc(.x, .y) += (tap.x, tap.y) * sample,  sample = low (…_lo) or high (…_hi) half of an even-aligned VGPR pair.
 // The tap pair lives in SGPRs (one 64-bit scalar operand), the sample needs no pairing of its own.
+// (Inline assembly: each FMA is opaque to the compiler, whose hazard recogniser keeps four wait states between an asm statement and the
+// next one that touches its result — a round of FOUR accumulation chains costs one s_nop (1048 s_nop among the 8453 instructions of the
+// 16-tap streaming kernel): callers interleave at least five independent chains.  Round 6 measured the compiler's own packed FMAs
+// (-DMIFWT_BUILTIN_FMA: __builtin_elementwise_fma on the broadcast sample selects the same v_pk_fma_f32 with an SGPR tap pair, no
+// s_nop): its scheduler then hoists loads and copies accumulators — the 16-tap streaming kernels go to 256 registers + scratch,
+// config 4 2.37 -> 2.77 / 3.2 ms; configs 2 / 3 within 1 % (profiles/r06c_fma_builtin_ab.txt).  Assembly stays.)
+#ifndef MIFWT_BUILTIN_FMA
 __device__ __forceinline__ void pkfma_lo(f2& acc, const f2 tap, const f2 pair) {
   asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(tap), "v"(pair));
 }
@@ -31,6 +38,12 @@ __device__ __forceinline__ f2 pkmul_hi(const f2 tap, const f2 pair) {
   asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(r) : "s"(tap), "v"(pair));
   return r;
 }
+#else
+__device__ __forceinline__ void pkfma_lo(f2& acc, const f2 tap, const f2 pair) { acc = __builtin_elementwise_fma(tap, (f2){pair.x, pair.x}, acc); }
+__device__ __forceinline__ void pkfma_hi(f2& acc, const f2 tap, const f2 pair) { acc = __builtin_elementwise_fma(tap, (f2){pair.y, pair.y}, acc); }
+__device__ __forceinline__ f2 pkmul_lo(const f2 tap, const f2 pair) { return tap * (f2){pair.x, pair.x}; }
+__device__ __forceinline__ f2 pkmul_hi(const f2 tap, const f2 pair) { return tap * (f2){pair.y, pair.y}; }
+#endif
 
 // Arithmetic layer of the tile kernels: f32 / f16 storage computes in packed f32 (the four asm helpers above), f64
 // storage in double (no packed f64 FMA on gfx950: two v_fma_f64 per "packed" step).  a*_lo / a*_hi have the meaning of

@@ -58,6 +58,14 @@ def test_bench_two_ranks_gloo_dry_run():
     res = _json_line(p.stdout)
     _check(res, 2)
     assert "cpu_baseline" not in res  # N = 1 only
+    # the N > 1 line also answers BASELINE's scaling question: the per-GPU shard of the multi-GPU configuration on every rank (here: the
+    # dry-run stand-in of it) and the gather of its coefficient lists
+    sh = res["config4_shard"]
+    assert "error" not in sh, sh
+    assert sh["n_gpus"] == 2 and sh["scaling"] == "weak" and sh["global_shape"][0] == 2 * sh["per_gpu_shape"][0]
+    assert sh["ms_per_step"] > 0 and sh["Msamples_per_s"] > 0
+    g = sh["coefficient_gather"]
+    assert g["ms"] > 0 and g["bytes_per_rank"] > 0 and "all_gather" in g["collectives"]
 
 
 def test_bench_rejects_mismatched_world():
