@@ -103,14 +103,18 @@ int mifwt_dwt_inv(const mifwt_level_desc* desc, const void* approx, const void* 
                   const double* rec_lo, const double* rec_hi, void* workspace, size_t workspace_bytes,
                   void* stream);
 
-/* DEVICE-RESIDENT TAPS (round 5).  The entry points above take the filter as HOST doubles (the kernels receive it in their launch
+/* DEVICE-RESIDENT TAPS (rounds 5 / 6).  The entry points above take the filter as HOST doubles (the kernels receive it in their launch
  * arguments); a learnable filter bank that lives on the GPU (the reference keeps its taps as tensors with autograd,
  * src/ptwt/_util.py:115-132; examples/network_compression/wavelet_linear.py:118,150) would have to be copied to the host — a stream
  * synchronisation — on every call.  These four take DEVICE pointers to L doubles each; the kernels read the taps themselves: no copy,
- * no synchronisation, capturable into a HIP graph.  They run the generic per-axis passes (kernel id 0: every dtype, mode, stride set
- * and filter length) — slower per byte than the fused kernels, which is the price of not knowing the taps on the host.
- * Same results as the host-tap entry points routed through the generic passes (MIFWT_OPT_FORCE_GENERIC), bit for bit.
+ * no synchronisation, capturable into a HIP graph.  Which kernel serves a call: mifwt_kernel_id_dtaps(desc, direction) — the fused 2-D
+ * kernels where they read device taps (round 6: LDS tiles, ids 7 / 8: every dtype and filter length they serve; one level through the
+ * streaming kernels, ids 16 / 22; the border kernels of the analysis adjoint; the streaming axis passes, ids 3 / 4: what a learnable-wavelet training step on image-sized
+ * planes runs on, src/ptwt/_util.py:115-132), the generic per-axis passes (id 0: every dtype, mode, stride set and filter length)
+ * everywhere else.  A kernel reads the L doubles once, when it starts, into the registers its by-value taps would occupy (same
+ * conversion, same packing): results are bit-identical to the host-tap entry points on the same kernel.
  * Workspace: mifwt_workspace_bytes_dtaps(desc, direction), direction as for mifwt_workspace_bytes (0 .. 3). */
+int mifwt_kernel_id_dtaps(const mifwt_level_desc* desc, int direction);
 size_t mifwt_workspace_bytes_dtaps(const mifwt_level_desc* desc, int direction);
 int mifwt_dwt_fwd_dtaps(const mifwt_level_desc* desc, const void* x, void* approx, void* const* details, const double* d_dec_lo,
                         const double* d_dec_hi, void* workspace, size_t workspace_bytes, void* stream);

@@ -145,6 +145,8 @@ def load_library() -> ctypes.CDLL:
     if not experiment or hasattr(lib, "mifwt_workspace_bytes_dtaps"):
         lib.mifwt_workspace_bytes_dtaps.restype = ctypes.c_size_t
         lib.mifwt_workspace_bytes_dtaps.argtypes = [desc_p, ctypes.c_int]
+        lib.mifwt_kernel_id_dtaps.restype = ctypes.c_int
+        lib.mifwt_kernel_id_dtaps.argtypes = [desc_p, ctypes.c_int]
         for name in ("mifwt_dwt_fwd_dtaps", "mifwt_dwt_inv_dtaps", "mifwt_dwt_fwd_adjoint_dtaps", "mifwt_dwt_inv_adjoint_dtaps"):
             getattr(lib, name).restype = ctypes.c_int
         lib.mifwt_dwt_fwd_dtaps.argtypes = [desc_p, vp, vp, vpp, vp, vp, vp, ctypes.c_size_t, vp]
@@ -1030,7 +1032,8 @@ class HipLevelEngine:
         if dev.index is not None and dev.index != torch.cuda.current_device():
             with torch.cuda.device(dev):
                 return HipLevelEngine._run(p, direction, anchor, call, kid, dtaps)
-        # (device-resident taps run the generic passes, whose scratch differs from the plan's route)
+        # (device-resident taps: the fused 2-D kernels where they read device taps, else the generic passes — whose scratch differs
+        # from the plan's route; mifwt_kernel_id_dtaps says which)
         wsb = int(_lib.mifwt_workspace_bytes_dtaps(p.ref, direction)) if dtaps else p.ws_bytes
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
         if level_events is None:
@@ -1042,7 +1045,8 @@ class HipLevelEngine:
             rc = call(ws.data_ptr() if ws is not None else None, wsb, stream.cuda_stream)
             ev[1].record(stream)
             d = p.desc
-            level_events.append((("fwd", "inv", "fwd_adj", "inv_adj")[direction], p.kid if kid is None else kid, tuple(d.sig_extent[: d.ndim]), ev[0], ev[1]))
+            kid_run = int(_lib.mifwt_kernel_id_dtaps(p.ref, direction)) if dtaps else (p.kid if kid is None else kid)
+            level_events.append((("fwd", "inv", "fwd_adj", "inv_adj")[direction], kid_run, tuple(d.sig_extent[: d.ndim]), ev[0], ev[1]))
         if rc != 0:
             _check(rc)
         # the scratch block returns to the caching allocator when `ws` dies; the allocator only hands it to

@@ -112,10 +112,11 @@ def _host_floats_of(t: torch.Tensor) -> List[float]:
     return [float(v) for v in t.detach().double().cpu().reshape(-1).tolist()]
 
 
-def _host_taps_of(t: torch.Tensor):
-    """The taps of a filter tensor for a level call: the tensor itself (kernels read device memory) when it lives on the GPU and device
-    taps are not switched off, else host floats (one device-to-host copy)."""
-    if t.is_cuda and _wavelets._device_taps_mode != "never":
+def _host_taps_of(t: torch.Tensor, device: Optional[torch.device] = None):
+    """The taps of a filter tensor for a level call on data that lives on ``device``: the tensor itself (kernels read device memory) when
+    it lives on THAT GPU and device taps are not switched off, else host floats (one device-to-host copy) — a kernel launched on cuda:1
+    must not be handed a raw cuda:0 pointer."""
+    if t.is_cuda and _wavelets._device_taps_mode != "never" and (device is None or t.device == device):
         return _engine.DevTaps(t)
     return [float(v) for v in t.detach().double().cpu().reshape(-1).tolist()]
 
@@ -127,7 +128,7 @@ class _Axis1(torch.autograd.Function):
     def forward(ctx, x, lo_t, hi_t, mode_id):
         ctx.mode_id = mode_id
         ctx.save_for_backward(x, lo_t, hi_t)
-        return _engine.ENGINE.analysis(x, _host_taps_of(lo_t), _host_taps_of(hi_t), mode_id)
+        return _engine.ENGINE.analysis(x, _host_taps_of(lo_t, x.device), _host_taps_of(hi_t, x.device), mode_id)
 
     @staticmethod
     def backward(ctx, g):
@@ -147,7 +148,7 @@ class _Axis1Adj(torch.autograd.Function):
     def forward(ctx, g, lo_t, hi_t, mode_id, n):
         ctx.mode_id = mode_id
         ctx.save_for_backward(g, lo_t, hi_t)
-        return _engine.ENGINE.analysis_adjoint(g, (n,), _host_taps_of(lo_t), _host_taps_of(hi_t), mode_id)
+        return _engine.ENGINE.analysis_adjoint(g, (n,), _host_taps_of(lo_t, g.device), _host_taps_of(hi_t, g.device), mode_id)
 
     @staticmethod
     def backward(ctx, gg):
@@ -188,7 +189,7 @@ class _Syn1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, d, lo_t, hi_t, n_out):
         ctx.save_for_backward(a, d, lo_t, hi_t)
-        return _engine.ENGINE.synthesis(a, [d], _host_taps_of(lo_t), _host_taps_of(hi_t), [n_out])
+        return _engine.ENGINE.synthesis(a, [d], _host_taps_of(lo_t, a.device), _host_taps_of(hi_t, a.device), [n_out])
 
     @staticmethod
     def backward(ctx, g_y):
@@ -210,7 +211,7 @@ class _Syn1Adj(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g_y, lo_t, hi_t, m):
         ctx.save_for_backward(g_y, lo_t, hi_t)
-        return _engine.ENGINE.synthesis_adjoint(g_y, (m,), _host_taps_of(lo_t), _host_taps_of(hi_t))
+        return _engine.ENGINE.synthesis_adjoint(g_y, (m,), _host_taps_of(lo_t, g_y.device), _host_taps_of(hi_t, g_y.device))
 
     @staticmethod
     def backward(ctx, gg):
@@ -513,12 +514,25 @@ class _SynthesisChain1d(torch.autograd.Function):
         # trimmed output sample is a zero of the zero extension) — the 1-D multi-level launches (kernels 17 / 14), see _SynthesisPyramid
         fused = not torch.is_grad_enabled() and not _engine._is_dev(rec_lo) and g_y.dim() == 2
         zero = _engine.MODE_IDS["zero"]
+        flen = len(rec_lo)
         while todo:
             bufs = None
             if fused and len(todo) >= 2:
-                bufs = _engine.ENGINE.analysis_tail(g if g.stride(-1) == 1 else g.contiguous(), list(rec_lo)[::-1], list(rec_hi)[::-1], zero, len(todo))
-                if bufs is not None and (len(bufs) < 2 or any(tuple(b.shape[2:]) != tuple(shp) for b, shp in zip(bufs, todo))):
-                    bufs = None
+                # what a zero-mode analysis of g yields level by level (floor((n + L - 1) / 2)) against the coefficient shapes the forward
+                # took: decided on the host BEFORE anything is launched — a chain with a crop the adjoint launch cannot express (a
+                # separable crop of more than one sample) goes level by level from here on instead of launching, discarding and retrying
+                n, ok = int(g.shape[-1]), 0
+                for shp in todo:
+                    n = (n + flen - 1) // 2
+                    if (n,) != tuple(shp):
+                        break
+                    ok += 1
+                if ok < 2:
+                    fused = False
+                else:
+                    bufs = _engine.ENGINE.analysis_tail(g if g.stride(-1) == 1 else g.contiguous(), list(rec_lo)[::-1], list(rec_hi)[::-1], zero, ok)
+                    if bufs is not None and (len(bufs) < 2 or any(tuple(b.shape[2:]) != tuple(shp) for b, shp in zip(bufs, todo))):
+                        bufs, fused = None, False
             if bufs is None:
                 gb = _SynthesisAdjointLevel.apply(g, todo[0], rec_lo, rec_hi)
                 grads.insert(0, gb[:, 1])
@@ -620,11 +634,21 @@ class _SynthesisPyramid(torch.autograd.Function):
             bufs = None
             if fused and len(todo) >= 2:
                 gin = g if g.stride(-1) == 1 else g.contiguous()
-                k = _engine.ENGINE.pyramid_levels(gin, len(rec_lo), zero, len(todo))  # (a query: nothing is launched)
+                # the zero-mode analysis extents (floor((n + L - 1) / 2) per axis and level) against the coefficient shapes of the forward,
+                # on the host, before anything is launched: a crop the adjoint launch cannot express sends the rest level by level
+                ns, ok = [int(v) for v in gin.shape[1:]], 0
+                for shp in todo:
+                    ns = [(n + len(rec_lo) - 1) // 2 for n in ns]
+                    if tuple(ns) != tuple(shp):
+                        break
+                    ok += 1
+                k = _engine.ENGINE.pyramid_levels(gin, len(rec_lo), zero, ok) if ok >= 2 else 0  # (a query: nothing is launched)
+                if ok < 2:
+                    fused = False
                 if k >= 2:
                     bufs = _engine.ENGINE.analysis_pyramid(gin, list(rec_lo)[::-1], list(rec_hi)[::-1], zero, k)
                 if bufs is not None and (len(bufs) < 2 or any(tuple(b.shape[2:]) != tuple(shp) for b, shp in zip(bufs, todo))):
-                    bufs = None
+                    bufs, fused = None, False
             if bufs is None:
                 gb = _SynthesisAdjointLevel.apply(g, todo[0], rec_lo, rec_hi)
                 grads = [gb[:, 1], gb[:, 2], gb[:, 3]] + grads

@@ -37,6 +37,7 @@ struct BorderArgs {
   uint32_t slabs[ND], rest_border[ND];     // decode_border: samples in the border hyperplanes of axis d / border samples of a box of the axes after d
   FastDiv dv_full[ND], dv_border[ND], dv_n[ND];  // divisions by (full hyperplane of the axes after d), rest_border[d], N[d]
   T lo[kMaxTaps], hi[kMaxTaps];
+  DevTapArg dt;  // device-resident taps (mifwt_common.h); dt.lo == nullptr: lo / hi count
 };
 
 // the e-th border sample of a box of extents N with border widths B: coordinates n.  Samples are enumerated slab by slab: first the
@@ -120,8 +121,15 @@ __global__ void __launch_bounds__(256) adjoint_border_kernel(const BorderArgs<T,
   // the taps are indexed per lane: from LDS (from the kernel arguments every such read is a memory request)
   __shared__ T s_lo[kMaxTaps], s_hi[kMaxTaps];
   if (threadIdx.x < kMaxTaps) {
-    s_lo[threadIdx.x] = a.lo[threadIdx.x];
-    s_hi[threadIdx.x] = a.hi[threadIdx.x];
+    const int m = (int)threadIdx.x;
+    if (a.dt.lo) {  // (a learnable filter bank that lives on the GPU)
+      const int mm = a.dt.rev ? a.L - 1 - m : m;
+      s_lo[m] = m < a.L ? (T)a.dt.lo[mm] : (T)0;
+      s_hi[m] = m < a.L ? (T)a.dt.hi[mm] : (T)0;
+    } else {
+      s_lo[m] = a.lo[m];
+      s_hi[m] = a.hi[m];
+    }
   }
   __syncthreads();
   const uint32_t e = (blockIdx.x * 256u + threadIdx.x) / kLanesPerSample;
@@ -235,8 +243,14 @@ __global__ void __launch_bounds__(kBorder2Threads) adjoint_border2_kernel(const 
   const int tid = (int)threadIdx.x, sub = tid % G;
   BPair<T>* const X = reinterpret_cast<BPair<T>*>(s_hi + kMaxTaps) + (tid / G) * (2 * krmax);  // [frame][row of the frame] of this line
   if (tid < kMaxTaps) {
-    s_lo[tid] = a.lo[tid];
-    s_hi[tid] = a.hi[tid];
+    if (a.dt.lo) {  // (a learnable filter bank that lives on the GPU)
+      const int mm = a.dt.rev ? a.L - 1 - tid : tid;
+      s_lo[tid] = tid < a.L ? (T)a.dt.lo[mm] : (T)0;
+      s_hi[tid] = tid < a.L ? (T)a.dt.hi[mm] : (T)0;
+    } else {
+      s_lo[tid] = a.lo[tid];
+      s_hi[tid] = a.hi[tid];
+    }
   }
   __syncthreads();
   const int N0 = a.N[0], N1 = a.N[1];
@@ -395,6 +409,7 @@ int launch_border(const mifwt_level_desc* d, const void* g_approx, const void* c
     a.lo[m] = m < a.L ? (T)lo[m] : (T)0;
     a.hi[m] = m < a.L ? (T)hi[m] : (T)0;
   }
+  a.dt = dev_tap_arg(a.L);
   if (per_image == 0 || d->batch == 0) return MIFWT_OK;
   if constexpr (ND == 2) {
     int threads = 0;

@@ -484,22 +484,63 @@ int mifwt_dwt_inv_adjoint(const mifwt_level_desc* desc, const void* g_y, void* g
   return run_fwd(&z, g_y, g_approx, g_details, lo, hi, workspace, workspace_bytes, stream);
 }
 
-// ---- device-resident taps (include/mifwt.h): the four level operations on the generic axis passes, the filter read from device
-// memory by the kernels.  Nothing here touches the taps on the host.
+// ---- device-resident taps (include/mifwt.h): the four level operations with the filter read from device memory by the kernels.
+// Nothing here touches the taps on the host.  Round 5: the generic axis passes.  Round 6: the fused 2-D kernels that serve a
+// learnable-wavelet training step on image-sized planes — LDS tiles (ids 7 / 8), one level through the streaming kernels (ids 16 / 22),
+// the border kernels of the analysis adjoint — and the streaming axis passes (ids 3 / 4: 1-D levels and the per-axis maps of the tap
+// gradients; ids 5 / 6: the composed 3-D route) take the same device arrays (DevTapArg, mifwt_common.h); everything else stays on the
+// generic passes.
 namespace {
 struct DtapsScope {
-  DtapsScope(const double* lo, const double* hi, int rev) { mifwt::g_dtaps = {lo, hi, rev}; }
+  DtapsScope(const double* lo, const double* hi, int rev) {
+    mifwt::g_dtaps = {lo, hi, rev};
+    mifwt::g_dtaps_taken = 0;
+  }
   ~DtapsScope() { mifwt::g_dtaps = {nullptr, nullptr, 0}; }
+  // a fused route must have handed the device taps to every kernel it launched: one that ran on the (zero) host taps is a bug, and loud
+  static int checked(int rc) { return rc == MIFWT_OK && mifwt::g_dtaps_taken == 0 ? MIFWT_ERR_LAUNCH : rc; }
 };
 const double kNoHostTaps[MIFWT_MAX_FILT] = {0};
+// kernel ids whose kernels read DevTapArg
+bool dtaps_fused(int kid) {
+  return kid == kDwt2FwdTile || kid == kDwt2InvTile || kid == kDwt2FwdPyr || kid == kDwt2InvPyr || kid == kDwt1FwdRow || kid == kDwt1InvRow;
+}
+// which kernel serves a device-tap call: that of the host-tap call where it reads device taps (direction 2: also the border kernel),
+// else the generic passes
+int dtaps_kernel(const mifwt_level_desc* desc, int direction) {
+  if (g_options[MIFWT_OPT_FORCE_GENERIC]) return kGeneric;
+  int kid = kGeneric;
+  if (direction == 0 || direction == 1) {
+    kid = pick_kernel(desc, direction);
+  } else if (direction == 2) {
+    if (desc->mode == MIFWT_MODE_ZERO || adjoint_border_supported(desc)) kid = pick_kernel(desc, 1);
+  } else {
+    const mifwt_level_desc z = as_zero_mode(desc);
+    kid = pick_kernel(&z, 0);
+  }
+  return dtaps_fused(kid) ? kid : kGeneric;
+}
 }  // namespace
+
+int mifwt_kernel_id_dtaps(const mifwt_level_desc* desc, int direction) {
+  if (!desc || direction < 0 || direction > 3) return MIFWT_ERR_BADARG;
+  mifwt_level_desc z = *desc;
+  if (direction == 3) z.mode = MIFWT_MODE_ZERO;
+  const int rc = validate(&z, direction == 1 ? 1 : 0);
+  if (rc != MIFWT_OK) return rc;
+  return dtaps_kernel(desc, direction);
+}
 
 size_t mifwt_workspace_bytes_dtaps(const mifwt_level_desc* desc, int direction) {
   if (direction == 3) {
     const mifwt_level_desc z = as_zero_mode(desc);
-    return validate(&z, 0) == MIFWT_OK ? generic_ws(&z, 0) : 0;
+    if (validate(&z, 0) != MIFWT_OK) return 0;
+    const int kid = dtaps_kernel(desc, 3);
+    return kid == kGeneric ? generic_ws(&z, 0) : route_ws(&z, 0, kid);
   }
   if (validate(desc, direction == 1 ? 1 : 0) != MIFWT_OK) return 0;
+  const int kid = dtaps_kernel(desc, direction);
+  if (kid != kGeneric) return route_ws(desc, direction == 0 ? 0 : 1, kid);
   return generic_ws(desc, direction == 0 ? 0 : 1);
 }
 
@@ -511,9 +552,11 @@ int mifwt_dwt_fwd_dtaps(const mifwt_level_desc* desc, const void* x, void* appro
   for (int s = 1; s < (1 << desc->ndim); ++s)
     if (!details[s - 1]) return MIFWT_ERR_BADARG;
   if (desc->batch == 0) return MIFWT_OK;
+  DtapsScope scope(d_dec_lo, d_dec_hi, 0);
+  if (dtaps_kernel(desc, 0) != kGeneric)
+    return DtapsScope::checked(run_fwd(desc, x, approx, details, kNoHostTaps, kNoHostTaps, workspace, workspace_bytes, stream));
   const size_t need = generic_ws(desc, 0);
   if (need > 0 && (!workspace || workspace_bytes < need)) return MIFWT_ERR_WORKSPACE;
-  DtapsScope scope(d_dec_lo, d_dec_hi, 0);
   return generic_fwd(desc, x, approx, details, kNoHostTaps, kNoHostTaps, workspace, static_cast<hipStream_t>(stream));
 }
 
@@ -525,20 +568,34 @@ int mifwt_dwt_inv_dtaps(const mifwt_level_desc* desc, const void* approx, const 
   for (int s = 1; s < (1 << desc->ndim); ++s)
     if (!details[s - 1]) return MIFWT_ERR_BADARG;
   if (desc->batch == 0) return MIFWT_OK;
+  DtapsScope scope(d_rec_lo, d_rec_hi, 0);
+  if (dtaps_kernel(desc, 1) != kGeneric)
+    return DtapsScope::checked(run_inv(desc, approx, details, y, kNoHostTaps, kNoHostTaps, workspace, workspace_bytes, stream));
   const size_t need = generic_ws(desc, 1);
   if (need > 0 && (!workspace || workspace_bytes < need)) return MIFWT_ERR_WORKSPACE;
-  DtapsScope scope(d_rec_lo, d_rec_hi, 0);
   return generic_inv(desc, approx, details, y, kNoHostTaps, kNoHostTaps, workspace, static_cast<hipStream_t>(stream));
 }
 
 int mifwt_dwt_fwd_adjoint_dtaps(const mifwt_level_desc* desc, const void* g_approx, const void* const* g_details, void* g_x,
                                 const double* d_dec_lo, const double* d_dec_hi, void* workspace, size_t workspace_bytes, void* stream) {
-  const int rc = validate(desc, 0);
+  int rc = validate(desc, 0);
   if (rc != MIFWT_OK) return rc;
   if (!g_x || !g_approx || !g_details || !d_dec_lo || !d_dec_hi) return MIFWT_ERR_BADARG;
   for (int s = 1; s < (1 << desc->ndim); ++s)
     if (!g_details[s - 1]) return MIFWT_ERR_BADARG;
   if (desc->batch == 0) return MIFWT_OK;
+  if (dtaps_kernel(desc, 2) != kGeneric) {
+    // (mifwt_dwt_fwd_adjoint: the synthesis kernel with the dec taps REVERSED over the whole signal, then — a boundary extension — the
+    // border kernel with the dec taps as they are)
+    const mifwt_level_desc z = as_zero_mode(desc);
+    {
+      DtapsScope scope(d_dec_lo, d_dec_hi, 1);
+      rc = DtapsScope::checked(run_inv(&z, g_approx, g_details, g_x, kNoHostTaps, kNoHostTaps, workspace, workspace_bytes, stream));
+    }
+    if (rc != MIFWT_OK || desc->mode == MIFWT_MODE_ZERO) return rc;
+    DtapsScope scope(d_dec_lo, d_dec_hi, 0);
+    return DtapsScope::checked(adjoint_border(desc, g_approx, g_details, g_x, kNoHostTaps, kNoHostTaps, static_cast<hipStream_t>(stream)));
+  }
   const size_t need = generic_ws(desc, 1);
   if (need > 0 && (!workspace || workspace_bytes < need)) return MIFWT_ERR_WORKSPACE;
   DtapsScope scope(d_dec_lo, d_dec_hi, 0);
@@ -557,9 +614,11 @@ int mifwt_dwt_inv_adjoint_dtaps(const mifwt_level_desc* desc, const void* g_y, v
   for (int s = 1; s < (1 << desc->ndim); ++s)
     if (!g_details[s - 1]) return MIFWT_ERR_BADARG;
   if (desc->batch == 0) return MIFWT_OK;
+  DtapsScope scope(d_rec_lo, d_rec_hi, 1);
+  if (dtaps_kernel(desc, 3) != kGeneric)
+    return DtapsScope::checked(run_fwd(&z, g_y, g_approx, g_details, kNoHostTaps, kNoHostTaps, workspace, workspace_bytes, stream));
   const size_t need = generic_ws(&z, 0);
   if (need > 0 && (!workspace || workspace_bytes < need)) return MIFWT_ERR_WORKSPACE;
-  DtapsScope scope(d_rec_lo, d_rec_hi, 1);
   return generic_fwd(&z, g_y, g_approx, g_details, kNoHostTaps, kNoHostTaps, workspace, static_cast<hipStream_t>(stream));
 }
 

@@ -91,13 +91,28 @@ struct StreamArgs {
   int per_chunk;   // outer: output rows (analysis) / row pairs (synthesis) per chunk;  inner: rows per group
   int64_t ntasks;  // waves with work
   A lo[L], hi[L];  // taps, PyWavelets order
+  DevTapArg dt;    // device-resident taps (mifwt_common.h); dt.lo == nullptr: lo / hi count
 };
+
+// the taps of a pass: by value, or (a learnable filter bank that lives on the GPU) read once from device memory
+template <typename A, int L>
+__device__ __forceinline__ void stream_taps(const StreamArgs<A, L>& a, A (&tlo)[L], A (&thi)[L]) {
+  if (a.dt.lo) {
+#pragma unroll
+    for (int m = 0; m < L; ++m) tlo[m] = dtap_lo<A>(a.dt, m), thi[m] = dtap_hi<A>(a.dt, m);
+  } else {
+#pragma unroll
+    for (int m = 0; m < L; ++m) tlo[m] = a.lo[m], thi[m] = a.hi[m];
+  }
+}
 
 // ------------------------------------------------------------------------------------------------------
 // OUTER axis, analysis.  Task = (strip of 64*EV inner elements) x (chunk of output rows) x batch x job.
 template <typename T, int L>
 __global__ void __launch_bounds__(256) outer_fwd_kernel(const StreamArgs<typename ElemTraits<T>::Acc, L> a) {
   using A = typename ElemTraits<T>::Acc;
+  A tlo[L], thi[L];
+  stream_taps(a, tlo, thi);
   constexpr int E = ElemTraits<T>::EV;
   constexpr int RING = L + 2, U = RING / 2;
   const int lane = threadIdx.x & 63;
@@ -157,8 +172,8 @@ __global__ void __launch_bounds__(256) outer_fwd_kernel(const StreamArgs<typenam
         const A(&r)[E] = ring[(2 * u + L - 1 - m) % RING];  // row 2k + 1 - m
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-          lo[e] = m == 0 ? a.lo[0] * r[e] : fma(a.lo[m], r[e], lo[e]);
-          hi[e] = m == 0 ? a.hi[0] * r[e] : fma(a.hi[m], r[e], hi[e]);
+          lo[e] = m == 0 ? tlo[0] * r[e] : fma(tlo[m], r[e], lo[e]);
+          hi[e] = m == 0 ? thi[0] * r[e] : fma(thi[m], r[e], hi[e]);
         }
       }
       T* lp = lop + (int64_t)k * jb.out0_s[1];
@@ -182,6 +197,8 @@ __global__ void __launch_bounds__(256) outer_fwd_kernel(const StreamArgs<typenam
 template <typename T, int L>
 __global__ void __launch_bounds__(256) outer_inv_kernel(const StreamArgs<typename ElemTraits<T>::Acc, L> a) {
   using A = typename ElemTraits<T>::Acc;
+  A tlo[L], thi[L];
+  stream_taps(a, tlo, thi);
   constexpr int E = ElemTraits<T>::EV;
   constexpr int HL = L / 2, RING = HL + 1, U = RING;
   const int lane = threadIdx.x & 63;
@@ -238,8 +255,8 @@ __global__ void __launch_bounds__(256) outer_inv_kernel(const StreamArgs<typenam
       for (int i = 0; i < HL; ++i) {
         const A(&va)[E] = ra[(u + i) % RING];
         const A(&vd)[E] = rd[(u + i) % RING];
-        const A gl0 = a.lo[L - 2 - 2 * i], gl1 = a.lo[L - 1 - 2 * i];
-        const A gh0 = a.hi[L - 2 - 2 * i], gh1 = a.hi[L - 1 - 2 * i];
+        const A gl0 = tlo[L - 2 - 2 * i], gl1 = tlo[L - 1 - 2 * i];
+        const A gh0 = thi[L - 2 - 2 * i], gh1 = thi[L - 1 - 2 * i];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           y0[e] = i == 0 ? gl0 * va[e] : fma(gl0, va[e], y0[e]);
@@ -271,6 +288,8 @@ __global__ void __launch_bounds__(256) outer_inv_kernel(const StreamArgs<typenam
 template <typename T, int L>
 __global__ void __launch_bounds__(256) inner_fwd_kernel(const StreamArgs<typename ElemTraits<T>::Acc, L> a) {
   using A = typename ElemTraits<T>::Acc;
+  A tlo[L], thi[L];
+  stream_taps(a, tlo, thi);
   constexpr int EO = ElemTraits<T>::EO;
   constexpr int WN = 2 * EO + L - 2;                          // window: extended columns 2k0-(L-2) .. 2k0+2EO-1
   constexpr int LV = sizeof(T) == 8 ? 2 : 4;                  // elements per window load
@@ -337,8 +356,8 @@ __global__ void __launch_bounds__(256) inner_fwd_kernel(const StreamArgs<typenam
 #pragma unroll
       for (int m = 0; m < L; ++m) {
         const A v = cur[2 * e + L - 1 - m];  // extended column 2(k0+e) + 1 - m
-        lo[e] = m == 0 ? a.lo[0] * v : fma(a.lo[m], v, lo[e]);
-        hi[e] = m == 0 ? a.hi[0] * v : fma(a.hi[m], v, hi[e]);
+        lo[e] = m == 0 ? tlo[0] * v : fma(tlo[m], v, lo[e]);
+        hi[e] = m == 0 ? thi[0] * v : fma(thi[m], v, hi[e]);
       }
     }
     T* lp = static_cast<T*>(jb.out0) + lo_o + k0;
@@ -365,6 +384,8 @@ __global__ void __launch_bounds__(256) inner_fwd_kernel(const StreamArgs<typenam
 template <typename T, int L>
 __global__ void __launch_bounds__(256) inner_inv_kernel(const StreamArgs<typename ElemTraits<T>::Acc, L> a) {
   using A = typename ElemTraits<T>::Acc;
+  A tlo[L], thi[L];
+  stream_taps(a, tlo, thi);
   constexpr int EO = ElemTraits<T>::EO;   // even
   constexpr int HL = L / 2;
   constexpr int WN = HL + EO / 2 - 1;     // coefficients p0 .. p0 + WN - 1 of each band
@@ -428,7 +449,7 @@ __global__ void __launch_bounds__(256) inner_inv_kernel(const StreamArgs<typenam
       const int pp = e >> 1, rr = e & 1;  // sample n0 + e = 2 (p0 + pp) + rr
 #pragma unroll
       for (int i = 0; i < HL; ++i) {
-        const A gl = a.lo[L - 2 - 2 * i + rr], gh = a.hi[L - 2 - 2 * i + rr];
+        const A gl = tlo[L - 2 - 2 * i + rr], gh = thi[L - 2 - 2 * i + rr];
         y[e] = i == 0 ? gl * ca[pp + i] : fma(gl, ca[pp + i], y[e]);
         y[e] = fma(gh, cd[pp + i], y[e]);
       }
@@ -467,6 +488,7 @@ int stream_launch(int kind, const StreamCall& c) {  // kind: 0 outer fwd, 1 oute
     a.lo[m] = (A)c.lo[m];
     a.hi[m] = (A)c.hi[m];
   }
+  a.dt = dev_tap_arg(L);
   int64_t ntasks;
   if (kind < 2) {
     if (c.batch > INT32_MAX) return MIFWT_ERR_UNSUPPORTED;

@@ -133,6 +133,33 @@ struct DeviceTaps {
   int rev;
 };
 extern thread_local DeviceTaps g_dtaps;
+// ... and (round 6) the FUSED kernels that serve the learnable-wavelet training loop: their launch code copies this thread's
+// `g_dtaps` into the kernel arguments (DevTapArg; lo == nullptr: the taps travel by value as before) and the kernel reads the L doubles
+// once, when it starts, into the registers its by-value taps would occupy — same conversions, same packing, bit-identical results.
+struct DevTapArg {
+  const double* lo;
+  const double* hi;
+  int rev, len;
+};
+extern thread_local int g_dtaps_taken;  // launches that copied g_dtaps into their arguments (checked by the mifwt_*_dtaps entry points)
+inline DevTapArg dev_tap_arg(int filt_len) {
+  if (g_dtaps.lo) ++g_dtaps_taken;
+  return {g_dtaps.lo, g_dtaps.hi, g_dtaps.rev, filt_len};
+}
+#ifdef __HIPCC__
+// wave-uniform value in a scalar register (the fused kernels keep their taps in SGPR pairs)
+__device__ __forceinline__ float dtap_uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ double dtap_uniform(double v) {
+  const uint64_t b = __builtin_bit_cast(uint64_t, v);
+  const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b), h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+  return __builtin_bit_cast(double, ((uint64_t)h << 32) | l);
+}
+// tap m of the low-pass / high-pass filter of the pass, in the kernel's arithmetic type S (the conversion the host does for by-value taps)
+template <typename S>
+__device__ __forceinline__ S dtap_lo(const DevTapArg& dt, int m) { return dtap_uniform((S)dt.lo[dt.rev ? dt.len - 1 - m : m]); }
+template <typename S>
+__device__ __forceinline__ S dtap_hi(const DevTapArg& dt, int m) { return dtap_uniform((S)dt.hi[dt.rev ? dt.len - 1 - m : m]); }
+#endif
 int launch_axis_fwd(int dtype, const AxisJob* jobs, int njobs, const int64_t out_ext[4], int taxis, int64_t n_in,
                     int mode, int filt_len, const double* lo, const double* hi, hipStream_t stream);
 int launch_axis_inv(int dtype, const AxisJob* jobs, int njobs, const int64_t out_ext[4], int taxis, int64_t m_in,

@@ -155,7 +155,9 @@ int dwt2_fwd_fused(const mifwt_level_desc* d, const void* x, void* approx, void*
                    const double* hi, hipStream_t stream) {
   switch (dwt2_fwd_choice(d)) {
     case kDwt2FwdTile: return dwt2_fwd_tile(d, x, approx, details, lo, hi, stream);
-    case kDwt2FwdStream: return dwt2_fwd_stream(d, x, approx, details, lo, hi, stream);
+    case kDwt2FwdStream:
+      if (g_dtaps.lo) return MIFWT_ERR_UNSUPPORTED;  // (device-resident taps: this kernel takes its taps by value only — never silently on zeros)
+      return dwt2_fwd_stream(d, x, approx, details, lo, hi, stream);
     case kDwt2FwdPyr: {
       const mifwt_level_desc* dd[1] = {d};
       void* const* dp[1] = {details};
@@ -222,8 +224,12 @@ int dwt2_inv_fused(const mifwt_level_desc* d, const void* approx, const void* co
                    const double* hi, hipStream_t stream) {
   switch (dwt2_inv_choice(d)) {
     case kDwt2InvTile: return dwt2_inv_tile(d, approx, details, y, lo, hi, stream);
-    case kDwt2InvStream: return dwt2_inv_stream(d, approx, details, y, lo, hi, stream);
-    case kDwt2InvMfma: return dwt2_inv_mfma(d, approx, details, y, lo, hi, stream);
+    case kDwt2InvStream:
+      if (g_dtaps.lo) return MIFWT_ERR_UNSUPPORTED;  // (device-resident taps: these kernels take their taps by value only)
+      return dwt2_inv_stream(d, approx, details, y, lo, hi, stream);
+    case kDwt2InvMfma:
+      if (g_dtaps.lo) return MIFWT_ERR_UNSUPPORTED;
+      return dwt2_inv_mfma(d, approx, details, y, lo, hi, stream);
     case kDwt2InvPyr: {
       const mifwt_level_desc* dd[1] = {d};
       const void* const* dp[1] = {details};

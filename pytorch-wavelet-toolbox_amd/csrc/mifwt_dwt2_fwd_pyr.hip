@@ -85,6 +85,7 @@ struct PyrArgs {
   int l2split;  // the level-2 waves take one row pair in each half of a step (else both behind the step's second barrier)
   unsigned long long* prof;
   int dbg;
+  DevTapArg dt;                        // device-resident taps (mifwt_common.h); dt.lo == nullptr: `tap` counts
   FastDiv hn_div;                      // division by H[NLEV]
   uint32_t wg_start[kPyrMaxWG + 1];    // chunk k = rows [wg_start[k], wg_start[k + 1]) of the batch's level-NLEV rows laid end to end
   f2 tap[L];
@@ -209,8 +210,13 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
 
   f2 tap[L];
   if (role != kRoleLoad) {
+    if (a.dt.lo) {  // (a learnable filter bank that lives on the GPU: read once from device memory)
 #pragma unroll
-    for (int m = 0; m < L; ++m) tap[m] = a.tap[m];
+      for (int m = 0; m < L; ++m) tap[m] = (f2){dtap_lo<float>(a.dt, m), dtap_hi<float>(a.dt, m)};
+    } else {
+#pragma unroll
+      for (int m = 0; m < L; ++m) tap[m] = a.tap[m];
+    }
     // LDS initialisation (pads in zero mode, the zero rows of the rings), once per workgroup — every unit has the same geometry and
     // nothing ever writes these places: the level-1 waves clear the staging area, the level-2 waves the rings
     const int nst = a.nbuf * kPyrSub * a.pitch0 / 16, nrg = ((kPyrRing + 1) * (a.pitch1 + a.pitch2)) / 16;
@@ -1359,6 +1365,7 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
   std::copy(p.wg_start, p.wg_start + p.nwg + 1, a.wg_start);
   for (int k = p.nwg + 1; k <= kPyrMaxWG; ++k) a.wg_start[k] = a.wg_start[p.nwg];
   for (int m = 0; m < L; ++m) a.tap[m] = (f2){(float)lo[m], (float)hi[m]};
+  a.dt = dev_tap_arg(L);
   const int64_t nwg = (int64_t)p.nwg * p.ngroups;
   // (the per-wave cycle profile of tools/pyr_prof.py exists for the three-level 8-tap kernel only)
   constexpr bool kCanProf = kDiag && L == 8 && NLEV == 3;  // (-DMIFWT_DIAG builds)

@@ -66,6 +66,7 @@ struct IPyrArgs {
   int dbg;
   f2 tlo[L / 2];  // (rec_lo[2j], rec_lo[2j+1])
   f2 thi[L / 2];
+  DevTapArg dt;   // device-resident taps (mifwt_common.h); dt.lo == nullptr: tlo / thi count
 };
 
 // where the tap pairs live: SGPR pairs (default) or VGPR pairs (experiment build -DMIFWT_IPYR_TAPV: a lone wave issues a packed FMA with
@@ -387,10 +388,18 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
   // =====================================================================================================================
   // synthesis waves
   f2 tlo[HL], thi[HL];
+  if (a.dt.lo) {  // (a learnable filter bank that lives on the GPU: read once from device memory)
 #pragma unroll
-  for (int j = 0; j < HL; ++j) {
-    tlo[j] = a.tlo[j];
-    thi[j] = a.thi[j];
+    for (int j = 0; j < HL; ++j) {
+      tlo[j] = (f2){dtap_lo<float>(a.dt, 2 * j), dtap_lo<float>(a.dt, 2 * j + 1)};
+      thi[j] = (f2){dtap_hi<float>(a.dt, 2 * j), dtap_hi<float>(a.dt, 2 * j + 1)};
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < HL; ++j) {
+      tlo[j] = a.tlo[j];
+      thi[j] = a.thi[j];
+    }
   }
   IpAcc<L> acc;
 #pragma unroll
@@ -760,6 +769,7 @@ static int launch_ipyr(const mifwt_level_desc* const* d, const void* approx, con
     a.tlo[j] = (f2){(float)lo[2 * j], (float)lo[2 * j + 1]};
     a.thi[j] = (f2){(float)hi[2 * j], (float)hi[2 * j + 1]};
   }
+  a.dt = dev_tap_arg(L);
   const int64_t nwg = d[0]->batch * p.nseg;
   if (nwg > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
   static DynLdsOnce lds_once;

@@ -36,6 +36,7 @@ struct Dwt2TileArgs {
   int mode;
   int sync_stage;
   typename TileArith<T>::vec2 tap[L];  // (dec_lo[m], dec_hi[m]) in the arithmetic type
+  DevTapArg dt;                        // device-resident taps (mifwt_common.h); dt.lo == nullptr: `tap` counts
 };
 
 // element offset of input image `img` (one- or two-level batch)
@@ -91,6 +92,15 @@ __global__ void __launch_bounds__(256, tile_occupancy(L, TR, sizeof(typename Til
   const int img = (int)a.div_r.divmod(a.div_c.divmod((uint32_t)bid, utc), utr);
   const int tc = (int)utc, tr = (int)utr;
   const int k0 = tc * kTC, j0 = tr * TR;
+  // the taps: by value, or (a learnable filter bank that lives on the GPU) read once from device memory
+  A2 tapv[L];
+  if (a.dt.lo) {
+#pragma unroll
+    for (int m = 0; m < L; ++m) tapv[m] = (A2){dtap_lo<A>(a.dt, m), dtap_hi<A>(a.dt, m)};
+  } else {
+#pragma unroll
+    for (int m = 0; m < L; ++m) tapv[m] = a.tap[m];
+  }
 
   // ---- 1. input tile -> LDS ------------------------------------------------------------------------------------------
   const uint32_t img_bytes = ((uint32_t)(a.H - 1) * (uint32_t)a.xs_h + (uint32_t)a.W) * ES;
@@ -163,11 +173,11 @@ __global__ void __launch_bounds__(256, tile_occupancy(L, TR, sizeof(typename Til
       for (int p = 0; p < L / 2; ++p) {
         const A2 xx = row[p];  // tile columns 2k + 2p, 2k + 2p + 1  <->  taps L-1-2p, L-2-2p
         if (p == 0) {
-          acc = amul_lo(a.tap[L - 1], xx);
+          acc = amul_lo(tapv[L - 1], xx);
         } else {
-          afma_lo(acc, a.tap[L - 1 - 2 * p], xx);
+          afma_lo(acc, tapv[L - 1 - 2 * p], xx);
         }
-        afma_hi(acc, a.tap[L - 2 - 2 * p], xx);
+        afma_hi(acc, tapv[L - 2 - 2 * p], xx);
       }
       wave_lds_fence();  // every lane's reads of row r are issued (DS ops of a wave run in order) before its overwrite
       *reinterpret_cast<A2*>(&xt[r * XP + 2 * lane]) = acc;
@@ -193,11 +203,11 @@ __global__ void __launch_bounds__(256, tile_occupancy(L, TR, sizeof(typename Til
     for (int m = 0; m < L; ++m) {
       const A2 hv = win[2 * i + (L - 1) - m];  // row 2j + 1 - m of the extended plane
       if (m == 0) {
-        lo2 = amul_lo(a.tap[0], hv);
-        hi2 = amul_hi(a.tap[0], hv);
+        lo2 = amul_lo(tapv[0], hv);
+        hi2 = amul_hi(tapv[0], hv);
       } else {
-        afma_lo(lo2, a.tap[m], hv);
-        afma_hi(hi2, a.tap[m], hv);
+        afma_lo(lo2, tapv[m], hv);
+        afma_hi(hi2, tapv[m], hv);
       }
     }
     if (j < a.Ho && k < a.Wo) {
@@ -237,6 +247,7 @@ int launch_tile(const mifwt_level_desc* d, const void* x, void* approx, void* co
   a.sync_stage = g_options[MIFWT_OPT_SYNC_STAGE];
   for (int m = 0; m < L; ++m)
     a.tap[m] = (typename TileArith<T>::vec2){(typename TileArith<T>::type)lo[m], (typename TileArith<T>::type)hi[m]};
+  a.dt = dev_tap_arg(L);
   a.tiles_c = (a.Wo + kTC - 1) / kTC;
   a.tiles_r = (a.Ho + TR - 1) / TR;
   a.div_c = make_fastdiv((uint32_t)a.tiles_c);

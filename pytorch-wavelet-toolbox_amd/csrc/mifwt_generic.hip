@@ -37,6 +37,7 @@ struct AxisJobs {
 };
 
 thread_local DeviceTaps g_dtaps = {nullptr, nullptr, 0};
+thread_local int g_dtaps_taken = 0;
 
 // tap m of the pass: from the launch arguments, or (DT) from the device arrays of a filter bank that lives on the GPU
 template <bool DT, typename A>

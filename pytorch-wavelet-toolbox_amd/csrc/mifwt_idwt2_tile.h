@@ -28,6 +28,7 @@ struct Idwt2TileArgs {
   FastDiv div_c, div_r;  // by tiles_c, tiles_r
   typename TileArith<T>::vec2 tlo[L / 2];  // (rec_lo[2j], rec_lo[2j+1]) in the arithmetic type
   typename TileArith<T>::vec2 thi[L / 2];  // (rec_hi[2j], rec_hi[2j+1])
+  DevTapArg dt;                            // device-resident taps (mifwt_common.h); dt.lo == nullptr: tlo / thi count
 };
 
 constexpr int idwt_tile_occupancy(int L, int TRO, int esz = 4) {
@@ -73,6 +74,18 @@ __global__ void __launch_bounds__(256, idwt_tile_occupancy(L, TRO, sizeof(typena
   const int img = (int)a.div_r.divmod(a.div_c.divmod((uint32_t)bid, utc), utr);
   const int tc = (int)utc, tr = (int)utr;
   __builtin_assume(wave >= 0 && wave < 4);
+  // the taps: by value, or (a learnable filter bank that lives on the GPU) read once from device memory
+  A2 tlo[HL], thi[HL];
+  if (a.dt.lo) {
+#pragma unroll
+    for (int j = 0; j < HL; ++j) {
+      tlo[j] = (A2){dtap_lo<A>(a.dt, 2 * j), dtap_lo<A>(a.dt, 2 * j + 1)};
+      thi[j] = (A2){dtap_hi<A>(a.dt, 2 * j), dtap_hi<A>(a.dt, 2 * j + 1)};
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < HL; ++j) tlo[j] = a.tlo[j], thi[j] = a.thi[j];
+  }
   const int q0 = tc * NQ;        // first coefficient column
   const int y0 = tr * TRO;       // first output row (even)
   const int m0 = y0 >> 1;        // first coefficient row
@@ -108,7 +121,7 @@ __global__ void __launch_bounds__(256, idwt_tile_occupancy(L, TRO, sizeof(typena
     A2 xl, xh;                      // (row 2pp, row 2pp + 1) of X_lo / X_hi
 #pragma unroll
     for (int i = 0; i < HL; ++i) {
-      const A2 tl = a.tlo[HL - 1 - i], th = a.thi[HL - 1 - i];
+      const A2 tl = tlo[HL - 1 - i], th = thi[HL - 1 - i];
       const A2 caa = {ct[0][pp + i][lane], ct[1][pp + i][lane]};  // .x = aa, .y = ad
       const A2 cda = {ct[2][pp + i][lane], ct[3][pp + i][lane]};  // .x = da, .y = dd
       if (i == 0) {
@@ -137,11 +150,11 @@ __global__ void __launch_bounds__(256, idwt_tile_occupancy(L, TRO, sizeof(typena
     for (int i = 0; i < HL; ++i) {
       const A2 w = xt[r][(lane + i) & 63];  // lanes >= NQ wrap harmlessly (not stored)
       if (i == 0) {
-        o = amul_lo(a.tlo[HL - 1], w);
+        o = amul_lo(tlo[HL - 1], w);
       } else {
-        afma_lo(o, a.tlo[HL - 1 - i], w);
+        afma_lo(o, tlo[HL - 1 - i], w);
       }
-      afma_hi(o, a.thi[HL - 1 - i], w);
+      afma_hi(o, thi[HL - 1 - i], w);
     }
     const int yr = y0 + r;
     if (lane_on && yr < a.H) {
@@ -178,6 +191,7 @@ int launch_idwt_tile(const mifwt_level_desc* d, const void* approx, const void* 
     a.tlo[j] = (typename TileArith<T>::vec2){(A)lo[2 * j], (A)lo[2 * j + 1]};
     a.thi[j] = (typename TileArith<T>::vec2){(A)hi[2 * j], (A)hi[2 * j + 1]};
   }
+  a.dt = dev_tap_arg(L);
   a.tiles_c = (a.W + 2 * NQ - 1) / (2 * NQ);
   a.tiles_r = (a.H + TRO - 1) / TRO;
   a.div_c = make_fastdiv((uint32_t)a.tiles_c);

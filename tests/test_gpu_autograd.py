@@ -721,3 +721,64 @@ def test_learnable_taps_stay_on_the_gpu_no_sync_and_capturable():
         assert G.relerr(a.cpu().numpy(), b.cpu().double().numpy()) < 2e-6, n
     assert not torch.equal(y0[0], y1[0]), "the replay did not see the updated taps"
     assert torch.equal(y1[0], want1), "replay after the update differs from an eager call with the updated taps"
+
+
+def test_learnable_taps_run_on_the_fused_kernels_bit_identical_to_host_taps():
+    """Round 6: a learnable filter bank on the GPU no longer leaves the fused kernels.  The per-level ops of a
+    differentiable call with tap tensors reach the LDS-tile kernels (ids 7 / 8), one level of the streaming kernels (ids 16 / 22) and the
+    border kernels with the taps as DEVICE memory (C ABI mifwt_*_dtaps, DevTapArg): same kernel ids as the host-tap call
+    (``level_events``), results and data gradients BIT-identical to it (a kernel reads the doubles once and converts them as the host
+    does), tap gradients equal to rounding of the correlation kernel's atomic sums (it sees the same inputs), no host synchronisation."""
+    import json
+    import os
+
+    from ptwt_amd import _engine
+
+    with open(os.path.join(G.GOLDEN, "pywt_filter_banks.json")) as f:
+        banks = json.load(f)
+    g = torch.Generator().manual_seed(11)
+    cases = [  # (shape, wavelet, mode, level, dtype, kernel ids the forward / backward must show)
+        ((2, 1024, 1024), "db4", "reflect", 2, torch.float32, {16, 7}, {22, 8}),
+        ((3, 300, 260), "db3", "symmetric", 2, torch.float32, {7}, {8}),
+        ((2, 257, 300), "db2", "zero", 2, torch.float64, {7}, {8}),
+        ((2, 200, 180), "sym5", "constant", 1, torch.float32, {7}, {8}),
+    ]
+    for shape, wav, mode, level, dtype, kf, kb in cases:
+        x = torch.randn(*shape, generator=g, dtype=dtype).to(dev())
+        res = {}
+        for how in ("device", "host"):
+            ptwt_amd.set_device_taps("auto" if how == "device" else "never")
+            try:
+                taps = [torch.tensor(banks[wav][f], dtype=torch.float64, device=dev(), requires_grad=True) for f in ("dec_lo", "dec_hi", "rec_lo", "rec_hi")]
+                xx = x.clone().requires_grad_(True)
+                with torch.no_grad():
+                    c0 = ptwt_amd.wavedec2(xx, tuple(taps), mode=mode, level=level)
+                    w_c = [weight(t, i) for i, t in enumerate(flat(c0))]
+                    w_y = weight(ptwt_amd.waverec2(c0, tuple(taps)), 3)
+                torch.cuda.synchronize()
+                _engine.level_events = []
+                if how == "device":
+                    torch.cuda.set_sync_debug_mode("error")
+                try:
+                    coeffs = ptwt_amd.wavedec2(xx, tuple(taps), mode=mode, level=level)
+                    y = ptwt_amd.waverec2(coeffs, tuple(taps))
+                    loss = sum((w * t).sum() for w, t in zip(w_c, flat(coeffs))) + (w_y * y).sum()
+                    grads = torch.autograd.grad(loss, [xx] + taps)
+                finally:
+                    torch.cuda.set_sync_debug_mode("default")
+                ev = _engine.level_events
+                _engine.level_events = None
+                res[how] = ([t.detach().clone() for t in flat(coeffs)] + [y.detach().clone()], [t.clone() for t in grads],
+                            {e[1] for e in ev if e[0] == "fwd"}, {e[1] for e in ev if e[0] == "inv"}, {e[1] for e in ev if e[0].endswith("_adj")})
+            finally:
+                ptwt_amd.set_device_taps("auto")
+        (vd, gd, fd, idv, ad), (vh, gh, fh, ih, ah) = res["device"], res["host"]
+        # the same kernels as the host-tap call, the fused ones among them, NOTHING on the generic passes (id 0) — forward levels, the
+        # adjoints, and the 1-D per-axis maps of the tap gradients (streaming axis kernels, ids 3 / 4)
+        assert fd == fh and idv == ih and ad == ah, (shape, wav, fd, fh, idv, ih, ad, ah)
+        assert kf <= fd and kb <= idv and 0 not in (fd | idv | ad), (shape, wav, fd, idv, ad)
+        for a, b in zip(vd, vh):
+            assert torch.equal(a, b), (shape, wav, mode, "values")
+        assert torch.equal(gd[0], gh[0]), (shape, wav, mode, "data gradient")
+        for a, b in zip(gd[1:], gh[1:]):  # (the correlation kernel sums with atomics: the same inputs, not the same order of additions)
+            assert G.relerr(a.cpu().numpy(), b.cpu().numpy()) < 1e-12, (shape, wav, mode, "tap gradient")
