@@ -148,12 +148,19 @@ inline DevTapArg dev_tap_arg(int filt_len) {
 }
 #ifdef __HIPCC__
 // wave-uniform value in a scalar register (the fused kernels keep their taps in SGPR pairs)
-__device__ __forceinline__ float dtap_uniform(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
-__device__ __forceinline__ double dtap_uniform(double v) {
-  const uint64_t b = __builtin_bit_cast(uint64_t, v);
-  const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b), h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
-  return __builtin_bit_cast(double, ((uint64_t)h << 32) | l);
+// (v_readfirstlane through inline assembly: the compiler knows the converted tap is uniform, drops the builtin as redundant and keeps
+// the value — every tap of every kernel, both branches merged — in a VECTOR register: 79 -> 134 registers in the streaming axis kernels.
+// The wait states around it are the ones the compiler would insert for a readfirstlane of its own and cannot for an opaque asm
+// statement on gfx950: one between a VALU write of the source register and the read — without it the low word of a double tap came
+// out stale, 1e-7 off — and two between the SGPR write and a VALU that reads it.  Kernel entry only.)
+__device__ __forceinline__ int dtap_rfl(int v) {
+  int r;
+  asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 1" : "=s"(r) : "v"(v));
+  return r;
 }
+__device__ __forceinline__ float dtap_uniform(float v) { return __builtin_bit_cast(float, dtap_rfl(__builtin_bit_cast(int, v))); }
+// (a double tap is loaded by s_load and never converted: it is in scalar registers already)
+__device__ __forceinline__ double dtap_uniform(double v) { return v; }
 // tap m of the low-pass / high-pass filter of the pass, in the kernel's arithmetic type S (the conversion the host does for by-value taps)
 template <typename S>
 __device__ __forceinline__ S dtap_lo(const DevTapArg& dt, int m) { return dtap_uniform((S)dt.lo[dt.rev ? dt.len - 1 - m : m]); }

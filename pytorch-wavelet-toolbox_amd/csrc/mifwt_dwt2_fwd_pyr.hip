@@ -153,7 +153,9 @@ __device__ __forceinline__ void pyr_role(int wave, int nl1, int nchunks, int twa
   }
 }
 
-template <int L, int NLEV, bool PROF, int NW>
+// DT: the taps come from device memory (a.dt; a learnable filter bank that lives on the GPU) — an instance of its own, so that the default
+// instance's registers are exactly what they were (mifwt_dwt2_inv_pyr.hip)
+template <int L, int NLEV, bool PROF, int NW, bool DT = false>
 __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, NLEV> a) {
   constexpr int HL = L - 2, HP = L / 2;
   constexpr int NC1 = 2;          // columns per level-1 lane (three were measured: 112.6 against 108.5 us on config 2)
@@ -210,7 +212,7 @@ __global__ void __launch_bounds__(64 * NW) dwt2_fwd_pyr_kernel(const PyrArgs<L, 
 
   f2 tap[L];
   if (role != kRoleLoad) {
-    if (a.dt.lo) {  // (a learnable filter bank that lives on the GPU: read once from device memory)
+    if constexpr (DT) {  // (a learnable filter bank that lives on the GPU: read once from device memory)
 #pragma unroll
       for (int m = 0; m < L; ++m) tap[m] = (f2){dtap_lo<float>(a.dt, m), dtap_hi<float>(a.dt, m)};
     } else {
@@ -1375,6 +1377,22 @@ static int launch_pyr(const mifwt_level_desc* const* d, const void* x, void* con
   if (kCanProf && !lds_once_prof12.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, 12>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
   count_launch(MIFWT_VARIANT_FWD_PYR_ST8);
   const dim3 grid((unsigned)nwg), block(64 * p.nwaves);
+  if (a.dt.lo) {  // device-resident taps: the one-level form only (a learnable bank goes level by level), twelve or sixteen waves
+    if constexpr (NLEV == 1) {
+      static DynLdsOnce lds_dt12, lds_dt16;
+      if (p.nwaves == 12) {
+        if (!lds_dt12.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, 1, false, 12, true>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
+        hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, 1, false, 12, true>), grid, block, p.lds, stream, a);
+      } else if constexpr (kHas16) {
+        if (!lds_dt16.ensure(reinterpret_cast<const void*>(&dwt2_fwd_pyr_kernel<L, 1, false, 16, true>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
+        hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, 1, false, 16, true>), grid, block, p.lds, stream, a);
+      } else {
+        return MIFWT_ERR_UNSUPPORTED;
+      }
+      return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
+    }
+    return MIFWT_ERR_UNSUPPORTED;
+  }
   if (p.nwaves == 12) {
     if (kCanProf && MIFWT_PROFP(a)) hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, kCanProf, 12>), grid, block, p.lds, stream, a);
     else hipLaunchKernelGGL((dwt2_fwd_pyr_kernel<L, NLEV, false, 12>), grid, block, p.lds, stream, a);

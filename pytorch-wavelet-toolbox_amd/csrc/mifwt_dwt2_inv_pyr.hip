@@ -243,7 +243,10 @@ __device__ __forceinline__ void ipyr_wait_vm(int n) {
   }
 }
 
-template <int L, int NLEV>
+// DT: the taps come from device memory (a.dt; a learnable filter bank that lives on the GPU) — an instance of its own: the synthesis waves
+// of the default instance run at the 128-register limit, and the loads' temporaries cost it 56 bytes of scratch and a quarter of its speed
+// (waverec2 of config 2 0.0926 -> 0.1152 ms with one instance for both)
+template <int L, int NLEV, bool DT>
 __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs<L, NLEV> a) {
   constexpr int HL = L / 2;
   constexpr int NW = L / 4 + 1;  // f2 pieces of a window: coefficient columns 2 G .. 2 G + HL
@@ -271,6 +274,15 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
     }
   }
   if (role < 0) return;  // (a wave that has ended does not take part in the barriers of the others)
+
+  f2 tlo_in[L / 2], thi_in[L / 2];
+  if constexpr (DT) {
+#pragma unroll
+    for (int j = 0; j < L / 2; ++j) {
+      tlo_in[j] = (f2){dtap_lo<float>(a.dt, 2 * j), dtap_lo<float>(a.dt, 2 * j + 1)};
+      thi_in[j] = (f2){dtap_hi<float>(a.dt, 2 * j), dtap_hi<float>(a.dt, 2 * j + 1)};
+    }
+  }
 
   const int seg = blockIdx.x % a.nseg, img = blockIdx.x / a.nseg;
   const int y0 = seg * a.seg_rows, y1 = min(a.H, y0 + a.seg_rows);
@@ -388,18 +400,10 @@ __global__ void __launch_bounds__(64 * kIpWaves) idwt2_pyr_kernel(const IPyrArgs
   // =====================================================================================================================
   // synthesis waves
   f2 tlo[HL], thi[HL];
-  if (a.dt.lo) {  // (a learnable filter bank that lives on the GPU: read once from device memory)
 #pragma unroll
-    for (int j = 0; j < HL; ++j) {
-      tlo[j] = (f2){dtap_lo<float>(a.dt, 2 * j), dtap_lo<float>(a.dt, 2 * j + 1)};
-      thi[j] = (f2){dtap_hi<float>(a.dt, 2 * j), dtap_hi<float>(a.dt, 2 * j + 1)};
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < HL; ++j) {
-      tlo[j] = a.tlo[j];
-      thi[j] = a.thi[j];
-    }
+  for (int j = 0; j < HL; ++j) {
+    tlo[j] = DT ? tlo_in[j] : a.tlo[j];
+    thi[j] = DT ? thi_in[j] : a.thi[j];
   }
   IpAcc<L> acc;
 #pragma unroll
@@ -773,8 +777,17 @@ static int launch_ipyr(const mifwt_level_desc* const* d, const void* approx, con
   const int64_t nwg = d[0]->batch * p.nseg;
   if (nwg > INT32_MAX / 8) return MIFWT_ERR_UNSUPPORTED;
   static DynLdsOnce lds_once;
-  if (!lds_once.ensure(reinterpret_cast<const void*>(&idwt2_pyr_kernel<L, NLEV>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
-  hipLaunchKernelGGL((idwt2_pyr_kernel<L, NLEV>), dim3((unsigned)nwg), dim3(64 * kIpWaves), p.lds, stream, a);
+  if (a.dt.lo) {  // device-resident taps: the one-level form only (a learnable bank goes level by level)
+    if constexpr (NLEV == 1) {
+      static DynLdsOnce lds_once_dt;
+      if (!lds_once_dt.ensure(reinterpret_cast<const void*>(&idwt2_pyr_kernel<L, 1, true>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
+      hipLaunchKernelGGL((idwt2_pyr_kernel<L, 1, true>), dim3((unsigned)nwg), dim3(64 * kIpWaves), p.lds, stream, a);
+      return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
+    }
+    return MIFWT_ERR_UNSUPPORTED;
+  }
+  if (!lds_once.ensure(reinterpret_cast<const void*>(&idwt2_pyr_kernel<L, NLEV, false>), 160 * 1024)) return MIFWT_ERR_LAUNCH;
+  hipLaunchKernelGGL((idwt2_pyr_kernel<L, NLEV, false>), dim3((unsigned)nwg), dim3(64 * kIpWaves), p.lds, stream, a);
   return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
 }
 

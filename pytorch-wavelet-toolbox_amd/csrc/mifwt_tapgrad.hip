@@ -15,7 +15,7 @@
 // One thread block strides over (row, k),
 // keeps L partial sums per thread in registers (chunks of 32 taps), reduces them across the wave with DPP shuffles and
 // issues one double-precision atomic per tap and wave.
-#include "mifwt_common.h"
+#include "mifwt_stream.h"
 
 namespace mifwt {
 
@@ -54,6 +54,79 @@ __global__ void __launch_bounds__(256) tap_correlate_kernel(const T* __restrict_
   }
 }
 
+// The decimated levels (kstride 2, one sample per tap step, L <= 32) — what a learnable-wavelet training step runs 24 times per call on
+// image-sized planes.  Round 6: the kernel above maps every one of its 32 x (elements) samples through the boundary rule and divides a
+// 64-bit index per element: 0.84 ms per call on config 2's levels, 82 % of a training step (torch profiler, tools/learnable_prof.py).
+// Here a WAVE takes 64 consecutive k of one row: it stages the 126 + L samples of b the 64 windows span into LDS once (the boundary rule
+// applied per staged sample: three per lane), then every lane reads its L consecutive samples from 2 lane on (8-byte reads, conflict-free)
+// and keeps L partial sums; one wave reduction and one double-precision atomic per tap when the wave is through with its tasks.
+template <typename T, int LT>
+__global__ void __launch_bounds__(256) tap_correlate_rows_kernel(const T* __restrict__ a, const T* __restrict__ b, double* __restrict__ out,
+                                                                uint32_t ntasks, FastDiv chunks, int m_len, int n_len, int64_t a_rs, int64_t b_rs,
+                                                                int L, int c0, int sgn, int mode) {
+  using A = typename std::conditional<std::is_same<T, double>::value, double, float>::type;
+  constexpr int KW = 64, SPAN = 2 * KW + 32;  // (126 + L <= 158 staged samples)
+  __shared__ __attribute__((aligned(16))) A win[4][SPAN];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  A* const w = win[wave];
+  A acc[LT];
+#pragma unroll
+  for (int t = 0; t < LT; ++t) acc[t] = A(0);
+  const int span = 2 * KW - 2 + L;
+  for (uint32_t task = blockIdx.x * 4u + (uint32_t)wave; task < ntasks; task += gridDim.x * 4u) {
+    uint32_t chunk;
+    const uint32_t row = chunks.divmod(task, chunk);
+    const int k0 = (int)chunk * KW;
+    const int base = 2 * k0 + c0 - (sgn < 0 ? L - 1 : 0);  // the first sample of b any of the wave's windows touches
+    const T* br = b + (int64_t)row * b_rs;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int i = lane + 64 * j;
+      if (i < span) {
+        const int src = ext_index_near(base + i, n_len, mode);
+        w[i] = src >= 0 ? (A)br[src] : A(0);
+      }
+    }
+    const int k = k0 + lane;
+    const A av = k < m_len ? (A)a[(int64_t)row * a_rs + k] : A(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // tap t reads sample 2 lane + t (sgn > 0) / 2 lane + L - 1 - t (sgn < 0) of the staged span
+    if (sgn > 0) {
+#pragma unroll
+      for (int t = 0; t < LT; t += 2) {
+        if (t < L) {
+          const A x0 = w[2 * lane + t], x1 = w[2 * lane + t + 1];
+          acc[t] = fma(av, x0, acc[t]);
+          if (t + 1 < L) acc[t + 1] = fma(av, x1, acc[t + 1]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < LT; ++t)
+        if (t < L) acc[t] = fma(av, w[2 * lane + L - 1 - t], acc[t]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  // wave sums, then ONE atomic per tap and WORKGROUP (the four waves' sums meet in LDS): every atomic of a launch lands on the same L
+  // doubles, and 2048 x 4 waves x L of them were what the first version of this kernel spent its time on
+  __shared__ double part[4][LT];
+#pragma unroll
+  for (int t = 0; t < LT; ++t) {
+    if (t < L) {
+      double v = (double)acc[t];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) part[wave][t] = v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < (unsigned)L) atomicAdd(&out[threadIdx.x], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
 }  // namespace
 
 }  // namespace mifwt
@@ -61,12 +134,37 @@ __global__ void __launch_bounds__(256) tap_correlate_kernel(const T* __restrict_
 namespace mifwt {
 namespace {
 
+template <typename T>
+int tap_correlate_rows(int64_t rows, int64_t m_len, int64_t n_len, const T* a, int64_t a_rs, const T* b, int64_t b_rs, int L, int c0,
+                       int sgn, int mode, double* out, hipStream_t st) {
+  const int64_t chunks = (m_len + 63) / 64, ntasks = rows * chunks;
+  const int64_t want = (ntasks + 3) / 4;
+  const unsigned grid = (unsigned)(want < 1024 ? want : 1024);  // (four workgroups per CU: the loads of one hide behind the sums of another)
+  const FastDiv dv = make_fastdiv((uint32_t)chunks);
+#define MIFWT_TC_LAUNCH(LT) \
+  hipLaunchKernelGGL((tap_correlate_rows_kernel<T, LT>), dim3(grid), dim3(256), 0, st, a, b, out, (uint32_t)ntasks, dv, (int)m_len, (int)n_len, a_rs, \
+                     b_rs, L, c0, sgn, mode)
+  if (L <= 8) MIFWT_TC_LAUNCH(8);
+  else if (L <= 16) MIFWT_TC_LAUNCH(16);
+  else MIFWT_TC_LAUNCH(32);
+#undef MIFWT_TC_LAUNCH
+  return hipGetLastError() == hipSuccess ? MIFWT_OK : MIFWT_ERR_LAUNCH;
+}
+
 int tap_correlate(int dtype, int64_t rows, int64_t m_len, int64_t n_len, const void* a, int64_t a_row_stride, const void* b,
                   int64_t b_row_stride, int filt_len, int c0, int sgn, int kstride, int mode, double* out, void* stream) {
   if (!a || !b || !out || rows < 0 || m_len < 1 || n_len < 1 || filt_len < 1 || filt_len > MIFWT_MAX_FILT) return MIFWT_ERR_BADARG;
   if (mode < MIFWT_MODE_ZERO || mode > MIFWT_MODE_SYMMETRIC) return MIFWT_ERR_BADARG;
   if (m_len > INT32_MAX / 4 || n_len > INT32_MAX / 4) return MIFWT_ERR_UNSUPPORTED;
   if (rows == 0) return MIFWT_OK;
+  hipStream_t st0 = static_cast<hipStream_t>(stream);
+  // the decimated levels on the row kernel (every launch of a learnable-wavelet training step); dilated / long filters below
+  if (kstride == 2 && (sgn == 1 || sgn == -1) && filt_len <= 32 && rows * ((m_len + 63) / 64) < (int64_t(1) << 31) && !g_options[MIFWT_OPT_FORCE_GENERIC]) {
+    if (dtype == MIFWT_F32)
+      return tap_correlate_rows(rows, m_len, n_len, static_cast<const float*>(a), a_row_stride, static_cast<const float*>(b), b_row_stride, filt_len, c0, sgn, mode, out, st0);
+    if (dtype == MIFWT_F64)
+      return tap_correlate_rows(rows, m_len, n_len, static_cast<const double*>(a), a_row_stride, static_cast<const double*>(b), b_row_stride, filt_len, c0, sgn, mode, out, st0);
+  }
   const int64_t total = rows * m_len;
   const int64_t want = (total + 255) / 256;
   const unsigned grid = (unsigned)(want < 2048 ? want : 2048);

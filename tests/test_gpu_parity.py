@@ -39,7 +39,7 @@ def check_tree(got, want, tol, what=""):
 
 def test_extension_loaded_and_fast_path_selected():
     lib = _engine.load_library()
-    assert lib.mifwt_abi_version() == _engine.ABI_VERSION == 2
+    assert lib.mifwt_abi_version() == _engine.ABI_VERSION == 3
     assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (1024, 1024)) == 16    # one level through the streaming multi-level kernel (round 4)
     assert _engine.kernel_id(2, torch.float32, "reflect", 8, 64, (640, 640)) == 7       # fused LDS-tile kernel
     assert _engine.kernel_id(2, torch.float32, "reflect", 16, 64, (4096, 4096)) == 1   # fused streaming kernel

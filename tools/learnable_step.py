@@ -17,7 +17,7 @@ def step(taps, rec):
         loss = ptwt_amd.waverec2(c, tuple(taps)).square().mean()
     else:
         loss = c[0].square().mean() + sum(t.square().mean() for lv in c[1:] for t in lv)
-    return torch.autograd.grad(loss, [xx] + taps)
+    return torch.autograd.grad(loss, [xx] + (taps if rec else taps[:2]))
 for rec in (False, True):
     for mode in ('auto', 'never', 'auto', 'never'):
         ptwt_amd.set_device_taps(mode)
