@@ -331,6 +331,45 @@ def secondary_lines(dev, steps=20, warmup=5, buffers=3):
             half_scope.__exit__(None, None, None)
         if DEVICE_KIND == "cuda":
             torch.cuda.empty_cache()
+    # a learnable-wavelet training step (the reason the reference keeps its taps in the autograd graph, src/ptwt/_util.py:115-132;
+    # examples/network_compression/wavelet_linear.py:118,150): wavedec2 of config 2's batch with the four filters as leaf tensors on the
+    # GPU, forward + backward w.r.t. the data AND the decomposition filters; taps read by the kernels from device memory (no host
+    # synchronisation), and the same step with the taps read back to the host per call
+    if DEVICE_KIND == "cuda":
+        name = "wavedec2_learnable_step_db4_L3_64x1024x1024_f32"
+        try:
+            from ptwt_amd import _wavelets
+
+            wv = _wavelets.as_wavelet("db4")
+            x = torch.randn(64, 1024, 1024, device=dev)
+            res = {}
+            for how in ("auto", "never"):
+                ptwt_amd.set_device_taps(how)
+                taps = [torch.tensor(list(f), dtype=torch.float64, device=dev, requires_grad=True) for f in wv.filter_bank]
+
+                def tstep():
+                    xx = x.detach().requires_grad_(True)
+                    c = ptwt_amd.wavedec2(xx, tuple(taps), mode="reflect", level=3)
+                    loss = c[0].square().mean() + sum(t.square().mean() for lv in c[1:] for t in lv)
+                    return torch.autograd.grad(loss, [xx] + taps[:2])
+
+                for _ in range(3):
+                    tstep()
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    tstep()
+                sync()
+                res[how] = (time.perf_counter() - t0) / 10 * 1e3
+            out.append({"workload": name, "ms_per_step": round(res["auto"], 3), "host_taps_ms_per_step": round(res["never"], 3),
+                        "note": "forward + backward w.r.t. data and dec filters (leaf tensors on the GPU); ms_per_step: taps read by the fused kernels "
+                                "from device memory, no synchronisation; host_taps: the bank copied to the host per call (round 5, both on the "
+                                "first tap-gradient kernel: 24.2 ms)"})
+        except Exception as exc:
+            out.append({"workload": name, "error": repr(exc)[:200]})
+        finally:
+            ptwt_amd.set_device_taps("auto")
+            torch.cuda.empty_cache()
     # launch-bound calls: the same call sequence eager and replayed from a HIP graph (ptwt_amd.capture) — host time is what the
     # eager call costs on a small batch, the replay runs at the kernels' own time
     if DEVICE_KIND == "cuda":
