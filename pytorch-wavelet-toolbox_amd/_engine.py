@@ -145,6 +145,7 @@ def load_library() -> ctypes.CDLL:
     if not experiment or hasattr(lib, "mifwt_workspace_bytes_dtaps"):
         lib.mifwt_workspace_bytes_dtaps.restype = ctypes.c_size_t
         lib.mifwt_workspace_bytes_dtaps.argtypes = [desc_p, ctypes.c_int]
+    if not experiment or hasattr(lib, "mifwt_kernel_id_dtaps"):  # (round 6; an older experiment build: level_events report id 0 for device taps)
         lib.mifwt_kernel_id_dtaps.restype = ctypes.c_int
         lib.mifwt_kernel_id_dtaps.argtypes = [desc_p, ctypes.c_int]
         for name in ("mifwt_dwt_fwd_dtaps", "mifwt_dwt_inv_dtaps", "mifwt_dwt_fwd_adjoint_dtaps", "mifwt_dwt_inv_adjoint_dtaps"):
@@ -1045,7 +1046,7 @@ class HipLevelEngine:
             rc = call(ws.data_ptr() if ws is not None else None, wsb, stream.cuda_stream)
             ev[1].record(stream)
             d = p.desc
-            kid_run = int(_lib.mifwt_kernel_id_dtaps(p.ref, direction)) if dtaps else (p.kid if kid is None else kid)
+            kid_run = (int(_lib.mifwt_kernel_id_dtaps(p.ref, direction)) if hasattr(_lib, "mifwt_kernel_id_dtaps") else 0) if dtaps else (p.kid if kid is None else kid)
             level_events.append((("fwd", "inv", "fwd_adj", "inv_adj")[direction], kid_run, tuple(d.sig_extent[: d.ndim]), ev[0], ev[1]))
         if rc != 0:
             _check(rc)

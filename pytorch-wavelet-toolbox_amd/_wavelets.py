@@ -113,11 +113,14 @@ def host_taps(wavelet) -> Tuple[Tuple[float, ...], Tuple[float, ...], Tuple[floa
 
 # ---- device-resident taps -------------------------------------------------------------------------------------------------------
 # A filter bank given as four tensors on the GPU (a learnable wavelet, src/ptwt/_util.py:115-132) can stay there: the level kernels
-# of the generic route read their taps from device memory (C ABI mifwt_*_dtaps), so a call copies nothing to the host, synchronises
-# nothing and can be captured into a HIP graph.  The price: those levels run the generic per-axis passes, not the fused kernels.
+# read their taps from device memory (C ABI mifwt_*_dtaps), so a call copies nothing to the host, synchronises nothing and can be
+# captured into a HIP graph.  Since round 6 that costs nothing on the planes a training step runs on: the fused per-level kernels (LDS
+# tiles, one level of the streaming kernels, the border kernels, the streaming axis passes) read device taps, bit-identical to host
+# taps; only what they do not serve (3-D levels, matrix-core and 16-tap streaming kernels) falls to the generic per-axis passes.  The
+# multi-level launches are not used with device taps (a call that is not learnable reads its bank to the host once and keeps them).
 #   "auto"   (default) device taps for banks that are learnable (a tensor requires grad, grad mode on) or while a HIP graph is being
-#            captured; anything else is read to the host once per call (fused kernels);
-#   "always" every tensor-valued bank on the GPU stays there;   "never" round 4's behaviour.
+#            captured; anything else is read to the host once per call (fused kernels incl. the multi-level launches);
+#   "always" every tensor-valued bank on the GPU stays there;   "never" round 4's behaviour (one device-to-host copy per call).
 _device_taps_mode = "auto"
 
 
