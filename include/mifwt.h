@@ -125,6 +125,26 @@ int mifwt_dwt_fwd_adjoint_dtaps(const mifwt_level_desc* desc, const void* g_appr
 int mifwt_dwt_inv_adjoint_dtaps(const mifwt_level_desc* desc, const void* g_y, void* g_approx, void* const* g_details,
                                 const double* d_rec_lo, const double* d_rec_hi, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Round 6, for the tap gradients of 2-D levels with every operand in its natural layout (no transposed copies):
+ * mifwt_dwt1_fwd_outer — one 1-D analysis level along the MIDDLE axis of [batch, n, inner] arrays (inner contiguous; element strides):
+ *   lo_out / hi_out [batch, floor((n + L - 1) / 2), inner]; taps as HOST doubles (dec_lo / dec_hi) or, when d_dec_lo / d_dec_hi are non-null,
+ *   DEVICE doubles (the host pointers are then ignored).  f32 / f64, the filter lengths of the streaming axis kernels (even L <= 20, 24, 32).
+ * mifwt_dwt1_inv_outer — its inverse: (lo, hi) [batch, m, inner] -> y [batch, n_out, inner], n_out = 2 m - L + 2 or one less (the reference's
+ *   crop, src/ptwt/_util.py:231-244).
+ * mifwt_tap_correlate_planes — mifwt_tap_correlate's reduction on operands [batch, rows, columns] (columns contiguous; batch / row strides in
+ *   elements): along = 1: out[t] += sum a[b, r, k] b_ext[b, r, 2k + c0 + sgn t] (a: [batch, R, M], b: [batch, R, N]);
+ *   along = 0: out[t] += sum a[b, k, c] b_ext[b, 2k + c0 + sgn t, c] (a: [batch, M, C], b: [batch, N, C]).  L <= 32, f32 / f64. */
+int mifwt_dwt1_fwd_outer(int dtype, int64_t batch, int64_t n, int64_t inner, const void* x, int64_t x_batch_stride, int64_t x_axis_stride, void* lo_out,
+                         void* hi_out, int64_t out_batch_stride, int64_t out_axis_stride, int mode, int filt_len, const double* dec_lo,
+                         const double* dec_hi, const double* d_dec_lo, const double* d_dec_hi, void* stream);
+int mifwt_dwt1_inv_outer(int dtype, int64_t batch, int64_t m, int64_t n_out, int64_t inner, const void* lo_in, int64_t lo_batch_stride,
+                         int64_t lo_axis_stride, const void* hi_in, int64_t hi_batch_stride, int64_t hi_axis_stride, void* y, int64_t y_batch_stride,
+                         int64_t y_axis_stride, int filt_len, const double* rec_lo, const double* rec_hi, const double* d_rec_lo,
+                         const double* d_rec_hi, void* stream);
+int mifwt_tap_correlate_planes(int dtype, int along, int64_t batch, int64_t a_rows, int64_t a_cols, int64_t b_rows, int64_t b_cols, const void* a,
+                               int64_t a_batch_stride, int64_t a_row_stride, const void* b, int64_t b_batch_stride, int64_t b_row_stride,
+                               int filt_len, int c0, int sgn, int mode, double* out, void* stream);
+
 /* TWO consecutive 2-D analysis levels in one launch — two trips of the reference's level loop
  * (src/ptwt/conv_transform_2.py:142-149) whose intermediate approximation never reaches HBM: a pyramid returns only the
  * detail bands of a level that is not the last (conv_transform_2.py:150-156), so the write + re-read of that

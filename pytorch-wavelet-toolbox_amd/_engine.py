@@ -157,6 +157,16 @@ def load_library() -> ctypes.CDLL:
     if not experiment or hasattr(lib, "mifwt_launch_count"):
         lib.mifwt_launch_count.restype = ctypes.c_uint64
         lib.mifwt_launch_count.argtypes = [ctypes.c_int]
+    if not experiment or hasattr(lib, "mifwt_tap_correlate_planes"):  # (round 6)
+        lib.mifwt_tap_correlate_planes.restype = ctypes.c_int
+        lib.mifwt_tap_correlate_planes.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 5 + [vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64,
+                                                   ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
+        lib.mifwt_dwt1_inv_outer.restype = ctypes.c_int
+        lib.mifwt_dwt1_inv_outer.argtypes = [ctypes.c_int] + [ctypes.c_int64] * 4 + [vp, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64, vp,
+                                             ctypes.c_int64, ctypes.c_int64, ctypes.c_int, dbl_p, dbl_p, vp, vp, vp]
+        lib.mifwt_dwt1_fwd_outer.restype = ctypes.c_int
+        lib.mifwt_dwt1_fwd_outer.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int64, vp, vp, ctypes.c_int64,
+                                             ctypes.c_int64, ctypes.c_int, ctypes.c_int, dbl_p, dbl_p, vp, vp, vp]
     lib.mifwt_set_option.restype = ctypes.c_int
     lib.mifwt_set_option.argtypes = [ctypes.c_int, ctypes.c_int]
     _lib = lib
@@ -1010,6 +1020,73 @@ class HipLevelEngine:
                                          b.data_ptr(), b.stride(0), filt_len, c0, sgn, mode_id, out.data_ptr(),
                                          _raw_stream(a.device.index if a.device.index is not None else torch.cuda.current_device()))
         _check(rc)
+
+    def tap_correlate_planes(self, along: int, a: torch.Tensor, b: torch.Tensor, filt_len: int, c0: int, sgn: int, mode_id: int,
+                             out: torch.Tensor) -> None:
+        """The reduction of :meth:`tap_correlate` on operands in their natural layout ``[batch, rows, columns]`` (unit stride along the
+        columns, any batch / row strides: strided views of level buffers need no copy).  ``along`` 1: along the columns
+        (``out[t] += sum a[b, r, k] * b_ext[b, r, 2k + c0 + sgn t]``), 0: along the rows (``a[b, k, c] * b_ext[b, 2k + c0 + sgn t, c]``).
+        C ABI ``mifwt_tap_correlate_planes``."""
+        _require_gpu(a)
+        lib = load_library()
+        if a.stride(-1) != 1:
+            a = a.contiguous()
+        if b.stride(-1) != 1:
+            b = b.contiguous()
+        assert a.dim() == 3 and b.dim() == 3 and a.shape[0] == b.shape[0] and a.dtype == b.dtype and out.dtype == torch.float64
+        with torch.cuda.device(a.device):
+            rc = lib.mifwt_tap_correlate_planes(_DTYPE_IDS[a.dtype], along, a.shape[0], a.shape[1], a.shape[2], b.shape[1], b.shape[2], a.data_ptr(),
+                                                a.stride(0), a.stride(1), b.data_ptr(), b.stride(0), b.stride(1), filt_len, c0, sgn, mode_id,
+                                                out.data_ptr(), _raw_stream(a.device.index if a.device.index is not None else torch.cuda.current_device()))
+        _check(rc)
+
+    def analysis_outer(self, x: torch.Tensor, dec_lo, dec_hi, mode_id: int):
+        """One 1-D analysis level along the MIDDLE axis of ``x`` [B, N, C] (unit stride along C, any batch / row strides) ->
+        ``(lo, hi)`` [B, M, C] each (planes of one [B, 2, M, C] buffer): the streaming outer-axis kernel on its own (C ABI
+        ``mifwt_dwt1_fwd_outer``); taps as host numbers or :class:`DevTaps`."""
+        _require_gpu(x)
+        lib = load_library()
+        if x.stride(-1) != 1:
+            x = x.contiguous()
+        B, N, C = x.shape
+        flen = len(dec_lo)
+        M = (N + flen - 1) // 2
+        buf = torch.empty((B, 2, M, C), dtype=x.dtype, device=x.device)
+        if B and N and C:
+            dev_taps = _is_dev(dec_lo)
+            lo = None if dev_taps else _taps_array(dec_lo)
+            hi = None if dev_taps else _taps_array(dec_hi)
+            with torch.cuda.device(x.device):
+                rc = lib.mifwt_dwt1_fwd_outer(_DTYPE_IDS[x.dtype], B, N, C, x.data_ptr(), x.stride(0), x.stride(1), buf.data_ptr(),
+                                              buf.data_ptr() + M * C * x.element_size(), 2 * M * C, C, mode_id, flen, lo, hi,
+                                              dec_lo.ptr if dev_taps else None, dec_hi.ptr if dev_taps else None,
+                                              _raw_stream(x.device.index if x.device.index is not None else torch.cuda.current_device()))
+            _check(rc)
+        return buf[:, 0], buf[:, 1]
+
+    def synthesis_outer(self, lo: torch.Tensor, hi: torch.Tensor, rec_lo, rec_hi, n_out: int) -> torch.Tensor:
+        """One 1-D synthesis level along the MIDDLE axis: ``lo``, ``hi`` [B, M, C] (unit stride along C) -> [B, n_out, C]
+        (C ABI ``mifwt_dwt1_inv_outer``); taps as host numbers or :class:`DevTaps`."""
+        _require_gpu(lo)
+        lib = load_library()
+        if lo.stride(-1) != 1:
+            lo = lo.contiguous()
+        if hi.stride(-1) != 1:
+            hi = hi.contiguous()
+        B, M, C = lo.shape
+        flen = len(rec_lo)
+        y = torch.empty((B, n_out, C), dtype=lo.dtype, device=lo.device)
+        if B and M and C:
+            dev_taps = _is_dev(rec_lo)
+            tl = None if dev_taps else _taps_array(rec_lo)
+            th = None if dev_taps else _taps_array(rec_hi)
+            with torch.cuda.device(lo.device):
+                rc = lib.mifwt_dwt1_inv_outer(_DTYPE_IDS[lo.dtype], B, M, n_out, C, lo.data_ptr(), lo.stride(0), lo.stride(1), hi.data_ptr(), hi.stride(0),
+                                              hi.stride(1), y.data_ptr(), n_out * C, C, flen, tl, th, rec_lo.ptr if dev_taps else None,
+                                              rec_hi.ptr if dev_taps else None,
+                                              _raw_stream(lo.device.index if lo.device.index is not None else torch.cuda.current_device()))
+            _check(rc)
+        return y
 
     def tap_correlate_dilated(self, a: torch.Tensor, b: torch.Tensor, filt_len: int, c0: int, tstep: int, out: torch.Tensor) -> None:
         """``out[t] += sum_{row, k} a[row, k] * b[row, (k + c0 + tstep t) mod N]`` (C ABI ``mifwt_tap_correlate_dilated``): the tap

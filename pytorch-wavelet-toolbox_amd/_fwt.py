@@ -51,6 +51,23 @@ def _analysis_tap_grads(x, g_buf, dec_lo, dec_hi, mode_id):
     g_lo = torch.zeros(flen, dtype=torch.float64, device=x.device)
     g_hi = torch.zeros_like(g_lo)
     eng = _engine.ENGINE
+    if nd == 2 and flen <= 32 and hasattr(eng, "tap_correlate_planes"):
+        # Two axes, every operand in its NATURAL layout (round 6: the transposed copies in front of the row reductions were a third of
+        # a training step).  Along the rows axis H: z = the level along W of every row (inner-axis kernel), reduced along H by the
+        # column kernel; along W: z = the level along H (outer-axis kernel on its own), reduced along W by the row kernel.  The band
+        # planes of g_buf are strided views, taken as they are.
+        B, H, W = x.shape
+        xc = x if x.stride(-1) == 1 else x.contiguous()
+        rows = xc.reshape(B * H, W)  # (a view of a dense input; a copy of a plane of a level buffer: the deeper levels, a quarter each)
+        pb = eng.analysis(rows, dec_lo, dec_hi, mode_id).reshape(B, H, 2, -1)  # [B, H, (lo, hi along W), Mw]
+        for r in range(2):
+            z = pb[:, :, r]  # [B, H, Mw]
+            for sigma, out in ((0, g_lo), (1, g_hi)):
+                eng.tap_correlate_planes(0, g_buf[:, _band_index(2, 0, sigma, r)], z, flen, 1, -1, mode_id, out)
+        for r, z in enumerate(eng.analysis_outer(xc, dec_lo, dec_hi, mode_id)):  # (lo, hi along H) [B, Mh, W]
+            for sigma, out in ((0, g_lo), (1, g_hi)):
+                eng.tap_correlate_planes(1, g_buf[:, _band_index(2, 1, sigma, r)], z, flen, 1, -1, mode_id, out)
+        return g_lo, g_hi
     for a in range(nd):
         if nd == 1:
             parts = [x]  # [B, N]
@@ -80,6 +97,21 @@ def _synthesis_tap_grads(g_y, approx, details, rec_lo, rec_hi):
     g_hi = torch.zeros_like(g_lo)
     eng = _engine.ENGINE
     bands = [approx] + list(details)
+    if nd == 2 and flen <= 32 and hasattr(eng, "synthesis_outer"):
+        # two axes, every operand in its natural layout (see _analysis_tap_grads).  Along H: u = the two bands with letter sigma along H
+        # synthesised along W (inner-axis kernel, rows (b, k_h)), reduced along H by the column kernel; along W: u = the two bands with
+        # letter sigma along W synthesised along H (outer-axis kernel), reduced along W by the row kernel.
+        B, Ny, Nx = g_y.shape
+        gyc = g_y if g_y.stride(-1) == 1 else g_y.contiguous()
+        for sigma, out in ((0, g_lo), (1, g_hi)):
+            lo_w, hi_w = bands[_band_index(2, 0, sigma, 0)], bands[_band_index(2, 0, sigma, 1)]  # [B, Mh, Mw]: low / high along W
+            Mh, Mw = lo_w.shape[1:]
+            u = eng.synthesis(lo_w.reshape(B * Mh, Mw), [hi_w.reshape(B * Mh, Mw)], rec_lo, rec_hi, [Nx]).reshape(B, Mh, Nx)
+            eng.tap_correlate_planes(0, u, gyc, flen, -(flen - 2), 1, 0, out)
+            lo_h, hi_h = bands[_band_index(2, 1, sigma, 0)], bands[_band_index(2, 1, sigma, 1)]  # low / high along H
+            u = eng.synthesis_outer(lo_h, hi_h, rec_lo, rec_hi, Ny)  # [B, Ny, Mw]
+            eng.tap_correlate_planes(1, u, gyc, flen, -(flen - 2), 1, 0, out)
+        return g_lo, g_hi
     for a in range(nd):
         gy2 = _rows_last(g_y, a)
         for sigma, out in ((0, g_lo), (1, g_hi)):

@@ -622,6 +622,83 @@ int mifwt_dwt_inv_adjoint_dtaps(const mifwt_level_desc* desc, const void* g_y, v
   return generic_fwd(&z, g_y, g_approx, g_details, kNoHostTaps, kNoHostTaps, workspace, static_cast<hipStream_t>(stream));
 }
 
+// One 1-D analysis level along the MIDDLE axis of [batch, n, inner] arrays (inner contiguous) — the streaming outer-axis kernel
+// (mifwt_axis_stream.h) on its own: what the tap gradients of a 2-D level along its column axis need of the input (the level along
+// the rows only), in the natural layout.  d_dec_lo / d_dec_hi: device taps (non-null: the host taps are ignored).
+int mifwt_dwt1_fwd_outer(int dtype, int64_t batch, int64_t n, int64_t inner, const void* x, int64_t x_batch_stride, int64_t x_axis_stride, void* lo_out,
+                         void* hi_out, int64_t out_batch_stride, int64_t out_axis_stride, int mode, int filt_len, const double* dec_lo,
+                         const double* dec_hi, const double* d_dec_lo, const double* d_dec_hi, void* stream) {
+  if (!x || !lo_out || !hi_out || batch < 0 || n < 1 || inner < 1) return MIFWT_ERR_BADARG;
+  if (!((dec_lo && dec_hi) || (d_dec_lo && d_dec_hi))) return MIFWT_ERR_BADARG;
+  if (mode < MIFWT_MODE_ZERO || mode > MIFWT_MODE_SYMMETRIC) return MIFWT_ERR_BADARG;
+  if ((dtype != MIFWT_F32 && dtype != MIFWT_F64) || !stream_filter_supported(filt_len)) return MIFWT_ERR_UNSUPPORTED;
+  if (batch == 0) return MIFWT_OK;
+  StreamJob jb;
+  memset(&jb, 0, sizeof(jb));
+  jb.in0 = x;
+  jb.out0 = lo_out;
+  jb.out1 = hi_out;
+  jb.in0_s[0] = x_batch_stride, jb.in0_s[1] = x_axis_stride;
+  jb.out0_s[0] = jb.out1_s[0] = out_batch_stride, jb.out0_s[1] = jb.out1_s[1] = out_axis_stride;
+  StreamCall c;
+  memset(&c, 0, sizeof(c));
+  c.filt_len = filt_len;
+  c.mode = mode;
+  c.jobs = &jb;
+  c.njobs = 1;
+  c.batch = batch;
+  c.inner = inner;
+  c.n_in = n;
+  c.n_out = (n + filt_len - 1) / 2;
+  c.lo = d_dec_lo ? kNoHostTaps : dec_lo;
+  c.hi = d_dec_lo ? kNoHostTaps : dec_hi;
+  c.stream = static_cast<hipStream_t>(stream);
+  if (d_dec_lo) {
+    DtapsScope scope(d_dec_lo, d_dec_hi, 0);
+    return DtapsScope::checked(stream_call(dtype, kOuterFwd, c));
+  }
+  return stream_call(dtype, kOuterFwd, c);
+}
+
+// ... and its inverse: one 1-D synthesis level along the middle axis, (lo, hi) [batch, m, inner] -> y [batch, n_out, inner] (n_out = the
+// cropped extent, 2 m - L + 2 or one less): the bands of a 2-D level synthesised along the rows axis only, for the tap gradients
+// along the columns.
+int mifwt_dwt1_inv_outer(int dtype, int64_t batch, int64_t m, int64_t n_out, int64_t inner, const void* lo_in, int64_t lo_batch_stride,
+                         int64_t lo_axis_stride, const void* hi_in, int64_t hi_batch_stride, int64_t hi_axis_stride, void* y, int64_t y_batch_stride,
+                         int64_t y_axis_stride, int filt_len, const double* rec_lo, const double* rec_hi, const double* d_rec_lo,
+                         const double* d_rec_hi, void* stream) {
+  if (!lo_in || !hi_in || !y || batch < 0 || m < 1 || inner < 1 || n_out < 1) return MIFWT_ERR_BADARG;
+  if (!((rec_lo && rec_hi) || (d_rec_lo && d_rec_hi))) return MIFWT_ERR_BADARG;
+  if (n_out > 2 * m - filt_len + 2 || n_out < 2 * m - filt_len + 1) return MIFWT_ERR_BADARG;
+  if ((dtype != MIFWT_F32 && dtype != MIFWT_F64) || !stream_filter_supported(filt_len)) return MIFWT_ERR_UNSUPPORTED;
+  if (batch == 0) return MIFWT_OK;
+  StreamJob jb;
+  memset(&jb, 0, sizeof(jb));
+  jb.in0 = lo_in;
+  jb.in1 = hi_in;
+  jb.out0 = y;
+  jb.in0_s[0] = lo_batch_stride, jb.in0_s[1] = lo_axis_stride;
+  jb.in1_s[0] = hi_batch_stride, jb.in1_s[1] = hi_axis_stride;
+  jb.out0_s[0] = y_batch_stride, jb.out0_s[1] = y_axis_stride;
+  StreamCall c;
+  memset(&c, 0, sizeof(c));
+  c.filt_len = filt_len;
+  c.jobs = &jb;
+  c.njobs = 1;
+  c.batch = batch;
+  c.inner = inner;
+  c.n_in = m;
+  c.n_out = n_out;
+  c.lo = d_rec_lo ? kNoHostTaps : rec_lo;
+  c.hi = d_rec_lo ? kNoHostTaps : rec_hi;
+  c.stream = static_cast<hipStream_t>(stream);
+  if (d_rec_lo) {
+    DtapsScope scope(d_rec_lo, d_rec_hi, 0);
+    return DtapsScope::checked(stream_call(dtype, kOuterInv, c));
+  }
+  return stream_call(dtype, kOuterInv, c);
+}
+
 // Two consecutive 2-D analysis levels in one launch (mifwt_dwt2_fwd_pair.hip); d2 describes the second level, whose
 // input is the (never materialised) approximation of d1.
 int mifwt_dwt2_fwd_pair_supported(const mifwt_level_desc* d1, const mifwt_level_desc* d2) {

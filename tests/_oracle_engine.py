@@ -201,6 +201,26 @@ class OracleLevelEngine:
             vals = np.where(idx >= 0, bn[:, np.clip(idx, 0, n - 1)], 0.0)
             out[t] += float((an * vals).sum())
 
+    def tap_correlate_planes(self, along, a, b, filt_len, c0, sgn, mode_id, out):
+        """[batch, rows, columns] operands: along 1 = the reduction of tap_correlate along the columns, 0 = along the rows"""
+        if along == 1:
+            return self.tap_correlate(a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1]), filt_len, c0, sgn, mode_id, out)
+        at, bt = a.transpose(1, 2), b.transpose(1, 2)
+        return self.tap_correlate(at.reshape(-1, at.shape[-1]), bt.reshape(-1, bt.shape[-1]), filt_len, c0, sgn, mode_id, out)
+
+    def analysis_outer(self, x, dec_lo, dec_hi, mode_id):
+        """[B, N, C] -> (lo, hi) [B, M, C]: one level along the middle axis"""
+        xt = x.transpose(1, 2)
+        buf = self.analysis(xt.reshape(-1, xt.shape[-1]), dec_lo, dec_hi, mode_id)  # [B * C, 2, M]
+        buf = buf.reshape(x.shape[0], x.shape[2], 2, -1)
+        return buf[:, :, 0].transpose(1, 2), buf[:, :, 1].transpose(1, 2)
+
+    def synthesis_outer(self, lo, hi, rec_lo, rec_hi, n_out):
+        """(lo, hi) [B, M, C] -> [B, n_out, C]: one synthesis level along the middle axis"""
+        lt, ht = lo.transpose(1, 2), hi.transpose(1, 2)
+        y = self.synthesis(lt.reshape(-1, lt.shape[-1]), [ht.reshape(-1, ht.shape[-1])], rec_lo, rec_hi, [n_out])  # [B * C, n_out]
+        return y.reshape(lo.shape[0], lo.shape[2], n_out).transpose(1, 2)
+
     def tap_correlate_dilated(self, a, b, filt_len, c0, tstep, out):
         """out[t] += sum_{row, k} a[row, k] b[row, (k + c0 + tstep t) mod N]"""
         an, bn = a.detach().numpy().astype(np.float64), b.detach().numpy().astype(np.float64)

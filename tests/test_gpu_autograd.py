@@ -782,3 +782,56 @@ def test_learnable_taps_run_on_the_fused_kernels_bit_identical_to_host_taps():
         assert torch.equal(gd[0], gh[0]), (shape, wav, mode, "data gradient")
         for a, b in zip(gd[1:], gh[1:]):  # (the correlation kernel sums with atomics: the same inputs, not the same order of additions)
             assert G.relerr(a.cpu().numpy(), b.cpu().numpy()) < 1e-12, (shape, wav, mode, "tap gradient")
+
+
+def test_natural_layout_tap_gradient_kernels_vs_transposed_row_kernels():
+    """Round 6: the tap gradients of a 2-D level run on operands in their natural layout — ``tap_correlate_planes`` (along the columns:
+    the row kernel with a two-level row index; along the rows: the column kernel with its sliding register window), the outer-axis
+    level kernels on their own (``analysis_outer`` / ``synthesis_outer``).  Each against what the host layer did before: transposed
+    copies in front of the row kernels (whose results the reference's tap-gradient goldens pin).  Every mode, both signs, odd extents,
+    strided views (planes of a level buffer), f32 / f64, 2 .. 20 taps."""
+    from ptwt_amd import _engine
+
+    eng = _engine.ENGINE
+    g = torch.Generator().manual_seed(23)
+    for dtype, tol in ((torch.float64, 1e-12), (torch.float32, 2e-5)):
+        for flen in (2, 4, 8, 10, 16, 20):
+            for mode in ("zero", "constant", "reflect", "periodic", "symmetric"):
+                mid = _engine.MODE_IDS[mode]
+                B, H, W = 3, 2 * flen + 9, 2 * flen + 70
+                Mh, Mw = (H + flen - 1) // 2, (W + flen - 1) // 2
+                big = torch.randn(B, 4, H, W, generator=g, dtype=dtype).to(dev())
+                x = big[:, 1]  # a strided view: batch stride 4 H W
+                gb = torch.randn(B, 4, Mh, Mw, generator=g, dtype=dtype).to(dev())
+                lo = [float(v) for v in torch.randn(flen, generator=g, dtype=torch.float64)]
+                hi = [float(v) for v in torch.randn(flen, generator=g, dtype=torch.float64)]
+                # the outer-axis level against the inner-axis level of the transposed planes
+                zl, zh = eng.analysis_outer(x, lo, hi, mid)
+                xt = x.transpose(1, 2).contiguous()
+                ref = eng.analysis(xt.reshape(B * W, H), lo, hi, mid).reshape(B, W, 2, Mh)
+                assert torch.equal(zl, ref[:, :, 0].transpose(1, 2)) and torch.equal(zh, ref[:, :, 1].transpose(1, 2)), (dtype, flen, mode)
+                for sgn, c0, m_id in ((-1, 1, mid), (1, -(flen - 2), 0)):
+                    # along the columns: a [B, R, M], b [B, R, N]
+                    a, b = gb[:, 2], (zl if sgn < 0 else torch.randn(B, Mh, 2 * Mw - flen + 2, generator=g, dtype=dtype).to(dev()))
+                    got = torch.zeros(flen, dtype=torch.float64, device=dev())
+                    want = torch.zeros_like(got)
+                    eng.tap_correlate_planes(1, a, b, flen, c0, sgn, m_id, got)
+                    eng.tap_correlate(a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1]), flen, c0, sgn, m_id, want)
+                    assert G.relerr(got.cpu().numpy(), want.cpu().numpy()) < tol, (dtype, flen, mode, sgn, "columns")
+                    # along the rows: a [B, M, C], b [B, N, C]
+                    a2 = gb[:, 1]
+                    b2 = torch.randn(B, H if sgn < 0 else 2 * Mh - flen + 2, Mw, generator=g, dtype=dtype).to(dev())
+                    got = torch.zeros(flen, dtype=torch.float64, device=dev())
+                    want = torch.zeros_like(got)
+                    eng.tap_correlate_planes(0, a2, b2, flen, c0, sgn, m_id, got)
+                    at, bt = a2.transpose(1, 2).contiguous(), b2.transpose(1, 2).contiguous()
+                    eng.tap_correlate(at.reshape(-1, at.shape[-1]), bt.reshape(-1, bt.shape[-1]), flen, c0, sgn, m_id, want)
+                    assert G.relerr(got.cpu().numpy(), want.cpu().numpy()) < tol, (dtype, flen, mode, sgn, "rows")
+                # the outer-axis synthesis against the inner-axis synthesis of the transposed planes (both crops)
+                for n_out in (2 * Mh - flen + 2, 2 * Mh - flen + 1):
+                    if n_out < 1:
+                        continue
+                    y = eng.synthesis_outer(gb[:, 0], gb[:, 3], lo, hi, n_out)
+                    lt, ht = gb[:, 0].transpose(1, 2).contiguous(), gb[:, 3].transpose(1, 2).contiguous()
+                    yr = eng.synthesis(lt.reshape(B * Mw, Mh), [ht.reshape(B * Mw, Mh)], lo, hi, [n_out]).reshape(B, Mw, n_out).transpose(1, 2)
+                    assert torch.equal(y, yr), (dtype, flen, mode, n_out)
