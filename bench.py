@@ -363,8 +363,8 @@ def secondary_lines(dev, steps=20, warmup=5, buffers=3):
                 res[how] = (time.perf_counter() - t0) / 10 * 1e3
             out.append({"workload": name, "ms_per_step": round(res["auto"], 3), "host_taps_ms_per_step": round(res["never"], 3),
                         "note": "forward + backward w.r.t. data and dec filters (leaf tensors on the GPU); ms_per_step: taps read by the fused kernels "
-                                "from device memory, no synchronisation; host_taps: the bank copied to the host per call (round 5, both on the "
-                                "first tap-gradient kernel: 24.2 ms)"})
+                                "from device memory, no synchronisation; host_taps: the bank copied to the host per call (start of round 6, first "
+                                "tap-gradient kernel + transposed copies: 24.2 ms)"})
         except Exception as exc:
             out.append({"workload": name, "error": repr(exc)[:200]})
         finally:
