@@ -816,6 +816,12 @@ def _check_pad(extents: Sequence[int], flen: int, mode: str) -> None:
 
 
 # ------------------------------------------------------------------------------------------ analysis
+# geometry of a graph-free decomposition -> the launches it took ((0, levels asked of the multi-level launch) / (1, 0) level pair /
+# (2, levels) 1-D tail / (3, 0) one level); idempotent values, single dict operations (see the synthesis memos below)
+_route_memo: dict = {}
+_engine._routing_caches.append(_route_memo)
+
+
 def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: AxisHint, ndim: int):
     """Multi-level analysis.  Returns ``(layout, approx [B,*M], [buffer [B,2^n,*M] per level, coarsest first])``."""
     axes = _ensure_axes(axes, ndim)
@@ -834,6 +840,37 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
     bufs: List[torch.Tensor] = []
     cur = x
     done = 0
+    # Calls that need no graph (inference: the common case, and every timed loop) REPLAY the launches their geometry took last time:
+    # which levels fuse is a function of the geometry and the routing options alone, and the pad checks below raise by geometry alone —
+    # a geometry is memoised only after it passed them.  (32 x 1000^2 db5 periodic level 5, five launches: 79 -> ~60 us of host time a
+    # call, which is what that call costs once the GPU needs less: tools/host_profile_ref.py)
+    rkey = None
+    if not on_device and not (torch.is_grad_enabled() and (x.requires_grad or tap_t is not None)):
+        mode_id = _mode_id(mode)
+        eng = _engine.ENGINE
+        rkey = (ndim, x.shape, x.stride(), x.dtype, x.device, flen, mode_id, level, id(eng), _engine.MAX_PYRAMID_LEVELS, _engine.ROW_ALIGN,
+                _engine.PYRAMID_ROW_ALIGN)
+        steps = _route_memo.get(rkey)
+        if steps is not None:
+            for kind, arg in steps:
+                if kind == 0:
+                    got = eng.analysis_pyramid(cur, dec_lo, dec_hi, mode_id, arg)
+                elif kind == 1:
+                    got = eng.analysis_pair(cur, dec_lo, dec_hi, mode_id)
+                elif kind == 2:
+                    got = eng.analysis_tail(cur, dec_lo, dec_hi, mode_id, arg)
+                else:
+                    got = (eng.analysis(cur, dec_lo, dec_hi, mode_id),)
+                if got is None:  # (cannot happen while the memo is cleared with the plans; never guess: take the long way)
+                    break
+                bufs.extend(got)
+                cur = got[-1][:, 0]
+            else:
+                bufs.reverse()
+                return layout, cur, bufs
+            _route_memo.pop(rkey, None)
+            bufs, cur = [], x
+    steps = []
     while done < level:
         mode_id = _mode_id(mode)
         _check_pad(cur.shape[1:], flen, "reflect" if mode is None else mode)
@@ -860,6 +897,7 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
             else:
                 pyr = _engine.ENGINE.analysis_pyramid(cur, dec_lo, dec_hi, mode_id, want)
                 if pyr is not None:
+                    steps.append((0, want))
                     bufs.extend(pyr)
                     cur = pyr[-1][:, 0]
                     done += len(pyr)
@@ -871,6 +909,7 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
             _check_pad(n1, flen, "reflect" if mode is None else mode)
             pair = _engine.ENGINE.analysis_pair(cur, dec_lo, dec_hi, mode_id)
             if pair is not None:
+                steps.append((1, 0))
                 bufs.extend(pair)
                 cur = pair[1][:, 0]
                 done += 2
@@ -896,6 +935,7 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
             else:
                 tail = _engine.ENGINE.analysis_tail(cur, dec_lo, dec_hi, mode_id, level - done)
                 if tail is not None:
+                    steps.append((2, level - done))
                     bufs.extend(tail)
                     cur = tail[-1][:, 0]
                     done += len(tail)
@@ -904,9 +944,14 @@ def analysis(data: torch.Tensor, wavelet, mode, level: Optional[int], axes: Axis
         if differentiable:
             buf = _AnalysisLevel.apply(cur, dec_lo, dec_hi, mode_id, *((tap_t[0], tap_t[1]) if tap_t else (None, None)))
         else:
+            steps.append((3, 0))
             buf = _engine.ENGINE.analysis(cur, dec_lo, dec_hi, mode_id)
         bufs.append(buf)
         cur = buf[:, 0]
+    if rkey is not None:
+        if len(_route_memo) > 512:
+            _route_memo.clear()
+        _route_memo[rkey] = tuple(steps)
     bufs.reverse()
     return layout, cur, bufs
 
