@@ -503,6 +503,11 @@ int stream_launch(int kind, const StreamCall& c) {  // kind: 0 outer fwd, 1 oute
     int64_t per_chunk = kind == 0 ? 16 : 8;
     const int64_t lanes_tasks = nstrips * c.batch * c.njobs;
     while (per_chunk < units && lanes_tasks * ((units + per_chunk - 1) / per_chunk) > 8 * 4 * 256 * 4) per_chunk *= 2;
+    // ... and a SMALL launch (fewer waves than one per SIMD: the deep levels of a 3-D decomposition) is a chain of row requests a wave
+    // waits for one after the other — shorter chunks, more of them: 32 x 54 x (4 x 31^2) db5, 16 -> 4 output rows a chunk: 25 -> 12 us
+    // (the halo rows a chunk re-reads come from L2 there)
+    const int64_t min_chunk = kind == 0 ? 4 : 2;
+    while (per_chunk > min_chunk && lanes_tasks * ((units + per_chunk - 1) / per_chunk) < 4 * 256 * 4) per_chunk /= 2;
     if (per_chunk > units) per_chunk = units > 0 ? units : 1;
     a.per_chunk = (int)per_chunk;
     const int64_t nchunks = (units + per_chunk - 1) / per_chunk;

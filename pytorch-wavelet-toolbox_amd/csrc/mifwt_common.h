@@ -31,7 +31,7 @@ constexpr bool kDiag = false;
 // 8 = kernel 22 without its fast warm-up, 64 = column strips of 64 in the 3-D analysis walk, 512 = 8-byte stores in the 3-D synthesis walk,
 // 1024 = analysis adjoints on the generic passes, 4096 = the per-sample border kernel, 8192 = level-2 waves of kernel 16 behind the step's
 // second barrier, bits 19 / 20 = kernel 16 without its tail wave / in its sixteen-wave form
-constexpr int kRouteBits = 8 | 64 | 512 | 1024 | 4096 | 8192 | 524288 | 1048576;
+constexpr int kRouteBits = 8 | 64 | 512 | 1024 | 4096 | 8192 | 524288 | 1048576 | 2097152;
 inline int exp_word() { return kDiag ? g_options[MIFWT_OPT_EXP] : 0; }
 extern unsigned long long g_launch_counts[16];  // mifwt_launch_count(): launches per kernel variant (MIFWT_VARIANT_*)
 inline void count_launch(int variant) { __atomic_fetch_add(&g_launch_counts[variant], 1ull, __ATOMIC_RELAXED); }
@@ -322,6 +322,11 @@ int dwt3_fwd_tile(const mifwt_level_desc* d, const void* x, void* approx, void* 
                   const double* dec_lo, const double* dec_hi, hipStream_t stream);
 // fully fused 3-D analysis level, workgroups walking along the depth axis (mifwt_dwt3_fwd_walk.hip): f32, even L <= 10, every mode
 bool dwt3_fwd_walk_supported(const mifwt_level_desc* d);
+// ... its SLAB form for 8 / 10 taps on rows of at most 128 samples (mifwt_dwt3_fwd_slab.hip): f32, every mode; dwt3_fwd_walk runs it
+// where it applies (MIFWT_OPT_DEBUG bit 21 keeps the strip form)
+bool dwt3_fwd_slab_supported(const mifwt_level_desc* d);
+int dwt3_fwd_slab(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo, const double* hi,
+                  hipStream_t stream);
 int dwt3_fwd_walk(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo, const double* hi,
                   hipStream_t stream);
 // ... and its synthesis mirror (mifwt_dwt3_inv_walk.hip): f32, even L <= 8, dense coefficient rows

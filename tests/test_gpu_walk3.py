@@ -281,3 +281,58 @@ def test_walk3_gradients_agree_with_the_brick_route():
     assert G.relerr(to_np(gx_w), to_np(gx_b)) < 1e-6
     for a, b in zip(gc_w, gc_b):
         assert G.relerr(to_np(a), to_np(b)) < 1e-6
+
+
+STRIPS = 2097152  # MIFWT_OPT_DEBUG routing bit: kernel 24 keeps its strip form for eight / ten taps
+
+
+@pytest.mark.parametrize("wavelet", ["db4", "db5"])
+def test_walk3_slab_form_vs_oracle_and_strip_form(wavelet):
+    """The slab form of kernel 24 (mifwt_dwt3_fwd_slab.hip: eight / ten taps, rows of at most 128 samples — the reference's own 3-D speed
+    shape, examples/speed_tests/timeitconv_3d.py): every mode against the oracle, one and several slabs per volume, ragged last slab, odd
+    extents, the smallest volume, short depth segments, strided input — and bit-identical to the strip form (the same sums in the same order)."""
+    rng = np.random.default_rng(len(wavelet) + 60)
+    flen = len(O.filter_bank(wavelet)[0])
+    shapes = [(2, 30, 100, 100), (3, 21, 23, 37), (1, 54, 54, 54), (2, 20, 31, 128), (1, flen, flen, flen), (2, 17, 75, 90), (1, 13, 97, 11)]
+    for shape in shapes:
+        x = rng.standard_normal(shape)
+        xg = torch.from_numpy(x).float().to(dev())
+        for mode in MODES:
+            try:
+                want = O.wavedec3(x, wavelet, mode=mode, level=1)
+            except RuntimeError:
+                continue
+            for seg in (0, 2, 5):
+                _engine.set_option(_engine.OPT_ROWS_PER_CHUNK, seg)
+                try:
+                    got, kids = _walk(lambda: ptwt_amd.wavedec3(xg, wavelet, mode=mode, level=1))
+                    if seg == 0:
+                        _engine.set_option(_engine.OPT_DEBUG, STRIPS)
+                        try:
+                            strips, kids_s = _walk(lambda: ptwt_amd.wavedec3(xg, wavelet, mode=mode, level=1))
+                        finally:
+                            _engine.set_option(_engine.OPT_DEBUG, 0)
+                finally:
+                    _engine.set_option(_engine.OPT_ROWS_PER_CHUNK, 0)
+                assert kids == [24], (kids, shape, mode)
+                check_tree(got, want, TOL32, f"dwt3 slab {wavelet} {mode} {shape} seg {seg}")
+                if seg == 0:
+                    assert kids_s == [24]
+                    assert torch.equal(got[0], strips[0]) and all(torch.equal(got[1][k], strips[1][k]) for k in got[1]), (shape, mode)
+    # a slice of a bigger tensor; the default route of the reference's shape is this kernel for ten taps
+    big = torch.from_numpy(rng.standard_normal((2, 40, 45, 120))).float().to(dev())
+    xs = big[:, 3:37, 2:43, 5:105]
+    for mode in ("reflect", "periodic", "zero"):
+        want = O.wavedec3(to_np(xs).astype(np.float64), wavelet, mode=mode, level=2)
+        got, kids = _walk(lambda: ptwt_amd.wavedec3(xs, wavelet, mode=mode, level=2))
+        assert kids == [24, 24], kids
+        check_tree(got, want, TOL32, f"dwt3 slab strided {wavelet} {mode}")
+    if wavelet == "db5":
+        xg = torch.randn(4, 100, 100, 100, device=dev())
+        _engine.level_events = []
+        try:
+            ptwt_amd.wavedec3(xg, "db5", mode="periodic", level=3)
+            kids = [e[1] for e in _engine.level_events]
+        finally:
+            _engine.level_events = None
+        assert kids == [24, 24, 24], kids
