@@ -448,7 +448,9 @@ bool dwt3_fwd_walk_supported(const mifwt_level_desc* d) {
 int dwt3_fwd_walk(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo, const double* hi,
                   hipStream_t stream) {
   // eight / ten taps on rows of at most 128 samples: the slab form (mifwt_dwt3_fwd_slab.hip; MIFWT_OPT_DEBUG bit 21 keeps the strips)
-  if (!(g_options[MIFWT_OPT_DEBUG] & 2097152) && dwt3_fwd_slab_supported(d)) return dwt3_fwd_slab(d, x, approx, details, lo, hi, stream);
+  // where it is ahead (or wherever it can run, MIFWT_OPT_TILE_MODE 4)
+  if (!(g_options[MIFWT_OPT_DEBUG] & 2097152) && (g_options[MIFWT_OPT_TILE_MODE] == 4 ? dwt3_fwd_slab_supported(d) : dwt3_fwd_slab_pays(d)))
+    return dwt3_fwd_slab(d, x, approx, details, lo, hi, stream);
   if (d->dtype == MIFWT_F64) {
     switch (d->filt_len) {
       case 2: return launch_walk3_l64<2>(d, x, approx, details, lo, hi, stream);

@@ -327,12 +327,13 @@ def test_walk3_slab_form_vs_oracle_and_strip_form(wavelet):
         got, kids = _walk(lambda: ptwt_amd.wavedec3(xs, wavelet, mode=mode, level=2))
         assert kids == [24, 24], kids
         check_tree(got, want, TOL32, f"dwt3 slab strided {wavelet} {mode}")
-    if wavelet == "db5":
-        xg = torch.randn(4, 100, 100, 100, device=dev())
-        _engine.level_events = []
-        try:
-            ptwt_amd.wavedec3(xg, "db5", mode="periodic", level=3)
-            kids = [e[1] for e in _engine.level_events]
-        finally:
-            _engine.level_events = None
-        assert kids == [24, 24, 24], kids
+    if wavelet == "db5":  # (where the cost model of the route sends it: 32 volumes here, one volume to the composed route)
+        for batch, want_kid in ((32, 24), (1, 5)):
+            xg = torch.randn(batch, 100, 100, 100, device=dev())
+            _engine.level_events = []
+            try:
+                ptwt_amd.wavedec3(xg, "db5", mode="periodic", level=1)
+                kids = [e[1] for e in _engine.level_events]
+            finally:
+                _engine.level_events = None
+            assert kids == [want_kid], (batch, kids)

@@ -6,7 +6,9 @@ TAG=${1:-r06k}
 OUT=$ROOT/gpurun_out/${TAG}_walk3_routes.txt
 : > $OUT
 export TMPDIR=/tmp
-for cfg in "db2 100" "db2 51" "db2 27" "db3 100" "db3 52" "db3 28" "db4 100" "db4 53" "db4 30" "db5 100" "db5 54" "db5 31"; do
+# CFGS="db5:100 db4:53 ..." picks the (wavelet, extent) pairs; BATCH the number of volumes
+for c in ${CFGS:-db2:100 db2:51 db2:27 db3:100 db3:52 db3:28 db4:100 db4:53 db4:30 db5:100 db5:54 db5:31}; do
+  cfg="${c%%:*} ${c##*:}"
   for tm in 1 4; do
     D=/tmp/w3_$$; rm -rf $D; mkdir -p $D
     ( cd /tmp; timeout 120 rocprofv3 --kernel-trace --output-format csv -d $D -o kt -- python $ROOT/tools/walk3_one.py $cfg $tm ${BATCH:-32} ) > $D/log.txt 2>&1
