@@ -189,6 +189,9 @@ CASES_3D = [
     ((2, 40, 41, 42), "db2", 2, "zero", torch.float64, {}),          # f64: 24 / 25 (two rows per workgroup), then the composed route on 21 x 22 x 22
     ((1, 70, 67, 131), "db3", 2, "symmetric", torch.float64, {}),    # f64: 24 / 25, odd extents, two 1-KiB requests per staged row
     ((1, 128, 66, 250), "db2", 1, "periodic", torch.float64, {}),    # f64: 24 / 25, four rows per workgroup (>= 2^20 samples)
+    ((24, 40, 50, 60), "db5", 1, "periodic", torch.float32, {}),     # 24 in its SLAB form by the default route (ten taps, 24 volumes of 1.2e5 samples)
+    ((2, 30, 101, 99), "db5", 1, "symmetric", torch.float32, {_engine.OPT_TILE_MODE: 4}),  # slab form: two slabs a volume, the second ragged, odd extents
+    ((3, 17, 23, 128), "db4", 1, "reflect", torch.float32, {_engine.OPT_TILE_MODE: 4}),    # slab form: eight taps, one row per request
 ]
 
 
@@ -196,7 +199,13 @@ CASES_3D = [
 def test_canaries_3d(guarded, case):
     shape, wavelet, level, mode, dtype, opts = case
     x = _x(*shape, dtype=dtype)
-    c = _run(guarded, f"wavedec3 {case}", lambda t: ptwt_amd.wavedec3(t, wavelet, mode=mode, level=level), [x])
+    for key, value in opts.items():
+        _engine.set_option(key, value)
+    try:
+        c = _run(guarded, f"wavedec3 {case}", lambda t: ptwt_amd.wavedec3(t, wavelet, mode=mode, level=level), [x])
+    finally:
+        for key in opts:
+            _engine.set_option(key, 0)
     keys = list(c[1].keys())
     flat = [c[0]] + [d[k] for d in c[1:] for k in keys]
     _run(guarded, f"waverec3 {case}", lambda *ts: ptwt_amd.waverec3((ts[0], *[dict(zip(keys, ts[1 + 7 * k : 8 + 7 * k])) for k in range(level)]), wavelet), flat)
