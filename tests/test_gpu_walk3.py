@@ -293,7 +293,7 @@ def test_walk3_slab_form_vs_oracle_and_strip_form(wavelet):
     extents, the smallest volume, short depth segments, strided input — and bit-identical to the strip form (the same sums in the same order)."""
     rng = np.random.default_rng(len(wavelet) + 60)
     flen = len(O.filter_bank(wavelet)[0])
-    shapes = [(2, 30, 100, 100), (3, 21, 23, 37), (1, 54, 54, 54), (2, 20, 31, 128), (1, flen, flen, flen), (2, 17, 75, 90), (1, 13, 97, 11)]
+    shapes = [(2, 30, 100, 100), (3, 21, 23, 37), (1, 54, 54, 54), (2, 20, 31, 128), (1, flen, flen, flen), (2, 17, 75, 90), (1, 13, 97, 11), (1, 12, 128, 128)]
     for shape in shapes:
         x = rng.standard_normal(shape)
         xg = torch.from_numpy(x).float().to(dev())
