@@ -56,13 +56,13 @@ struct Slab3Args {
   int raw_slot;       // bytes of a staged slice in LDS
   int wfp;            // (low, high) pairs of a row of the filtered image
   int npad;           // pad samples of a row: L - 2 in front, 2 Wo - W behind
-  int mode, exp, dbg;  // exp: MIFWT_OPT_EXP (A/B runs of diagnostics builds: 1 loaders at default priority, 2 row pass on the compute waves only); dbg: MIFWT_OPT_DEBUG of -DMIFWT_DIAG builds (timing experiments, results wrong): 1 no stores, 2 no requests, 4 no row pass, 8 no column / depth pass, 16 no pad fill
+  int mode, exp, dbg;  // exp: MIFWT_OPT_EXP (A/B runs of diagnostics builds: 1 loaders at default priority, 2 row pass on the compute waves only); dbg: MIFWT_OPT_DEBUG of -DMIFWT_DIAG builds (timing experiments, results wrong): 1 no stores, 2 no requests, 4 no row pass, 8 no column / depth pass, 16 no pad fill, 32 loaders keep only the barriers, 64 no depth pass either
   FastDiv div_wo, div_rin, div_g, div_s, div_ppl, div_npad, div_preq;  // (div_preq: by rpq * npad)
   f2 tap[L];
 };
 
 // at most n requests of this wave may still be in flight (they complete in order: everything older has landed); the count of an
-// s_waitcnt is an immediate: a binary dispatch over 0 .. kSlabMaxReq
+// s_waitcnt is an immediate: a binary dispatch over 0 .. 2 kSlabMaxReq (two slices in flight)
 template <int LO, int HI>
 __device__ __forceinline__ void slab_wait_range(int n) {
   if constexpr (LO == HI) {
