@@ -254,6 +254,9 @@ int pick_kernel(const mifwt_level_desc* d, int direction) {
       // 24.5 / 10.5; db3 100^3 / 52^3 / 28^3: 90.2 / 26.2 / 23.5 against 116.4 / 33.9 / 14.1; db4 100^3 / 53^3 / 30^3: 133.7 / 55.4 / 22.3
       // against 133.9 / 31.9 / 18.6; db5: 199.7 / 75.5 / 44.0 against 134.9 / 38.6 / 20.3 — profiles/r06k_walk3_routes.txt)
       if (tm == 0 && d->dtype == MIFWT_F32 && d->batch >= 16 && d->filt_len <= 6 && vol >= 100000) return kDwt3FwdWalk;
+      // (and config 3's second level, 8 x 129^3 db2: 34.4 against 40.4 us on the bricks — 48 us inside the pyramid, where its input is a
+      // plane of the first level's buffer; 8 x 66^3: 17.2 against 13.8: profiles/r06y_walk3_routes.txt)
+      if (tm == 0 && d->dtype == MIFWT_F32 && d->batch >= 8 && d->filt_len <= 6 && vol >= (int64_t(1) << 21)) return kDwt3FwdWalk;
       // eight / ten taps on rows of at most 128 samples: the slab form of the walk where its cost model says so
       if (tm == 0 && !(g_options[MIFWT_OPT_DEBUG] & 2097152) && dwt3_fwd_slab_pays(d)) return kDwt3FwdWalk;
       // f64 has no bricks: the walk kernel against the composed route (planes + depth pass) — 8 x 256^3 / 129^3 / 66^3 / 40^3, us: db2 444 / 69 /

@@ -7,5 +7,5 @@ wav, n, tm = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 b = int(sys.argv[4]) if len(sys.argv) > 4 else 32
 x = torch.randn(b, n, n, n, device='cuda')
 E.set_option(E.OPT_TILE_MODE, tm)
-for _ in range(60): ptwt.wavedec3(x, wav, mode='periodic', level=1)
+for _ in range(60): ptwt.wavedec3(x, wav, mode=os.environ.get('W3MODE', 'periodic'), level=1)
 torch.cuda.synchronize()
