@@ -322,7 +322,9 @@ def test_stream_routes_selected():
     kid = _engine.kernel_id
     assert kid(1, torch.float32, "reflect", 8, 4, (1000,)) == 3 and kid(1, torch.float32, "zero", 8, 4, (1000,), direction=1) == 4
     assert kid(1, torch.float64, "reflect", 2, 1, (4096,)) == 3
-    assert kid(3, torch.float32, "zero", 4, 8, (256, 256, 256)) == 24 and kid(3, torch.float32, "zero", 4, 8, (129, 129, 129)) == 9  # 3-D analysis: depth-walking kernel on big volumes (round 4), LDS bricks below
+    assert kid(3, torch.float32, "zero", 4, 8, (256, 256, 256)) == 24 and kid(3, torch.float32, "zero", 4, 4, (129, 129, 129)) == 9  # 3-D analysis: depth-walking kernel on big volumes (round 4), LDS bricks below
+    assert kid(3, torch.float32, "zero", 4, 8, (129, 129, 129)) == 24 and kid(3, torch.float32, "zero", 4, 8, (66, 66, 66)) == 9  # (round 6: from 2^21 samples on with eight volumes or more — config 3's second level)
+    assert kid(3, torch.float32, "periodic", 10, 32, (100, 100, 100)) == 24 and kid(3, torch.float32, "periodic", 10, 2, (100, 100, 100)) == 5  # ten taps: the slab form where the batch fills the chip
     assert kid(3, torch.float32, "zero", 8, 8, (256, 256, 256)) == 24 and kid(3, torch.float32, "zero", 12, 8, (256, 256, 256)) == 5 and kid(3, torch.float32, "zero", 4, 8, (256, 256, 256), direction=1) == 25 and kid(3, torch.float32, "zero", 4, 8, (64, 64, 64), direction=1) == 10 and kid(3, torch.float32, "zero", 10, 8, (256, 256, 256), direction=1) == 6
     # f64 volumes (round 5): the f64 instances of the walk kernels from 32^3 samples on (rows of at most 256 samples; synthesis up to 8 taps),
     # below and beyond the composed route — the f64 tile kernel over every depth slice + one depth pass — instead of three axis passes
