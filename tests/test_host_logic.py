@@ -251,7 +251,8 @@ def test_cabi_descriptor_validation_and_dispatch():
     assert _engine.kernel_id(1, torch.float64, "zero", 2, 1, (4096,)) == 3
     assert _engine.kernel_id(1, torch.float32, "zero", 8, 1, (4096,), direction=1) == 4
     assert _engine.kernel_id(3, torch.float32, "zero", 4, 8, (256, 256, 256)) == 24  # depth-walking fused kernel (big volumes)
-    assert _engine.kernel_id(3, torch.float32, "zero", 4, 8, (128, 128, 128)) == 9   # fully fused LDS-brick kernel
+    assert _engine.kernel_id(3, torch.float32, "zero", 4, 4, (128, 128, 128)) == 9   # fully fused LDS-brick kernel
+    assert _engine.kernel_id(3, torch.float32, "zero", 4, 8, (128, 128, 128)) == 24  # (round 6: eight volumes of 2^21 samples on walk too)
     assert _engine.kernel_id(3, torch.float32, "zero", 12, 8, (256, 256, 256)) == 5  # fused planes + depth pass
     assert _engine.kernel_id(3, torch.float32, "zero", 4, 8, (256, 256, 256), direction=1) == 25  # depth-walking fused synthesis (from ~1 M outputs)
     assert _engine.kernel_id(3, torch.float32, "zero", 4, 8, (64, 64, 64), direction=1) == 10  # fully fused LDS-brick synthesis
@@ -642,5 +643,73 @@ def test_f64_volume_routes_without_a_gpu():
     assert kid(3, f64, "zero", 8, 2, (100, 100, 100), direction=1) == 25 and kid(3, f64, "zero", 8, 2, (256, 256, 256), direction=1) == 6
     # f32 keeps its routes: walk from 2^22 samples on, bricks below, eight taps from 2^20 on
     f32 = torch.float32
-    assert kid(3, f32, "zero", 4, 8, (256, 256, 256)) == 24 and kid(3, f32, "zero", 4, 8, (129, 129, 129)) == 9
+    assert kid(3, f32, "zero", 4, 8, (256, 256, 256)) == 24 and kid(3, f32, "zero", 4, 4, (129, 129, 129)) == 9
     assert kid(3, f32, "zero", 8, 8, (128, 128, 128)) == 24 and kid(3, f32, "zero", 8, 8, (54, 54, 54)) == 5
+
+
+def test_3d_analysis_routes_of_round_6_without_a_gpu():
+    """Batch-aware 3-D analysis routing (csrc/mifwt_api.hip, `dwt3_fwd_slab_pays`; profiles/r06k / r06p / r06y_walk3_routes.txt): the
+    depth-walking kernel (id 24) takes smaller volumes once the batch fills the chip, and eight / ten taps on rows of at most 128 samples
+    take its slab form where the measured table says so — else the bricks (9) / the composed route (5)."""
+    import torch
+    from ptwt_amd import _engine
+
+    kid, f32 = _engine.kernel_id, torch.float32
+    # L <= 6: from 2^22 samples a volume; from 2^21 with eight volumes; from 10^5 with sixteen
+    assert kid(3, f32, "zero", 4, 8, (129, 129, 129)) == 24 and kid(3, f32, "zero", 4, 4, (129, 129, 129)) == 9
+    assert kid(3, f32, "zero", 4, 8, (66, 66, 66)) == 9 and kid(3, f32, "periodic", 4, 32, (51, 51, 51)) == 24
+    assert kid(3, f32, "periodic", 6, 32, (52, 52, 52)) == 24 and kid(3, f32, "periodic", 4, 32, (27, 27, 27)) == 9
+    # ten taps (the reference's 3-D speed shape: 32 x 100^3 db5 periodic): slab form from 2^23 samples a batch on big volumes, 2.4 M on small ones
+    assert kid(3, f32, "periodic", 10, 32, (100, 100, 100)) == 24 and kid(3, f32, "periodic", 10, 16, (100, 100, 100)) == 24
+    assert kid(3, f32, "periodic", 10, 8, (100, 100, 100)) == 5 and kid(3, f32, "periodic", 10, 1, (100, 100, 100)) == 5
+    assert kid(3, f32, "periodic", 10, 32, (54, 54, 54)) == 24 and kid(3, f32, "periodic", 10, 8, (54, 54, 54)) == 5
+    assert kid(3, f32, "periodic", 10, 32, (31, 31, 31)) == 5  # below 10^5 samples a volume: composed
+    assert kid(3, f32, "reflect", 10, 32, (100, 100, 129)) == 5  # rows of more than 128 samples are not the slab form's
+    # eight taps: slab form from 4 M samples a batch (2.3 M on small volumes); big volumes keep the walk kernel either way
+    assert kid(3, f32, "symmetric", 8, 4, (100, 100, 100)) == 24 and kid(3, f32, "symmetric", 8, 2, (100, 100, 100)) == 5
+    assert kid(3, f32, "symmetric", 8, 16, (53, 53, 53)) == 24 and kid(3, f32, "symmetric", 8, 8, (53, 53, 53)) == 5
+    assert kid(3, f32, "zero", 8, 1, (128, 128, 128)) == 24 and kid(3, f32, "zero", 8, 32, (30, 30, 30)) == 5
+    # f64 and half storage never take the slab form
+    assert kid(3, torch.float64, "periodic", 10, 32, (100, 100, 100)) == 5
+
+
+def test_graph_free_calls_replay_their_route(oracle_engine):
+    """`_fwt._route_memo`: a decomposition that builds no graph replays the launches its geometry took last time — same results, no
+    memo for calls that raise, none for differentiable calls, cleared when a routing option changes."""
+    import numpy as np
+    import torch
+    import ptwt_amd
+    from ptwt_amd import _engine, _fwt
+
+    _fwt._route_memo.clear()
+    x = torch.from_numpy(np.random.default_rng(5).standard_normal((2, 40, 52)))
+    first = ptwt_amd.wavedec2(x, "db2", mode="symmetric", level=3)
+    assert len(_fwt._route_memo) == 1
+    (steps,) = _fwt._route_memo.values()
+    assert len(steps) >= 1 and all(kind in (0, 1, 2, 3) for kind, _ in steps)
+    again = ptwt_amd.wavedec2(x, "db2", mode="symmetric", level=3)
+    assert len(_fwt._route_memo) == 1
+    for a, b in zip([first[0]] + [t for lv in first[1:] for t in lv], [again[0]] + [t for lv in again[1:] for t in lv]):
+        assert torch.equal(a, b)
+    # another mode / level / layout is another geometry; 1-D and 3-D calls memoise too
+    ptwt_amd.wavedec2(x, "db2", mode="zero", level=2)
+    ptwt_amd.wavedec2(x.transpose(1, 2), "db2", mode="symmetric", level=3)
+    ptwt_amd.wavedec(x[0], "db3", level=2)
+    ptwt_amd.wavedec3(x.reshape(2, 8, 5, 52), "haar", level=1)
+    assert len(_fwt._route_memo) == 5
+    # a geometry whose pad check raises is never memoised (the reference's error comes back every time)
+    n = len(_fwt._route_memo)
+    for _ in range(2):
+        with pytest.raises(RuntimeError):
+            ptwt_amd.wavedec2(x[:, :5, :5], "db4", mode="reflect", level=1)
+    assert len(_fwt._route_memo) == n
+    # differentiable calls take the autograd ops, not the replay
+    xg = x.clone().requires_grad_(True)
+    ptwt_amd.wavedec2(xg, "db2", mode="symmetric", level=3)
+    assert len(_fwt._route_memo) == n
+    with torch.no_grad():
+        ptwt_amd.wavedec2(xg, "db2", mode="symmetric", level=3)  # (same geometry as the first call: replayed)
+    assert len(_fwt._route_memo) == n
+    # a routing option clears it with the plans
+    _engine.set_option(_engine.OPT_TILE_MODE, 0)
+    assert len(_fwt._route_memo) == 0
