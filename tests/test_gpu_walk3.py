@@ -337,3 +337,26 @@ def test_walk3_slab_form_vs_oracle_and_strip_form(wavelet):
             finally:
                 _engine.level_events = None
             assert kids == [want_kid], (batch, kids)
+
+
+def test_slab_form_through_the_public_calls_round_trip_and_separable_face():
+    """What a user of the reference's 3-D speed workload sees: `wavedec3` / `fswavedec3` of a batch of ten-tap volumes take the slab form
+    by the default route, agree with the oracle, and `waverec3` / `fswaverec3` of their coefficients give the input back."""
+    rng = np.random.default_rng(99)
+    x = rng.standard_normal((24, 40, 50, 60))
+    xg = torch.from_numpy(x).float().to(dev())
+    for mode in ("periodic", "reflect"):
+        _engine.level_events = []
+        try:
+            got = ptwt_amd.wavedec3(xg, "db5", mode=mode, level=2)
+            fs = ptwt_amd.fswavedec3(xg, "db5", mode=mode, level=1)
+            kids = [e[1] for e in _engine.level_events]
+        finally:
+            _engine.level_events = None
+        assert kids[0] == 24 and kids[2] == 24, kids  # (24 volumes of 1.2e5 samples: the slab form's route; the second level: 1.8e4 samples, composed)
+        check_tree(got, O.wavedec3(x, "db5", mode=mode, level=2), TOL32, f"wavedec3 db5 {mode}")
+        check_tree(fs, O.fswavedec3(x, "db5", mode=mode, level=1), TOL32, f"fswavedec3 db5 {mode}")
+        rec = ptwt_amd.waverec3(got, "db5")
+        assert G.relerr(to_np(rec[..., :40, :50, :60]), x) < 5e-6, mode
+        rec = ptwt_amd.fswaverec3(fs, "db5")
+        assert G.relerr(to_np(rec[..., :40, :50, :60]), x) < 5e-6, mode
