@@ -186,6 +186,14 @@ int mifwt_dwt2_fwd_pyramid(int nlevels, const mifwt_level_desc* const* descs, co
  * serve the call, MIFWT_ERR_BADARG if `capacity` < n + 1. */
 int mifwt_dwt2_fwd_pyramid_schedule(int nlevels, const mifwt_level_desc* const* descs, unsigned int* wg_start, int capacity);
 
+/* Plan of the SLAB form of kernel id 24 for one 3-D analysis level (eight / ten taps, f32, rows of at most 128 samples;
+ * csrc/mifwt_dwt3_fwd_slab.hip — one level of wavedec3 / fswavedec3, src/ptwt/conv_transform_3.py:121-141) — diagnostics and tests:
+ * out[0 .. 11] = output rows of a slab, slabs per volume, compute waves of a workgroup, floats of a staged row, rows per 1-KiB
+ * request, staged rows of a slice, (low, high) pairs of a row of the filtered image, pad samples of a row, depth segments, output
+ * slices per segment, bytes of LDS, 1 if the default route takes this form for the level (else 0).  Returns 12; MIFWT_ERR_UNSUPPORTED
+ * where the form does not apply, MIFWT_ERR_BADARG if `capacity` < 12. */
+int mifwt_dwt3_fwd_slab_plan(const mifwt_level_desc* desc, int* out, int capacity);
+
 /* SEVERAL levels of a 2-D reconstruction in one launch — trips of waverec2's level loop (src/ptwt/conv_transform_2.py:222-249);
  * the running approximation never reaches HBM.
  * descs[0] describes the COARSEST level, descs[nlevels-1] the finest, each exactly as a mifwt_dwt_inv call would: coef_extent = the
@@ -347,7 +355,9 @@ size_t mifwt_workspace_bytes(const mifwt_level_desc* desc, int direction);
  *   24 / 25  fully fused 3-D analysis / synthesis level, workgroups walking along the depth axis (f32 and f64; analysis: even L <= 10,
  *          every mode, rows <= 512 samples (f64: 256), picked from 2^22 samples per volume on and for 8 taps; synthesis: even L <= 8,
  *          dense coefficient rows, picked from 2^20 output samples on; f64, which has no bricks: analysis from 2^15 / 2^17 / 2^19 samples
- *          on for <= 4 / 6 / 8 taps, synthesis from 2^16 (<= 4 taps) / 2^19 output samples on)
+ *          on for <= 4 / 6 / 8 taps, synthesis from 2^16 (<= 4 taps) / 2^19 output samples on).  Round 6: batches of 8 / 16 volumes and
+ *          more from 2^21 / 10^5 samples per volume on (L <= 6); a SLAB form of the analysis kernel for 8 / 10 taps on rows of at most
+ *          128 samples (f32, every mode: a workgroup filters every staged row once), picked by volume and batch (mifwt_dwt3_fwd_slab_plan)
  *   11 / 23  fused 2-D analysis / synthesis level on the matrix cores (banded-Toeplitz MFMA; f16 storage, even L in [18, 32]; both walk down
  *          column panels; the synthesis kernel from 16 tiles of 32 x 128 samples per call on, the vector tile kernel 8 below that)
  *   12 / 13  two fused 2-D analysis / synthesis levels per launch (mifwt_dwt2_fwd_pair / mifwt_dwt2_inv_pair; never

@@ -787,6 +787,12 @@ int mifwt_dwt2_fwd_pyramid_schedule(int nlevels, const mifwt_level_desc* const* 
   if (pyramid_route(nlevels, descs) != 1) return MIFWT_ERR_UNSUPPORTED;
   return dwt2_fwd_pyr_schedule(nlevels, descs, wg_start, capacity);
 }
+int mifwt_dwt3_fwd_slab_plan(const mifwt_level_desc* desc, int* out, int capacity) {
+  if (!desc || !out) return MIFWT_ERR_BADARG;
+  const int rc = validate(desc, 0);
+  if (rc != MIFWT_OK) return rc;
+  return dwt3_fwd_slab_plan_query(desc, out, capacity);
+}
 // Every level of a 2-D reconstruction of a small plane in one launch (mifwt_dwt2_inv_small.hip); descs[0] = the coarsest level.
 int mifwt_dwt2_inv_pyramid_supported(int nlevels, const mifwt_level_desc* const* descs) {
   if (!descs || nlevels < 1 || nlevels > 8) return 0;

@@ -325,6 +325,7 @@ bool dwt3_fwd_walk_supported(const mifwt_level_desc* d);
 // ... its SLAB form for 8 / 10 taps on rows of at most 128 samples (mifwt_dwt3_fwd_slab.hip): f32, every mode; dwt3_fwd_walk runs it
 // where it applies (MIFWT_OPT_DEBUG bit 21 keeps the strip form)
 bool dwt3_fwd_slab_supported(const mifwt_level_desc* d);
+int dwt3_fwd_slab_plan_query(const mifwt_level_desc* d, int* out, int capacity);  // (mifwt_dwt3_fwd_slab_plan)
 bool dwt3_fwd_slab_pays(const mifwt_level_desc* d);  // ... and is ahead of the composed route (a cost model fitted to measurements)
 int dwt3_fwd_slab(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo, const double* hi,
                   hipStream_t stream);

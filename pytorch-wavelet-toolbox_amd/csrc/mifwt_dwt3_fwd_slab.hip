@@ -502,6 +502,16 @@ bool dwt3_fwd_slab_pays(const mifwt_level_desc* d) {
   return vol >= 500000 ? total >= 4000000 : total >= 2300000;
 }
 
+int dwt3_fwd_slab_plan_query(const mifwt_level_desc* d, int* out, int capacity) {
+  if (capacity < 12) return MIFWT_ERR_BADARG;
+  if (!dwt3_fwd_slab_supported(d)) return MIFWT_ERR_UNSUPPORTED;
+  SlabPlan p;
+  if (!slab_plan(d, &p)) return MIFWT_ERR_UNSUPPORTED;
+  const int v[12] = {p.rw, p.ngroups, p.ncw, p.pitch_f, p.rpq, p.rin_max, p.wfp, p.npad, p.nseg, p.seg_out, p.lds, dwt3_fwd_slab_pays(d) ? 1 : 0};
+  for (int i = 0; i < 12; ++i) out[i] = v[i];
+  return 12;
+}
+
 int dwt3_fwd_slab(const mifwt_level_desc* d, const void* x, void* approx, void* const* details, const double* lo, const double* hi,
                   hipStream_t stream) {
   if (!dwt3_fwd_slab_supported(d)) return MIFWT_ERR_UNSUPPORTED;

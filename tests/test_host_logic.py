@@ -713,3 +713,66 @@ def test_graph_free_calls_replay_their_route(oracle_engine):
     # a routing option clears it with the plans
     _engine.set_option(_engine.OPT_TILE_MODE, 0)
     assert len(_fwt._route_memo) == 0
+
+
+def test_slab_plan_invariants_without_a_gpu():
+    """`mifwt_dwt3_fwd_slab_plan`: what the slab form of kernel 24 (csrc/mifwt_dwt3_fwd_slab.hip) relies on, for every geometry of a sweep —
+    the workgroup's LDS fits a CU, a loader wave keeps at most 20 requests and 8 x 64 pad samples a slice, the row pitches spread the
+    16-byte accesses of neighbouring rows over the banks (4 x odd floats, 2 x odd pairs), a row holds its pads and the row pass's last
+    group of four outputs, slabs and depth segments cover the volume."""
+    lib = _engine.load_library()
+    lib.mifwt_dwt3_fwd_slab_plan.restype = ctypes.c_int
+    lib.mifwt_dwt3_fwd_slab_plan.argtypes = [ctypes.POINTER(_engine.LevelDesc), ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    out = (ctypes.c_int * 12)()
+
+    def desc(batch, shape, flen, dtype=0, mode="periodic"):
+        nd = len(shape)
+        coef = tuple((n + flen - 1) // 2 for n in shape)
+        d = _engine.LevelDesc()
+        d.ndim, d.dtype, d.mode, d.filt_len, d.batch = nd, dtype, _engine.MODE_IDS[mode], flen, batch
+        s_sig = s_coef = 1
+        for a in reversed(range(nd)):
+            d.sig_extent[a], d.coef_extent[a] = shape[a], coef[a]
+            d.sig_stride[1 + a] = s_sig
+            d.approx_stride[1 + a] = d.detail_stride[1 + a] = s_coef
+            s_sig, s_coef = s_sig * shape[a], s_coef * coef[a]
+        d.sig_stride[0] = s_sig
+        d.approx_stride[0] = d.detail_stride[0] = s_coef << nd
+        return d, coef
+
+    def plan(batch, shape, flen, dtype=0, mode="periodic"):
+        d, coef = desc(batch, shape, flen, dtype, mode)
+        return lib.mifwt_dwt3_fwd_slab_plan(ctypes.byref(d), out, 12), list(out), coef
+
+    seen = 0
+    for flen in (8, 10):
+        for batch in (1, 7, 32, 500):
+            for shape in ((100, 100, 100), (54, 54, 54), (31, 31, 31), (flen, flen, flen), (12, 128, 128), (200, 17, 33), (13, 97, 11),
+                          (64, 128, 10), (20, 31, 128), (40, 41, 127), (9 + flen, 66, 65)):
+                rc, (rw, ngroups, ncw, pitch_f, rpq, rin_max, wfp, npad, nseg, seg_out, lds, pays), (Do, Ho, Wo) = plan(batch, shape, flen)
+                assert rc == 12, (rc, flen, batch, shape)
+                seen += 1
+                W, HL = shape[2], flen - 2
+                assert rw % 2 == 0 and rw * ngroups >= Ho and rw * (ngroups - 1) < Ho
+                assert 1 <= ncw <= 12 and 64 * ncw >= (rw // 2) * Wo
+                assert rin_max == 2 * rw + HL and npad == HL + 2 * Wo - W
+                assert pitch_f % 4 == 0 and (pitch_f // 4) % 2 == 1 and pitch_f >= 8 + max(2 * Wo, W) and pitch_f <= 4 * 64
+                assert rpq == 64 // (pitch_f // 4) >= 1
+                assert wfp % 2 == 0 and (wfp // 2) % 2 == 1 and wfp >= 4 * ((Wo + 3) // 4)
+                nreq = -(-rin_max // rpq)
+                nown = -(-nreq // 4)
+                assert nown <= 20 and nown * rpq * npad <= 64 * 8
+                raw = (-(-rin_max // rpq) * rpq) * pitch_f * 4 + 32
+                assert lds == 3 * raw + rin_max * wfp * 8 and lds <= 160 * 1024
+                assert nseg >= 1 and seg_out >= 1 and nseg * seg_out >= Do and (nseg - 1) * seg_out < Do
+                assert pays in (0, 1)
+    assert seen == 2 * 4 * 11
+    # where the form does not apply: other filter lengths, rows of more than 128 samples, an extent shorter than the filter, f64 / f16, two axes
+    assert plan(32, (100, 100, 100), 6)[0] == -2 and plan(32, (100, 100, 129), 10)[0] == -2 and plan(32, (9, 100, 100), 10)[0] == -2
+    assert plan(32, (100, 100, 100), 10, dtype=1)[0] == -2
+    assert plan(4, (100, 100), 10)[0] == -2
+    d, _ = desc(32, (100, 100, 100), 10)
+    assert lib.mifwt_dwt3_fwd_slab_plan(ctypes.byref(d), out, 11) == -1 and lib.mifwt_dwt3_fwd_slab_plan(None, out, 12) == -1
+    # the reference's 3-D speed shape: two slabs of 28 rows, twelve compute waves, rows of 116 floats two per request, the default route
+    assert plan(32, (100, 100, 100), 10)[1][:8] == [28, 2, 12, 116, 2, 64, 58, 16] and plan(32, (100, 100, 100), 10)[1][11] == 1
+    assert plan(2, (100, 100, 100), 10)[1][11] == 0
