@@ -12,19 +12,22 @@ L = len(taps[0]); M = (N + L - 1) // 2
 arr = lambda t: (ctypes.c_double * L)(*t)
 dlo, dhi, rlo, rhi = (arr(t) for t in taps)
 xs = [torch.randn(B, N, N, device='cuda') for _ in range(2)]
+PITCH = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # row pitch of the coefficient planes in samples (0: dense)
 def desc(inter):
     d = E.LevelDesc()
     d.ndim, d.dtype, d.mode, d.filt_len, d.batch = 2, 0, E.MODE_IDS['reflect'], L, B
     d.sig_extent[0] = d.sig_extent[1] = N
     d.coef_extent[0] = d.coef_extent[1] = M
     d.sig_stride[0], d.sig_stride[1], d.sig_stride[2] = N * N, N, 1
+    P = PITCH or M
     for st in (d.approx_stride, d.detail_stride):
-        st[0], st[1], st[2] = 4 * M * M, (4 * M if inter else M), 1
+        st[0], st[1], st[2] = 4 * M * P, (4 * P if inter else P), 1
     return d
 def run(inter, reps=12):
     d = desc(inter)
-    bufs = [torch.empty(B, 4 * M * M, device='cuda') for _ in range(2)]
-    step = 4 * M if inter else 4 * M * M
+    P = PITCH or M
+    bufs = [torch.empty(B, 4 * M * P, device='cuda') for _ in range(2)]
+    step = 4 * P if inter else 4 * M * P
     kid_f, kid_i = lib.mifwt_kernel_id(ctypes.byref(d), 0), lib.mifwt_kernel_id(ctypes.byref(d), 1)
     wsb = max(lib.mifwt_workspace_bytes(ctypes.byref(d), 0), lib.mifwt_workspace_bytes(ctypes.byref(d), 1))
     ws = torch.empty(max(1, wsb), dtype=torch.uint8, device='cuda')
@@ -47,4 +50,4 @@ def run(inter, reps=12):
 for rep in range(2):
     for inter in (False, True):
         kf, ki, (tf, ti) = run(inter)
-        print('%s: analysis (id %d) %.3f ms, synthesis (id %d) %.3f ms' % ('rows side by side' if inter else 'planes           ', kf, tf, ki, ti))
+        print('pitch %d ' % (PITCH or M) + '%s: analysis (id %d) %.3f ms, synthesis (id %d) %.3f ms' % ('rows side by side' if inter else 'planes           ', kf, tf, ki, ti))
